@@ -1,0 +1,178 @@
+/*
+ * sdfgrid.h -- C ABI of libsdfgrid.so: the MI355X-native voxelise-and-raymarch path of sdf-viewer.
+ *
+ * This is the drop-in boundary for the reference's hot path (paths relative to the reference root):
+ *   - grid fill   src/app/scene/sdf/mod.rs:128-217  (SDFViewer::update, one SDFSurface::sample per voxel)
+ *   - raymarch    src/app/scene/sdf/material.frag:92-182 (per-pixel sphere tracing of the two textures)
+ * for the embedded demo SDF (src/sdf/demo/).  The reference exposes its SDFs over a per-point C ABI
+ * (src/sdf/ffi.rs:42-337) and leaves batching as a TODO (src/sdf/mod.rs:39); the sdfv_* calls below
+ * are those batched entry points.  The per-point ABI itself (bounding_box/sample/children/... with the
+ * reference's unprefixed names) is exported by the companion libsdfdemo_provider.so, see sdf_provider.h.
+ *
+ * Conventions
+ *   - plain C types only; every pointer documented as HOST or DEVICE (HIP device memory, gfx950).
+ *   - output buffers are owned by the caller; the library never frees them (reference: callee-allocates
+ *     + *_free, ffi.rs:52-55; the batched API inverts that because buffers are GBs and live on device).
+ *   - every call returns 0 on success or a negative sdfv_status; sdfv_last_error() returns a
+ *     thread-local message.  Nothing aborts (reference convention: log + zero result, ffi.rs:46-49).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls only enqueue work;
+ *     the caller synchronises the stream.  A handle/stream pair is single-owner, like the reference's
+ *     thread-local registry (ffi.rs:15-17).
+ *   - textures are RGBA32F, row-major with x fastest: flat = (z*H + y)*W + x (scene/sdf/mod.rs:177);
+ *     tex0 = (clamped distance + 0.1, linear r, g, b), tex1 = (metallic, roughness, occlusion, AIR_DIST).
+ */
+#ifndef SDFGRID_H
+#define SDFGRID_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDFV_ABI_VERSION 1
+
+typedef enum sdfv_status {
+    SDFV_OK = 0,
+    SDFV_ERR_INVALID_ARGUMENT = -1,
+    SDFV_ERR_UNKNOWN_SDF = -2, /* ffi.rs:46-49 "Failed to find SDF with ID" */
+    SDFV_ERR_HIP = -3,
+    SDFV_ERR_NO_DEVICE = -4
+} sdfv_status;
+
+/* src/sdf/mod.rs:104-118: #[repr(C)] struct SDFSample, 28 bytes */
+typedef struct sdfv_sample {
+    float distance;
+    float color[3];
+    float metallic;
+    float roughness;
+    float occlusion;
+} sdfv_sample;
+
+/* SDF ids of the demo hierarchy: demo/mod.rs:84 (root 0), cube.rs:92-94 (1), sphere.rs:50-52 (2) */
+enum { SDFV_SDF_DEMO = 0, SDFV_SDF_CUBE = 1, SDFV_SDF_SPHERE = 2 };
+/* cube.rs:20-24 enum Material */
+enum { SDFV_MATERIAL_BRICK = 0, SDFV_MATERIAL_NORMAL = 1 };
+
+/* The demo SDF's parameters = its clap flags (cube.rs:15-18, sphere.rs:11-14, demo/mod.rs:26-29). */
+typedef struct sdfv_demo_params {
+    float    cube_half_side;               /* -c, default 0.95 */
+    uint32_t cube_material;                /* -t, default brick */
+    float    sphere_radius;                /* -s, default 1.05 */
+    uint32_t sphere_material;              /* -l, default normal */
+    float    max_distance_custom_material; /* -m, default 0.05 */
+    uint32_t disable_sphere;               /* -d, default false */
+} sdfv_demo_params;
+
+/* A voxel grid, or a z-slab of one (multi-GPU: rank r holds slices [z_begin, z_end) of the global
+ * grid; the texture pointers handed to the calls address slice z_begin).  scene/sdf/mod.rs:46-117. */
+typedef struct sdfv_grid {
+    uint32_t dims[3];   /* global W, H, D */
+    float    bb_min[3]; /* SDFSurface::bounding_box()[0] */
+    float    bb_max[3]; /* SDFSurface::bounding_box()[1] */
+    uint32_t z_begin;   /* first slice held */
+    uint32_t z_end;     /* one past the last slice held; dense grid: 0, dims[2] */
+} sdfv_grid;
+
+/* three-d Camera::new_perspective (scene/mod.rs:82-95) flattened to what the shader consumes. */
+typedef struct sdfv_camera {
+    float eye[3];     /* cameraPosition, material.rs:62 */
+    float right[3];   /* orthonormal view basis */
+    float up[3];
+    float forward[3];
+    float tan_half_fovy;
+    float aspect;     /* width / height of the FULL image */
+    float bvp[16];    /* column-major bias * projection * view, material.rs:89-97 */
+} sdfv_camera;
+
+/* The shader's uniforms (material.rs:50-73) + three-d's tone/colour mapping selectors. */
+typedef struct sdfv_render_params {
+    float    bounds_min[3];            /* sdfBoundsMin */
+    float    bounds_max[3];            /* sdfBoundsMax */
+    uint32_t tex_size[3];              /* sdfTexSize */
+    float    lod_dist_between_samples; /* sdfLODDistBetweenSamples: 1 = loaded (LINEAR), >1 = loading (NEAREST snap) */
+    float    tint[4];                  /* surfaceColorTint */
+    float    ambient[3];               /* AmbientLight intensity*colour, scene/mod.rs:106 */
+    float    gamma;                    /* GAMMA_CORRECTION define (env "gamma", material.rs:39); <= 0 = undefined */
+    uint32_t tone_mapping;             /* 0 none, 1 Reinhard, 2 ACES (three-d default), 3 filmic */
+    uint32_t color_mapping;            /* 0 none, 1 compute-to-sRGB (three-d default) */
+} sdfv_render_params;
+
+/* Optional per-pixel march record (parity/debug): everything main() knows before shading. */
+typedef struct sdfv_march_aux {
+    int32_t status;   /* 1 hit, -1 out of steps, -2 out of bounds (material.frag:99-109), 0 pixel off the box */
+    int32_t steps;    /* tex0 fetches done by sdfRaycast */
+    float   hit_pos[3];
+    float   t;        /* distanceFromOrigin */
+    float   raw0[4];  /* tex0 sample at the hit */
+    float   raw1[4];  /* tex1 sample at the hit */
+    float   normal[3];
+    float   depth;    /* gl_FragDepth, material.frag:180-181 */
+} sdfv_march_aux;
+
+/* ---- library ---- */
+uint32_t    sdfv_abi_version(void);
+const char *sdfv_last_error(void);  /* thread-local, never NULL */
+int         sdfv_device_count(void); /* number of HIP devices visible, 0 if none */
+float       sdfv_air_dist(void);     /* AIR_DIST, scene/sdf/mod.rs:42 */
+
+void sdfv_demo_params_default(sdfv_demo_params *p);
+/* SDFViewer::from_bb voxel sizing, scene/sdf/mod.rs:46-72 */
+int  sdfv_grid_from_bb(const float bb_min[3], const float bb_max[3], uint32_t max_voxels_side, sdfv_grid *out);
+/* SDFViewerMaterial::new defaults + scene lights, material.rs:23-31, scene/mod.rs:106 */
+void sdfv_render_params_default(sdfv_render_params *rp, const sdfv_grid *grid);
+/* Camera::new_perspective(eye, target, up, degrees(fovy), near, far), scene/mod.rs:82-95 */
+int  sdfv_camera_look_at(sdfv_camera *cam, const float eye[3], const float target[3], const float up[3],
+                         float fovy_degrees, float aspect, float z_near, float z_far);
+
+/* ---- grid fill (DEVICE pointers, 16 B per voxel per texture, 16-byte aligned) ---- */
+
+/* SDFViewer::new_voxels initial state: both textures = [AIR_DIST; 4] (scene/sdf/mod.rs:76-77). */
+int sdfv_grid_init(const sdfv_grid *grid, float *tex0, float *tex1, void *stream);
+
+/* Dense fill: the state SDFViewer::update (scene/sdf/mod.rs:128-217) converges to on a fresh grid once
+ * the LoadingManager is exhausted.  Store-only (32 B/voxel), does not read the textures; writes tex1.a =
+ * AIR_DIST itself, so no prior sdfv_grid_init is needed. */
+int sdfv_fill_grid(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid,
+                   float *tex0, float *tex1, void *stream);
+
+/* One LoadingManager pass (loading.rs:50-76) with step `step` (a power of two >= 1) over the slab:
+ * visits voxels whose x, y and GLOBAL z are multiples of step and applies update_required
+ * (scene/sdf/mod.rs:184-190): tex0.r == AIR_DIST, or position inside changed_box (HOST, 6 floats
+ * min.xyz max.xyz, may be NULL).  Requires initialised textures. */
+int sdfv_fill_grid_pass(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid,
+                        uint32_t step, const float *changed_box,
+                        float *tex0, float *tex1, void *stream);
+
+/* ---- batched point sampling (the "Batched sampling" TODO, src/sdf/mod.rs:39) ---- */
+/* points: DEVICE, n x 3 floats.  out: DEVICE, n x sdfv_sample.  SDFSurface::sample(p, distance_only). */
+int sdfv_sample_points(const sdfv_demo_params *params, uint32_t sdf_id, const float *points, size_t n,
+                       int distance_only, sdfv_sample *out, void *stream);
+/* out: DEVICE, n x 3 floats.  SDFSurface::normal(p, eps): eps <= 0 means None (ffi.rs:326).
+ * use_default != 0 evaluates normal_default_impl (defaults.rs:49-56) instead of the demo's overrides. */
+int sdfv_normal_points(const sdfv_demo_params *params, uint32_t sdf_id, const float *points, size_t n,
+                       float eps, int use_default, float *out, void *stream);
+
+/* ---- raymarch ---- */
+/* material.frag main() for every pixel of rows [y0, y1) of n_cameras W x H images (row 0 = top).
+ * tex0/tex1: DEVICE, the FULL grid rp->tex_size.  cameras: HOST array.  rgba: DEVICE,
+ * n_cameras x (y1-y0) x W x 4 floats (outColor).  aux: DEVICE or NULL, same pixel layout. */
+int sdfv_raymarch(const sdfv_render_params *rp, const float *tex0, const float *tex1,
+                  const sdfv_camera *cameras, uint32_t n_cameras,
+                  uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                  float *rgba, sdfv_march_aux *aux, void *stream);
+
+/* ---- host-buffer conveniences (allocate, run, copy back, synchronise; PCIe-inclusive) ---- */
+int sdfv_fill_grid_host(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid,
+                        float *tex0_host, float *tex1_host);
+int sdfv_sample_points_host(const sdfv_demo_params *params, uint32_t sdf_id, const float *points_host, size_t n,
+                            int distance_only, sdfv_sample *out_host);
+int sdfv_raymarch_host(const sdfv_render_params *rp, const float *tex0_host, const float *tex1_host,
+                       const sdfv_camera *cameras, uint32_t n_cameras, uint32_t width, uint32_t height,
+                       float *rgba_host, sdfv_march_aux *aux_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

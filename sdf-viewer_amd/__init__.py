@@ -1,0 +1,149 @@
+"""sdf-viewer_amd -- Python harness over libsdfgrid.so (the MI355X-native voxelise-and-raymarch path).
+
+The product is the C-ABI shared library (include/sdfgrid.h, sdf-viewer_amd/csrc/); this package is the
+thin test/bench harness above it.  PyTorch is used only as plumbing: device memory (tensors whose
+data_ptr() is handed to the C ABI), the current HIP stream, and torch.distributed for the multi-GPU
+halo exchange.  Import fails loudly if the library has not been built -- there is no CPU path.
+
+The package directory name contains a hyphen; import it with
+    importlib.import_module("sdf-viewer_amd")
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi
+from ._capi import (Camera, DemoParams, Grid, MarchAux, RenderParams, Sample, SdfvError, check, f3, lib,  # noqa: F401
+                    MATERIAL_BRICK, MATERIAL_NORMAL, SDF_CUBE, SDF_DEMO, SDF_SPHERE)
+
+AIR_DIST = lib.sdfv_air_dist()  # scene/sdf/mod.rs:42
+AUX_FLOATS = C.sizeof(MarchAux) // 4
+
+
+def default_params(**overrides):
+    """SDFDemo::default(): the clap defaults (cube.rs:15-18, sphere.rs:11-14, demo/mod.rs:26-29)."""
+    p = DemoParams()
+    lib.sdfv_demo_params_default(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def make_grid(dims, bb_min=(-1.0, -1.0, -1.0), bb_max=(1.0, 1.0, 1.0), z_begin=0, z_end=None):
+    g = Grid()
+    g.dims = (C.c_uint32 * 3)(*[int(d) for d in dims])
+    g.bb_min = f3(bb_min)
+    g.bb_max = f3(bb_max)
+    g.z_begin = int(z_begin)
+    g.z_end = int(dims[2] if z_end is None else z_end)
+    return g
+
+
+def grid_from_bb(bb_min, bb_max, max_voxels_side):
+    """SDFViewer::from_bb voxel sizing (scene/sdf/mod.rs:46-72)."""
+    g = Grid()
+    check(lib.sdfv_grid_from_bb(f3(bb_min), f3(bb_max), int(max_voxels_side), C.byref(g)))
+    return g
+
+
+def slab_voxels(grid):
+    return int(grid.dims[0]) * int(grid.dims[1]) * (int(grid.z_end) - int(grid.z_begin))
+
+
+def alloc_textures(grid, device="cuda"):
+    """Two RGBA32F textures for the slab described by `grid` (uninitialised device memory)."""
+    shape = (int(grid.z_end) - int(grid.z_begin), int(grid.dims[1]), int(grid.dims[0]), 4)
+    return (torch.empty(shape, dtype=torch.float32, device=device),
+            torch.empty(shape, dtype=torch.float32, device=device))
+
+
+def _stream_ptr(stream=None):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)
+
+
+def _dev_ptr(t, what):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+        raise TypeError(f"{what} must be a contiguous float32 CUDA(HIP) tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def grid_init(grid, tex0, tex1, stream=None):
+    check(lib.sdfv_grid_init(C.byref(grid), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"), _stream_ptr(stream)))
+
+
+def fill_grid(params, grid, tex0, tex1, sdf_id=SDF_DEMO, stream=None):
+    """Dense fill = final state of SDFViewer::update (scene/sdf/mod.rs:128-217)."""
+    assert tex0.numel() == slab_voxels(grid) * 4 and tex1.numel() == slab_voxels(grid) * 4
+    check(lib.sdfv_fill_grid(C.byref(params), sdf_id, C.byref(grid), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"),
+                             _stream_ptr(stream)))
+
+
+def fill_grid_pass(params, grid, step, tex0, tex1, changed_box=None, sdf_id=SDF_DEMO, stream=None):
+    """One LoadingManager pass (loading.rs:50-76) with update_required (scene/sdf/mod.rs:184-190)."""
+    box = None if changed_box is None else (C.c_float * 6)(*[float(x) for x in changed_box])
+    check(lib.sdfv_fill_grid_pass(C.byref(params), sdf_id, C.byref(grid), int(step), box, _dev_ptr(tex0, "tex0"),
+                                  _dev_ptr(tex1, "tex1"), _stream_ptr(stream)))
+
+
+def sample_points(params, points, distance_only=False, sdf_id=SDF_DEMO, stream=None):
+    """Batched SDFSurface::sample.  points: [n,3] CUDA tensor -> [n,7] (distance, rgb, metallic, roughness, occlusion)."""
+    n = points.shape[0]
+    out = torch.empty((n, 7), dtype=torch.float32, device=points.device)
+    check(lib.sdfv_sample_points(C.byref(params), sdf_id, _dev_ptr(points, "points"), n, int(bool(distance_only)),
+                                 C.c_void_p(out.data_ptr()), _stream_ptr(stream)))
+    return out
+
+
+def normal_points(params, points, eps=None, use_default=False, sdf_id=SDF_DEMO, stream=None):
+    """Batched SDFSurface::normal(p, eps) (eps None -> <= 0 over the ABI, ffi.rs:326)."""
+    n = points.shape[0]
+    out = torch.empty((n, 3), dtype=torch.float32, device=points.device)
+    check(lib.sdfv_normal_points(C.byref(params), sdf_id, _dev_ptr(points, "points"), n,
+                                 float(eps) if eps else 0.0, int(bool(use_default)), C.c_void_p(out.data_ptr()),
+                                 _stream_ptr(stream)))
+    return out
+
+
+def default_render_params(grid):
+    rp = RenderParams()
+    lib.sdfv_render_params_default(C.byref(rp), C.byref(grid))
+    return rp
+
+
+def camera_look_at(eye=(2.5, 3.0, 5.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fovy_degrees=45.0, aspect=1.0,
+                   z_near=0.1, z_far=1000.0):
+    """Camera::new_perspective with the reference's defaults (scene/mod.rs:82-95)."""
+    cam = Camera()
+    check(lib.sdfv_camera_look_at(C.byref(cam), f3(eye), f3(target), f3(up), fovy_degrees, aspect, z_near, z_far))
+    return cam
+
+
+def orbit_cameras(n, aspect, eye0=(2.5, 3.0, 5.0)):
+    """camera k on the orbit of camera 0 around +y, azimuth atan2(z, x) + 2*pi*k/n."""
+    import math
+    r = math.hypot(eye0[0], eye0[2])
+    a0 = math.atan2(eye0[2], eye0[0])
+    cams = []
+    for k in range(n):
+        a = a0 + 2.0 * math.pi * k / n
+        cams.append(camera_look_at(eye=(r * math.cos(a), eye0[1], r * math.sin(a)), aspect=aspect))
+    return cams
+
+
+def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=False, stream=None, out=None):
+    """material.frag main() over rows [y0,y1).  Returns rgba [n_cam, rows, W, 4] (+ aux [n_cam, rows, W, 18] words)."""
+    if isinstance(cameras, Camera):
+        cameras = [cameras]
+    y1 = height if y1 is None else y1
+    n = len(cameras)
+    cam_arr = (Camera * n)(*cameras)
+    rgba = out if out is not None else torch.empty((n, y1 - y0, width, 4), dtype=torch.float32, device=tex0.device)
+    aux = torch.empty((n, y1 - y0, width, AUX_FLOATS), dtype=torch.int32, device=tex0.device) if want_aux else None
+    check(lib.sdfv_raymarch(C.byref(rp), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"), cam_arr, n, width, height,
+                            y0, y1, C.c_void_p(rgba.data_ptr()), C.c_void_p(aux.data_ptr()) if want_aux else None,
+                            _stream_ptr(stream)))
+    return (rgba, aux) if want_aux else rgba

@@ -1,0 +1,111 @@
+"""ctypes binding of include/sdfgrid.h (libsdfgrid.so).
+
+This is the stub a maintainer of the reference would write in Rust as `extern "C"` declarations
+(see INTEGRATION.md); here it is ctypes because the image has no Rust toolchain.  There is no
+fallback: if the shared library is missing or was not built, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdfgrid.so")
+
+
+class SdfvError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libsdfgrid error {code}: {message}")
+        self.code = code
+
+
+class Sample(C.Structure):  # src/sdf/mod.rs:104-118
+    _fields_ = [("distance", C.c_float), ("color", C.c_float * 3), ("metallic", C.c_float),
+                ("roughness", C.c_float), ("occlusion", C.c_float)]
+
+
+class DemoParams(C.Structure):  # cube.rs:15-18, sphere.rs:11-14, demo/mod.rs:26-29
+    _fields_ = [("cube_half_side", C.c_float), ("cube_material", C.c_uint32),
+                ("sphere_radius", C.c_float), ("sphere_material", C.c_uint32),
+                ("max_distance_custom_material", C.c_float), ("disable_sphere", C.c_uint32)]
+
+
+class Grid(C.Structure):
+    _fields_ = [("dims", C.c_uint32 * 3), ("bb_min", C.c_float * 3), ("bb_max", C.c_float * 3),
+                ("z_begin", C.c_uint32), ("z_end", C.c_uint32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("right", C.c_float * 3), ("up", C.c_float * 3),
+                ("forward", C.c_float * 3), ("tan_half_fovy", C.c_float), ("aspect", C.c_float),
+                ("bvp", C.c_float * 16)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3), ("tex_size", C.c_uint32 * 3),
+                ("lod_dist_between_samples", C.c_float), ("tint", C.c_float * 4), ("ambient", C.c_float * 3),
+                ("gamma", C.c_float), ("tone_mapping", C.c_uint32), ("color_mapping", C.c_uint32)]
+
+
+class MarchAux(C.Structure):
+    _fields_ = [("status", C.c_int32), ("steps", C.c_int32), ("hit_pos", C.c_float * 3), ("t", C.c_float),
+                ("raw0", C.c_float * 4), ("raw1", C.c_float * 4), ("normal", C.c_float * 3), ("depth", C.c_float)]
+
+
+assert C.sizeof(Sample) == 28 and C.sizeof(MarchAux) == 72 and C.sizeof(Camera) == 120
+
+SDF_DEMO, SDF_CUBE, SDF_SPHERE = 0, 1, 2
+MATERIAL_BRICK, MATERIAL_NORMAL = 0, 1
+
+# name -> (restype, argtypes); every symbol include/sdfgrid.h declares
+PROTOTYPES = {
+    "sdfv_abi_version": (C.c_uint32, []),
+    "sdfv_last_error": (C.c_char_p, []),
+    "sdfv_device_count": (C.c_int, []),
+    "sdfv_air_dist": (C.c_float, []),
+    "sdfv_demo_params_default": (None, [C.POINTER(DemoParams)]),
+    "sdfv_grid_from_bb": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(Grid)]),
+    "sdfv_render_params_default": (None, [C.POINTER(RenderParams), C.POINTER(Grid)]),
+    "sdfv_camera_look_at": (C.c_int, [C.POINTER(Camera), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float]),
+    "sdfv_grid_init": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdfv_fill_grid": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p, C.c_void_p,
+                                 C.c_void_p]),
+    "sdfv_fill_grid_pass": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_uint32,
+                                      C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdfv_sample_points": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_int,
+                                     C.c_void_p, C.c_void_p]),
+    "sdfv_normal_points": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_float,
+                                     C.c_int, C.c_void_p, C.c_void_p]),
+    "sdfv_raymarch": (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(Camera), C.c_uint32,
+                                C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                C.c_void_p]),
+    "sdfv_fill_grid_host": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p, C.c_void_p]),
+    "sdfv_sample_points_host": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_int,
+                                          C.c_void_p]),
+    "sdfv_raymarch_host": (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(Camera),
+                                     C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+}
+
+
+def load(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C sdf-viewer_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export what the header declares
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+lib = load()
+
+
+def check(rc):
+    if rc != 0:
+        raise SdfvError(rc, lib.sdfv_last_error().decode("utf-8", "replace"))
+
+
+def f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])

@@ -1,0 +1,183 @@
+// demo_sdf_device.h -- the embedded demo SDF (cube minus sphere) as gfx950 device code.
+//
+// Implements SDFSurface::sample for the three ids of the demo hierarchy, op for op in the order the
+// reference evaluates them (all device code is built with -ffp-contract=off; HIP's default
+// correctly-rounded fp32 divide/sqrt is relied upon):
+//   SDFDemo::sample          src/sdf/demo/mod.rs:51-75
+//   SDFDemoCube::sample      src/sdf/demo/cube.rs:79-89,  normal :164-177
+//   Material::render         src/sdf/demo/cube.rs:51-58
+//   sample_brick_texture     src/sdf/demo/cube.rs:181-222
+//   SDFDemoSphere::sample    src/sdf/demo/sphere.rs:37-47, normal :122-124
+// and the texel packing of SDFViewer::update, src/app/scene/sdf/mod.rs:196-208.
+//
+// Work whose result the reference discards is skipped (e.g. the sphere's normalize when the cube's
+// sample wins, or any material when the custom inter-surface material overrides it); every value that
+// reaches the output is computed by the same operations.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sdfgrid.h"
+
+namespace sdfv {
+
+// f32 `%` with a power-of-two modulus m (inv_m = 1/m), a >= 0.  a*inv_m, trunc, *m and the final
+// subtraction are all exact, so this equals fmodf(a, m) bit for bit (cube.rs:192 `% BRICK_WIDTH`).
+__device__ __forceinline__ float fmod_pow2(float a, float m, float inv_m) {
+    return a - truncf(a * inv_m) * m;
+}
+
+struct Mat {
+    float r, g, b, metallic, roughness, occlusion;
+};
+
+// compute_tex2d, cube.rs:189-202.  v/0.25 == v*4 and floor(row)/4 == floor(row)*0.25 exactly.
+__device__ __forceinline__ Mat brick_tex2d(float u, float v) {
+    const float BRICK_WIDTH = 0.5f, BRICK_HEIGHT = 0.25f;
+    const float max_cement_displacement = 0.2f / 2.0f * 0.25f;  // CEMENT_THICKNESS / 2.0 * BRICK_HEIGHT
+    float row_num = v * 4.0f;
+    float brick_offset = floorf(row_num) * 0.25f;
+    float bx = fmod_pow2(fabsf(u + brick_offset), BRICK_WIDTH, 2.0f);
+    float by = fmod_pow2(fabsf(v), BRICK_HEIGHT, 4.0f);
+    bool cement = bx < max_cement_displacement || bx > BRICK_WIDTH - max_cement_displacement ||
+                  by < max_cement_displacement || by > BRICK_HEIGHT - max_cement_displacement;
+    Mat m;
+    m.r = cement ? 56.0f / 255.0f : 150.0f / 255.0f;
+    m.g = cement ? 70.0f / 255.0f : 24.0f / 255.0f;
+    m.b = cement ? 60.0f / 255.0f : 10.0f / 255.0f;
+    m.metallic = cement ? 0.4f : 0.2f;
+    m.roughness = cement ? 0.5f : 0.8f;
+    m.occlusion = cement ? 1.0f : 0.0f;
+    return m;
+}
+
+// Material::render (cube.rs:51-58) on normal n.  Brick: tri-planar uv pick, cube.rs:205-220.
+__device__ __forceinline__ Mat material_render(uint32_t material, float px, float py, float pz,
+                                               float nx, float ny, float nz) {
+    float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
+    if (material == SDFV_MATERIAL_BRICK) {
+        float u, v;
+        if (ax > ay) {
+            if (ax > az) { u = pz; v = py; } else { u = px; v = py; }
+        } else if (ay > az) { u = pz; v = px; }
+        else { u = px; v = py; }
+        return brick_tex2d(u, v);
+    }
+    Mat m;  // SDFSample::new(dist, |n|): metallic = roughness = occlusion = 0 (src/sdf/mod.rs:120-126)
+    m.r = ax; m.g = ay; m.b = az;
+    m.metallic = 0.0f; m.roughness = 0.0f; m.occlusion = 0.0f;
+    return m;
+}
+
+__device__ __forceinline__ float signum_f32(float x) {  // f32::signum (NaN never reaches it here)
+    return __builtin_signbit(x) ? -1.0f : 1.0f;
+}
+
+__device__ __forceinline__ Mat zero_mat() {
+    Mat m; m.r = m.g = m.b = m.metallic = m.roughness = m.occlusion = 0.0f; return m;
+}
+
+// SDFDemoCube::sample material part; d_box already known.  cube.rs:83-88 + normal :164-177.
+__device__ __forceinline__ Mat cube_material(const sdfv_demo_params& prm, float px, float py, float pz,
+                                             float d_box, bool distance_only) {
+    if (distance_only || d_box > 0.1f) return zero_mat();
+    float side = prm.cube_half_side;
+    float nx = fabsf(px) > side ? signum_f32(px) : 0.0f;
+    float ny = fabsf(py) > side ? signum_f32(py) : 0.0f;
+    float nz = fabsf(pz) > side ? signum_f32(pz) : 0.0f;
+    return material_render(prm.cube_material, px, py, pz, nx, ny, nz);
+}
+
+// SDFDemoSphere::sample material part; len = |p| already known.  sphere.rs:41-46 + normal :122-124
+// (cgmath normalize = p * (1/|p|)).
+__device__ __forceinline__ Mat sphere_material(const sdfv_demo_params& prm, float px, float py, float pz,
+                                               float len, float d_sph, bool distance_only) {
+    if (distance_only || d_sph > 0.1f) return zero_mat();
+    float inv = 1.0f / len;
+    return material_render(prm.sphere_material, px, py, pz, px * inv, py * inv, pz * inv);
+}
+
+__device__ __forceinline__ float cube_distance(const sdfv_demo_params& prm, float px, float py, float pz) {
+    return fmaxf(fmaxf(fabsf(px), fabsf(py)), fabsf(pz)) - prm.cube_half_side;  // cube.rs:81
+}
+
+// p.distance(0): |0 - p|, dot = (x*x + y*y) + z*z (cgmath 0.18).  sphere.rs:39
+__device__ __forceinline__ float vec_length(float x, float y, float z) {
+    return sqrtf(x * x + y * y + z * z);
+}
+
+struct Sample {
+    float distance;
+    Mat m;
+};
+
+// SDFSurface::sample(p, distance_only) for sdf_id in {demo, cube, sphere}.
+__device__ __forceinline__ Sample demo_sample(const sdfv_demo_params& prm, uint32_t sdf_id,
+                                              float px, float py, float pz, bool distance_only) {
+    Sample s;
+    if (sdf_id == SDFV_SDF_CUBE) {
+        s.distance = cube_distance(prm, px, py, pz);
+        s.m = cube_material(prm, px, py, pz, s.distance, distance_only);
+        return s;
+    }
+    if (sdf_id == SDFV_SDF_SPHERE) {
+        float len = vec_length(px, py, pz);
+        s.distance = len - prm.sphere_radius;
+        s.m = sphere_material(prm, px, py, pz, len, s.distance, distance_only);
+        return s;
+    }
+    // SDFDemo::sample, demo/mod.rs:51-75
+    float d_box = cube_distance(prm, px, py, pz);
+    if (prm.disable_sphere) {
+        s.distance = d_box;
+        s.m = cube_material(prm, px, py, pz, d_box, distance_only);
+        return s;
+    }
+    float len = vec_length(px, py, pz);
+    float d_sph = len - prm.sphere_radius;
+    s.distance = fmaxf(d_box, -d_sph);
+    float inter = fabsf(d_box) - fabsf(d_sph);
+    if (fabsf(inter) <= prm.max_distance_custom_material) {
+        s.m.r = 0.5f; s.m.g = 0.6f; s.m.b = 0.7f;
+        s.m.metallic = 0.5f; s.m.roughness = 0.0f; s.m.occlusion = 0.0f;
+    } else if (inter < 0.0f) {
+        s.m = cube_material(prm, px, py, pz, d_box, distance_only);
+    } else {
+        s.m = sphere_material(prm, px, py, pz, len, d_sph, distance_only);
+    }
+    return s;
+}
+
+// three-d-asset Srgba::from(Vec3): (c * 255.0) as u8 -- truncating, saturating, NaN -> 0.
+__device__ __forceinline__ uint32_t srgb_quantize(float c) {
+    float v = fminf(fmaxf(c * 255.0f, 0.0f), 255.0f);  // fmaxf(NaN, 0) = 0
+    return (uint32_t)v;
+}
+
+// SDFViewer::update's packing, scene/sdf/mod.rs:196-208.  lut = to_linear_srgb per u8 (256 floats).
+template <typename Lut>
+__device__ __forceinline__ void pack_sample(const Sample& s, const Lut& lut, float air_dist,
+                                            float4& t0, float4& t1) {
+    float r = s.m.r, g = s.m.g, b = s.m.b;
+    if (r == 0.0f && g == 0.0f && b == 0.0f) { r = 0.5f; g = 0.5f; b = 0.5f; }
+    t0.x = fminf(fmaxf(1e-1f + s.distance, 0.0f), 1.0f);
+    t0.y = lut[srgb_quantize(r)];
+    t0.z = lut[srgb_quantize(g)];
+    t0.w = lut[srgb_quantize(b)];
+    t1.x = s.m.metallic;
+    t1.y = s.m.roughness;
+    t1.z = s.m.occlusion <= 0.0f ? 1.0f : s.m.occlusion;
+    t1.w = air_dist;  // never written by update(): new_voxels' init value (scene/sdf/mod.rs:76-77)
+}
+
+// voxel index -> position, scene/sdf/mod.rs:178-182: idx/(dim-1), *size, +min, each rounded.
+__device__ __forceinline__ float voxel_coord(uint32_t idx, float dim_minus_1, float bb_size, float bb_min) {
+    float p = (float)idx;
+    p = p / dim_minus_1;
+    p = p * bb_size;
+    p = p + bb_min;
+    return p;
+}
+
+}  // namespace sdfv

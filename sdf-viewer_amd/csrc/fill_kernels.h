@@ -1,0 +1,45 @@
+// fill_kernels.h -- launch interface of the grid-fill kernels (see fill_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sdfgrid.h"
+
+namespace sdfv {
+
+struct FillArgs {
+    sdfv_demo_params prm;
+    uint32_t sdf_id;
+    uint32_t W, H, D;        // global dims
+    uint32_t z_begin;        // first global slice held by tex0/tex1
+    uint32_t slab_d;         // slices held
+    float dm1[3];            // (float)dim - 1.0f          (scene/sdf/mod.rs:168)
+    float bb_size[3];        // bb[1] - bb[0]              (scene/sdf/mod.rs:167)
+    float bb_min[3];
+    float air_dist;
+    uint32_t row_stride_y;   // set by the launcher
+    uint32_t row_stride_z;
+    float4* tex0;
+    float4* tex1;
+};
+
+struct PassArgs {
+    uint32_t step;
+    uint32_t nx, ny, nz;     // visited voxels per axis in this slab
+    uint32_t z_first;        // first visited GLOBAL z (multiple of step, >= z_begin)
+    uint32_t has_box;
+    float box[6];
+};
+
+struct FillLaunch {
+    uint32_t target_blocks;  // persistent workgroups to aim for
+    bool nontemporal;
+};
+
+size_t fill_dense_lds_bytes(const FillArgs& a);
+hipError_t launch_fill_dense(const FillArgs& a, const FillLaunch& cfg, hipStream_t stream);
+hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& p, hipStream_t stream);
+hipError_t launch_grid_init(float* tex0, float* tex1, uint64_t n_voxels, float air, hipStream_t stream);
+
+}  // namespace sdfv

@@ -1,0 +1,29 @@
+// raymarch_kernels.h -- launch interface of the sphere-tracing kernel (see raymarch_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sdfgrid.h"
+
+namespace sdfv {
+
+struct RaymarchArgs {
+    sdfv_render_params rp;
+    float bsize[3];              // bounds_max - bounds_min (material.frag:44)
+    const float4* tex0;          // full grid, rp.tex_size
+    const float4* tex1;
+    uint32_t n_cameras;          // cameras in this launch (<= kMaxCamerasPerLaunch), by value in kernarg
+    uint32_t width, height;      // full image
+    uint32_t y0, y1;             // rows rendered by this launch
+    uint32_t compute_normal;     // evaluate sdfNormal per hit even when no aux is stored
+    float4* rgba;                // n_cameras x (y1-y0) x width
+    sdfv_march_aux* aux;         // same layout or nullptr
+    sdfv_camera cameras[16];
+};
+
+constexpr uint32_t kMaxCamerasPerLaunch = 16;
+
+hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream);
+
+}  // namespace sdfv

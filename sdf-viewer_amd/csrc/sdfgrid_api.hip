@@ -1,0 +1,385 @@
+// sdfgrid_api.hip -- the extern "C" surface declared in include/sdfgrid.h.
+// Validates arguments, builds the kernel argument blocks and enqueues the gfx950 kernels.  There is
+// no CPU fallback: without a HIP device every compute entry point fails with SDFV_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/sdfgrid.h"
+#include "fill_kernels.h"
+#include "points_kernels.h"
+#include "raymarch_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice)
+        return fail(SDFV_ERR_NO_DEVICE, "%s: no HIP device (%s)", what, hipGetErrorString(e));
+    return fail(SDFV_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define SDFV_HIP(call)                                   \
+    do {                                                 \
+        hipError_t e_ = (call);                          \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+bool known_sdf(uint32_t id) { return id <= SDFV_SDF_SPHERE; }
+
+int check_params(const sdfv_demo_params* p, uint32_t sdf_id) {
+    if (!p) return fail(SDFV_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (!known_sdf(sdf_id)) {
+        fprintf(stderr, "Failed to find SDF with ID %u\n", sdf_id);  // ffi.rs:47
+        return fail(SDFV_ERR_UNKNOWN_SDF, "Failed to find SDF with ID %u", sdf_id);
+    }
+    if (p->cube_material > SDFV_MATERIAL_NORMAL || p->sphere_material > SDFV_MATERIAL_NORMAL)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "Invalid cube material");  // cube.rs:33
+    return SDFV_OK;
+}
+
+int check_grid(const sdfv_grid* g) {
+    if (!g) return fail(SDFV_ERR_INVALID_ARGUMENT, "grid is NULL");
+    if (g->z_begin > g->z_end || g->z_end > g->dims[2])
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "slab [%u,%u) outside depth %u", g->z_begin, g->z_end, g->dims[2]);
+    return SDFV_OK;
+}
+
+int need_device() {
+    static int cached = 0;  // only a positive answer is cached
+    if (cached > 0) return SDFV_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(SDFV_ERR_NO_DEVICE, "no HIP device visible: libsdfgrid has no CPU path");
+    }
+    cached = n;
+    return SDFV_OK;
+}
+
+float air_dist() {
+    volatile float a = 1e-1f, b = 0.001234f;  // scene/sdf/mod.rs:42, f32 const evaluation
+    return a + b;
+}
+
+sdfv::FillArgs make_fill_args(const sdfv_demo_params& p, uint32_t sdf_id, const sdfv_grid& g, float* tex0,
+                              float* tex1) {
+    sdfv::FillArgs a;
+    memset(&a, 0, sizeof(a));
+    a.prm = p;
+    a.sdf_id = sdf_id;
+    a.W = g.dims[0];
+    a.H = g.dims[1];
+    a.D = g.dims[2];
+    a.z_begin = g.z_begin;
+    a.slab_d = g.z_end - g.z_begin;
+    for (int i = 0; i < 3; ++i) {
+        a.dm1[i] = (float)g.dims[i] - 1.0f;           // scene/sdf/mod.rs:168
+        a.bb_size[i] = g.bb_max[i] - g.bb_min[i];      // scene/sdf/mod.rs:167
+        a.bb_min[i] = g.bb_min[i];
+    }
+    a.air_dist = air_dist();
+    a.tex0 = reinterpret_cast<float4*>(tex0);
+    a.tex1 = reinterpret_cast<float4*>(tex1);
+    return a;
+}
+
+// Persistent workgroups to aim for: 256 CUs x 8 resident 256-thread workgroups (guide: memory-bound grids
+// cap near CUs x 8 and stride the rest).  SDFV_FILL_BLOCKS / SDFV_FILL_NT override for tuning runs.
+sdfv::FillLaunch fill_launch_config() {
+    sdfv::FillLaunch c;
+    c.target_blocks = 2048;
+    c.nontemporal = true;
+    if (const char* s = getenv("SDFV_FILL_BLOCKS")) {
+        int v = atoi(s);
+        if (v > 0) c.target_blocks = (uint32_t)v;
+    }
+    if (const char* s = getenv("SDFV_FILL_NT")) c.nontemporal = atoi(s) != 0;
+    return c;
+}
+
+struct DeviceBuf {
+    void* p = nullptr;
+    ~DeviceBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+uint32_t sdfv_abi_version(void) { return SDFV_ABI_VERSION; }
+
+const char* sdfv_last_error(void) { return g_err; }
+
+int sdfv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+float sdfv_air_dist(void) { return air_dist(); }
+
+void sdfv_demo_params_default(sdfv_demo_params* p) {
+    if (!p) return;
+    p->cube_half_side = 0.95f;                // cube.rs:17
+    p->cube_material = SDFV_MATERIAL_BRICK;   // cube.rs:15
+    p->sphere_radius = 1.05f;                 // sphere.rs:13
+    p->sphere_material = SDFV_MATERIAL_NORMAL;  // sphere.rs:11
+    p->max_distance_custom_material = 0.05f;  // demo/mod.rs:26
+    p->disable_sphere = 0;                    // demo/mod.rs:28
+}
+
+int sdfv_grid_from_bb(const float bb_min[3], const float bb_max[3], uint32_t max_voxels_side, sdfv_grid* out) {
+    if (!bb_min || !bb_max || !out) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
+    // scene/sdf/mod.rs:46-72: the longest axis gets max_voxels_side (ties: the LAST longest axis, as
+    // Iterator::max_by), the others (N as f32 * size_i / size_max) as usize.
+    float size[3] = {bb_max[0] - bb_min[0], bb_max[1] - bb_min[1], bb_max[2] - bb_min[2]};
+    int max_dim = 0;
+    for (int i = 1; i < 3; ++i)
+        if (size[i] >= size[max_dim]) max_dim = i;
+    for (int i = 0; i < 3; ++i) {
+        if (i == max_dim) {
+            out->dims[i] = max_voxels_side;
+        } else {
+            float v = (float)max_voxels_side * size[i] / size[max_dim];
+            out->dims[i] = v > 0.0f ? (uint32_t)v : 0u;
+        }
+        out->bb_min[i] = bb_min[i];
+        out->bb_max[i] = bb_max[i];
+    }
+    out->z_begin = 0;
+    out->z_end = out->dims[2];
+    return SDFV_OK;
+}
+
+void sdfv_render_params_default(sdfv_render_params* rp, const sdfv_grid* grid) {
+    if (!rp) return;
+    memset(rp, 0, sizeof(*rp));
+    for (int i = 0; i < 3; ++i) {
+        if (grid) {
+            rp->bounds_min[i] = grid->bb_min[i];
+            rp->bounds_max[i] = grid->bb_max[i];
+            rp->tex_size[i] = grid->dims[i];
+        }
+        rp->ambient[i] = 1.0f;  // AmbientLight::new(&ctx, 1.0, Srgba::WHITE), scene/mod.rs:106
+    }
+    rp->lod_dist_between_samples = 1.0f;  // material.rs:28
+    rp->tint[0] = rp->tint[1] = rp->tint[2] = rp->tint[3] = 1.0f;  // Srgba::WHITE, material.rs:29
+    rp->gamma = 0.0f;
+    rp->tone_mapping = 2;   // three-d 0.18 default (ACES)
+    rp->color_mapping = 1;  // three-d 0.18 default (compute to sRGB)
+}
+
+int sdfv_camera_look_at(sdfv_camera* cam, const float eye[3], const float target[3], const float up[3],
+                        float fovy_degrees, float aspect, float z_near, float z_far) {
+    if (!cam || !eye || !target || !up) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
+    // cgmath look_at_rh: f = normalize(target - eye), s = normalize(f x up), u = s x f
+    float f[3] = {target[0] - eye[0], target[1] - eye[1], target[2] - eye[2]};
+    float fl = 1.0f / sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+    for (float& c : f) c *= fl;
+    float s[3] = {f[1] * up[2] - f[2] * up[1], f[2] * up[0] - f[0] * up[2], f[0] * up[1] - f[1] * up[0]};
+    float sl = 1.0f / sqrtf(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);
+    for (float& c : s) c *= sl;
+    float u[3] = {s[1] * f[2] - s[2] * f[1], s[2] * f[0] - s[0] * f[2], s[0] * f[1] - s[1] * f[0]};
+    for (int i = 0; i < 3; ++i) {
+        cam->eye[i] = eye[i];
+        cam->right[i] = s[i];
+        cam->up[i] = u[i];
+        cam->forward[i] = f[i];
+    }
+    cam->tan_half_fovy = tanf(fovy_degrees * (3.14159265358979323846f / 180.0f) / 2.0f);
+    cam->aspect = aspect;
+    const float view[16] = {s[0], u[0], -f[0], 0.0f, s[1], u[1], -f[1], 0.0f, s[2], u[2], -f[2], 0.0f,
+                            -(eye[0] * s[0] + eye[1] * s[1] + eye[2] * s[2]),
+                            -(eye[0] * u[0] + eye[1] * u[1] + eye[2] * u[2]),
+                            (eye[0] * f[0] + eye[1] * f[1] + eye[2] * f[2]), 1.0f};
+    const float ct = 1.0f / cam->tan_half_fovy;
+    const float proj[16] = {ct / aspect, 0, 0, 0, 0, ct, 0, 0,
+                            0, 0, (z_far + z_near) / (z_near - z_far), -1.0f,
+                            0, 0, (2.0f * z_far * z_near) / (z_near - z_far), 0};
+    const float bias[16] = {0.5f, 0, 0, 0, 0, 0.5f, 0, 0, 0, 0, 0.5f, 0, 0.5f, 0.5f, 0.5f, 1.0f};  // material.rs:90-95
+    float pv[16];
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) {
+            float acc = 0.0f;
+            for (int k = 0; k < 4; ++k) acc += proj[k * 4 + r] * view[c * 4 + k];
+            pv[c * 4 + r] = acc;
+        }
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) {
+            float acc = 0.0f;
+            for (int k = 0; k < 4; ++k) acc += bias[k * 4 + r] * pv[c * 4 + k];
+            cam->bvp[c * 4 + r] = acc;
+        }
+    return SDFV_OK;
+}
+
+int sdfv_grid_init(const sdfv_grid* grid, float* tex0, float* tex1, void* stream) {
+    if (int rc = check_grid(grid)) return rc;
+    if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
+    if (int rc = need_device()) return rc;
+    const uint64_t n = (uint64_t)grid->dims[0] * grid->dims[1] * (grid->z_end - grid->z_begin);
+    SDFV_HIP(sdfv::launch_grid_init(tex0, tex1, n, air_dist(), (hipStream_t)stream));
+    return SDFV_OK;
+}
+
+int sdfv_fill_grid(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, float* tex0, float* tex1,
+                   void* stream) {
+    if (int rc = check_params(params, sdf_id)) return rc;
+    if (int rc = check_grid(grid)) return rc;
+    if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
+    if (((uintptr_t)tex0 | (uintptr_t)tex1) & 15) return fail(SDFV_ERR_INVALID_ARGUMENT, "textures must be 16-byte aligned");
+    if (int rc = need_device()) return rc;
+    sdfv::FillArgs a = make_fill_args(*params, sdf_id, *grid, tex0, tex1);
+    if (sdfv::fill_dense_lds_bytes(a) > 60 * 1024)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "H + slab depth = %u exceeds the coordinate-table budget", a.H + a.slab_d);
+    SDFV_HIP(sdfv::launch_fill_dense(a, fill_launch_config(), (hipStream_t)stream));
+    return SDFV_OK;
+}
+
+int sdfv_fill_grid_pass(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, uint32_t step,
+                        const float* changed_box, float* tex0, float* tex1, void* stream) {
+    if (int rc = check_params(params, sdf_id)) return rc;
+    if (int rc = check_grid(grid)) return rc;
+    if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
+    if (step == 0 || (step & (step - 1))) return fail(SDFV_ERR_INVALID_ARGUMENT, "step %u is not a power of two", step);
+    if (int rc = need_device()) return rc;
+    sdfv::FillArgs a = make_fill_args(*params, sdf_id, *grid, tex0, tex1);
+    sdfv::PassArgs p;
+    memset(&p, 0, sizeof(p));
+    p.step = step;
+    p.nx = (a.W + step - 1) / step;  // loading.rs:82: ceil(limit / step) visits per axis
+    p.ny = (a.H + step - 1) / step;
+    p.z_first = ((grid->z_begin + step - 1) / step) * step;
+    p.nz = p.z_first < grid->z_end ? (grid->z_end - p.z_first + step - 1) / step : 0;
+    p.has_box = changed_box != nullptr;
+    if (changed_box) memcpy(p.box, changed_box, sizeof(p.box));
+    SDFV_HIP(sdfv::launch_fill_pass(a, p, (hipStream_t)stream));
+    return SDFV_OK;
+}
+
+int sdfv_sample_points(const sdfv_demo_params* params, uint32_t sdf_id, const float* points, size_t n,
+                       int distance_only, sdfv_sample* out, void* stream) {
+    if (int rc = check_params(params, sdf_id)) return rc;
+    if (n && (!points || !out)) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (int rc = need_device()) return rc;
+    SDFV_HIP(sdfv::launch_sample_points(*params, sdf_id, points, n, distance_only != 0, out, (hipStream_t)stream));
+    return SDFV_OK;
+}
+
+int sdfv_normal_points(const sdfv_demo_params* params, uint32_t sdf_id, const float* points, size_t n, float eps,
+                       int use_default, float* out, void* stream) {
+    if (int rc = check_params(params, sdf_id)) return rc;
+    if (n && (!points || !out)) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (int rc = need_device()) return rc;
+    SDFV_HIP(sdfv::launch_normal_points(*params, sdf_id, points, n, eps, use_default != 0, out, (hipStream_t)stream));
+    return SDFV_OK;
+}
+
+int sdfv_raymarch(const sdfv_render_params* rp, const float* tex0, const float* tex1, const sdfv_camera* cameras,
+                  uint32_t n_cameras, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, float* rgba,
+                  sdfv_march_aux* aux, void* stream) {
+    if (!rp || !tex0 || !tex1 || !rgba) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_cameras && !cameras) return fail(SDFV_ERR_INVALID_ARGUMENT, "cameras is NULL");
+    if (y0 > y1 || y1 > height) return fail(SDFV_ERR_INVALID_ARGUMENT, "rows [%u,%u) outside height %u", y0, y1, height);
+    if (rp->tex_size[0] == 0 || rp->tex_size[1] == 0 || rp->tex_size[2] == 0)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "empty texture");
+    if (!(rp->lod_dist_between_samples >= 1.0f)) return fail(SDFV_ERR_INVALID_ARGUMENT, "lod_dist_between_samples < 1");
+    if (int rc = need_device()) return rc;
+    sdfv::RaymarchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rp = *rp;
+    for (int i = 0; i < 3; ++i) a.bsize[i] = rp->bounds_max[i] - rp->bounds_min[i];
+    a.tex0 = reinterpret_cast<const float4*>(tex0);
+    a.tex1 = reinterpret_cast<const float4*>(tex1);
+    a.width = width;
+    a.height = height;
+    a.y0 = y0;
+    a.y1 = y1;
+    a.compute_normal = getenv("SDFV_RAYMARCH_SKIP_NORMAL") ? 0u : 1u;
+    const uint64_t pixels_per_cam = (uint64_t)(y1 - y0) * width;
+    for (uint32_t c0 = 0; c0 < n_cameras; c0 += sdfv::kMaxCamerasPerLaunch) {
+        const uint32_t nc = n_cameras - c0 < sdfv::kMaxCamerasPerLaunch ? n_cameras - c0 : sdfv::kMaxCamerasPerLaunch;
+        a.n_cameras = nc;
+        memcpy(a.cameras, cameras + c0, nc * sizeof(sdfv_camera));
+        a.rgba = reinterpret_cast<float4*>(rgba) + c0 * pixels_per_cam;
+        a.aux = aux ? aux + c0 * pixels_per_cam : nullptr;
+        SDFV_HIP(sdfv::launch_raymarch(a, (hipStream_t)stream));
+    }
+    return SDFV_OK;
+}
+
+int sdfv_fill_grid_host(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, float* tex0_host,
+                        float* tex1_host) {
+    if (int rc = check_grid(grid)) return rc;
+    if (!tex0_host || !tex1_host) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
+    if (int rc = need_device()) return rc;
+    const size_t bytes = (size_t)grid->dims[0] * grid->dims[1] * (grid->z_end - grid->z_begin) * 16;
+    if (bytes == 0) return SDFV_OK;
+    DeviceBuf d0, d1;
+    SDFV_HIP(hipMalloc(&d0.p, bytes));
+    SDFV_HIP(hipMalloc(&d1.p, bytes));
+    if (int rc = sdfv_fill_grid(params, sdf_id, grid, (float*)d0.p, (float*)d1.p, nullptr)) return rc;
+    SDFV_HIP(hipMemcpy(tex0_host, d0.p, bytes, hipMemcpyDeviceToHost));
+    SDFV_HIP(hipMemcpy(tex1_host, d1.p, bytes, hipMemcpyDeviceToHost));
+    return SDFV_OK;
+}
+
+int sdfv_sample_points_host(const sdfv_demo_params* params, uint32_t sdf_id, const float* points_host, size_t n,
+                            int distance_only, sdfv_sample* out_host) {
+    if (n && (!points_host || !out_host)) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (int rc = check_params(params, sdf_id)) return rc;
+    if (int rc = need_device()) return rc;
+    if (n == 0) return SDFV_OK;
+    DeviceBuf dp, ds;
+    SDFV_HIP(hipMalloc(&dp.p, n * 12));
+    SDFV_HIP(hipMalloc(&ds.p, n * sizeof(sdfv_sample)));
+    SDFV_HIP(hipMemcpy(dp.p, points_host, n * 12, hipMemcpyHostToDevice));
+    if (int rc = sdfv_sample_points(params, sdf_id, (const float*)dp.p, n, distance_only, (sdfv_sample*)ds.p, nullptr))
+        return rc;
+    SDFV_HIP(hipMemcpy(out_host, ds.p, n * sizeof(sdfv_sample), hipMemcpyDeviceToHost));
+    return SDFV_OK;
+}
+
+int sdfv_raymarch_host(const sdfv_render_params* rp, const float* tex0_host, const float* tex1_host,
+                       const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width, uint32_t height,
+                       float* rgba_host, sdfv_march_aux* aux_host) {
+    if (!rp || !tex0_host || !tex1_host || !rgba_host) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (int rc = need_device()) return rc;
+    const size_t tex_bytes = (size_t)rp->tex_size[0] * rp->tex_size[1] * rp->tex_size[2] * 16;
+    const size_t px = (size_t)n_cameras * width * height;
+    if (tex_bytes == 0 || px == 0) return SDFV_OK;
+    DeviceBuf d0, d1, dr, da;
+    SDFV_HIP(hipMalloc(&d0.p, tex_bytes));
+    SDFV_HIP(hipMalloc(&d1.p, tex_bytes));
+    SDFV_HIP(hipMalloc(&dr.p, px * 16));
+    if (aux_host) SDFV_HIP(hipMalloc(&da.p, px * sizeof(sdfv_march_aux)));
+    SDFV_HIP(hipMemcpy(d0.p, tex0_host, tex_bytes, hipMemcpyHostToDevice));
+    SDFV_HIP(hipMemcpy(d1.p, tex1_host, tex_bytes, hipMemcpyHostToDevice));
+    if (int rc = sdfv_raymarch(rp, (const float*)d0.p, (const float*)d1.p, cameras, n_cameras, width, height, 0, height,
+                               (float*)dr.p, (sdfv_march_aux*)da.p, nullptr))
+        return rc;
+    SDFV_HIP(hipMemcpy(rgba_host, dr.p, px * 16, hipMemcpyDeviceToHost));
+    if (aux_host) SDFV_HIP(hipMemcpy(aux_host, da.p, px * sizeof(sdfv_march_aux), hipMemcpyDeviceToHost));
+    return SDFV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+"""Multi-GPU layout of the path: z-slab sharding of the grid fill with a one-voxel halo exchange, and
+camera/row splitting of the raymarch over replicated grids (the reference has no sharding
+of any kind -- its hot loop carries `// TODO: Cross-platform parallel iteration?`, scene/sdf/mod.rs:174).
+
+One process per GPU.  Voxels are independent, so the fill needs NO data-path collective; the only exchange
+is the halo: after the fill each rank sends its first/last owned z-slice of both textures to its z-neighbour
+and receives the neighbour's into a ghost slice, so trilinear sampling (material.frag:42-45) at a slab
+boundary reads local memory.  On GPUs `torch.distributed` backend "nccl" is RCCL: the grouped
+isend/irecv below become one ncclGroupStart/End of ncclSend/ncclRecv pairs, each neighbour pair riding one
+xGMI link per direction.  On CPU (tests) the same code runs over gloo.
+"""
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+def slab_range(depth, rank, world):
+    """Slices [z_begin, z_end) owned by `rank`: contiguous, balanced to within one slice."""
+    return depth * rank // world, depth * (rank + 1) // world
+
+
+def weak_scaling_dims(side, world):
+    """Global grid with side^3 voxels per rank: doubles x, then y, then z as world doubles (1,2,4,8 -> cube of
+    2*side at 8 ranks = BASELINE.json config 4 when side = 512)."""
+    dims = [side, side, side]
+    axis, w = 2, world
+    while w > 1:
+        assert w % 2 == 0, "weak-scaling layout is defined for power-of-two world sizes"
+        dims[axis] *= 2
+        axis = (axis - 1) % 3
+        w //= 2
+    return tuple(dims)
+
+
+@dataclass
+class SlabTextures:
+    """tex0/tex1 of one rank's slab plus ghost slices: [ghost_lo?][owned z_begin..z_end)[ghost_hi?]."""
+    tex0: torch.Tensor
+    tex1: torch.Tensor
+    z_begin: int
+    z_end: int
+    ghost_lo: int  # 1 if a lower neighbour exists
+    ghost_hi: int
+
+    @property
+    def owned0(self):
+        return self.tex0[self.ghost_lo:self.ghost_lo + (self.z_end - self.z_begin)]
+
+    @property
+    def owned1(self):
+        return self.tex1[self.ghost_lo:self.ghost_lo + (self.z_end - self.z_begin)]
+
+
+def alloc_slab(dims, rank, world, device, fill_value=None):
+    z0, z1 = slab_range(dims[2], rank, world)
+    glo = 1 if rank > 0 else 0
+    ghi = 1 if rank < world - 1 else 0
+    shape = (glo + (z1 - z0) + ghi, dims[1], dims[0], 4)
+    t0 = torch.empty(shape, dtype=torch.float32, device=device)
+    t1 = torch.empty(shape, dtype=torch.float32, device=device)
+    if fill_value is not None:
+        t0.fill_(fill_value)
+        t1.fill_(fill_value)
+    return SlabTextures(t0, t1, z0, z1, glo, ghi)
+
+
+def halo_exchange(slab, rank, world, group=None):
+    """One-voxel (= one z-slice) halo of both textures with ranks rank-1 / rank+1; non-periodic ends.
+    Returns the number of bytes this rank sent."""
+    if world == 1:
+        return 0
+    ops = []
+    sent = 0
+    n_owned = slab.z_end - slab.z_begin
+    for t in (slab.tex0, slab.tex1):
+        first_owned = t[slab.ghost_lo]
+        last_owned = t[slab.ghost_lo + n_owned - 1]
+        if rank > 0:
+            ops.append(dist.P2POp(dist.isend, first_owned, rank - 1, group))
+            ops.append(dist.P2POp(dist.irecv, t[0], rank - 1, group))
+            sent += first_owned.numel() * 4
+        if rank < world - 1:
+            ops.append(dist.P2POp(dist.isend, last_owned, rank + 1, group))
+            ops.append(dist.P2POp(dist.irecv, t[t.shape[0] - 1], rank + 1, group))
+            sent += last_owned.numel() * 4
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    return sent
+
+
+def gather_replica(slab, dims, world, group=None):
+    """Full grid on every rank from the slabs (all-gather; slabs may differ by one slice, so each is
+    padded to the deepest slab for the collective and trimmed afterwards)."""
+    ranges = [slab_range(dims[2], r, world) for r in range(world)]
+    deepest = max(z1 - z0 for z0, z1 in ranges)
+    outs = []
+    for owned in (slab.owned0, slab.owned1):
+        padded = torch.zeros((deepest, dims[1], dims[0], 4), dtype=owned.dtype, device=owned.device)
+        padded[:owned.shape[0]] = owned
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded, group=group)
+        outs.append(torch.cat([p[:z1 - z0] for p, (z0, z1) in zip(parts, ranges)], dim=0))
+    return outs[0], outs[1]
+
+
+def split_cameras(n_cameras, rank, world):
+    """Cameras dealt to ranks in contiguous blocks (config 5: 64 cameras over 8 GPUs = 8 each)."""
+    return range(n_cameras * rank // world, n_cameras * (rank + 1) // world)

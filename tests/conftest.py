@@ -1,0 +1,38 @@
+import importlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure_built():
+    """Build liboracle.so / libsdfgrid.so when missing (they are git-ignored; on the GPU box the prebuilt
+    files travel with the snapshot)."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    if not os.path.exists(os.path.join(ROOT, "sdf-viewer_amd", "libsdfgrid.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "sdf-viewer_amd", "csrc")], stdout=subprocess.DEVNULL)
+
+
+_ensure_built()
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return importlib.import_module("sdf-viewer_amd")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_binding
+    return oracle_binding

@@ -1,0 +1,182 @@
+"""GPU parity tests of the grid fill (through the C ABI): bit-exact against the oracle and the committed
+golden fixtures at small sizes; size-independent properties at BASELINE.json's full sizes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+PARAM_KEYS = ["cube_half_side", "cube_material", "sphere_radius", "sphere_material",
+              "max_distance_custom_material", "disable_sphere"]
+INTS = {"cube_material", "sphere_material", "disable_sphere"}
+
+
+def kw_from_row(row):
+    return {k: (int(v) if k in INTS else float(v)) for k, v in zip(PARAM_KEYS, row)}
+
+
+def gpu_fill(pkg, prm, dims, bb_min=(-1, -1, -1), bb_max=(1, 1, 1), z0=0, z1=None, sdf_id=0):
+    g = pkg.make_grid(dims, bb_min, bb_max, z0, z1)
+    t0, t1 = pkg.alloc_textures(g)
+    t0.fill_(-7.0)
+    t1.fill_(-7.0)
+    pkg.fill_grid(prm, g, t0, t1, sdf_id=sdf_id)
+    torch.cuda.synchronize()
+    return t0, t1
+
+
+def assert_bits_equal(gpu_tensor, ref):
+    got = gpu_tensor.cpu().numpy()
+    assert got.shape == ref.shape
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_golden_grid_fixture(pkg):
+    g = np.load(os.path.join(GOLD, "grid_9x7x5.npz"))
+    dims = tuple(int(d) for d in g["dims"])
+    for k, row in enumerate(g["params"]):
+        t0, t1 = gpu_fill(pkg, pkg.default_params(**kw_from_row(row)), dims, g["bb_min"], g["bb_max"])
+        assert_bits_equal(t0, g[f"tex0_{k}"])
+        assert_bits_equal(t1, g[f"tex1_{k}"])
+
+
+@pytest.mark.parametrize("dims", [(64, 64, 64), (8, 11, 17), (2, 2, 2), (33, 5, 70), (130, 3, 9), (300, 4, 3),
+                                  (1, 5, 7), (5, 1, 1)])
+def test_dense_fill_matches_oracle(pkg, oracle, dims):
+    prm = pkg.default_params()
+    t0, t1 = gpu_fill(pkg, prm, dims)
+    r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims)
+    assert_bits_equal(t0, r0)
+    assert_bits_equal(t1, r1)
+
+
+@pytest.mark.parametrize("kw", [dict(cube_material=1, sphere_material=0), dict(disable_sphere=1),
+                                dict(cube_half_side=0.5, sphere_radius=0.6, max_distance_custom_material=0.0),
+                                dict(cube_half_side=0.8, sphere_radius=0.3, max_distance_custom_material=0.25),
+                                dict(sphere_radius=1.25, cube_half_side=1.0)])
+@pytest.mark.parametrize("sdf_id", [0, 1, 2])
+def test_params_and_subtrees(pkg, oracle, kw, sdf_id):
+    """Every child SDF can be rendered on its own (app/mod.rs:200-208); parameters as the clap flags."""
+    prm = pkg.default_params(**kw)
+    dims = (40, 37, 21)
+    bb = ((-1.0, -0.75, -1.0), (1.0, 1.0, 0.5))
+    t0, t1 = gpu_fill(pkg, prm, dims, *bb, sdf_id=sdf_id)
+    r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, *bb, sdf_id=sdf_id)
+    assert_bits_equal(t0, r0)
+    assert_bits_equal(t1, r1)
+
+
+def test_slab_fill_equals_full_fill(pkg, oracle):
+    """z-slab sharding: filling slabs independently reproduces the dense grid bit for bit."""
+    prm = pkg.default_params()
+    dims = (48, 40, 37)
+    full0, full1 = gpu_fill(pkg, prm, dims)
+    bounds = [0, 9, 10, 25, 37]
+    parts0, parts1 = [], []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        s0, s1 = gpu_fill(pkg, prm, dims, z0=a, z1=b)
+        parts0.append(s0)
+        parts1.append(s1)
+    assert torch.equal(torch.cat(parts0), full0) and torch.equal(torch.cat(parts1), full1)
+    r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, z0=9, z1=10)
+    assert_bits_equal(parts0[1], r0)
+
+
+def test_progressive_passes_converge_to_dense(pkg, oracle):
+    """LoadingManager passes (step 4, 2, 1) with update_required end in the dense state; every
+    intermediate state equals the oracle's LoadingManager-ordered loop stopped at the pass boundary."""
+    prm = pkg.default_params()
+    oprm = oracle.params_from(prm)
+    dims = (21, 18, 13)
+    g = pkg.make_grid(dims)
+    t0, t1 = pkg.alloc_textures(g)
+    pkg.grid_init(g, t0, t1)
+    torch.cuda.synchronize()
+    assert (t0 == pkg.AIR_DIST).all() and (t1 == pkg.AIR_DIST).all()
+    r0, r1 = oracle.grid_init(dims)
+    lm = oracle.lm_new(dims, 3)
+    for step in (4, 2, 1):
+        pkg.fill_grid_pass(prm, g, step, t0, t1)
+        n = -(-dims[0] // step) * -(-dims[1] // step) * -(-dims[2] // step)
+        assert oracle.viewer_update(oprm, dims, lm, r0, r1, max_iterations=n) == n
+        torch.cuda.synchronize()
+        assert_bits_equal(t0, r0)
+        assert_bits_equal(t1, r1)
+    d0, d1 = gpu_fill(pkg, prm, dims)
+    assert torch.equal(t0, d0) and torch.equal(t1, d1)
+
+
+def test_changed_box_refill(pkg, oracle):
+    """Parameter edit -> changed() box -> only voxels inside the box (or still AIR) are re-sampled
+    (scene/sdf/mod.rs:131-154,184-190)."""
+    dims = (24, 24, 24)
+    prm = pkg.default_params()
+    t0, t1 = gpu_fill(pkg, prm, dims)
+    r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims)
+    prm2 = pkg.default_params(sphere_radius=0.8, cube_material=1)
+    box = (-0.5, -1.0, -0.25, 0.5, 0.1, 1.0)
+    g = pkg.make_grid(dims)
+    lm = oracle.lm_new(dims, 3)
+    for step in (4, 2, 1):
+        pkg.fill_grid_pass(prm2, g, step, t0, t1, changed_box=box)
+    oracle.viewer_update(oracle.params_from(prm2), dims, lm, r0, r1, changed_box=box)
+    torch.cuda.synchronize()
+    assert_bits_equal(t0, r0)
+    assert_bits_equal(t1, r1)
+    assert not torch.equal(t0, gpu_fill(pkg, prm, dims)[0])
+
+
+@pytest.mark.parametrize("side", [256, 512])
+def test_full_size_properties(pkg, oracle, side):
+    """BASELINE.json sizes: properties that do not need a full CPU fill."""
+    prm = pkg.default_params()
+    dims = (side, side, side)
+    t0, t1 = gpu_fill(pkg, prm, dims)
+    # (1) range / untouched-channel invariants of the packing
+    assert float(t0[..., 0].min()) >= 0.0 and float(t0[..., 0].max()) <= 1.0
+    assert bool((t1[..., 3] == pkg.AIR_DIST).all())
+    assert bool(torch.isfinite(t0).all()) and bool(torch.isfinite(t1).all())
+    assert not bool((t0 == -7.0).any()) and not bool((t1 == -7.0).any())  # every voxel written
+    # (2) 4096 seeded voxels + the 8 corners against the oracle, bit for bit
+    rng = np.random.default_rng(side)
+    idx = rng.integers(0, side, size=(4096, 3))
+    idx[:8] = [[x, y, z] for x in (0, side - 1) for y in (0, side - 1) for z in (0, side - 1)]
+    ti = torch.from_numpy(idx).cuda()
+    got0 = t0[ti[:, 2], ti[:, 1], ti[:, 0]].cpu().numpy()
+    got1 = t1[ti[:, 2], ti[:, 1], ti[:, 0]].cpu().numpy()
+    pts = np.array([[oracle.L.or_voxel_coord(int(i), side, -1.0, 1.0) for i in v] for v in idx], np.float32)
+    samples = oracle.sample_many(oracle.params_from(prm), pts)
+    for k in range(len(idx)):
+        w0, w1 = oracle.pack(samples[k])
+        assert (got0[k].view(np.uint32) == w0.view(np.uint32)).all(), (idx[k], got0[k], w0)
+        assert (got1[k].view(np.uint32) == w1.view(np.uint32)).all(), (idx[k], got1[k], w1)
+    # (3) three whole slices against the oracle (first, middle, last)
+    for z in (0, side // 2, side - 1):
+        r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, z0=z, z1=z + 1)
+        assert_bits_equal(t0[z:z + 1], r0)
+        assert_bits_equal(t1[z:z + 1], r1)
+    # (4) idempotence: a LoadingManager pass over the finished grid changes nothing
+    before = (t0.view(torch.int32).sum(dtype=torch.int64).item(), t1.view(torch.int32).sum(dtype=torch.int64).item())
+    pkg.fill_grid_pass(prm, pkg.make_grid(dims), 1, t0, t1)
+    torch.cuda.synchronize()
+    after = (t0.view(torch.int32).sum(dtype=torch.int64).item(), t1.view(torch.int32).sum(dtype=torch.int64).item())
+    assert before == after
+    # (5) slab sharding at full size: an 8-way slab equals the same slices of the dense fill
+    z0, z1 = 3 * side // 8, 4 * side // 8
+    s0, s1 = gpu_fill(pkg, prm, dims, z0=z0, z1=z1)
+    assert torch.equal(s0, t0[z0:z1]) and torch.equal(s1, t1[z0:z1])
+
+
+def test_host_buffer_entry_point(pkg, oracle):
+    import ctypes as C
+    prm = pkg.default_params()
+    dims = (16, 12, 10)
+    g = pkg.make_grid(dims)
+    t0 = np.zeros((10, 12, 16, 4), np.float32)
+    t1 = np.zeros_like(t0)
+    pkg.check(pkg.lib.sdfv_fill_grid_host(C.byref(prm), 0, C.byref(g), t0.ctypes.data, t1.ctypes.data))
+    r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims)
+    np.testing.assert_array_equal(t0.view(np.uint32), r0.view(np.uint32))
+    np.testing.assert_array_equal(t1.view(np.uint32), r1.view(np.uint32))

@@ -1,0 +1,87 @@
+"""world_size-2 and -3 gloo tests (CPU) of the multi-GPU layout: slab partition, halo exchange, replica gather,
+camera split.  Slab contents are produced by the oracle here (no GPU in this container); the exchange code
+is the same one bench.py runs over RCCL."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, dims, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        par = importlib.import_module("sdf-viewer_amd.parallel")
+        import oracle_binding as oracle
+        prm = oracle.default_params()
+        slab = par.alloc_slab(dims, rank, world, "cpu", fill_value=float("nan"))
+        o0, o1 = oracle.fill_dense(prm, dims, z0=slab.z_begin, z1=slab.z_end, threads=1)
+        slab.owned0.copy_(torch.from_numpy(o0))
+        slab.owned1.copy_(torch.from_numpy(o1))
+        sent = par.halo_exchange(slab, rank, world)
+        # ghosts must equal what a local recompute of the neighbour's slice gives (the SDF is analytic)
+        ok = True
+        if slab.ghost_lo:
+            g0, g1 = oracle.fill_dense(prm, dims, z0=slab.z_begin - 1, z1=slab.z_begin, threads=1)
+            ok &= np.array_equal(slab.tex0[0].numpy().view(np.uint32), g0[0].view(np.uint32))
+            ok &= np.array_equal(slab.tex1[0].numpy().view(np.uint32), g1[0].view(np.uint32))
+        if slab.ghost_hi:
+            g0, g1 = oracle.fill_dense(prm, dims, z0=slab.z_end, z1=slab.z_end + 1, threads=1)
+            ok &= np.array_equal(slab.tex0[-1].numpy().view(np.uint32), g0[0].view(np.uint32))
+            ok &= np.array_equal(slab.tex1[-1].numpy().view(np.uint32), g1[0].view(np.uint32))
+        expect_sent = (slab.ghost_lo + slab.ghost_hi) * 2 * dims[0] * dims[1] * 16
+        ok &= sent == expect_sent
+        # owned region untouched by the exchange
+        ok &= np.array_equal(slab.owned0.numpy().view(np.uint32), o0.view(np.uint32))
+        # replica gather == dense fill
+        r0, r1 = par.gather_replica(slab, dims, world)
+        d0, d1 = oracle.fill_dense(prm, dims, threads=1)
+        ok &= np.array_equal(r0.numpy().view(np.uint32), d0.view(np.uint32))
+        ok &= np.array_equal(r1.numpy().view(np.uint32), d1.view(np.uint32))
+        q.put((rank, bool(ok), slab.z_begin, slab.z_end))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims", [(2, (12, 10, 16)), (3, (8, 6, 11))])
+def test_halo_exchange_and_gather_gloo(world, dims):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dims, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in results), results
+    # slabs tile [0, D) exactly
+    assert results[0][2] == 0 and results[-1][3] == dims[2]
+    assert all(a[3] == b[2] for a, b in zip(results[:-1], results[1:]))
+
+
+def test_partition_helpers():
+    par = importlib.import_module("sdf-viewer_amd.parallel")
+    for depth in (1, 7, 64, 1024):
+        for world in (1, 2, 3, 8):
+            rs = [par.slab_range(depth, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == depth
+            assert all(a[1] == b[0] for a, b in zip(rs[:-1], rs[1:]))
+            assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1
+    assert par.weak_scaling_dims(256, 1) == (256, 256, 256)
+    assert par.weak_scaling_dims(256, 2) == (256, 256, 512)
+    assert par.weak_scaling_dims(256, 4) == (256, 512, 512)
+    assert par.weak_scaling_dims(512, 8) == (1024, 1024, 1024)   # BASELINE.json config 4
+    cams = [list(par.split_cameras(64, r, 8)) for r in range(8)]
+    assert sum(cams, []) == list(range(64)) and all(len(c) == 8 for c in cams)
