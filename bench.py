@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py -- Mvoxels/s grid fill + Mrays/s sphere-trace, demo SDF (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic input: fill the voxel grid from the
+demo SDF, then sphere-trace it.  The metric is a PAIR (voxels and rays are different units), so the two
+halves are timed in two separately bracketed regions of exactly K steps each:
+    value       = Mvoxels/s of the fill  (the half BASELINE.json's target is stated on)
+    value_rays  = Mrays/s of the raymarch (all W*H pixels counted, misses included)
+    ms_per_step = fill ms + raymarch ms.
+Inputs are deterministic (integer lattice + fixed cameras) and already resident in HBM; outputs stay in HBM.
+
+N = 1 workload: BASELINE.json configs[1] (256^3 grid + 1920x1080).  --workload 512 selects configs[2]
+(512^3 + 3840x2160).  N > 1 (weak scaling): the grid grows to side^3 voxels PER RANK, sharded by z-slab,
+each fill step followed by the one-voxel RCCL halo exchange; the raymarch renders one camera per rank
+(orbit) over a replica of the N = 1 grid.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FILL_BYTES_PER_VOXEL = 32  # tex0 16 B + tex1 16 B, store-only
+
+WORKLOADS = {
+    "256": dict(side=256, width=1920, height=1080, name="demo_sdf 256^3 grid + 1920x1080 sphere-trace (configs[1])"),
+    "512": dict(side=512, width=3840, height=2160, name="demo_sdf 512^3 grid + 3840x2160 sphere-trace (configs[2])"),
+    "64": dict(side=64, width=512, height=512, name="demo_sdf 64^3 grid + 512x512 sphere-trace (configs[0])"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="256")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def timed_region(fn, steps, torch, dist, world, device):
+    """EXACTLY `steps` calls of fn bracketed by barrier + synchronize on both sides; MAX over ranks.
+    Also returns the HIP-event time of the region on the launch stream (kernel time incl. launch gaps)."""
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, ev_ms = float(t[0]), float(t[1])
+    return dt, ev_ms
+
+
+def cpu_baseline(workload, budget_s):
+    """The oracle (a port: the Rust reference cannot be built here) timed on this box's host cores on a bounded
+    sample of the same workload: whole z-slices of the same grid for the fill, whole rows of the same image
+    for the raymarch.  1 thread = stand-in for the reference's single-threaded loop (scene/sdf/mod.rs:173-215)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_binding as oracle
+    side, W, H = workload["side"], workload["width"], workload["height"]
+    prm = oracle.default_params()
+    dims = (side, side, side)
+    # fill: time one slice to size the sample, then run the sample in the middle of the grid
+    t = time.perf_counter()
+    oracle.fill_dense(prm, dims, z0=side // 2, z1=side // 2 + 1, threads=1)
+    per_slice = max(time.perf_counter() - t, 1e-4)
+    n_slices = int(max(1, min(side, (budget_s * 0.5) / per_slice)))
+    z0 = (side - n_slices) // 2
+    buf0 = np.zeros((n_slices, side, side, 4), np.float32)  # pre-touched: no first-touch page faults in the timing
+    buf1 = np.zeros_like(buf0)
+    t = time.perf_counter()
+    oracle.L.or_fill_dense(oracle.C.byref(prm), 0, oracle.u3(dims), oracle.f3((-1, -1, -1)), oracle.f3((1, 1, 1)),
+                           z0, z0 + n_slices, buf0.ctypes.data, buf1.ctypes.data, 1)
+    fill_dt = time.perf_counter() - t
+    fill_mvox = n_slices * side * side / fill_dt / 1e6
+    # raymarch on a small grid replica of the same SDF is NOT the same workload; use the real grid size
+    # but only a band of rows.  The grid itself comes from the oracle (all cores, untimed).
+    cores = os.cpu_count() or 1
+    g0, g1 = oracle.fill_dense(prm, dims, threads=cores) if side <= 256 else (None, None)
+    rays = None
+    if g0 is not None:
+        rp = oracle.default_render_params(dims)
+        cam = oracle.camera_look_at(aspect=W / H)
+        band = 8
+        t = time.perf_counter()
+        oracle.raymarch(rp, g0, g1, cam, W, H, y0=H // 2 - band // 2, y1=H // 2 + band // 2, threads=1, want_aux=False)
+        per_band = max(time.perf_counter() - t, 1e-4)
+        rows = int(max(band, min(H, band * (budget_s * 0.5) / per_band)))
+        y0 = (H - rows) // 2
+        t = time.perf_counter()
+        oracle.raymarch(rp, g0, g1, cam, W, H, y0=y0, y1=y0 + rows, threads=1, want_aux=False)
+        rays = rows * W / (time.perf_counter() - t) / 1e6
+    return {"value": round(fill_mvox, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+            "sample": f"{n_slices} central z-slices of the {side}^3 grid ({n_slices * side * side} voxels, "
+                      f"{fill_dt:.1f} s), oracle/grid_fill.c -O2 -ffp-contract=off, 1 thread",
+            "value_rays": None if rays is None else round(rays, 3), "unit_rays": "Mrays/s",
+            "sample_rays": None if rays is None else f"{rows} central rows of the {W}x{H} image, 1 thread",
+            "host_cores_available": cores}
+
+
+def load_traffic(workload_key):
+    """HBM bytes per launch from the committed PMC pass (profiles/*_pmc.json), or None."""
+    path = os.path.join(ROOT, "profiles", "fill_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        return d.get(workload_key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    pkg = importlib.import_module("sdf-viewer_amd")
+    par = importlib.import_module("sdf-viewer_amd.parallel")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libsdfgrid has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    wl = WORKLOADS[args.workload]
+    side, W, H = wl["side"], wl["width"], wl["height"]
+    prm = pkg.default_params()
+
+    # ---------------- fill: side^3 voxels per rank, z-slab of the weak-scaled global grid ----------------
+    gdims = par.weak_scaling_dims(side, world)
+    slab = par.alloc_slab(gdims, rank, world, device)
+    grid = pkg.make_grid(gdims, z_begin=slab.z_begin, z_end=slab.z_end)
+    owned0, owned1 = slab.owned0, slab.owned1
+    voxels_per_rank = pkg.slab_voxels(grid)
+
+    def fill_step():
+        pkg.fill_grid(prm, grid, owned0, owned1)
+        if world > 1:
+            par.halo_exchange(slab, rank, world)
+
+    def fill_only():
+        pkg.fill_grid(prm, grid, owned0, owned1)
+
+    for _ in range(args.warmup):
+        fill_step()
+    fill_dt, _ = timed_region(fill_step, args.steps, torch, dist, world, device)
+    # dominant kernel alone (no halo), HIP events on the launch stream
+    _, kern_ms_total = timed_region(fill_only, args.steps, torch, dist, world, device)
+    kern_ms = kern_ms_total / args.steps
+    total_voxels = voxels_per_rank * world  # identical per rank by construction
+    fill_mvox = total_voxels * args.steps / fill_dt / 1e6
+    achieved_gbs = FILL_BYTES_PER_VOXEL * voxels_per_rank / (kern_ms * 1e-3) / 1e9
+
+    # ---------------- raymarch: one camera per rank over a replica of the N=1 grid ----------------
+    rdims = (side, side, side)
+    rgrid = pkg.make_grid(rdims)
+    r0, r1 = pkg.alloc_textures(rgrid, device=device)
+    pkg.fill_grid(prm, rgrid, r0, r1)
+    rp = pkg.default_render_params(rgrid)
+    cams = pkg.orbit_cameras(world, aspect=W / H)  # camera 0 = the reference default (scene/mod.rs:82-95)
+    my_cams = [cams[i] for i in par.split_cameras(world, rank, world)]
+    rgba = torch.empty((len(my_cams), H, W, 4), dtype=torch.float32, device=device)
+
+    def march_step():
+        pkg.raymarch(rp, r0, r1, my_cams, W, H, out=rgba)
+
+    for _ in range(args.warmup):
+        march_step()
+    march_dt, march_ev_ms = timed_region(march_step, args.steps, torch, dist, world, device)
+    total_rays = W * H * world
+    march_mrays = total_rays * args.steps / march_dt / 1e6
+
+    if world > 1:
+        # outside the timed regions: the gathered slabs must equal a dense local fill of the global grid
+        if gdims[0] * gdims[1] * gdims[2] * 32 <= 8 << 30:
+            full0, full1 = par.gather_replica(slab, gdims, world)
+            chk0, chk1 = pkg.alloc_textures(pkg.make_grid(gdims), device=device)
+            pkg.fill_grid(prm, pkg.make_grid(gdims), chk0, chk1)
+            torch.cuda.synchronize()
+            assert torch.equal(full0, chk0) and torch.equal(full1, chk1), "sharded fill != dense fill"
+            del full0, full1, chk0, chk1
+
+    if rank == 0:
+        out = {
+            "metric": "Mvoxels/s grid fill (value) + Mrays/s sphere-trace (value_rays), demo SDF",
+            "value": round(fill_mvox, 1),
+            "unit": "Mvoxels/s",
+            "value_rays": round(march_mrays, 1),
+            "unit_rays": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round((fill_dt + march_dt) / args.steps * 1e3, 4),
+            "ms_per_step_fill": round(fill_dt / args.steps * 1e3, 4),
+            "ms_per_step_raymarch": round(march_dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (demo SDF defaults on the integer lattice, fixed cameras; no RNG)",
+            "config": {"workload": wl["name"], "grid_global": list(gdims), "voxels_per_gpu": voxels_per_rank,
+                       "image": [W, H], "cameras_per_gpu": len(my_cams),
+                       "parallelism": "single GPU" if world == 1 else f"z-slab x{world} + 1-voxel RCCL halo; 1 camera/GPU"},
+            "roofline": {"kernel": "fill_dense_kernel", "bound": "hbm",
+                         "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                         "traffic": load_traffic(args.workload),
+                         "algorithmic_bytes_per_launch": FILL_BYTES_PER_VOXEL * voxels_per_rank,
+                         "avg_launch_ms": round(kern_ms, 5)},
+            "raymarch_kernel_ms": round(march_ev_ms / args.steps, 4),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
