@@ -171,6 +171,143 @@ __device__ __forceinline__ void pack_sample(const Sample& s, const Lut& lut, flo
     t1.w = air_dist;  // never written by update(): new_voxels' init value (scene/sdf/mod.rs:76-77)
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused sample + pack for the dense fill (scene/sdf/mod.rs:193-208 applied to SDFDemo::sample).
+//
+// Same arithmetic as demo_sample() + pack_sample(), arranged for the store-bound kernel:
+//  * every material whose colour is a constant (brick, cement, the custom inter-surface material,
+//    the 0.5 grey that replaces an all-zero colour) is packed at COMPILE time: quantise + table lookup
+//    of a constant is a constant, so only the "normal" material (colour = |n|) touches the table;
+//  * the configuration (which SDF, which materials) is a template policy, so the common default
+//    configuration carries no uniform branches; RuntimeCfg reads them from the parameter block.
+// ---------------------------------------------------------------------------------------------
+constexpr float kSrgbToLinear[256] = {
+#include "srgb_lut.inc"
+};
+
+constexpr uint32_t quantize_constexpr(float c) {  // srgb_quantize() for compile-time constants
+    float v = c * 255.0f;
+    return !(v > 0.0f) ? 0u : (v >= 255.0f ? 255u : (uint32_t)v);
+}
+constexpr float linear_of(float c) { return kSrgbToLinear[quantize_constexpr(c)]; }
+
+struct Packed {  // what update() writes besides tex0.r: tex0.gba and tex1.rgb
+    float lr, lg, lb, metallic, roughness, occlusion;
+};
+
+// occlusion <= 0 -> 1 (scene/sdf/mod.rs:208) is folded into the constants below.
+constexpr Packed kPackedCement = {linear_of(56.0f / 255.0f), linear_of(70.0f / 255.0f), linear_of(60.0f / 255.0f),
+                                  0.4f, 0.5f, 1.0f};
+constexpr Packed kPackedBrick = {linear_of(150.0f / 255.0f), linear_of(24.0f / 255.0f), linear_of(10.0f / 255.0f),
+                                 0.2f, 0.8f, 1.0f};
+constexpr Packed kPackedCustom = {linear_of(0.5f), linear_of(0.6f), linear_of(0.7f), 0.5f, 0.0f, 1.0f};
+constexpr Packed kPackedAir = {linear_of(0.5f), linear_of(0.5f), linear_of(0.5f), 0.0f, 0.0f, 1.0f};  // zero colour -> 0.5
+
+struct DefaultCfg {  // SDFDemo::default(): brick cube minus normal-shaded sphere
+    static constexpr bool kStatic = true;
+    __device__ static __forceinline__ uint32_t sdf_id(uint32_t) { return SDFV_SDF_DEMO; }
+    __device__ static __forceinline__ uint32_t cube_material(const sdfv_demo_params&) { return SDFV_MATERIAL_BRICK; }
+    __device__ static __forceinline__ uint32_t sphere_material(const sdfv_demo_params&) { return SDFV_MATERIAL_NORMAL; }
+    __device__ static __forceinline__ bool disable_sphere(const sdfv_demo_params&) { return false; }
+};
+struct RuntimeCfg {
+    static constexpr bool kStatic = false;
+    __device__ static __forceinline__ uint32_t sdf_id(uint32_t id) { return id; }
+    __device__ static __forceinline__ uint32_t cube_material(const sdfv_demo_params& p) { return p.cube_material; }
+    __device__ static __forceinline__ uint32_t sphere_material(const sdfv_demo_params& p) { return p.sphere_material; }
+    __device__ static __forceinline__ bool disable_sphere(const sdfv_demo_params& p) { return p.disable_sphere != 0; }
+};
+
+__device__ __forceinline__ Packed select_packed(bool c, const Packed& a, const Packed& b) {
+    Packed r;
+    r.lr = c ? a.lr : b.lr; r.lg = c ? a.lg : b.lg; r.lb = c ? a.lb : b.lb;
+    r.metallic = c ? a.metallic : b.metallic; r.roughness = c ? a.roughness : b.roughness;
+    r.occlusion = c ? a.occlusion : b.occlusion;
+    return r;
+}
+
+// Material::render + packing for a normal n.  `lut` is only read by the Normal material.
+template <typename Lut>
+__device__ __forceinline__ Packed render_packed(uint32_t material, float px, float py, float pz,
+                                                float nx, float ny, float nz, const Lut& lut) {
+    float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
+    if (material == SDFV_MATERIAL_BRICK) {
+        float u, v;
+        if (ax > ay) {
+            if (ax > az) { u = pz; v = py; } else { u = px; v = py; }
+        } else if (ay > az) { u = pz; v = px; }
+        else { u = px; v = py; }
+        const float BRICK_WIDTH = 0.5f, BRICK_HEIGHT = 0.25f;
+        const float mcd = 0.2f / 2.0f * 0.25f;
+        float brick_offset = floorf(v * 4.0f) * 0.25f;
+        float bx = fmod_pow2(fabsf(u + brick_offset), BRICK_WIDTH, 2.0f);
+        float by = fmod_pow2(fabsf(v), BRICK_HEIGHT, 4.0f);
+        bool cement = bx < mcd || bx > BRICK_WIDTH - mcd || by < mcd || by > BRICK_HEIGHT - mcd;
+        return select_packed(cement, kPackedCement, kPackedBrick);
+    }
+    Packed r;  // colour |n|, metallic = roughness = 0, occlusion 0 -> 1
+    bool zero = ax == 0.0f && ay == 0.0f && az == 0.0f;
+    float cr = zero ? 0.5f : ax, cg = zero ? 0.5f : ay, cb = zero ? 0.5f : az;
+    r.lr = lut[srgb_quantize(cr)];
+    r.lg = lut[srgb_quantize(cg)];
+    r.lb = lut[srgb_quantize(cb)];
+    r.metallic = 0.0f; r.roughness = 0.0f; r.occlusion = 1.0f;
+    return r;
+}
+
+template <typename Cfg, typename Lut>
+__device__ __forceinline__ Packed cube_packed(const sdfv_demo_params& prm, float px, float py, float pz,
+                                              float d_box, const Lut& lut) {
+    if (d_box > 0.1f) return kPackedAir;  // cube.rs:83-85
+    float side = prm.cube_half_side;
+    float nx = fabsf(px) > side ? signum_f32(px) : 0.0f;
+    float ny = fabsf(py) > side ? signum_f32(py) : 0.0f;
+    float nz = fabsf(pz) > side ? signum_f32(pz) : 0.0f;
+    return render_packed(Cfg::cube_material(prm), px, py, pz, nx, ny, nz, lut);
+}
+
+template <typename Cfg, typename Lut>
+__device__ __forceinline__ Packed sphere_packed(const sdfv_demo_params& prm, float px, float py, float pz,
+                                                float len, float d_sph, const Lut& lut) {
+    if (d_sph > 0.1f) return kPackedAir;  // sphere.rs:41-43
+    float inv = 1.0f / len;
+    return render_packed(Cfg::sphere_material(prm), px, py, pz, px * inv, py * inv, pz * inv, lut);
+}
+
+// sample(p, false) + packing.  xx_yy = px*px + py*py may be hoisted by the caller.
+template <typename Cfg, typename Lut>
+__device__ __forceinline__ void fill_voxel(const sdfv_demo_params& prm, uint32_t sdf_id_rt, float px, float py,
+                                           float pz, const Lut& lut, float air_dist, float4& t0, float4& t1) {
+    const uint32_t sdf_id = Cfg::sdf_id(sdf_id_rt);
+    float distance;
+    Packed m;
+    if (sdf_id == SDFV_SDF_CUBE || (sdf_id == SDFV_SDF_DEMO && Cfg::disable_sphere(prm))) {
+        distance = cube_distance(prm, px, py, pz);
+        m = cube_packed<Cfg>(prm, px, py, pz, distance, lut);
+    } else if (sdf_id == SDFV_SDF_SPHERE) {
+        float len = vec_length(px, py, pz);
+        distance = len - prm.sphere_radius;
+        m = sphere_packed<Cfg>(prm, px, py, pz, len, distance, lut);
+    } else {
+        float d_box = cube_distance(prm, px, py, pz);
+        float len = vec_length(px, py, pz);
+        float d_sph = len - prm.sphere_radius;
+        distance = fmaxf(d_box, -d_sph);
+        float inter = fabsf(d_box) - fabsf(d_sph);
+        if (fabsf(inter) <= prm.max_distance_custom_material) {
+            m = kPackedCustom;
+        } else if (inter < 0.0f) {
+            m = cube_packed<Cfg>(prm, px, py, pz, d_box, lut);
+        } else {
+            m = sphere_packed<Cfg>(prm, px, py, pz, len, d_sph, lut);
+        }
+    }
+    t0.x = fminf(fmaxf(1e-1f + distance, 0.0f), 1.0f);
+    t0.y = m.lr; t0.z = m.lg; t0.w = m.lb;
+    t1.x = m.metallic; t1.y = m.roughness; t1.z = m.occlusion; t1.w = air_dist;
+}
+
 // voxel index -> position, scene/sdf/mod.rs:178-182: idx/(dim-1), *size, +min, each rounded.
 __device__ __forceinline__ float voxel_coord(uint32_t idx, float dim_minus_1, float bb_size, float bb_min) {
     float p = (float)idx;

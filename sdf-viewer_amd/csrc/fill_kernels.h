@@ -18,8 +18,7 @@ struct FillArgs {
     float bb_size[3];        // bb[1] - bb[0]              (scene/sdf/mod.rs:167)
     float bb_min[3];
     float air_dist;
-    uint32_t row_stride_y;   // set by the launcher
-    uint32_t row_stride_z;
+    uint32_t x_chunks;       // set by the launcher: ceil(W / TX)
     float4* tex0;
     float4* tex1;
 };
@@ -33,11 +32,9 @@ struct PassArgs {
 };
 
 struct FillLaunch {
-    uint32_t target_blocks;  // persistent workgroups to aim for
-    bool nontemporal;
+    bool nontemporal;  // global_store_dwordx4 ... nt (measured: within noise of plain stores)
 };
 
-size_t fill_dense_lds_bytes(const FillArgs& a);
 hipError_t launch_fill_dense(const FillArgs& a, const FillLaunch& cfg, hipStream_t stream);
 hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& p, hipStream_t stream);
 hipError_t launch_grid_init(float* tex0, float* tex1, uint64_t n_voxels, float air, hipStream_t stream);

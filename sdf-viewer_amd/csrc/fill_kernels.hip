@@ -3,14 +3,11 @@
 //
 // Dense kernel (fill_dense_kernel): the final state of a fresh grid.  One thread per voxel, x fastest, so
 // a 64-lane wave emits two contiguous 1 KiB bursts (tex0, tex1) of global_store_dwordx4.  No global
-// loads at all: the position derives from the index.  Per-workgroup LDS staging holds what is O(1)
-// or O(N) and shared by every voxel the workgroup touches:
-//   - the demo SDF's parameter block (the "CSG-tree params"),
+// loads at all: the position derives from the index.  Per-workgroup LDS staging holds
 //   - the 256-entry sRGB->linear table (colour passes through u8, scene/sdf/mod.rs:201),
-//   - the y and z coordinate tables (idx/(dim-1)*size+min costs an IEEE divide per axis; x is fixed
-//     per thread and hoisted, y/z are staged once per workgroup instead of per voxel).
-// Workgroups are persistent: a (x-chunk, row-phase) pair walks rows with a fixed stride, so the
-// staging cost is amortised over thousands of voxels per thread.
+//   - the (y, z) coordinates of the workgroup's rows (idx/(dim-1)*size+min costs an IEEE divide per
+//     axis: x is fixed per thread and computed once, y/z once per row instead of once per voxel);
+// the demo SDF's parameter block (the "CSG-tree params") rides in the kernel arguments, i.e. SGPRs.
 //
 // Pass kernel (fill_pass_kernel): one LoadingManager pass with stride `step` and the update_required
 // test (reads tex0.r, 4 B per visited voxel) -- the progressive / changed_box path.
@@ -45,56 +42,43 @@ __device__ __forceinline__ void store_texel(float4* dst, const float4& v) {
     }
 }
 
-// TX = lanes along x per row segment (64, 128 or 256); TY = 256 / TX rows per workgroup step.
-template <int TX, bool NT>
+// TX = lanes along x per row segment (64, 128 or 256); a workgroup owns TY = 256 / TX consecutive rows x TX
+// voxels and does ONE voxel per thread, so the grid walks memory front to back in dispatch order exactly
+// like a memset.  Measured on MI355X (profiles/r01_v1_fill_sweep.json, r01_v2_fill_sweep.json): persistent
+// strided workgroups lose 25-40 % of the store rate and 2/4/8 rows per thread lose 7/11/14 %.
+template <int TX, bool NT, typename Cfg>
 __global__ __launch_bounds__(kBlock) void fill_dense_kernel(FillArgs a) {
     constexpr int TY = kBlock / TX;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* s_lut = reinterpret_cast<float*>(smem);                 // 256
-    float* s_y = s_lut + 256;                                       // H
-    float* s_z = s_y + a.H;                                         // slab depth
-    sdfv_demo_params* s_prm = reinterpret_cast<sdfv_demo_params*>(s_z + a.slab_d);
+    __shared__ float s_lut[256];
+    __shared__ float2 s_yz[TY];
 
     const uint32_t tid = threadIdx.x;
+    const uint32_t n_rows = a.H * a.slab_d;  // rows of the slab: row = z_local * H + y
+    // 1-D grid, x-chunk fastest: workgroup id -> (row group, x chunk); both uniform (SGPRs)
+    const uint32_t row_group = a.x_chunks == 1 ? blockIdx.x : blockIdx.x / a.x_chunks;
+    const uint32_t chunk = blockIdx.x - row_group * a.x_chunks;
+    const uint32_t row0 = row_group * TY;
     s_lut[tid] = c_srgb_lut[tid];
-    for (uint32_t i = tid; i < a.H; i += kBlock) s_y[i] = voxel_coord(i, a.dm1[1], a.bb_size[1], a.bb_min[1]);
-    for (uint32_t i = tid; i < a.slab_d; i += kBlock)
-        s_z[i] = voxel_coord(a.z_begin + i, a.dm1[2], a.bb_size[2], a.bb_min[2]);
-    if (tid == 0) *s_prm = a.prm;
+    if (tid < TY && row0 + tid < n_rows) {
+        const uint32_t row = row0 + tid;
+        const uint32_t zl = row / a.H, y = row - zl * a.H;
+        s_yz[tid] = make_float2(voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]),
+                                voxel_coord(a.z_begin + zl, a.dm1[2], a.bb_size[2], a.bb_min[2]));
+    }
     __syncthreads();
 
-    const sdfv_demo_params prm = *s_prm;
     const LdsLut lut{s_lut};
-
     const uint32_t tx = tid % TX, ty = tid / TX;
-    const uint32_t x = blockIdx.x * TX + tx;
-    if (x >= a.W) return;
+    const uint32_t x = chunk * TX + tx;
+    const uint32_t row = row0 + ty;
+    if (x >= a.W || row >= n_rows) return;
     const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
-
-    // rows of the slab: row = z_local * H + y.  This thread walks row0, row0 + stride, ...
-    const uint64_t n_rows = (uint64_t)a.H * a.slab_d;
-    uint64_t row = (uint64_t)blockIdx.y * TY + ty;
-    if (row >= n_rows) return;
-    uint32_t y = (uint32_t)(row % a.H), zl = (uint32_t)(row / a.H);
-    const uint32_t dy = a.row_stride_y, dz = a.row_stride_z;  // (gridDim.y * TY) % H, / H
-
-    float4* t0 = a.tex0 + row * a.W + x;
-    float4* t1 = a.tex1 + row * a.W + x;
-    const uint64_t step_elems = (uint64_t)gridDim.y * TY * a.W;
-
-    while (zl < a.slab_d) {
-        const float py = s_y[y], pz = s_z[zl];
-        Sample s = demo_sample(prm, a.sdf_id, px, py, pz, false);
-        float4 v0, v1;
-        pack_sample(s, lut, a.air_dist, v0, v1);
-        store_texel<NT>(t0, v0);
-        store_texel<NT>(t1, v1);
-        t0 += step_elems;
-        t1 += step_elems;
-        y += dy;
-        zl += dz;
-        if (y >= a.H) { y -= a.H; zl += 1; }
-    }
+    const float2 yz = s_yz[ty];
+    float4 v0, v1;
+    fill_voxel<Cfg>(a.prm, a.sdf_id, px, yz.x, yz.y, lut, a.air_dist, v0, v1);
+    const uint64_t o = (uint64_t)row * a.W + x;
+    store_texel<NT>(a.tex0 + o, v0);
+    store_texel<NT>(a.tex1 + o, v1);
 }
 
 struct GlobalLut {
@@ -142,34 +126,33 @@ __global__ __launch_bounds__(kBlock) void grid_init_kernel(float4* tex0, float4*
     }
 }
 
-template <int TX>
-hipError_t launch_dense_tx(const FillArgs& args, const FillLaunch& cfg, hipStream_t stream) {
-    FillArgs a = args;
+bool is_default_config(const FillArgs& a) {
+    return a.sdf_id == SDFV_SDF_DEMO && a.prm.cube_material == SDFV_MATERIAL_BRICK &&
+           a.prm.sphere_material == SDFV_MATERIAL_NORMAL && a.prm.disable_sphere == 0;
+}
+
+template <int TX, bool NT>
+hipError_t launch_dense_cfg(const FillArgs& args, hipStream_t stream) {
     constexpr int TY = kBlock / TX;
-    const uint32_t cx = (a.W + TX - 1) / TX;
+    FillArgs a = args;
+    a.x_chunks = (a.W + TX - 1) / TX;
     const uint64_t n_rows = (uint64_t)a.H * a.slab_d;
-    uint64_t row_blocks = (n_rows + TY - 1) / TY;
-    uint64_t want = cfg.target_blocks / cx;
-    if (want < 1) want = 1;
-    if (row_blocks > want) row_blocks = want;
-    if (row_blocks > 65535) row_blocks = 65535;
-    const uint64_t stride_rows = row_blocks * TY;
-    a.row_stride_y = (uint32_t)(stride_rows % a.H);
-    a.row_stride_z = (uint32_t)(stride_rows / a.H);
-    const size_t lds = (256 + (size_t)a.H + a.slab_d) * sizeof(float) + sizeof(sdfv_demo_params);
-    dim3 grid(cx, (uint32_t)row_blocks, 1);
-    if (cfg.nontemporal)
-        hipLaunchKernelGGL((fill_dense_kernel<TX, true>), grid, dim3(kBlock), lds, stream, a);
+    const uint64_t blocks = a.x_chunks * ((n_rows + TY - 1) / TY);
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    dim3 grid((uint32_t)blocks, 1, 1);
+    if (is_default_config(a))
+        hipLaunchKernelGGL((fill_dense_kernel<TX, NT, DefaultCfg>), grid, dim3(kBlock), 0, stream, a);
     else
-        hipLaunchKernelGGL((fill_dense_kernel<TX, false>), grid, dim3(kBlock), lds, stream, a);
+        hipLaunchKernelGGL((fill_dense_kernel<TX, NT, RuntimeCfg>), grid, dim3(kBlock), 0, stream, a);
     return hipGetLastError();
 }
 
-}  // namespace
-
-size_t fill_dense_lds_bytes(const FillArgs& a) {
-    return (256 + (size_t)a.H + a.slab_d) * sizeof(float) + sizeof(sdfv_demo_params);
+template <int TX>
+hipError_t launch_dense_tx(const FillArgs& a, const FillLaunch& cfg, hipStream_t stream) {
+    return cfg.nontemporal ? launch_dense_cfg<TX, true>(a, stream) : launch_dense_cfg<TX, false>(a, stream);
 }
+
+}  // namespace
 
 hipError_t launch_fill_dense(const FillArgs& a, const FillLaunch& cfg, hipStream_t stream) {
     if (a.W == 0 || a.H == 0 || a.slab_d == 0) return hipSuccess;

@@ -11,6 +11,8 @@ namespace sdfv {
 struct RaymarchArgs {
     sdfv_render_params rp;
     float bsize[3];              // bounds_max - bounds_min (material.frag:44)
+    float inv_bsize[3];          // exact reciprocals, valid when pow2_extent
+    uint32_t pow2_extent;        // every bsize[i] is an exact power of two
     const float4* tex0;          // full grid, rp.tex_size
     const float4* tex1;
     uint32_t n_cameras;          // cameras in this launch (<= kMaxCamerasPerLaunch), by value in kernarg
@@ -19,6 +21,7 @@ struct RaymarchArgs {
     uint32_t compute_normal;     // evaluate sdfNormal per hit even when no aux is stored
     float4* rgba;                // n_cameras x (y1-y0) x width
     sdfv_march_aux* aux;         // same layout or nullptr
+    unsigned long long* wave_timing;  // tuning only: per wave {start, end, iterations, xcc|cu} or nullptr
     sdfv_camera cameras[16];
 };
 

@@ -80,7 +80,14 @@ __device__ __forceinline__ float trilerp(float t000, float t100, float t010, flo
     return mixf(mixf(c00, c10, ay), mixf(c01, c11, ay), az);
 }
 
+// p01 = (p - sdfBoundsMin) / (sdfBoundsMax - sdfBoundsMin), material.frag:44.  When every extent is an exact
+// power of two (the demo's [-1,1]^3: 2.0) dividing equals multiplying by the exact reciprocal, bit for
+// bit, and the three IEEE divides (~12 instructions each) leave the per-step dependency chain.
+template <bool POW2>
 __device__ __forceinline__ V3 to_p01(const RaymarchArgs& a, V3 p) {
+    if (POW2)
+        return mk((p.x - a.rp.bounds_min[0]) * a.inv_bsize[0], (p.y - a.rp.bounds_min[1]) * a.inv_bsize[1],
+                  (p.z - a.rp.bounds_min[2]) * a.inv_bsize[2]);
     return mk((p.x - a.rp.bounds_min[0]) / a.bsize[0], (p.y - a.rp.bounds_min[1]) / a.bsize[1],
               (p.z - a.rp.bounds_min[2]) / a.bsize[2]);
 }
@@ -96,9 +103,9 @@ __device__ __forceinline__ uint64_t nearest_offset(const RaymarchArgs& a, const 
 }
 
 // sdfSampleRawInterp(.., p).r only -- what the march and the normal need.  material.frag:42-53
-template <bool LINEAR>
+template <bool LINEAR, bool POW2>
 __device__ __forceinline__ float sample_r(const RaymarchArgs& a, const Tex& t, V3 p) {
-    V3 q = to_p01(a, p);
+    V3 q = to_p01<POW2>(a, p);
     const float* base = reinterpret_cast<const float*>(t.data);
     if (LINEAR) {
         Footprint f = footprint(t, q.x, q.y, q.z);
@@ -109,9 +116,9 @@ __device__ __forceinline__ float sample_r(const RaymarchArgs& a, const Tex& t, V
     return base[nearest_offset(a, t, q) * 4];
 }
 
-template <bool LINEAR>
+template <bool LINEAR, bool POW2>
 __device__ __forceinline__ float4 sample_rgba(const RaymarchArgs& a, const Tex& t, V3 p) {
-    V3 q = to_p01(a, p);
+    V3 q = to_p01<POW2>(a, p);
     if (LINEAR) {
         Footprint f = footprint(t, q.x, q.y, q.z);
         float4 t000 = t.data[f.o000], t100 = t.data[f.o100], t010 = t.data[f.o010], t110 = t.data[f.o110];
@@ -124,6 +131,37 @@ __device__ __forceinline__ float4 sample_rgba(const RaymarchArgs& a, const Tex& 
         return r;
     }
     return t.data[nearest_offset(a, t, q)];
+}
+
+// The march's sampler: tex0.r with a one-cell register cache.  Sphere tracing takes its smallest steps
+// exactly on the longest rays (grazing a surface), so consecutive samples usually fall in the same
+// texel cell: the 8 corner values are kept in registers and re-fetched only when floor(u,v,w) changes.
+// Values and operation order are those of sample_r(); only redundant loads are skipped.
+struct CellCache {
+    float fu, fv, fw;  // floor of the unnormalised texel coordinates of the cached cell
+    float t000, t100, t010, t110, t001, t101, t011, t111;
+};
+
+template <bool POW2>
+__device__ __forceinline__ float march_sample(const RaymarchArgs& a, const Tex& t, V3 p, CellCache& c) {
+    V3 q = to_p01<POW2>(a, p);
+    float u = q.x * (float)t.w - 0.5f, v = q.y * (float)t.h - 0.5f, w = q.z * (float)t.d - 0.5f;
+    float fu = floorf(u), fv = floorf(v), fw = floorf(w);
+    float ax = u - fu, ay = v - fv, az = w - fw;
+    if (fu != c.fu || fv != c.fv || fw != c.fw) {
+        c.fu = fu; c.fv = fv; c.fw = fw;
+        int i0 = (int)fu, j0 = (int)fv, k0 = (int)fw;
+        uint32_t i0m = mirror_index(i0, t.w), i1m = mirror_index(i0 + 1, t.w);
+        uint32_t j0m = mirror_index(j0, t.h) * (uint32_t)t.w, j1m = mirror_index(j0 + 1, t.h) * (uint32_t)t.w;
+        uint64_t slice = (uint64_t)t.w * t.h;
+        const float* b0 = reinterpret_cast<const float*>(t.data + mirror_index(k0, t.d) * slice);
+        const float* b1 = reinterpret_cast<const float*>(t.data + mirror_index(k0 + 1, t.d) * slice);
+        c.t000 = b0[(j0m + i0m) * 4u]; c.t100 = b0[(j0m + i1m) * 4u];
+        c.t010 = b0[(j1m + i0m) * 4u]; c.t110 = b0[(j1m + i1m) * 4u];
+        c.t001 = b1[(j0m + i0m) * 4u]; c.t101 = b1[(j0m + i1m) * 4u];
+        c.t011 = b1[(j1m + i0m) * 4u]; c.t111 = b1[(j1m + i1m) * 4u];
+    }
+    return trilerp(c.t000, c.t100, c.t010, c.t110, c.t001, c.t101, c.t011, c.t111, ax, ay, az);
 }
 
 // sdfOutOfBoundsDist, material.frag:83-88
@@ -170,7 +208,7 @@ __device__ __forceinline__ float4 shade(const RaymarchArgs& a, float4 raw0, floa
     return make_float4(out[0], out[1], out[2], a.rp.tint[3]);
 }
 
-template <bool LINEAR>
+template <bool LINEAR, bool POW2>
 __global__ __launch_bounds__(256) void raymarch_kernel(RaymarchArgs a) {
     // 8x8 pixel tile per wave, 2x2 waves per workgroup
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -183,6 +221,7 @@ __global__ __launch_bounds__(256) void raymarch_kernel(RaymarchArgs a) {
     const Tex tex0{a.tex0, (int)a.rp.tex_size[0], (int)a.rp.tex_size[1], (int)a.rp.tex_size[2]};
     const Tex tex1{a.tex1, tex0.w, tex0.h, tex0.d};
 
+    const unsigned long long t_start = a.wave_timing ? __builtin_readcyclecounter() : 0ull;
     sdfv_march_aux aux;
     aux.status = 0; aux.steps = 0;
     aux.hit_pos[0] = aux.hit_pos[1] = aux.hit_pos[2] = 0.0f;
@@ -224,14 +263,20 @@ __global__ __launch_bounds__(256) void raymarch_kernel(RaymarchArgs a) {
     int status = covered ? -1 : 0;  // -1 = out of steps unless something else ends the ray
     int steps = 0;
     bool marching = covered;
+    int iterations = 0;
+    CellCache cell;
+    cell.fu = cell.fv = cell.fw = -4.0f;  // never a valid floor(u): u >= -0.5 - 1e-4 * N while marching
+    cell.t000 = cell.t100 = cell.t010 = cell.t110 = cell.t001 = cell.t101 = cell.t011 = cell.t111 = 0.0f;
     for (int i = 0; i < 255; ++i) {
         if (__ballot(marching) == 0ull) break;  // wave-level early termination
+        ++iterations;
         if (marching) {
             if (oob_dist(a, ray_pos) > 1e-4f) {
                 status = -2;
                 marching = false;
             } else {
-                float sample_dist = sample_r<LINEAR>(a, tex0, ray_pos) - 1e-1f;
+                float sample_dist =
+                    (LINEAR ? march_sample<POW2>(a, tex0, ray_pos, cell) : sample_r<false, POW2>(a, tex0, ray_pos)) - 1e-1f;
                 ++steps;
                 if (sample_dist < 1e-5f) {
                     status = 1;
@@ -251,8 +296,8 @@ __global__ __launch_bounds__(256) void raymarch_kernel(RaymarchArgs a) {
         aux.t = dist_from_origin;
     }
     if (status == 1) {
-        float4 raw0 = sample_rgba<LINEAR>(a, tex0, ray_pos);  // == the march's last sample
-        float4 raw1 = sample_rgba<LINEAR>(a, tex1, ray_pos);  // material.frag:154
+        float4 raw0 = sample_rgba<LINEAR, POW2>(a, tex0, ray_pos);  // == the march's last sample
+        float4 raw1 = sample_rgba<LINEAR, POW2>(a, tex1, ray_pos);  // material.frag:154
         rgba = shade(a, raw0, raw1);
         if (a.aux || a.compute_normal) {
             // sdfNormal, material.frag:73-80
@@ -260,10 +305,10 @@ __global__ __launch_bounds__(256) void raymarch_kernel(RaymarchArgs a) {
             float syn = (float)tex0.h / a.rp.lod_dist_between_samples;
             float szn = (float)tex0.d / a.rp.lod_dist_between_samples;
             float h = 1.0f / sqrtf(sxn * sxn + syn * syn + szn * szn);
-            float d1 = sample_r<LINEAR>(a, tex0, mk(ray_pos.x + h, ray_pos.y - h, ray_pos.z - h)) - 1e-1f;  // k.xyy
-            float d2 = sample_r<LINEAR>(a, tex0, mk(ray_pos.x - h, ray_pos.y - h, ray_pos.z + h)) - 1e-1f;  // k.yyx
-            float d3 = sample_r<LINEAR>(a, tex0, mk(ray_pos.x - h, ray_pos.y + h, ray_pos.z - h)) - 1e-1f;  // k.yxy
-            float d4 = sample_r<LINEAR>(a, tex0, mk(ray_pos.x + h, ray_pos.y + h, ray_pos.z + h)) - 1e-1f;  // k.xxx
+            float d1 = sample_r<LINEAR, POW2>(a, tex0, mk(ray_pos.x + h, ray_pos.y - h, ray_pos.z - h)) - 1e-1f;  // k.xyy
+            float d2 = sample_r<LINEAR, POW2>(a, tex0, mk(ray_pos.x - h, ray_pos.y - h, ray_pos.z + h)) - 1e-1f;  // k.yyx
+            float d3 = sample_r<LINEAR, POW2>(a, tex0, mk(ray_pos.x - h, ray_pos.y + h, ray_pos.z - h)) - 1e-1f;  // k.yxy
+            float d4 = sample_r<LINEAR, POW2>(a, tex0, mk(ray_pos.x + h, ray_pos.y + h, ray_pos.z + h)) - 1e-1f;  // k.xxx
             V3 n = normalize(mk(d1 + -d2 + -d3 + d4, -d1 + -d2 + d3 + d4, -d1 + d2 + -d3 + d4));
             // gl_FragDepth, material.frag:180-181
             const float* m = cam.bvp;
@@ -280,6 +325,13 @@ __global__ __launch_bounds__(256) void raymarch_kernel(RaymarchArgs a) {
         }
     }
 
+    if (a.wave_timing && lane == 0) {
+        const uint64_t wave_id = ((uint64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
+        a.wave_timing[wave_id * 4 + 0] = t_start;
+        a.wave_timing[wave_id * 4 + 1] = __builtin_readcyclecounter();
+        a.wave_timing[wave_id * 4 + 2] = (unsigned long long)iterations;
+        a.wave_timing[wave_id * 4 + 3] = (unsigned long long)__ballot(covered);
+    }
     if (in_image) {
         const uint64_t o = ((uint64_t)cam_idx * (a.y1 - a.y0) + row) * a.width + px;
         a.rgba[o] = rgba;
@@ -293,10 +345,15 @@ hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream) {
     const uint32_t rows = a.y1 - a.y0;
     if (a.width == 0 || rows == 0 || a.n_cameras == 0) return hipSuccess;
     dim3 grid((a.width + 15) / 16, (rows + 15) / 16, a.n_cameras);
-    if (a.rp.lod_dist_between_samples == 1.0f)
-        hipLaunchKernelGGL(raymarch_kernel<true>, grid, dim3(256), 0, stream, a);
+    const bool linear = a.rp.lod_dist_between_samples == 1.0f;
+    if (linear && a.pow2_extent)
+        hipLaunchKernelGGL((raymarch_kernel<true, true>), grid, dim3(256), 0, stream, a);
+    else if (linear)
+        hipLaunchKernelGGL((raymarch_kernel<true, false>), grid, dim3(256), 0, stream, a);
+    else if (a.pow2_extent)
+        hipLaunchKernelGGL((raymarch_kernel<false, true>), grid, dim3(256), 0, stream, a);
     else
-        hipLaunchKernelGGL(raymarch_kernel<false>, grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((raymarch_kernel<false, false>), grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

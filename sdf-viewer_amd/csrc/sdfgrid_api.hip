@@ -97,16 +97,10 @@ sdfv::FillArgs make_fill_args(const sdfv_demo_params& p, uint32_t sdf_id, const 
     return a;
 }
 
-// Persistent workgroups to aim for: 256 CUs x 8 resident 256-thread workgroups (guide: memory-bound grids
-// cap near CUs x 8 and stride the rest).  SDFV_FILL_BLOCKS / SDFV_FILL_NT override for tuning runs.
+// Store policy of the dense fill.  SDFV_FILL_NT overrides for tuning runs.
 sdfv::FillLaunch fill_launch_config() {
     sdfv::FillLaunch c;
-    c.target_blocks = 2048;
-    c.nontemporal = true;
-    if (const char* s = getenv("SDFV_FILL_BLOCKS")) {
-        int v = atoi(s);
-        if (v > 0) c.target_blocks = (uint32_t)v;
-    }
+    c.nontemporal = false;
     if (const char* s = getenv("SDFV_FILL_NT")) c.nontemporal = atoi(s) != 0;
     return c;
 }
@@ -249,8 +243,8 @@ int sdfv_fill_grid(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_g
     if (((uintptr_t)tex0 | (uintptr_t)tex1) & 15) return fail(SDFV_ERR_INVALID_ARGUMENT, "textures must be 16-byte aligned");
     if (int rc = need_device()) return rc;
     sdfv::FillArgs a = make_fill_args(*params, sdf_id, *grid, tex0, tex1);
-    if (sdfv::fill_dense_lds_bytes(a) > 60 * 1024)
-        return fail(SDFV_ERR_INVALID_ARGUMENT, "H + slab depth = %u exceeds the coordinate-table budget", a.H + a.slab_d);
+    if ((uint64_t)a.H * a.slab_d > 0x7fffffffull || a.W > 0x7fffffffu)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "slab of %u x %u rows is too large for one launch", a.H, a.slab_d);
     SDFV_HIP(sdfv::launch_fill_dense(a, fill_launch_config(), (hipStream_t)stream));
     return SDFV_OK;
 }
@@ -303,11 +297,20 @@ int sdfv_raymarch(const sdfv_render_params* rp, const float* tex0, const float* 
     if (rp->tex_size[0] == 0 || rp->tex_size[1] == 0 || rp->tex_size[2] == 0)
         return fail(SDFV_ERR_INVALID_ARGUMENT, "empty texture");
     if (!(rp->lod_dist_between_samples >= 1.0f)) return fail(SDFV_ERR_INVALID_ARGUMENT, "lod_dist_between_samples < 1");
+    if ((uint64_t)rp->tex_size[0] * rp->tex_size[1] >= (1ull << 30) || rp->tex_size[2] >= (1u << 30))
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "texture slice too large for 32-bit texel indexing");
     if (int rc = need_device()) return rc;
     sdfv::RaymarchArgs a;
     memset(&a, 0, sizeof(a));
     a.rp = *rp;
-    for (int i = 0; i < 3; ++i) a.bsize[i] = rp->bounds_max[i] - rp->bounds_min[i];
+    a.pow2_extent = getenv("SDFV_RAYMARCH_NO_POW2") ? 0u : 1u;
+    for (int i = 0; i < 3; ++i) {
+        a.bsize[i] = rp->bounds_max[i] - rp->bounds_min[i];
+        a.inv_bsize[i] = 1.0f / a.bsize[i];
+        int e = 0;
+        // x / 2^k == x * 2^-k exactly (both correctly rounded), provided 2^-k is itself normal
+        if (!(a.bsize[i] > 0.0f) || frexpf(a.bsize[i], &e) != 0.5f || e < -100 || e > 100) a.pow2_extent = 0;
+    }
     a.tex0 = reinterpret_cast<const float4*>(tex0);
     a.tex1 = reinterpret_cast<const float4*>(tex1);
     a.width = width;
@@ -315,6 +318,8 @@ int sdfv_raymarch(const sdfv_render_params* rp, const float* tex0, const float* 
     a.y0 = y0;
     a.y1 = y1;
     a.compute_normal = getenv("SDFV_RAYMARCH_SKIP_NORMAL") ? 0u : 1u;
+    if (const char* s = getenv("SDFV_RAYMARCH_WAVE_TIMING"))  // tuning: address of a device buffer, 32 B per wave
+        a.wave_timing = reinterpret_cast<unsigned long long*>(strtoull(s, nullptr, 0));
     const uint64_t pixels_per_cam = (uint64_t)(y1 - y0) * width;
     for (uint32_t c0 = 0; c0 < n_cameras; c0 += sdfv::kMaxCamerasPerLaunch) {
         const uint32_t nc = n_cameras - c0 < sdfv::kMaxCamerasPerLaunch ? n_cameras - c0 : sdfv::kMaxCamerasPerLaunch;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Tuning sweep for the dense fill kernel (run on the GPU box): persistent-workgroup count x store policy x
+"""Tuning sweep for the dense fill kernel (run on the GPU box): rows per thread x store policy x
 grid size, interleaved rounds in ONE process, median/min of HIP-event times.  Also times a plain
 torch fill_ (memset-class, store-only) of the same bytes as the known-good store-bandwidth reference."""
 import importlib, os, sys, json
@@ -23,13 +23,13 @@ def main():
         g = pkg.make_grid((side,) * 3)
         t0, t1 = pkg.alloc_textures(g)
         nbytes = side ** 3 * 32
-        variants = [(b, nt) for nt in (1, 0) for b in (256, 512, 1024, 2048, 4096, 8192, 16384, 65536)]
+        variants = [(1, nt) for nt in (1, 0)]
         def memset():
             t0.fill_(1.0); t1.fill_(1.0)
         best = {}
         for rnd in range(3):
             for b, nt in variants:
-                os.environ["SDFV_FILL_BLOCKS"] = str(b); os.environ["SDFV_FILL_NT"] = str(nt)
+                os.environ["SDFV_FILL_ROWS"] = str(b); os.environ["SDFV_FILL_NT"] = str(nt)
                 ts = time_fn(lambda: pkg.fill_grid(prm, g, t0, t1), 8)
                 best.setdefault((b, nt), []).extend(ts)
             best.setdefault("memset", []).extend(time_fn(memset, 8))
