@@ -168,6 +168,8 @@ int sdfv_fill_grid_host(const sdfv_demo_params *params, uint32_t sdf_id, const s
                         float *tex0_host, float *tex1_host);
 int sdfv_sample_points_host(const sdfv_demo_params *params, uint32_t sdf_id, const float *points_host, size_t n,
                             int distance_only, sdfv_sample *out_host);
+int sdfv_normal_points_host(const sdfv_demo_params *params, uint32_t sdf_id, const float *points_host, size_t n,
+                            float eps, int use_default, float *out_host);
 int sdfv_raymarch_host(const sdfv_render_params *rp, const float *tex0_host, const float *tex1_host,
                        const sdfv_camera *cameras, uint32_t n_cameras, uint32_t width, uint32_t height,
                        float *rgba_host, sdfv_march_aux *aux_host);

@@ -364,6 +364,21 @@ int sdfv_sample_points_host(const sdfv_demo_params* params, uint32_t sdf_id, con
     return SDFV_OK;
 }
 
+int sdfv_normal_points_host(const sdfv_demo_params* params, uint32_t sdf_id, const float* points_host, size_t n,
+                            float eps, int use_default, float* out_host) {
+    if (n && (!points_host || !out_host)) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (int rc = check_params(params, sdf_id)) return rc;
+    if (int rc = need_device()) return rc;
+    if (n == 0) return SDFV_OK;
+    DeviceBuf dp, dn;
+    SDFV_HIP(hipMalloc(&dp.p, n * 12));
+    SDFV_HIP(hipMalloc(&dn.p, n * 12));
+    SDFV_HIP(hipMemcpy(dp.p, points_host, n * 12, hipMemcpyHostToDevice));
+    if (int rc = sdfv_normal_points(params, sdf_id, (const float*)dp.p, n, eps, use_default, (float*)dn.p, nullptr)) return rc;
+    SDFV_HIP(hipMemcpy(out_host, dn.p, n * 12, hipMemcpyDeviceToHost));
+    return SDFV_OK;
+}
+
 int sdfv_raymarch_host(const sdfv_render_params* rp, const float* tex0_host, const float* tex1_host,
                        const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width, uint32_t height,
                        float* rgba_host, sdfv_march_aux* aux_host) {

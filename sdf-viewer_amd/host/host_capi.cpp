@@ -1,0 +1,161 @@
+// host_capi.cpp -- flat C handles over the C++ host mirror (LoadingManager, SDFDemo, SDFViewer,
+// SDFViewerMaterial) so that the pytest suite can drive the same classes a C++ application links.
+// Test/tooling surface only; the product ABI is include/sdfgrid.h + include/sdf_provider.h.
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "loading_manager.hpp"
+#include "sdf_demo.hpp"
+#include "sdf_viewer.hpp"
+
+using namespace sdfviewer;
+
+extern "C" {
+
+// ---- LoadingManager ----
+void* sdfvh_lm_new(size_t lx, size_t ly, size_t lz, size_t passes) { return new LoadingManager({lx, ly, lz}, passes); }
+void sdfvh_lm_free(void* m) { delete static_cast<LoadingManager*>(m); }
+int sdfvh_lm_next(void* m, size_t out[3]) {
+    auto r = static_cast<LoadingManager*>(m)->next();
+    if (!r) return 0;
+    out[0] = (*r)[0]; out[1] = (*r)[1]; out[2] = (*r)[2];
+    return 1;
+}
+size_t sdfvh_lm_len(void* m) { return static_cast<LoadingManager*>(m)->len(); }
+size_t sdfvh_lm_total_iterations(void* m) { return static_cast<LoadingManager*>(m)->total_iterations(); }
+size_t sdfvh_lm_passes_left(void* m) { return static_cast<LoadingManager*>(m)->passes_left(); }
+size_t sdfvh_lm_step_size(void* m) { return static_cast<LoadingManager*>(m)->step_size(); }
+size_t sdfvh_lm_finish_pass(void* m) { return static_cast<LoadingManager*>(m)->finish_pass(); }
+uint32_t sdfvh_prev_power_of_2(uint32_t x) { return prev_power_of_2(x); }
+
+// ---- SDFDemo (handle = shared_ptr<SDFSurface>*) ----
+void* sdfvh_demo_new(int argc, const char* const* argv, char* err, size_t err_len) {
+    std::vector<std::string> args(argv, argv + (argc > 0 ? argc : 0));
+    std::string e;
+    auto d = SDFDemo::from_args(args, &e);
+    if (!d) {
+        if (err && err_len) {
+            strncpy(err, e.c_str(), err_len - 1);
+            err[err_len - 1] = 0;
+        }
+        return nullptr;
+    }
+    return new std::shared_ptr<SDFSurface>(d);
+}
+void sdfvh_sdf_free(void* h) { delete static_cast<std::shared_ptr<SDFSurface>*>(h); }
+static SDFSurface& S(void* h) { return **static_cast<std::shared_ptr<SDFSurface>*>(h); }
+uint32_t sdfvh_sdf_id(void* h) { return S(h).id(); }
+size_t sdfvh_sdf_name(void* h, char* out, size_t n) {
+    std::string s = S(h).name();
+    if (out && n) {
+        strncpy(out, s.c_str(), n - 1);
+        out[n - 1] = 0;
+    }
+    return s.size();
+}
+size_t sdfvh_sdf_n_children(void* h) { return S(h).children().size(); }
+void* sdfvh_sdf_child(void* h, size_t i) {
+    auto ch = S(h).children();
+    return i < ch.size() ? new std::shared_ptr<SDFSurface>(ch[i]) : nullptr;
+}
+void sdfvh_sdf_bounding_box(void* h, float out[6]) {
+    auto bb = S(h).bounding_box();
+    memcpy(out, &bb, 24);
+}
+int sdfvh_sdf_device_params(void* h, sdfv_demo_params* p, uint32_t* sdf_id) {
+    auto d = S(h).device_sdf();
+    if (!d) return -1;
+    *p = d->params;
+    *sdf_id = d->sdf_id;
+    return 0;
+}
+void sdfvh_sdf_sample(void* h, const float p[3], int distance_only, float out[7]) {
+    SDFSample s = S(h).sample(Vec3{p[0], p[1], p[2]}, distance_only != 0);
+    memcpy(out, &s, 28);
+}
+void sdfvh_sdf_normal(void* h, const float p[3], float eps, float out[3]) {
+    Vec3 n = S(h).normal(Vec3{p[0], p[1], p[2]}, eps > 0 ? std::optional<float>(eps) : std::nullopt);
+    memcpy(out, &n, 12);
+}
+void sdfvh_sdf_normal_default(void* h, const float p[3], float eps, float out[3]) {
+    Vec3 n = S(h).SDFSurface::normal(Vec3{p[0], p[1], p[2]}, eps > 0 ? std::optional<float>(eps) : std::nullopt);
+    memcpy(out, &n, 12);
+}
+// kind: 0 bool, 1 int, 2 float, 3 string.  Returns 0 = Ok, 1 = Err (message copied to err).
+int sdfvh_sdf_set_parameter(void* h, uint32_t param_id, int kind, int ival, float fval, const char* sval, char* err,
+                            size_t err_len) {
+    SDFParamValue v;
+    if (kind == 0) v = (bool)(ival != 0);
+    else if (kind == 1) v = (int32_t)ival;
+    else if (kind == 2) v = fval;
+    else v = std::string(sval ? sval : "");
+    auto r = S(h).set_parameter(param_id, v);
+    if (!r.ok && err && err_len) {
+        strncpy(err, r.error.c_str(), err_len - 1);
+        err[err_len - 1] = 0;
+    }
+    return r.ok ? 0 : 1;
+}
+int sdfvh_sdf_changed(void* h, float out[6]) {
+    auto b = S(h).changed();
+    if (!b) return 0;
+    memcpy(out, &*b, 24);
+    return 1;
+}
+// parameters as a text block: one line per parameter "id|name|kind|value|description"
+size_t sdfvh_sdf_parameters(void* h, char* out, size_t n) {
+    std::string s;
+    for (auto& p : S(h).parameters()) {
+        s += std::to_string(p.id) + "|" + p.name + "|" + std::to_string((uint32_t)p.kind.tag) + "|" +
+             param_value_debug(p.value) + "|" + p.description + "\n";
+    }
+    if (out && n) {
+        strncpy(out, s.c_str(), n - 1);
+        out[n - 1] = 0;
+    }
+    return s.size();
+}
+
+// ---- SDFViewer ----
+void* sdfvh_viewer_from_bb(const float bb[6], size_t max_voxels_side, size_t loading_passes) {
+    BoundingBox b{Vec3{bb[0], bb[1], bb[2]}, Vec3{bb[3], bb[4], bb[5]}};
+    return SDFViewer::from_bb(b, max_voxels_side, loading_passes).release();
+}
+void* sdfvh_viewer_new_voxels(size_t w, size_t h, size_t d, const float bb[6], size_t loading_passes) {
+    BoundingBox b{Vec3{bb[0], bb[1], bb[2]}, Vec3{bb[3], bb[4], bb[5]}};
+    return SDFViewer::new_voxels({w, h, d}, b, loading_passes).release();
+}
+void sdfvh_viewer_free(void* v) { delete static_cast<SDFViewer*>(v); }
+static SDFViewer& V(void* v) { return *static_cast<SDFViewer*>(v); }
+void sdfvh_viewer_dims(void* v, uint32_t out[3]) {
+    for (int i = 0; i < 3; ++i) out[i] = V(v).material.tex_size[i];
+}
+size_t sdfvh_viewer_update(void* v, void* sdf, double max_delta_seconds) {
+    return V(v).update(S(sdf), std::chrono::nanoseconds((long long)(max_delta_seconds * 1e9)));
+}
+void sdfvh_viewer_commit(void* v) { V(v).commit(); }
+float sdfvh_viewer_lod(void* v) { return V(v).material.lod_dist_between_samples; }
+size_t sdfvh_viewer_remaining(void* v) { return V(v).loading_mgr.len(); }
+size_t sdfvh_viewer_passes_left(void* v) { return V(v).loading_mgr.passes_left(); }
+int sdfvh_viewer_has_changed_box(void* v) { return V(v).changed_box ? 1 : 0; }
+int sdfvh_viewer_download(void* v, float* tex0, float* tex1) { return V(v).download(tex0, tex1); }
+void* sdfvh_viewer_tex0(void* v) { return V(v).tex0_device(); }
+void* sdfvh_viewer_tex1(void* v) { return V(v).tex1_device(); }
+// SDFViewerMaterial::render with the scene's default camera (scene/mod.rs:82-95) at width x height
+int sdfvh_viewer_render(void* v, uint32_t width, uint32_t height, const float eye[3], float* rgba_host) {
+    Camera cam;
+    if (eye) cam.position = Vec3{eye[0], eye[1], eye[2]};
+    cam.set_viewport(width, height);
+    DeviceBuffer out((size_t)width * height * 16);
+    if (!out.ok()) return -1;
+    int rc = V(v).material.render(cam, out.f32(), nullptr, V(v).stream);
+    if (rc != 0) return rc;
+    return hipMemcpy(rgba_host, out.get(), out.bytes(), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+
+}  // extern "C"

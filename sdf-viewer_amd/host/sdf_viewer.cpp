@@ -1,0 +1,176 @@
+// sdf_viewer.cpp -- see sdf_viewer.hpp.
+#include "sdf_viewer.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace sdfviewer {
+
+// ---- DeviceBuffer ----
+DeviceBuffer::DeviceBuffer(size_t bytes) : bytes_(bytes) {
+    if (bytes && hipMalloc(&ptr_, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        ptr_ = nullptr;
+    }
+}
+DeviceBuffer::~DeviceBuffer() {
+    if (owned_ && ptr_) (void)hipFree(ptr_);
+}
+DeviceBuffer& DeviceBuffer::operator=(DeviceBuffer&& o) noexcept {
+    if (this != &o) {
+        if (owned_ && ptr_) (void)hipFree(ptr_);
+        ptr_ = o.ptr_;
+        bytes_ = o.bytes_;
+        owned_ = o.owned_;
+        o.ptr_ = nullptr;
+        o.bytes_ = 0;
+    }
+    return *this;
+}
+
+// ---- Camera ----
+Camera Camera::new_perspective(uint32_t width, uint32_t height, Vec3 position, Vec3 target, Vec3 up,
+                               float fovy_degrees, float z_near, float z_far) {
+    Camera c;
+    c.viewport_width = width;
+    c.viewport_height = height;
+    c.position = position;
+    c.target = target;
+    c.up = up;
+    c.fovy_degrees = fovy_degrees;
+    c.z_near = z_near;
+    c.z_far = z_far;
+    return c;
+}
+
+sdfv_camera Camera::to_device() const {
+    sdfv_camera cam;
+    const float aspect = viewport_height ? (float)viewport_width / (float)viewport_height : 1.0f;
+    sdfv_camera_look_at(&cam, &position.x, &target.x, &up.x, fovy_degrees, aspect, z_near, z_far);
+    return cam;
+}
+
+// ---- SDFViewerMaterial ----
+sdfv_render_params SDFViewerMaterial::uniforms() const {
+    sdfv_render_params rp;
+    sdfv_render_params_default(&rp, nullptr);
+    rp.bounds_min[0] = voxels_bounds[0].x; rp.bounds_min[1] = voxels_bounds[0].y; rp.bounds_min[2] = voxels_bounds[0].z;
+    rp.bounds_max[0] = voxels_bounds[1].x; rp.bounds_max[1] = voxels_bounds[1].y; rp.bounds_max[2] = voxels_bounds[1].z;
+    for (int i = 0; i < 3; ++i) rp.tex_size[i] = tex_size[i];
+    rp.lod_dist_between_samples = lod_dist_between_samples;
+    for (int i = 0; i < 4; ++i) rp.tint[i] = color[i];
+    rp.gamma = gamma;
+    return rp;
+}
+
+int SDFViewerMaterial::render(const Camera& camera, float* rgba_device, sdfv_march_aux* aux_device, void* stream) const {
+    const sdfv_render_params rp = uniforms();
+    const sdfv_camera cam = camera.to_device();
+    return sdfv_raymarch(&rp, tex0->f32(), tex1->f32(), &cam, 1, camera.viewport_width, camera.viewport_height, 0,
+                         camera.viewport_height, rgba_device, aux_device, stream);
+}
+
+// ---- SDFViewer ----
+SDFViewer::SDFViewer(std::array<size_t, 3> voxels, const BoundingBox& bb, size_t passes)
+    : loading_mgr(voxels, passes), bounding_box(bb) {
+    const size_t bytes = voxels[0] * voxels[1] * voxels[2] * 16;
+    material.tex0 = std::make_shared<DeviceBuffer>(bytes);
+    material.tex1 = std::make_shared<DeviceBuffer>(bytes);
+    material.tex_size = {(uint32_t)voxels[0], (uint32_t)voxels[1], (uint32_t)voxels[2]};
+    material.voxels_bounds = bb;
+}
+
+std::unique_ptr<SDFViewer> SDFViewer::from_bb(const BoundingBox& bb, size_t max_voxels_side, size_t loading_passes) {
+    sdfv_grid g;
+    if (sdfv_grid_from_bb(&bb[0].x, &bb[1].x, (uint32_t)max_voxels_side, &g) != 0) return nullptr;
+    fprintf(stderr, "Using %ux%ux%u voxels (dimensions: %gx%gx%g)\n", g.dims[0], g.dims[1], g.dims[2],
+            (double)(bb[1].x - bb[0].x), (double)(bb[1].y - bb[0].y), (double)(bb[1].z - bb[0].z));  // :69-70
+    return new_voxels({g.dims[0], g.dims[1], g.dims[2]}, bb, loading_passes);
+}
+
+std::unique_ptr<SDFViewer> SDFViewer::new_voxels(std::array<size_t, 3> voxels, const BoundingBox& bb,
+                                                 size_t loading_passes) {
+    std::unique_ptr<SDFViewer> v(new SDFViewer(voxels, bb, loading_passes));
+    if (!v->material.tex0->ok() || !v->material.tex1->ok()) return nullptr;
+    const sdfv_grid g = v->grid();
+    if (sdfv_grid_init(&g, v->tex0_device(), v->tex1_device(), v->stream) != 0) return nullptr;  // [AIR_DIST; 4]
+    return v;
+}
+
+sdfv_grid SDFViewer::grid() const {
+    sdfv_grid g;
+    for (int i = 0; i < 3; ++i) g.dims[i] = material.tex_size[i];
+    g.bb_min[0] = bounding_box[0].x; g.bb_min[1] = bounding_box[0].y; g.bb_min[2] = bounding_box[0].z;
+    g.bb_max[0] = bounding_box[1].x; g.bb_max[1] = bounding_box[1].y; g.bb_max[2] = bounding_box[1].z;
+    g.z_begin = 0;
+    g.z_end = g.dims[2];
+    return g;
+}
+
+size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_time) {
+    // Check whether the SDF self-reports updates.  (:130-141)
+    bool just_changed_box = false;
+    if (auto new_box = sdf.changed()) {
+        changed_box = changed_box ? merge_bounding_boxes(*changed_box, *new_box) : *new_box;
+        changed_box_while_loading = loading_mgr.len() > 0 || changed_box_while_loading;
+        just_changed_box = true;
+    }
+    // Another full (3-pass) manager while changes are pending and the manager is idle.  (:146-156)
+    if (changed_box) {
+        if (loading_mgr.len() == 0) {
+            loading_mgr = LoadingManager(loading_mgr.limits, 3);
+            if (!just_changed_box) {
+                if (!changed_box_while_loading) changed_box.reset();
+                changed_box_while_loading = false;
+            }
+        }
+    }
+
+    const size_t start_iter = loading_mgr.total_iterations();
+    const auto dev = sdf.device_sdf();
+    if (!dev) {
+        error_ = "this SDFSurface cannot be evaluated on the device (no device_sdf())";
+        return 0;
+    }
+    const sdfv_grid g = grid();
+    const auto start_time = std::chrono::steady_clock::now();
+    bool first = true;
+    // "while first || start_time.elapsed() < max_delta_time" with a pass as the unit of work  (:173)
+    while (first || std::chrono::steady_clock::now() - start_time < max_delta_time) {
+        first = false;
+        const size_t step = loading_mgr.step_size();
+        if (step == 0) break;  // No more work to do!
+        float box[6];
+        const float* box_ptr = nullptr;
+        if (changed_box) {
+            box[0] = (*changed_box)[0].x; box[1] = (*changed_box)[0].y; box[2] = (*changed_box)[0].z;
+            box[3] = (*changed_box)[1].x; box[4] = (*changed_box)[1].y; box[5] = (*changed_box)[1].z;
+            box_ptr = box;
+        }
+        if (sdfv_fill_grid_pass(&dev->params, dev->sdf_id, &g, (uint32_t)step, box_ptr, tex0_device(), tex1_device(),
+                                stream) != 0) {
+            error_ = sdfv_last_error();
+            break;
+        }
+        loading_mgr.finish_pass();
+    }
+    return loading_mgr.total_iterations() - start_iter;
+}
+
+void SDFViewer::commit() {
+    // tex0.fill / tex1.fill re-upload nothing here: the textures already live on the device.  (:222-234)
+    material.lod_dist_between_samples = std::pow(2.0f, (float)(uint8_t)loading_mgr.passes_left());  // :226
+    // lod == 1 switches the GL filter to LINEAR (:227-230): the kernel selects the filter from the same uniform.
+}
+
+int SDFViewer::download(float* tex0_host, float* tex1_host) const {
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+    if (hipMemcpy(tex0_host, tex0_device(), material.tex0->bytes(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemcpy(tex1_host, tex1_device(), material.tex1->bytes(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return 0;
+}
+
+}  // namespace sdfviewer

@@ -1,0 +1,108 @@
+// sdf_viewer.hpp -- C++ mirror of the reference's viewer controller and raymarch material (L2):
+//   SDFViewer          src/app/scene/sdf/mod.rs:20-251   {from_bb, new_voxels, update, commit}
+//   SDFViewerMaterial  src/app/scene/sdf/material.rs:8-86
+//   Camera             three-d Camera::new_perspective as used by src/app/scene/mod.rs:82-95
+// with the two textures living in HBM instead of a CPU Vec + GL texture pair:
+//   - update() launches LoadingManager passes as kernels (sdfv_fill_grid_pass) -- or the dense kernel when a
+//     fresh grid can be finished within the call -- instead of calling sample() once per voxel;
+//   - commit() has nothing to upload (the reference re-uploads both whole textures, :220-239): it only
+//     publishes lod_dist_between_samples = 2^passes_left to the material;
+//   - SDFViewerMaterial::render() is the fragment shader over every pixel (sdfv_raymarch).
+#pragma once
+
+#include <chrono>
+#include <memory>
+#include <optional>
+
+#include "loading_manager.hpp"
+#include "sdf_surface.hpp"
+
+namespace sdfviewer {
+
+// three-d Camera (perspective) + the defaults of SDFViewerAppScene::new, scene/mod.rs:82-95
+struct Camera {
+    Vec3 position{2.5f, 3.0f, 5.0f};
+    Vec3 target{0.0f, 0.0f, 0.0f};
+    Vec3 up{0.0f, 1.0f, 0.0f};
+    float fovy_degrees = 45.0f;
+    float z_near = 0.1f, z_far = 1000.0f;
+    uint32_t viewport_width = 0, viewport_height = 0;  // "Updated at runtime"
+    static Camera new_perspective(uint32_t width, uint32_t height, Vec3 position, Vec3 target, Vec3 up,
+                                  float fovy_degrees, float z_near, float z_far);
+    void set_viewport(uint32_t width, uint32_t height) {
+        viewport_width = width;
+        viewport_height = height;
+    }
+    sdfv_camera to_device() const;
+};
+
+// Device memory owner (hipMalloc/hipFree) or a view over caller-owned device memory.
+class DeviceBuffer {
+   public:
+    DeviceBuffer() = default;
+    explicit DeviceBuffer(size_t bytes);
+    DeviceBuffer(void* external, size_t bytes) : ptr_(external), bytes_(bytes), owned_(false) {}
+    ~DeviceBuffer();
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    DeviceBuffer(DeviceBuffer&& o) noexcept { *this = std::move(o); }
+    DeviceBuffer& operator=(DeviceBuffer&& o) noexcept;
+    float* f32() const { return static_cast<float*>(ptr_); }
+    void* get() const { return ptr_; }
+    size_t bytes() const { return bytes_; }
+    bool ok() const { return ptr_ != nullptr || bytes_ == 0; }
+
+   private:
+    void* ptr_ = nullptr;
+    size_t bytes_ = 0;
+    bool owned_ = true;
+};
+
+// material.rs:8-31
+struct SDFViewerMaterial {
+    std::shared_ptr<DeviceBuffer> tex0;  // distance (R), colour (GBA)
+    std::shared_ptr<DeviceBuffer> tex1;  // material properties (RGB)
+    std::array<uint32_t, 3> tex_size{0, 0, 0};
+    BoundingBox voxels_bounds;
+    float lod_dist_between_samples = 1.0f;
+    float color[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // Srgba::WHITE.to_linear_srgb()
+    float gamma = 0.0f;                          // env "gamma" (material.rs:39); <= 0: not defined
+
+    sdfv_render_params uniforms() const;  // use_uniforms, material.rs:50-73
+    // Draws the volume: one ray per pixel of camera's viewport; rgba_device holds W*H*4 floats.
+    int render(const Camera& camera, float* rgba_device, sdfv_march_aux* aux_device, void* stream) const;
+};
+
+class SDFViewer {
+   public:
+    // scene/sdf/mod.rs:46-72
+    static std::unique_ptr<SDFViewer> from_bb(const BoundingBox& bb, size_t max_voxels_side, size_t loading_passes);
+    // scene/sdf/mod.rs:75-101 (allocates both textures on the device and fills them with AIR_DIST)
+    static std::unique_ptr<SDFViewer> new_voxels(std::array<size_t, 3> voxels, const BoundingBox& bb,
+                                                 size_t loading_passes);
+
+    // scene/sdf/mod.rs:128-217.  Returns the number of LoadingManager iterations consumed, like the reference.
+    // The time budget is checked between passes (the GPU does a whole pass per launch).
+    size_t update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_time);
+    // scene/sdf/mod.rs:220-239
+    void commit();
+
+    sdfv_grid grid() const;
+    float* tex0_device() const { return material.tex0->f32(); }
+    float* tex1_device() const { return material.tex1->f32(); }
+    int download(float* tex0_host, float* tex1_host) const;  // D2H copy of both textures (debug / GL interop)
+    const char* last_error() const { return error_.c_str(); }
+
+    SDFViewerMaterial material;      // volume.material
+    LoadingManager loading_mgr;
+    BoundingBox bounding_box;
+    std::optional<BoundingBox> changed_box;
+    bool changed_box_while_loading = false;
+    void* stream = nullptr;          // hipStream_t the kernels are enqueued on
+
+   private:
+    SDFViewer(std::array<size_t, 3> voxels, const BoundingBox& bb, size_t passes);
+    std::string error_;
+};
+
+}  // namespace sdfviewer

@@ -22,6 +22,9 @@ def _ensure_built():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     if not os.path.exists(os.path.join(ROOT, "sdf-viewer_amd", "libsdfgrid.so")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "sdf-viewer_amd", "csrc")], stdout=subprocess.DEVNULL)
+    if not (os.path.exists(os.path.join(ROOT, "sdf-viewer_amd", "libsdfviewer_host.so")) and
+            os.path.exists(os.path.join(ROOT, "sdf-viewer_amd", "libsdfdemo_provider.so"))):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "sdf-viewer_amd", "host")], stdout=subprocess.DEVNULL)
 
 
 _ensure_built()
@@ -30,6 +33,12 @@ _ensure_built()
 @pytest.fixture(scope="session")
 def pkg():
     return importlib.import_module("sdf-viewer_amd")
+
+
+@pytest.fixture(scope="session")
+def host():
+    import host_binding
+    return host_binding
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,149 @@
+"""GPU tests of the C++ host mirror above the C ABI: SDFViewer::{from_bb,new_voxels,update,commit} driving the
+pass kernels, SDFViewerMaterial::render, per-point sample()/normal() of the SDFSurface mirror and of the
+provider library (the reference's ffi.rs ABI) -- all against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_viewer_full_load_matches_dense_oracle(host, oracle):
+    """`app --max-voxels-side 64 --loading-passes 2 demo` (app/cli/mod.rs:13-18): load to completion."""
+    sdf = host.SDF.demo()
+    v = host.Viewer.from_bb([-1, -1, -1, 1, 1, 1], 64, 2)
+    assert v.dims() == (64, 64, 64)
+    t0, t1 = v.download()
+    assert (t0 == np.float32(oracle.AIR_DIST)).all() and (t1 == np.float32(oracle.AIR_DIST)).all()  # new_voxels
+    total = 0
+    while True:
+        n = v.update(sdf, 0.030)
+        total += n
+        if n == 0:
+            break
+        v.commit()
+    assert total == 64 ** 3 + 32 ** 3           # iterations of passes step 2 then step 1 (loading.rs:80-89)
+    assert v.remaining() == 0 and v.lod() == 1.0
+    t0, t1 = v.download()
+    r0, r1 = oracle.fill_dense(oracle.default_params(), (64, 64, 64))
+    np.testing.assert_array_equal(t0.view(np.uint32), r0.view(np.uint32))
+    np.testing.assert_array_equal(t1.view(np.uint32), r1.view(np.uint32))
+
+
+def test_viewer_progressive_states_and_lod(host, oracle):
+    """A zero time budget = exactly one pass per update(): every intermediate texture state and the
+    lod_dist_between_samples = 2^passes_left published by commit() follow the reference (mod.rs:226)."""
+    sdf = host.SDF.demo()
+    dims = (20, 17, 12)
+    v = host.Viewer.new_voxels(dims, [-1, -1, -1, 1, 1, 1], 3)
+    r0, r1 = oracle.grid_init(dims)
+    lm = oracle.lm_new(dims, 3)
+    oprm = oracle.default_params()
+    expected_lod = {4: 4.0, 2: 2.0, 1: 1.0}  # after the pass with that step: 2^passes_left of the NEXT step
+    for step in (4, 2, 1):
+        n = v.update(sdf, 0.0)
+        want = -(-dims[0] // step) * -(-dims[1] // step) * -(-dims[2] // step)
+        assert n == want == oracle.viewer_update(oprm, dims, lm, r0, r1, max_iterations=want)
+        v.commit()
+        assert v.lod() == expected_lod[step]
+        t0, t1 = v.download()
+        np.testing.assert_array_equal(t0.view(np.uint32), r0.view(np.uint32))
+        np.testing.assert_array_equal(t1.view(np.uint32), r1.view(np.uint32))
+    assert v.update(sdf, 0.0) == 0
+
+
+def test_viewer_parameter_edit_refills_changed_box(host, oracle):
+    """set_parameter -> changed() -> a fresh 3-pass manager re-samples the reported box (mod.rs:131-156)."""
+    sdf = host.SDF.demo()
+    dims = (16, 16, 16)
+    v = host.Viewer.new_voxels(dims, [-1, -1, -1, 1, 1, 1], 2)
+    while v.update(sdf, 1.0):
+        pass
+    assert sdf.children()[1].set_parameter(1, 0.7) is None  # sphere radius
+    total = 0
+    for _ in range(10):
+        n = v.update(sdf, 1.0)
+        total += n
+        if n == 0 and not v.has_changed_box():
+            break
+    assert total >= 16 ** 3 + 8 ** 3 + 4 ** 3
+    t0, t1 = v.download()
+    r0, r1 = oracle.fill_dense(oracle.default_params(sphere_radius=0.7), dims)  # the demo reports its whole bbox
+    np.testing.assert_array_equal(t0.view(np.uint32), r0.view(np.uint32))
+    np.testing.assert_array_equal(t1.view(np.uint32), r1.view(np.uint32))
+
+
+def test_material_render_matches_oracle(host, oracle):
+    sdf = host.SDF.demo()
+    dims = (48, 48, 48)
+    v = host.Viewer.new_voxels(dims, [-1, -1, -1, 1, 1, 1], 2)
+    while v.update(sdf, 1.0):
+        pass
+    v.commit()
+    img = v.render(96, 64)
+    t0, t1 = v.download()
+    rp = oracle.default_render_params(dims)
+    want, _ = oracle.raymarch(rp, t0, t1, oracle.camera_look_at(aspect=96 / 64), 96, 64, want_aux=False)
+    assert np.abs(img - want).max() <= 1e-4 and (img[..., 3] == want[..., 3]).all()
+    # a commit while loading renders the blocky LOD preview (material.frag:46-51)
+    v2 = host.Viewer.new_voxels(dims, [-1, -1, -1, 1, 1, 1], 3)
+    v2.update(sdf, 0.0)
+    v2.commit()
+    assert v2.lod() == 4.0
+    img2 = v2.render(96, 64)
+    a0, a1 = v2.download()
+    rp.lod_dist_between_samples = 4.0
+    want2, _ = oracle.raymarch(rp, a0, a1, oracle.camera_look_at(aspect=96 / 64), 96, 64, want_aux=False)
+    assert np.abs(img2 - want2).max() <= 1e-4
+
+
+def test_sdf_surface_per_point_calls(host, oracle):
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-1.1, 1.1, size=(40, 3)).astype(np.float32)
+    d = host.SDF.demo("-t", "normal", "-s", "0.9")
+    oprm = oracle.default_params(cube_material=1, sphere_radius=0.9)
+    for sdf, sid in ((d, 0), (d.children()[0], 1), (d.children()[1], 2)):
+        for p in pts:
+            for do in (False, True):
+                np.testing.assert_array_equal(sdf.sample(p, do).view(np.uint32),
+                                              oracle.sample(oprm, p, do, sid).view(np.uint32))
+            np.testing.assert_array_equal(sdf.normal(p).view(np.uint32),
+                                          oracle.normal_many(oprm, p[None], sdf_id=sid)[0].view(np.uint32))
+        # the trait's default normal (defaults.rs:49-56) evaluated on the host over 4 GPU samples
+        got = sdf.normal(pts[0], eps=0.01, default=True)
+        want = oracle.normal_many(oprm, pts[:1], eps=0.01, sdf_id=sid, use_default=True)[0]
+        np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_provider_abi_sample_and_normal(host, oracle):
+    """The reference's per-point ABI (ffi.rs:57-65,322-332): Box<SDFSample> / Box<Vector3>, freed by *_free."""
+    P = host.load_provider()
+    P.init()
+    oprm = oracle.default_params()
+    rng = np.random.default_rng(5)
+    for p in rng.uniform(-1.2, 1.2, size=(25, 3)).astype(np.float32):
+        for sid in (0, 1, 2):
+            s = P.sample(sid, host.Vec3(*p), False)
+            got = np.array(s.contents, np.float32)
+            P.sample_free(s)
+            np.testing.assert_array_equal(got.view(np.uint32), oracle.sample(oprm, p, False, sid).view(np.uint32))
+            n = P.normal(sid, host.Vec3(*p), 0.0)
+            gotn = np.array(n.contents, np.float32)
+            P.normal_free(n)
+            np.testing.assert_array_equal(gotn.view(np.uint32), oracle.normal_many(oprm, p[None], sdf_id=sid)[0].view(np.uint32))
+    s = P.sample(77, host.Vec3(0, 0, 0), False)   # unknown id -> SDFSample::new(0.0, zero) (ffi.rs:61-64)
+    assert list(s.contents) == [0.0] * 7
+    P.sample_free(s)
+    # parameter edits through the ABI change what sample() returns
+    v = host.ParamValueC()
+    v.tag = 0
+    v.v.boolean = True
+    r = P.set_parameter(0, 1, v)  # disable_sphere
+    assert r.contents.tag == 0
+    P.set_parameter_free(r)
+    s = P.sample(0, host.Vec3(0.2, 0.1, 0.0), False)
+    got = np.array(s.contents, np.float32)
+    P.sample_free(s)
+    np.testing.assert_array_equal(got.view(np.uint32),
+                                  oracle.sample(oracle.default_params(disable_sphere=1), (0.2, 0.1, 0.0)).view(np.uint32))

@@ -1,0 +1,197 @@
+"""CPU tests of the C++ host mirror: LoadingManager (the reference's own unit tests, loading.rs:117-171, run
+against the product's class), SDFDemo hierarchy / parameters / changed() semantics, provider exports."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+# ---- loading.rs:117-171 restated against sdfviewer::LoadingManager ----
+def loading_impl(host, limits):
+    hits = np.zeros(limits[0] * limits[1] * limits[2], np.int64)
+    num_passes = 3
+    manager = host.LoadingManager(limits, num_passes)
+    remaining = manager.len()
+    iterations = 0
+    total = iterations + remaining
+    while True:
+        v = manager.next()
+        if v is None:
+            break
+        flat = v[0] + v[1] * limits[0] + v[2] * limits[0] * limits[1]
+        hits[flat] += 1
+        assert hits[flat] <= num_passes
+        iterations += 1
+        remaining = manager.len()
+        assert total == iterations + remaining
+    assert (hits >= 1).all(), "developer error: voxel was not hit"
+
+
+def test_interlacing_cube_2(host):
+    loading_impl(host, (2, 2, 2))
+
+
+def test_interlacing_cube_8(host):
+    loading_impl(host, (8, 8, 8))
+
+
+def test_interlacing_cube_64(host):
+    loading_impl(host, (64, 64, 64))
+
+
+def test_interlacing_cube_11(host):
+    loading_impl(host, (11, 11, 11))
+
+
+def test_interlacing_non_cube(host):
+    loading_impl(host, (8, 11, 17))
+
+
+def test_loading_manager_matches_oracle_sequence(host, oracle):
+    for limits, passes in [((5, 3, 4), 3), ((8, 8, 8), 2), ((7, 1, 2), 4), ((3, 3, 3), 0), ((3, 3, 3), 1)]:
+        m = host.LoadingManager(limits, passes)
+        o = oracle.lm_new(limits, passes)
+        while True:
+            assert m.len() == oracle.L.or_lm_len(C.byref(o))
+            assert m.passes_left() == oracle.L.or_lm_passes_left(C.byref(o))
+            a, b = m.next(), oracle.lm_next(o)
+            assert a == b
+            if a is None:
+                break
+        assert m.total_iterations() == o.total_iterations
+
+
+def test_finish_pass_equals_stepping(host):
+    a, b = host.LoadingManager((9, 7, 5), 3), host.LoadingManager((9, 7, 5), 3)
+    for _ in range(4):  # partially consume the first pass of a
+        a.next()
+        b.next()
+    while a.step_size():
+        step = a.step_size()
+        n = a.finish_pass()
+        for _ in range(n):
+            b.next()
+        assert (a.step_size(), a.len(), a.total_iterations(), a.passes_left()) == \
+               (b.step_size(), b.len(), b.total_iterations(), b.passes_left()), step
+    assert a.next() is None and a.finish_pass() == 0
+    assert [host.H.sdfvh_prev_power_of_2(x) for x in (0, 1, 3, 8, 9)] == [0, 1, 2, 8, 8]
+
+
+# ---- SDFDemo hierarchy and parameters: demo/mod.rs:78-144, cube.rs:91-161, sphere.rs:49-119 ----
+def test_demo_hierarchy(host, pkg):
+    d = host.SDF.demo()
+    assert (d.id(), d.name()) == (0, "Demo")
+    ch = d.children()
+    assert [(c.id(), c.name()) for c in ch] == [(1, "DemoCube"), (2, "DemoSphere")]
+    assert list(d.bounding_box()) == [-1, -1, -1, 1, 1, 1]
+    prm, sid = d.device_params(pkg.DemoParams)
+    assert bytes(prm) == bytes(pkg.default_params()) and sid == 0
+    assert ch[1].device_params(pkg.DemoParams)[1] == 2
+
+
+def test_demo_parameters_listing(host):
+    d = host.SDF.demo()
+    ps = d.parameters()
+    assert [(p[0], p[1], p[2], p[3]) for p in ps] == [("0", "max_distance_custom_material", "2", "Float(0.05)"),
+                                                       ("1", "disable_sphere", "0", "Boolean(false)")]
+    cube, sphere = d.children()
+    assert [(p[1], p[2], p[3]) for p in cube.parameters()] == [("material", "3", 'String("Brick")'),
+                                                               ("half_side", "1", "Int(95)")]  # (0.95f32 * 100.) as i32: the f32 product rounds to 95.0
+    assert [(p[1], p[2], p[3]) for p in sphere.parameters()] == [("material", "3", 'String("Normal")'),
+                                                                 ("sphere_radius", "2", "Float(1.05)")]
+
+
+def test_set_parameter_shares_state_and_reports_changed(host, pkg):
+    d = host.SDF.demo()
+    cube, sphere = d.children()
+    assert d.changed() is None
+    assert sphere.set_parameter(1, 0.8) is None          # ID_RADIUS
+    assert cube.set_parameter(0, "normal") is None       # ID_MATERIAL, case-insensitive FromStr
+    assert cube.set_parameter(1, 50) is None             # ID_HALF_SIDE: value as f32 / 100
+    prm, _ = d.device_params(pkg.DemoParams)             # the root sees its children's modifications
+    assert np.float32(prm.sphere_radius) == np.float32(0.8) and prm.cube_material == 1
+    assert np.float32(prm.cube_half_side) == np.float32(0.5)
+    # changed_default_impl: one child per call, then the own flag, then None
+    assert list(d.changed()) == [-1, -1, -1, 1, 1, 1]    # cube
+    assert list(d.changed()) == [-1, -1, -1, 1, 1, 1]    # sphere
+    assert d.changed() is None
+    assert d.set_parameter(1, True) is None
+    assert d.changed() is not None and d.changed() is None
+    assert d.device_params(pkg.DemoParams)[0].disable_sphere == 1
+
+
+def test_set_parameter_errors(host):
+    d = host.SDF.demo()
+    assert d.set_parameter(7, 1.0) == "Unknown parameter 7 with value Float(1.0)"
+    assert d.set_parameter(0, True) == "Unknown parameter 0 with value Boolean(true)"   # wrong kind
+    cube = d.children()[0]
+    assert cube.set_parameter(1, 0.5) == "Unknown parameter 1 with value Float(0.5)"    # half_side wants Int
+    assert cube.set_parameter(0, "marble") == "Invalid cube material"
+    assert d.changed() is None
+
+
+def test_demo_from_cli_flags(host, pkg):
+    d = host.SDF.demo("-t", "normal", "--sphere-radius=0.9", "-m", "0.1", "-d", "true", "-c", "0.7", "-l", "BRICK")
+    prm, _ = d.device_params(pkg.DemoParams)
+    assert (prm.cube_material, prm.sphere_material, prm.disable_sphere) == (1, 0, 1)
+    assert [np.float32(x) for x in (prm.cube_half_side, prm.sphere_radius, prm.max_distance_custom_material)] == \
+           [np.float32(0.7), np.float32(0.9), np.float32(0.1)]
+    with pytest.raises(ValueError, match="Invalid cube material"):
+        host.SDF.demo("-t", "marble")
+    with pytest.raises(ValueError, match="wasn't expected"):
+        host.SDF.demo("--nope")
+
+
+def test_provider_exports_reference_symbols(host):
+    raw = C.CDLL(host.PROVIDER_PATH)
+    for name in host.PROVIDER_SYMBOLS:
+        getattr(raw, name)
+    assert C.sizeof(host.ParamC) == 88 and C.sizeof(host.ParamValueC) == 24 and C.sizeof(host.ParamKindC) == 24
+
+
+def test_provider_metadata_calls_without_gpu(host):
+    """children / name / parameters / set_parameter / changed need no device."""
+    P = host.load_provider()
+    P.init()
+    pl = P.children(0)
+    assert np.frombuffer(host.pl_bytes(pl.contents), np.uint32).tolist() == [1, 2]
+    P.children_free(pl)
+    for sid, want in ((0, b"Demo"), (1, b"DemoCube"), (2, b"DemoSphere")):
+        pl = P.name(sid)
+        assert host.pl_bytes(pl.contents) == want
+        P.name_free(pl)
+    pl = P.name(9)  # unknown id: stderr + null payload (ffi.rs:137-140)
+    assert pl.contents.ptr is None and pl.contents.len_bytes == 0
+    P.name_free(pl)
+    pl = P.parameters(1)
+    n = pl.contents.len_bytes // C.sizeof(host.ParamC)
+    params = C.cast(pl.contents.ptr, C.POINTER(host.ParamC * n)).contents
+    assert n == 2 and host.pl_bytes(params[0].name) == b"material" and params[0].kind.tag == 3
+    choices = params[0].kind.v.choices
+    items = C.cast(choices.ptr, C.POINTER(host.PointerLength * 2)).contents
+    assert [host.pl_bytes(i) for i in items] == [b"Brick", b"Normal"]
+    assert host.pl_bytes(params[0].value.v.string_) == b"Brick"
+    assert params[1].kind.tag == 1 and (params[1].kind.v.int_.range_start, params[1].kind.v.int_.range_end) == (0, 100)
+    assert params[1].value.v.int_ == 95
+    P.parameters_free(pl)
+    v = host.ParamValueC()
+    v.tag = 2
+    v.v.float_ = 0.75
+    r = P.set_parameter(2, 1, v)
+    assert r.contents.tag == 0
+    P.set_parameter_free(r)
+    r = P.set_parameter(2, 5, v)
+    assert r.contents.tag == 1 and host.pl_bytes(r.contents.error) == b"Unknown parameter 5 with value Float(0.75)"
+    P.set_parameter_free(r)
+    c = P.changed(0)
+    assert c.contents.tag == 1 and list(c.contents.bounds) == [-1, -1, -1, 1, 1, 1]
+    P.changed_free(c)
+    c = P.changed(0)
+    assert c.contents.tag == 0
+    P.changed_free(c)
+    bb = P.bounding_box(2)
+    assert list(bb.contents) == [-1, -1, -1, 1, 1, 1]
+    P.bounding_box_free(bb)
+    bb = P.bounding_box(42)
+    assert list(bb.contents) == [0] * 6
+    P.bounding_box_free(bb)
