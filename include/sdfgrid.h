@@ -163,6 +163,17 @@ int sdfv_raymarch(const sdfv_render_params *rp, const float *tex0, const float *
                   uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                   float *rgba, sdfv_march_aux *aux, void *stream);
 
+/* Device-side analogue of SDFViewer::commit (scene/sdf/mod.rs:220-239).  The textures already live in HBM, so
+ * there is nothing to upload; what a commit can do instead is derive the raymarch's acceleration data: `dist`
+ * (DEVICE, W*H*D floats) receives a compact copy of tex0.r.  Optional: pass it to sdfv_raymarch_accel. */
+int sdfv_commit_distance(const sdfv_grid *grid, const float *tex0, float *dist, void *stream);
+/* sdfv_raymarch with the compact distance volume (`dist` may be NULL = sdfv_raymarch).  Results are identical
+ * bit for bit; the march reads `dist` instead of the r channel of tex0. */
+int sdfv_raymarch_accel(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
+                        const sdfv_camera *cameras, uint32_t n_cameras,
+                        uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                        float *rgba, sdfv_march_aux *aux, void *stream);
+
 /* ---- host-buffer conveniences (allocate, run, copy back, synchronise; PCIe-inclusive) ---- */
 int sdfv_fill_grid_host(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid,
                         float *tex0_host, float *tex1_host);

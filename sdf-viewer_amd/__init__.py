@@ -134,8 +134,17 @@ def orbit_cameras(n, aspect, eye0=(2.5, 3.0, 5.0)):
     return cams
 
 
-def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=False, stream=None, out=None):
-    """material.frag main() over rows [y0,y1).  Returns rgba [n_cam, rows, W, 4] (+ aux [n_cam, rows, W, 18] words)."""
+def commit_distance(grid, tex0, dist=None, stream=None):
+    """Device-side commit: compact copy of tex0.r for the raymarch (sdfv_commit_distance)."""
+    if dist is None:
+        dist = torch.empty(tuple(tex0.shape[:-1]), dtype=torch.float32, device=tex0.device)
+    check(lib.sdfv_commit_distance(C.byref(grid), _dev_ptr(tex0, "tex0"), _dev_ptr(dist, "dist"), _stream_ptr(stream)))
+    return dist
+
+
+def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=False, stream=None, out=None, dist=None):
+    """material.frag main() over rows [y0,y1).  Returns rgba [n_cam, rows, W, 4] (+ aux [n_cam, rows, W, 18] words).
+    `dist` = optional compact distance volume from commit_distance()."""
     if isinstance(cameras, Camera):
         cameras = [cameras]
     y1 = height if y1 is None else y1
@@ -143,7 +152,8 @@ def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=Fal
     cam_arr = (Camera * n)(*cameras)
     rgba = out if out is not None else torch.empty((n, y1 - y0, width, 4), dtype=torch.float32, device=tex0.device)
     aux = torch.empty((n, y1 - y0, width, AUX_FLOATS), dtype=torch.int32, device=tex0.device) if want_aux else None
-    check(lib.sdfv_raymarch(C.byref(rp), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"), cam_arr, n, width, height,
-                            y0, y1, C.c_void_p(rgba.data_ptr()), C.c_void_p(aux.data_ptr()) if want_aux else None,
-                            _stream_ptr(stream)))
+    check(lib.sdfv_raymarch_accel(C.byref(rp), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"),
+                                  None if dist is None else _dev_ptr(dist, "dist"), cam_arr, n, width, height,
+                                  y0, y1, C.c_void_p(rgba.data_ptr()),
+                                  C.c_void_p(aux.data_ptr()) if want_aux else None, _stream_ptr(stream)))
     return (rgba, aux) if want_aux else rgba

@@ -37,6 +37,7 @@ struct FillLaunch {
 
 hipError_t launch_fill_dense(const FillArgs& a, const FillLaunch& cfg, hipStream_t stream);
 hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& p, hipStream_t stream);
+hipError_t launch_commit_distance(const float* tex0, float* dist, uint64_t n_voxels, hipStream_t stream);
 hipError_t launch_grid_init(float* tex0, float* tex1, uint64_t n_voxels, float air, hipStream_t stream);
 
 }  // namespace sdfv

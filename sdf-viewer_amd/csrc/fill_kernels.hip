@@ -131,6 +131,15 @@ bool is_default_config(const FillArgs& a) {
            a.prm.sphere_material == SDFV_MATERIAL_NORMAL && a.prm.disable_sphere == 0;
 }
 
+// SDFViewer::commit's device-side analogue: nothing to upload, but the raymarch likes a compact copy of
+// tex0.r (4 B/voxel instead of one dword in every 16 B).  Reads whole texels (coalesced dwordx4) and writes
+// one dword per voxel: 20 B/voxel of traffic, once per commit.
+__global__ __launch_bounds__(kBlock) void commit_distance_kernel(const float4* __restrict__ tex0,
+                                                                 float* __restrict__ dist, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
+        dist[i] = tex0[i].x;
+}
+
 template <int TX, bool NT>
 hipError_t launch_dense_cfg(const FillArgs& args, hipStream_t stream) {
     constexpr int TY = kBlock / TX;
@@ -167,6 +176,15 @@ hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& p, hipStream_t st
     uint64_t blocks = (n + kBlock - 1) / kBlock;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(fill_pass_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, stream, a, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_commit_distance(const float* tex0, float* dist, uint64_t n_voxels, hipStream_t stream) {
+    if (n_voxels == 0) return hipSuccess;
+    uint64_t blocks = (n_voxels + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(commit_distance_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const float4*>(tex0), dist, n_voxels);
     return hipGetLastError();
 }
 

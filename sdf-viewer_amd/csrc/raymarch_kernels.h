@@ -13,6 +13,13 @@ struct RaymarchArgs {
     float bsize[3];              // bounds_max - bounds_min (material.frag:44)
     float inv_bsize[3];          // exact reciprocals, valid when pow2_extent
     uint32_t pow2_extent;        // every bsize[i] is an exact power of two
+    uint32_t fast_index;         // 1e-4 * N / size <= 0.25 on every axis: MirroredRepeat == clamp while marching
+    const float* dist;           // compact copy of tex0.r (sdfv_commit_distance) or nullptr
+    uint32_t pow2_size;          // every tex_size[i] is a power of two (with pow2_extent: one fused scale per axis)
+    uint32_t symmetric_box;      // bounds_min == -bounds_max on every axis
+    uint32_t fast_normal;        // the normal's 4 taps also keep floor(u) in [-1, N-1]
+    float cull_center[3];        // bounding sphere of the box, radius inflated by 1 % (conservative tile cull)
+    float cull_radius2;
     const float4* tex0;          // full grid, rp.tex_size
     const float4* tex1;
     uint32_t n_cameras;          // cameras in this launch (<= kMaxCamerasPerLaunch), by value in kernarg

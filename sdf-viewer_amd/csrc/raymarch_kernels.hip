@@ -2,20 +2,26 @@
 // the fragment shader of the reference (src/app/scene/sdf/material.frag, whole file) as a HIP kernel.
 //
 // One thread per pixel.  A 64-lane wave covers an 8x8 pixel tile (neighbouring rays walk neighbouring
-// texels, so the 8 dword gathers of a trilinear fetch land in few cache lines); a 256-thread workgroup
-// covers 16x16.  The march loop is wave-synchronous: each iteration ballots the lanes still
-// marching and the wave leaves the loop as soon as the ballot is empty (early ray termination),
+// texels, so the gathers of a trilinear fetch land in few cache lines); a 256-thread workgroup covers
+// 16x16; blockIdx.z is the camera.  The march loop is wave-synchronous: each iteration ballots the lanes
+// still marching and the wave leaves the loop as soon as the ballot is empty (early ray termination)
 // instead of running the shader's fixed 255-iteration bound.
 //
 // texture(sampler3D) is restated in full fp32 (GL texel-centre convention, MirroredRepeat, mix() along
 // x, then y, then z): hardware texture filtering uses low-precision fixed-point weights and would not
-// hold the 1e-4 RGBA tolerance, so no hipTextureObject is used.  The march reads only tex0.r (4 of
-// every 16 bytes); the full tex0/tex1 texels are fetched once, at the hit.
+// hold the 1e-4 RGBA tolerance, so no hipTextureObject is used.  The march reads only tex0.r (or its
+// compact copy); the full tex0/tex1 texels are fetched once, at the hit.
 //
 // Ray set-up: the reference rasterises the bbox cube and the fragment's `pos` is a point on its
 // surface (scene/sdf/mod.rs:254-282, material.rs:75-81 Cull::None).  Here `pos` comes from a ray/AABB
 // slab test through the pixel centre: the entry point when the camera is outside the box, the exit
 // point when it is inside; pixels whose ray misses the box are transparent.
+//
+// What profiling says (profiles/, tools/wave_timing.py): a frame is latency-bound by its longest wave (one
+// grazing ray, up to 255 dependent iterations, ~8 cycles per instruction for a lone wave on its SIMD) and a
+// batch of cameras is VALU-issue-bound.  Both regimes pay per INSTRUCTION, so the fast kernels below
+// spend their effort on removing instructions from the per-iteration path without changing a single bit
+// of the result (see march_fast); the general kernel keeps the shader's structure for every other case.
 #include "raymarch_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -36,8 +42,7 @@ __device__ __forceinline__ V3 normalize(V3 a) {
 }
 __device__ __forceinline__ float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 
-// GL MIRRORED_REPEAT on a texel index.  The march keeps p within 1e-4 of the box, so i is in
-// [-1, n] in practice; the general case is kept for arbitrary callers.
+// GL MIRRORED_REPEAT on a texel index (general form).
 __device__ __forceinline__ uint32_t mirror_index(int i, int n) {
     if (i >= 0 && i < n) return (uint32_t)i;
     int period = 2 * n;
@@ -52,20 +57,29 @@ struct Tex {
 };
 
 struct Footprint {  // the 8 texel offsets and 3 weights of one LINEAR fetch
-    uint64_t o000, o100, o010, o110, o001, o101, o011, o111;
+    uint32_t o000, o100, o010, o110, o001, o101, o011, o111;
     float ax, ay, az;
 };
 
-__device__ __forceinline__ Footprint footprint(const Tex& t, float p01x, float p01y, float p01z) {
-    float u = p01x * (float)t.w - 0.5f, v = p01y * (float)t.h - 0.5f, w = p01z * (float)t.d - 0.5f;
+// FAST: floor(u) is known to be in [-1, N-1] on every axis, where MirroredRepeat == clamp.
+template <bool FAST>
+__device__ __forceinline__ Footprint footprint(const Tex& t, V3 p01) {
+    float u = p01.x * (float)t.w - 0.5f, v = p01.y * (float)t.h - 0.5f, w = p01.z * (float)t.d - 0.5f;
     float fu = floorf(u), fv = floorf(v), fw = floorf(w);
     Footprint f;
     f.ax = u - fu; f.ay = v - fv; f.az = w - fw;
     int i0 = (int)fu, j0 = (int)fv, k0 = (int)fw;
-    uint64_t i0m = mirror_index(i0, t.w), i1m = mirror_index(i0 + 1, t.w);
-    uint64_t j0m = (uint64_t)mirror_index(j0, t.h) * t.w, j1m = (uint64_t)mirror_index(j0 + 1, t.h) * t.w;
-    uint64_t slice = (uint64_t)t.w * t.h;
-    uint64_t k0m = mirror_index(k0, t.d) * slice, k1m = mirror_index(k0 + 1, t.d) * slice;
+    uint32_t i0m, i1m, j0m, j1m, k0m, k1m;
+    const uint32_t sy = (uint32_t)t.w, sz = (uint32_t)t.w * (uint32_t)t.h;
+    if (FAST) {
+        i0m = (uint32_t)max(i0, 0); i1m = (uint32_t)min(i0 + 1, t.w - 1);
+        j0m = (uint32_t)max(j0, 0) * sy; j1m = (uint32_t)min(j0 + 1, t.h - 1) * sy;
+        k0m = (uint32_t)max(k0, 0) * sz; k1m = (uint32_t)min(k0 + 1, t.d - 1) * sz;
+    } else {
+        i0m = mirror_index(i0, t.w); i1m = mirror_index(i0 + 1, t.w);
+        j0m = mirror_index(j0, t.h) * sy; j1m = mirror_index(j0 + 1, t.h) * sy;
+        k0m = mirror_index(k0, t.d) * sz; k1m = mirror_index(k0 + 1, t.d) * sz;
+    }
     f.o000 = k0m + j0m + i0m; f.o100 = k0m + j0m + i1m;
     f.o010 = k0m + j1m + i0m; f.o110 = k0m + j1m + i1m;
     f.o001 = k1m + j0m + i0m; f.o101 = k1m + j0m + i1m;
@@ -80,12 +94,12 @@ __device__ __forceinline__ float trilerp(float t000, float t100, float t010, flo
     return mixf(mixf(c00, c10, ay), mixf(c01, c11, ay), az);
 }
 
-// p01 = (p - sdfBoundsMin) / (sdfBoundsMax - sdfBoundsMin), material.frag:44.  When every extent is an exact
-// power of two (the demo's [-1,1]^3: 2.0) dividing equals multiplying by the exact reciprocal, bit for
-// bit, and the three IEEE divides (~12 instructions each) leave the per-step dependency chain.
-template <bool POW2>
+// p01 = (p - sdfBoundsMin) / (sdfBoundsMax - sdfBoundsMin), material.frag:44.  XF >= 1: every extent is an
+// exact power of two (the demo's [-1,1]^3: 2.0), so dividing equals multiplying by the exact reciprocal,
+// bit for bit, and three IEEE divides (~12 instructions each) leave the per-step dependency chain.
+template <int XF>
 __device__ __forceinline__ V3 to_p01(const RaymarchArgs& a, V3 p) {
-    if (POW2)
+    if (XF >= 1)
         return mk((p.x - a.rp.bounds_min[0]) * a.inv_bsize[0], (p.y - a.rp.bounds_min[1]) * a.inv_bsize[1],
                   (p.z - a.rp.bounds_min[2]) * a.inv_bsize[2]);
     return mk((p.x - a.rp.bounds_min[0]) / a.bsize[0], (p.y - a.rp.bounds_min[1]) / a.bsize[1],
@@ -93,34 +107,36 @@ __device__ __forceinline__ V3 to_p01(const RaymarchArgs& a, V3 p) {
 }
 
 // sdfSampleRawNearest's snapped coordinate + NEAREST fetch, material.frag:27-36
-__device__ __forceinline__ uint64_t nearest_offset(const RaymarchArgs& a, const Tex& t, V3 p01) {
+__device__ __forceinline__ uint32_t nearest_offset(const RaymarchArgs& a, const Tex& t, V3 p01) {
     float rx = (float)t.w / a.rp.lod_dist_between_samples;
     float ry = (float)t.h / a.rp.lod_dist_between_samples;
     float rz = (float)t.d / a.rp.lod_dist_between_samples;
     float qx = roundf(p01.x * rx) / rx, qy = roundf(p01.y * ry) / ry, qz = roundf(p01.z * rz) / rz;
     int i = (int)floorf(qx * (float)t.w), j = (int)floorf(qy * (float)t.h), k = (int)floorf(qz * (float)t.d);
-    return ((uint64_t)mirror_index(k, t.d) * t.h + mirror_index(j, t.h)) * t.w + mirror_index(i, t.w);
+    return (mirror_index(k, t.d) * (uint32_t)t.h + mirror_index(j, t.h)) * (uint32_t)t.w + mirror_index(i, t.w);
 }
 
 // sdfSampleRawInterp(.., p).r only -- what the march and the normal need.  material.frag:42-53
-template <bool LINEAR, bool POW2>
+template <bool LINEAR, int XF, bool FAST>
 __device__ __forceinline__ float sample_r(const RaymarchArgs& a, const Tex& t, V3 p) {
-    V3 q = to_p01<POW2>(a, p);
+    V3 q = to_p01<XF>(a, p);
     const float* base = reinterpret_cast<const float*>(t.data);
     if (LINEAR) {
-        Footprint f = footprint(t, q.x, q.y, q.z);
-        float t000 = base[f.o000 * 4], t100 = base[f.o100 * 4], t010 = base[f.o010 * 4], t110 = base[f.o110 * 4];
-        float t001 = base[f.o001 * 4], t101 = base[f.o101 * 4], t011 = base[f.o011 * 4], t111 = base[f.o111 * 4];
+        Footprint f = footprint<FAST>(t, q);
+        float t000 = base[(uint64_t)f.o000 * 4], t100 = base[(uint64_t)f.o100 * 4];
+        float t010 = base[(uint64_t)f.o010 * 4], t110 = base[(uint64_t)f.o110 * 4];
+        float t001 = base[(uint64_t)f.o001 * 4], t101 = base[(uint64_t)f.o101 * 4];
+        float t011 = base[(uint64_t)f.o011 * 4], t111 = base[(uint64_t)f.o111 * 4];
         return trilerp(t000, t100, t010, t110, t001, t101, t011, t111, f.ax, f.ay, f.az);
     }
-    return base[nearest_offset(a, t, q) * 4];
+    return base[(uint64_t)nearest_offset(a, t, q) * 4];
 }
 
-template <bool LINEAR, bool POW2>
+template <bool LINEAR, int XF, bool FAST>
 __device__ __forceinline__ float4 sample_rgba(const RaymarchArgs& a, const Tex& t, V3 p) {
-    V3 q = to_p01<POW2>(a, p);
+    V3 q = to_p01<XF>(a, p);
     if (LINEAR) {
-        Footprint f = footprint(t, q.x, q.y, q.z);
+        Footprint f = footprint<FAST>(t, q);
         float4 t000 = t.data[f.o000], t100 = t.data[f.o100], t010 = t.data[f.o010], t110 = t.data[f.o110];
         float4 t001 = t.data[f.o001], t101 = t.data[f.o101], t011 = t.data[f.o011], t111 = t.data[f.o111];
         float4 r;
@@ -133,43 +149,95 @@ __device__ __forceinline__ float4 sample_rgba(const RaymarchArgs& a, const Tex& 
     return t.data[nearest_offset(a, t, q)];
 }
 
-// The march's sampler: tex0.r with a one-cell register cache.  Sphere tracing takes its smallest steps
-// exactly on the longest rays (grazing a surface), so consecutive samples usually fall in the same
-// texel cell: the 8 corner values are kept in registers and re-fetched only when floor(u,v,w) changes.
-// Values and operation order are those of sample_r(); only redundant loads are skipped.
-struct CellCache {
-    float fu, fv, fw;  // floor of the unnormalised texel coordinates of the cached cell
-    float t000, t100, t010, t110, t001, t101, t011, t111;
-};
-
-template <bool POW2>
-__device__ __forceinline__ float march_sample(const RaymarchArgs& a, const Tex& t, V3 p, CellCache& c) {
-    V3 q = to_p01<POW2>(a, p);
-    float u = q.x * (float)t.w - 0.5f, v = q.y * (float)t.h - 0.5f, w = q.z * (float)t.d - 0.5f;
-    float fu = floorf(u), fv = floorf(v), fw = floorf(w);
-    float ax = u - fu, ay = v - fv, az = w - fw;
-    if (fu != c.fu || fv != c.fv || fw != c.fw) {
-        c.fu = fu; c.fv = fv; c.fw = fw;
-        int i0 = (int)fu, j0 = (int)fv, k0 = (int)fw;
-        uint32_t i0m = mirror_index(i0, t.w), i1m = mirror_index(i0 + 1, t.w);
-        uint32_t j0m = mirror_index(j0, t.h) * (uint32_t)t.w, j1m = mirror_index(j0 + 1, t.h) * (uint32_t)t.w;
-        uint64_t slice = (uint64_t)t.w * t.h;
-        const float* b0 = reinterpret_cast<const float*>(t.data + mirror_index(k0, t.d) * slice);
-        const float* b1 = reinterpret_cast<const float*>(t.data + mirror_index(k0 + 1, t.d) * slice);
-        c.t000 = b0[(j0m + i0m) * 4u]; c.t100 = b0[(j0m + i1m) * 4u];
-        c.t010 = b0[(j1m + i0m) * 4u]; c.t110 = b0[(j1m + i1m) * 4u];
-        c.t001 = b1[(j0m + i0m) * 4u]; c.t101 = b1[(j0m + i1m) * 4u];
-        c.t011 = b1[(j1m + i0m) * 4u]; c.t111 = b1[(j1m + i1m) * 4u];
-    }
-    return trilerp(c.t000, c.t100, c.t010, c.t110, c.t001, c.t101, c.t011, c.t111, ax, ay, az);
-}
-
-// sdfOutOfBoundsDist, material.frag:83-88
+// sdfOutOfBoundsDist, material.frag:83-88.  SYMM: sdfBoundsMin == -sdfBoundsMax (the demo's box); then
+// max(min - p, p - max) == |p| - max exactly (the larger operand is always the one equal to |p| - max),
+// which is one subtraction with an abs modifier per axis instead of two subtractions and a max.
+template <bool SYMM>
 __device__ __forceinline__ float oob_dist(const RaymarchArgs& a, V3 p) {
+    if (SYMM) {
+        return fmaxf(fabsf(p.x) - a.rp.bounds_max[0],
+                     fmaxf(fabsf(p.y) - a.rp.bounds_max[1], fabsf(p.z) - a.rp.bounds_max[2]));
+    }
     float ox = fmaxf(a.rp.bounds_min[0] - p.x, p.x - a.rp.bounds_max[0]);
     float oy = fmaxf(a.rp.bounds_min[1] - p.y, p.y - a.rp.bounds_max[1]);
     float oz = fmaxf(a.rp.bounds_min[2] - p.z, p.z - a.rp.bounds_max[2]);
     return fmaxf(ox, fmaxf(oy, oz));
+}
+
+// sdfRaycast's loop (material.frag:97-126) for the LINEAR filter, with everything the loop does not need
+// taken out of it.  Per iteration and lane: out-of-bounds test, texel coordinates, (re)fetch, trilinear
+// mix, hit test, advance.
+//  * Predicated straight-line code with ONE branch (the re-fetch): lanes that stopped no longer commit
+//    results, so the wave does not pay exec-mask bookkeeping for the shader's nested if/else.
+//  * One-cell register cache: sphere tracing takes its smallest steps exactly on the longest rays
+//    (grazing a surface), so consecutive samples usually fall in the same texel cell; the 8 corner values
+//    live in registers and are re-fetched only when floor(u,v,w) changes.
+//  * MirroredRepeat needs no modulo: a marching ray is within 1e-4 of the box, hence (the launcher checks
+//    1e-4 * N / size <= 0.25 per axis before selecting this kernel) floor(u) is in [-1, N-1], where
+//    mirror(i) == clamp(i, 0, N-1).
+//  * XF == 2: extents AND texture sizes are powers of two, so ((p-min)*inv)*N == (p-min)*(inv*N) exactly.
+//  * No per-iteration status/step counters: a stopped lane's ray_pos no longer moves, so afterwards
+//    "out of bounds" is re-derived from it (oob(ray_pos) > 1e-4 <=> it stopped on that test), and the
+//    step count is 1 + the last iteration the lane sampled in.
+//  * STRIDE = 4 reads tex0.r in place, STRIDE = 1 the compact distance volume (sdfv_commit_distance).
+//  * T: accumulate distanceFromOrigin (only the aux record consumes it).
+// Values and operation order are exactly those of sample_r() / the oracle; only redundant work is skipped.
+template <int XF, bool SYMM, int STRIDE, bool T>
+__device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* __restrict__ vol, const Tex& t,
+                                           V3 ray_dir, bool covered, V3& ray_pos, float& dist_from_origin,
+                                           int& status, int& steps, int& iterations) {
+    const float fw_ = (float)t.w, fh_ = (float)t.h, fd_ = (float)t.d;
+    const float kx = a.inv_bsize[0] * fw_, ky = a.inv_bsize[1] * fh_, kz = a.inv_bsize[2] * fd_;  // exact if XF == 2
+    const int wm1 = t.w - 1, hm1 = t.h - 1, dm1 = t.d - 1;
+    const uint32_t sy = (uint32_t)t.w, sz = (uint32_t)t.w * (uint32_t)t.h;
+    bool marching = covered;
+    int last_i = -1;
+    float cfu = -4.0f, cfv = -4.0f, cfw = -4.0f;  // never a valid floor(u) of a marching lane
+    float t000 = 0.0f, t100 = 0.0f, t010 = 0.0f, t110 = 0.0f, t001 = 0.0f, t101 = 0.0f, t011 = 0.0f, t111 = 0.0f;
+    for (int i = 0; i < 255; ++i) {
+        // Stop condition: out of bounds (material.frag:106-109)
+        marching = marching && !(oob_dist<SYMM>(a, ray_pos) > 1e-4f);
+        if (__ballot(marching) == 0ull) break;  // wave-level early termination
+        ++iterations;
+        last_i = marching ? i : last_i;
+        float u, v, w;
+        if (XF == 2) {
+            u = (ray_pos.x - a.rp.bounds_min[0]) * kx - 0.5f;
+            v = (ray_pos.y - a.rp.bounds_min[1]) * ky - 0.5f;
+            w = (ray_pos.z - a.rp.bounds_min[2]) * kz - 0.5f;
+        } else {
+            const V3 q = to_p01<XF>(a, ray_pos);
+            u = q.x * fw_ - 0.5f; v = q.y * fh_ - 0.5f; w = q.z * fd_ - 0.5f;
+        }
+        const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
+        const float ax = u - fu, ay = v - fv, az = w - fw;
+        if (marching && (fu != cfu || fv != cfv || fw != cfw)) {
+            cfu = fu; cfv = fv; cfw = fw;
+            const int i0 = (int)fu, j0 = (int)fv, k0 = (int)fw;
+            const uint32_t i0c = (uint32_t)max(i0, 0), i1c = (uint32_t)min(i0 + 1, wm1);
+            const uint32_t j0c = (uint32_t)max(j0, 0) * sy, j1c = (uint32_t)min(j0 + 1, hm1) * sy;
+            const uint32_t k0c = (uint32_t)max(k0, 0) * sz, k1c = (uint32_t)min(k0 + 1, dm1) * sz;
+            const uint32_t r00 = k0c + j0c, r10 = k0c + j1c, r01 = k1c + j0c, r11 = k1c + j1c;
+            t000 = vol[(uint64_t)(r00 + i0c) * STRIDE]; t100 = vol[(uint64_t)(r00 + i1c) * STRIDE];
+            t010 = vol[(uint64_t)(r10 + i0c) * STRIDE]; t110 = vol[(uint64_t)(r10 + i1c) * STRIDE];
+            t001 = vol[(uint64_t)(r01 + i0c) * STRIDE]; t101 = vol[(uint64_t)(r01 + i1c) * STRIDE];
+            t011 = vol[(uint64_t)(r11 + i0c) * STRIDE]; t111 = vol[(uint64_t)(r11 + i1c) * STRIDE];
+        }
+        const float sample_dist = trilerp(t000, t100, t010, t110, t001, t101, t011, t111, ax, ay, az) - 1e-1f;
+        // Stop condition: actually hit the surface (material.frag:117-121)
+        marching = marching && !(sample_dist < 1e-5f);
+        // Move the ray forward by the minimum distance to the surface (material.frag:124-125)
+        const V3 np = madd(ray_pos, ray_dir, sample_dist);
+        ray_pos.x = marching ? np.x : ray_pos.x;
+        ray_pos.y = marching ? np.y : ray_pos.y;
+        ray_pos.z = marching ? np.z : ray_pos.z;
+        if (T) {
+            const float nt = dist_from_origin + sample_dist;
+            dist_from_origin = marching ? nt : dist_from_origin;
+        }
+    }
+    steps = last_i + 1;
+    if (covered) status = marching ? -1 : (oob_dist<SYMM>(a, ray_pos) > 1e-4f ? -2 : 1);
 }
 
 // three-d 0.18.2 tone_mapping / color_mapping (material.frag:167-168) [not vendored in the reference]
@@ -208,8 +276,32 @@ __device__ __forceinline__ float4 shade(const RaymarchArgs& a, float4 raw0, floa
     return make_float4(out[0], out[1], out[2], a.rp.tint[3]);
 }
 
-template <bool LINEAR, bool POW2>
+__device__ __forceinline__ void aux_clear(sdfv_march_aux& aux) {
+    aux.status = 0; aux.steps = 0;
+    aux.hit_pos[0] = aux.hit_pos[1] = aux.hit_pos[2] = 0.0f;
+    aux.t = 0.0f;
+    aux.raw0[0] = aux.raw0[1] = aux.raw0[2] = aux.raw0[3] = 0.0f;
+    aux.raw1[0] = aux.raw1[1] = aux.raw1[2] = aux.raw1[3] = 0.0f;
+    aux.normal[0] = aux.normal[1] = aux.normal[2] = 0.0f;
+    aux.depth = 1.0f;
+}
+
+__device__ __forceinline__ void stamp_wave(const RaymarchArgs& a, uint32_t wave, unsigned long long t_start,
+                                           int iterations, unsigned long long covered_mask) {
+    const uint64_t wave_id = ((uint64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
+    a.wave_timing[wave_id * 4 + 0] = t_start;
+    a.wave_timing[wave_id * 4 + 1] = __builtin_readcyclecounter();
+    a.wave_timing[wave_id * 4 + 2] = (unsigned long long)iterations;
+    a.wave_timing[wave_id * 4 + 3] = covered_mask;
+}
+
+// MODE: 0 = general kernel (any filter, any extents: the shader's nested loop with full MirroredRepeat);
+//       1 = fast march over tex0.r; 2 = fast march over the compact distance volume (both LINEAR only).
+// XF:   0 = IEEE divide, 1 = exact power-of-two reciprocal, 2 = power-of-two extents and texture sizes.
+// AUX:  the per-pixel march record is stored (and distanceFromOrigin accumulated).
+template <int MODE, bool LINEAR, int XF, bool SYMM, bool AUX>
 __global__ __launch_bounds__(256) void raymarch_kernel(RaymarchArgs a) {
+    constexpr bool FAST = MODE != 0;
     // 8x8 pixel tile per wave, 2x2 waves per workgroup
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
@@ -218,125 +310,178 @@ __global__ __launch_bounds__(256) void raymarch_kernel(RaymarchArgs a) {
     const uint32_t cam_idx = blockIdx.z;
     const bool in_image = px < a.width && py < a.y1;
     const sdfv_camera& cam = a.cameras[cam_idx];
-    const Tex tex0{a.tex0, (int)a.rp.tex_size[0], (int)a.rp.tex_size[1], (int)a.rp.tex_size[2]};
-    const Tex tex1{a.tex1, tex0.w, tex0.h, tex0.d};
-
+    const uint64_t out_index = ((uint64_t)cam_idx * (a.y1 - a.y0) + row) * a.width + px;
     const unsigned long long t_start = a.wave_timing ? __builtin_readcyclecounter() : 0ull;
-    sdfv_march_aux aux;
-    aux.status = 0; aux.steps = 0;
-    aux.hit_pos[0] = aux.hit_pos[1] = aux.hit_pos[2] = 0.0f;
-    aux.t = 0.0f;
-    aux.raw0[0] = aux.raw0[1] = aux.raw0[2] = aux.raw0[3] = 0.0f;
-    aux.raw1[0] = aux.raw1[1] = aux.raw1[2] = aux.raw1[3] = 0.0f;
-    aux.normal[0] = aux.normal[1] = aux.normal[2] = 0.0f;
-    aux.depth = 1.0f;
-    float4 rgba = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
     // primary ray through the pixel centre (image row 0 = top)
-    float ndc_x = (((float)px + 0.5f) / (float)a.width) * 2.0f - 1.0f;
-    float ndc_y = 1.0f - (((float)py + 0.5f) / (float)a.height) * 2.0f;
-    float sx = ndc_x * cam.aspect * cam.tan_half_fovy;
-    float sy = ndc_y * cam.tan_half_fovy;
-    V3 eye = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
-    V3 d0 = normalize(mk(cam.forward[0] + cam.right[0] * sx + cam.up[0] * sy,
-                         cam.forward[1] + cam.right[1] * sx + cam.up[1] * sy,
-                         cam.forward[2] + cam.right[2] * sx + cam.up[2] * sy));
+    const float ndc_x = (((float)px + 0.5f) / (float)a.width) * 2.0f - 1.0f;
+    const float ndc_y = 1.0f - (((float)py + 0.5f) / (float)a.height) * 2.0f;
+    const float sx = ndc_x * cam.aspect * cam.tan_half_fovy;
+    const float sy = ndc_y * cam.tan_half_fovy;
+    const V3 eye = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
+    const V3 d_raw = mk(cam.forward[0] + cam.right[0] * sx + cam.up[0] * sy,
+                        cam.forward[1] + cam.right[1] * sx + cam.up[1] * sy,
+                        cam.forward[2] + cam.right[2] * sx + cam.up[2] * sy);
+
+    // Conservative tile cull (the reference gets it from rasterising the box).  A ray that misses the box's
+    // bounding sphere inflated by 1 % cannot be covered; if no lane of the wave can be covered, the wave
+    // writes its transparent pixels and leaves before the divisions of the exact slab test.
+    {
+        const V3 m = sub(eye, mk(a.cull_center[0], a.cull_center[1], a.cull_center[2]));
+        const float dd = d_raw.x * d_raw.x + d_raw.y * d_raw.y + d_raw.z * d_raw.z;
+        const float mm = m.x * m.x + m.y * m.y + m.z * m.z;
+        const float md = m.x * d_raw.x + m.y * d_raw.y + m.z * d_raw.z;
+        const float r2 = a.cull_radius2;
+        const bool miss = mm > r2 && (md >= 0.0f || mm * dd - md * md > r2 * dd);
+        if (__ballot(in_image && !miss) == 0ull) {
+            if (in_image) {
+                a.rgba[out_index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (AUX) {
+                    sdfv_march_aux aux;
+                    aux_clear(aux);
+                    a.aux[out_index] = aux;
+                }
+            }
+            if (a.wave_timing && lane == 0) stamp_wave(a, wave, t_start, 0, 0ull);
+            return;
+        }
+    }
+
+    const Tex tex0{a.tex0, (int)a.rp.tex_size[0], (int)a.rp.tex_size[1], (int)a.rp.tex_size[2]};
+    const Tex tex1{a.tex1, tex0.w, tex0.h, tex0.d};
+    const V3 d0 = normalize(d_raw);
 
     // bbox fragment via slab test
-    float tx1 = (a.rp.bounds_min[0] - eye.x) / d0.x, tx2 = (a.rp.bounds_max[0] - eye.x) / d0.x;
-    float ty1 = (a.rp.bounds_min[1] - eye.y) / d0.y, ty2 = (a.rp.bounds_max[1] - eye.y) / d0.y;
-    float tz1 = (a.rp.bounds_min[2] - eye.z) / d0.z, tz2 = (a.rp.bounds_max[2] - eye.z) / d0.z;
-    float tnear = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
-    float tfar = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+    const float tx1 = (a.rp.bounds_min[0] - eye.x) / d0.x, tx2 = (a.rp.bounds_max[0] - eye.x) / d0.x;
+    const float ty1 = (a.rp.bounds_min[1] - eye.y) / d0.y, ty2 = (a.rp.bounds_max[1] - eye.y) / d0.y;
+    const float tz1 = (a.rp.bounds_min[2] - eye.z) / d0.z, tz2 = (a.rp.bounds_max[2] - eye.z) / d0.z;
+    const float tnear = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+    const float tfar = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
     const bool covered = in_image && (tfar >= tnear && tfar > 0.0f);
-    float tfrag = tnear > 0.0f ? tnear : tfar;
-    V3 pos = madd(eye, d0, tfrag);
+    const float tfrag = tnear > 0.0f ? tnear : tfar;
+    const V3 pos = madd(eye, d0, tfrag);
 
     // main(), material.frag:133-139
     V3 ray_origin = pos;
-    V3 ray_dir = normalize(sub(ray_origin, eye));
-    if (oob_dist(a, madd(ray_origin, ray_dir, 0.2f)) > 0.0f) ray_origin = madd(eye, ray_dir, 0.2f);
+    const V3 ray_dir = normalize(sub(ray_origin, eye));
+    if (oob_dist<false>(a, madd(ray_origin, ray_dir, 0.2f)) > 0.0f) ray_origin = madd(eye, ray_dir, 0.2f);
 
     // sdfRaycast(rayOrigin, rayDir, 256), material.frag:92-128
     V3 ray_pos = ray_origin;
     float dist_from_origin = 0.0f;
     int status = covered ? -1 : 0;  // -1 = out of steps unless something else ends the ray
     int steps = 0;
-    bool marching = covered;
     int iterations = 0;
-    CellCache cell;
-    cell.fu = cell.fv = cell.fw = -4.0f;  // never a valid floor(u): u >= -0.5 - 1e-4 * N while marching
-    cell.t000 = cell.t100 = cell.t010 = cell.t110 = cell.t001 = cell.t101 = cell.t011 = cell.t111 = 0.0f;
-    for (int i = 0; i < 255; ++i) {
-        if (__ballot(marching) == 0ull) break;  // wave-level early termination
-        ++iterations;
-        if (marching) {
-            if (oob_dist(a, ray_pos) > 1e-4f) {
-                status = -2;
-                marching = false;
-            } else {
-                float sample_dist =
-                    (LINEAR ? march_sample<POW2>(a, tex0, ray_pos, cell) : sample_r<false, POW2>(a, tex0, ray_pos)) - 1e-1f;
-                ++steps;
-                if (sample_dist < 1e-5f) {
-                    status = 1;
+    if (MODE == 1) {
+        march_fast<XF, SYMM, 4, AUX>(a, reinterpret_cast<const float*>(a.tex0), tex0, ray_dir, covered, ray_pos,
+                                     dist_from_origin, status, steps, iterations);
+    } else if (MODE == 2) {
+        march_fast<XF, SYMM, 1, AUX>(a, a.dist, tex0, ray_dir, covered, ray_pos, dist_from_origin, status, steps,
+                                     iterations);
+    } else {
+        bool marching = covered;
+        for (int i = 0; i < 255; ++i) {
+            if (__ballot(marching) == 0ull) break;  // wave-level early termination
+            ++iterations;
+            if (marching) {
+                if (oob_dist<false>(a, ray_pos) > 1e-4f) {
+                    status = -2;
                     marching = false;
                 } else {
-                    dist_from_origin += sample_dist;
-                    ray_pos = madd(ray_pos, ray_dir, sample_dist);
+                    float sample_dist = sample_r<LINEAR, XF, false>(a, tex0, ray_pos) - 1e-1f;
+                    ++steps;
+                    if (sample_dist < 1e-5f) {
+                        status = 1;
+                        marching = false;
+                    } else {
+                        dist_from_origin += sample_dist;
+                        ray_pos = madd(ray_pos, ray_dir, sample_dist);
+                    }
                 }
             }
         }
     }
 
-    if (covered) {
-        aux.status = status;
-        aux.steps = steps;
-        aux.hit_pos[0] = ray_pos.x; aux.hit_pos[1] = ray_pos.y; aux.hit_pos[2] = ray_pos.z;
-        aux.t = dist_from_origin;
+    float4 rgba = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    sdfv_march_aux aux;
+    if (AUX) {
+        aux_clear(aux);
+        if (covered) {
+            aux.status = status;
+            aux.steps = steps;
+            aux.hit_pos[0] = ray_pos.x; aux.hit_pos[1] = ray_pos.y; aux.hit_pos[2] = ray_pos.z;
+            aux.t = dist_from_origin;
+        }
     }
     if (status == 1) {
-        float4 raw0 = sample_rgba<LINEAR, POW2>(a, tex0, ray_pos);  // == the march's last sample
-        float4 raw1 = sample_rgba<LINEAR, POW2>(a, tex1, ray_pos);  // material.frag:154
+        // The fast kernels know the hit point is within 1e-4 of the box; the normal's taps are h further out,
+        // a.fast_normal says whether floor(u) still stays in [-1, N-1] for them.
+        const float4 raw0 = sample_rgba<LINEAR, XF, FAST>(a, tex0, ray_pos);  // == the march's last sample
+        const float4 raw1 = sample_rgba<LINEAR, XF, FAST>(a, tex1, ray_pos);  // material.frag:154
         rgba = shade(a, raw0, raw1);
-        if (a.aux || a.compute_normal) {
+        if (AUX || a.compute_normal) {
             // sdfNormal, material.frag:73-80
-            float sxn = (float)tex0.w / a.rp.lod_dist_between_samples;
-            float syn = (float)tex0.h / a.rp.lod_dist_between_samples;
-            float szn = (float)tex0.d / a.rp.lod_dist_between_samples;
-            float h = 1.0f / sqrtf(sxn * sxn + syn * syn + szn * szn);
-            float d1 = sample_r<LINEAR, POW2>(a, tex0, mk(ray_pos.x + h, ray_pos.y - h, ray_pos.z - h)) - 1e-1f;  // k.xyy
-            float d2 = sample_r<LINEAR, POW2>(a, tex0, mk(ray_pos.x - h, ray_pos.y - h, ray_pos.z + h)) - 1e-1f;  // k.yyx
-            float d3 = sample_r<LINEAR, POW2>(a, tex0, mk(ray_pos.x - h, ray_pos.y + h, ray_pos.z - h)) - 1e-1f;  // k.yxy
-            float d4 = sample_r<LINEAR, POW2>(a, tex0, mk(ray_pos.x + h, ray_pos.y + h, ray_pos.z + h)) - 1e-1f;  // k.xxx
-            V3 n = normalize(mk(d1 + -d2 + -d3 + d4, -d1 + -d2 + d3 + d4, -d1 + d2 + -d3 + d4));
-            // gl_FragDepth, material.frag:180-181
-            const float* m = cam.bvp;
-            float hz = m[2] * ray_pos.x + m[6] * ray_pos.y + m[10] * ray_pos.z + m[14];
-            float hw = m[3] * ray_pos.x + m[7] * ray_pos.y + m[11] * ray_pos.z + m[15];
-            aux.raw0[0] = raw0.x; aux.raw0[1] = raw0.y; aux.raw0[2] = raw0.z; aux.raw0[3] = raw0.w;
-            aux.raw1[0] = raw1.x; aux.raw1[1] = raw1.y; aux.raw1[2] = raw1.z; aux.raw1[3] = raw1.w;
-            aux.normal[0] = n.x; aux.normal[1] = n.y; aux.normal[2] = n.z;
-            aux.depth = hz / hw;
-            if (a.compute_normal && !a.aux) {
-                // keep the normal live when nobody stores it, as the shader text computes it per hit
+            const float sxn = (float)tex0.w / a.rp.lod_dist_between_samples;
+            const float syn = (float)tex0.h / a.rp.lod_dist_between_samples;
+            const float szn = (float)tex0.d / a.rp.lod_dist_between_samples;
+            const float h = 1.0f / sqrtf(sxn * sxn + syn * syn + szn * szn);
+            const V3 p1 = mk(ray_pos.x + h, ray_pos.y - h, ray_pos.z - h);  // k.xyy
+            const V3 p2 = mk(ray_pos.x - h, ray_pos.y - h, ray_pos.z + h);  // k.yyx
+            const V3 p3 = mk(ray_pos.x - h, ray_pos.y + h, ray_pos.z - h);  // k.yxy
+            const V3 p4 = mk(ray_pos.x + h, ray_pos.y + h, ray_pos.z + h);  // k.xxx
+            float d1, d2, d3, d4;
+            if (FAST && a.fast_normal) {
+                d1 = sample_r<LINEAR, XF, true>(a, tex0, p1) - 1e-1f;
+                d2 = sample_r<LINEAR, XF, true>(a, tex0, p2) - 1e-1f;
+                d3 = sample_r<LINEAR, XF, true>(a, tex0, p3) - 1e-1f;
+                d4 = sample_r<LINEAR, XF, true>(a, tex0, p4) - 1e-1f;
+            } else {
+                d1 = sample_r<LINEAR, XF, false>(a, tex0, p1) - 1e-1f;
+                d2 = sample_r<LINEAR, XF, false>(a, tex0, p2) - 1e-1f;
+                d3 = sample_r<LINEAR, XF, false>(a, tex0, p3) - 1e-1f;
+                d4 = sample_r<LINEAR, XF, false>(a, tex0, p4) - 1e-1f;
+            }
+            const V3 n = normalize(mk(d1 + -d2 + -d3 + d4, -d1 + -d2 + d3 + d4, -d1 + d2 + -d3 + d4));
+            if (AUX) {
+                // gl_FragDepth, material.frag:180-181
+                const float* m = cam.bvp;
+                const float hz = m[2] * ray_pos.x + m[6] * ray_pos.y + m[10] * ray_pos.z + m[14];
+                const float hw = m[3] * ray_pos.x + m[7] * ray_pos.y + m[11] * ray_pos.z + m[15];
+                aux.raw0[0] = raw0.x; aux.raw0[1] = raw0.y; aux.raw0[2] = raw0.z; aux.raw0[3] = raw0.w;
+                aux.raw1[0] = raw1.x; aux.raw1[1] = raw1.y; aux.raw1[2] = raw1.z; aux.raw1[3] = raw1.w;
+                aux.normal[0] = n.x; aux.normal[1] = n.y; aux.normal[2] = n.z;
+                aux.depth = hz / hw;
+            } else {
+                // keep the normal live when nobody stores it: the shader text computes it per hit
                 asm volatile("" ::"v"(n.x), "v"(n.y), "v"(n.z));
             }
         }
     }
 
-    if (a.wave_timing && lane == 0) {
-        const uint64_t wave_id = ((uint64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
-        a.wave_timing[wave_id * 4 + 0] = t_start;
-        a.wave_timing[wave_id * 4 + 1] = __builtin_readcyclecounter();
-        a.wave_timing[wave_id * 4 + 2] = (unsigned long long)iterations;
-        a.wave_timing[wave_id * 4 + 3] = (unsigned long long)__ballot(covered);
-    }
+    if (a.wave_timing && lane == 0) stamp_wave(a, wave, t_start, iterations, __ballot(covered));
     if (in_image) {
-        const uint64_t o = ((uint64_t)cam_idx * (a.y1 - a.y0) + row) * a.width + px;
-        a.rgba[o] = rgba;
-        if (a.aux) a.aux[o] = aux;
+        a.rgba[out_index] = rgba;
+        if (AUX) a.aux[out_index] = aux;
     }
+}
+
+template <int MODE, bool LINEAR, int XF, bool SYMM>
+void launch_aux(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
+    if (a.aux)
+        hipLaunchKernelGGL((raymarch_kernel<MODE, LINEAR, XF, SYMM, true>), grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((raymarch_kernel<MODE, LINEAR, XF, SYMM, false>), grid, dim3(256), 0, stream, a);
+}
+
+template <int MODE>
+void launch_fast(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
+    const int xf = a.pow2_extent ? (a.pow2_size ? 2 : 1) : 0;
+    const bool symm = a.symmetric_box != 0;
+    if (xf == 2 && symm) launch_aux<MODE, true, 2, true>(a, grid, stream);
+    else if (xf == 2) launch_aux<MODE, true, 2, false>(a, grid, stream);
+    else if (xf == 1 && symm) launch_aux<MODE, true, 1, true>(a, grid, stream);
+    else if (xf == 1) launch_aux<MODE, true, 1, false>(a, grid, stream);
+    else launch_aux<MODE, true, 0, false>(a, grid, stream);
 }
 
 }  // namespace
@@ -346,14 +491,16 @@ hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream) {
     if (a.width == 0 || rows == 0 || a.n_cameras == 0) return hipSuccess;
     dim3 grid((a.width + 15) / 16, (rows + 15) / 16, a.n_cameras);
     const bool linear = a.rp.lod_dist_between_samples == 1.0f;
-    if (linear && a.pow2_extent)
-        hipLaunchKernelGGL((raymarch_kernel<true, true>), grid, dim3(256), 0, stream, a);
-    else if (linear)
-        hipLaunchKernelGGL((raymarch_kernel<true, false>), grid, dim3(256), 0, stream, a);
-    else if (a.pow2_extent)
-        hipLaunchKernelGGL((raymarch_kernel<false, true>), grid, dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL((raymarch_kernel<false, false>), grid, dim3(256), 0, stream, a);
+    if (linear && a.fast_index) {
+        if (a.dist) launch_fast<2>(a, grid, stream);
+        else launch_fast<1>(a, grid, stream);
+    } else if (linear) {
+        if (a.pow2_extent) launch_aux<0, true, 1, false>(a, grid, stream);
+        else launch_aux<0, true, 0, false>(a, grid, stream);
+    } else {
+        if (a.pow2_extent) launch_aux<0, false, 1, false>(a, grid, stream);
+        else launch_aux<0, false, 0, false>(a, grid, stream);
+    }
     return hipGetLastError();
 }
 

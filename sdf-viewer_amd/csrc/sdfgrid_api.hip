@@ -288,29 +288,68 @@ int sdfv_normal_points(const sdfv_demo_params* params, uint32_t sdf_id, const fl
     return SDFV_OK;
 }
 
+int sdfv_commit_distance(const sdfv_grid* grid, const float* tex0, float* dist, void* stream) {
+    if (int rc = check_grid(grid)) return rc;
+    if (!tex0 || !dist) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (int rc = need_device()) return rc;
+    const uint64_t n = (uint64_t)grid->dims[0] * grid->dims[1] * (grid->z_end - grid->z_begin);
+    SDFV_HIP(sdfv::launch_commit_distance(tex0, dist, n, (hipStream_t)stream));
+    return SDFV_OK;
+}
+
 int sdfv_raymarch(const sdfv_render_params* rp, const float* tex0, const float* tex1, const sdfv_camera* cameras,
                   uint32_t n_cameras, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, float* rgba,
                   sdfv_march_aux* aux, void* stream) {
+    return sdfv_raymarch_accel(rp, tex0, tex1, nullptr, cameras, n_cameras, width, height, y0, y1, rgba, aux, stream);
+}
+
+int sdfv_raymarch_accel(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
+                        const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width, uint32_t height, uint32_t y0,
+                        uint32_t y1, float* rgba, sdfv_march_aux* aux, void* stream) {
     if (!rp || !tex0 || !tex1 || !rgba) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n_cameras && !cameras) return fail(SDFV_ERR_INVALID_ARGUMENT, "cameras is NULL");
     if (y0 > y1 || y1 > height) return fail(SDFV_ERR_INVALID_ARGUMENT, "rows [%u,%u) outside height %u", y0, y1, height);
     if (rp->tex_size[0] == 0 || rp->tex_size[1] == 0 || rp->tex_size[2] == 0)
         return fail(SDFV_ERR_INVALID_ARGUMENT, "empty texture");
     if (!(rp->lod_dist_between_samples >= 1.0f)) return fail(SDFV_ERR_INVALID_ARGUMENT, "lod_dist_between_samples < 1");
-    if ((uint64_t)rp->tex_size[0] * rp->tex_size[1] >= (1ull << 30) || rp->tex_size[2] >= (1u << 30))
-        return fail(SDFV_ERR_INVALID_ARGUMENT, "texture slice too large for 32-bit texel indexing");
+    if ((uint64_t)rp->tex_size[0] * rp->tex_size[1] * rp->tex_size[2] >= (1ull << 32))
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "texture too large for 32-bit texel indexing");
     if (int rc = need_device()) return rc;
     sdfv::RaymarchArgs a;
     memset(&a, 0, sizeof(a));
     a.rp = *rp;
     a.pow2_extent = getenv("SDFV_RAYMARCH_NO_POW2") ? 0u : 1u;
+    a.fast_index = getenv("SDFV_RAYMARCH_GENERAL") ? 0u : 1u;
+    a.pow2_size = 1;
+    a.symmetric_box = 1;
+    a.fast_normal = 1;
+    a.dist = dist;
+    float inv_h2 = 0.0f, radius2 = 0.0f;
+    for (int i = 0; i < 3; ++i) {
+        const float s = (float)rp->tex_size[i] / rp->lod_dist_between_samples;
+        inv_h2 += s * s;
+    }
+    const float h_world = 1.0f / sqrtf(inv_h2);  // sdfNormal's tap offset, material.frag:74
     for (int i = 0; i < 3; ++i) {
         a.bsize[i] = rp->bounds_max[i] - rp->bounds_min[i];
         a.inv_bsize[i] = 1.0f / a.bsize[i];
+        const float n = (float)rp->tex_size[i];
+        // a marching ray stays within 1e-4 of the box (material.frag:106): floor(u) in [-1, N-1] needs
+        // 1e-4 * N / size well below 0.5; the normal's taps sit h_world further out
+        if (!(a.bsize[i] > 0.0f) || !(1e-4f * n / a.bsize[i] <= 0.25f)) a.fast_index = 0;
+        if (!(a.bsize[i] > 0.0f) || !((1e-4f + h_world) * n / a.bsize[i] <= 0.45f)) a.fast_normal = 0;
         int e = 0;
         // x / 2^k == x * 2^-k exactly (both correctly rounded), provided 2^-k is itself normal
         if (!(a.bsize[i] > 0.0f) || frexpf(a.bsize[i], &e) != 0.5f || e < -100 || e > 100) a.pow2_extent = 0;
+        if (rp->tex_size[i] & (rp->tex_size[i] - 1)) a.pow2_size = 0;
+        if (rp->bounds_min[i] != -rp->bounds_max[i]) a.symmetric_box = 0;
+        a.cull_center[i] = 0.5f * (rp->bounds_min[i] + rp->bounds_max[i]);
+        radius2 += 0.25f * a.bsize[i] * a.bsize[i];
     }
+    a.cull_radius2 = radius2 * 1.0201f + 1e-12f;  // (1.01 r)^2
+    if (!(a.cull_radius2 > 0.0f) || !std::isfinite(a.cull_radius2)) a.cull_radius2 = INFINITY;  // never cull
+    if (getenv("SDFV_RAYMARCH_NO_SYMM")) a.symmetric_box = 0;
+    if (getenv("SDFV_RAYMARCH_NO_POW2N")) a.pow2_size = 0;
     a.tex0 = reinterpret_cast<const float4*>(tex0);
     a.tex1 = reinterpret_cast<const float4*>(tex1);
     a.width = width;

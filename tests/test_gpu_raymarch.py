@@ -4,6 +4,8 @@ Everything fully determined by in-tree reference source (hit flag, step count, h
 samples, normal, depth) must be BIT-EXACT.  The shaded RGBA goes through pow() (ACES -> sRGB), where the
 device's libm differs from the host's in the last ulps: tolerance 1e-4 (BASELINE.json north_star), stated
 against the oracle's full-fp32 restatement."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -30,19 +32,35 @@ def compare(pkg, oracle, g, t0, t1, h0, h1, cam_kw, width, height, rp_edit=None,
     if rp_edit:
         rp_edit(rp)
     cam = pkg.camera_look_at(aspect=width / height, **cam_kw)
-    rgba, aux = pkg.raymarch(rp, t0, t1, cam, width, height, y0=y0, y1=y1, want_aux=True)
-    torch.cuda.synchronize()
-    got_rgba = rgba[0].cpu().numpy()
-    got_aux = aux_to_np(oracle, aux)[0]
     orp = oracle.copy_struct(oracle.RenderParams, rp)
     ocam = oracle.copy_struct(oracle.Camera, cam)
     want_rgba, want_aux = oracle.raymarch(orp, h0, h1, ocam, width, height, y0=y0, y1=y1)
-    for field in ("status", "steps"):
-        np.testing.assert_array_equal(got_aux[field], want_aux[field], err_msg=field)
-    for field in ("hit_pos", "t", "raw0", "raw1", "normal", "depth"):
-        np.testing.assert_array_equal(got_aux[field].view(np.uint32), want_aux[field].view(np.uint32), err_msg=field)
-    assert np.abs(got_rgba - want_rgba).max() <= RGBA_TOL
-    np.testing.assert_array_equal(got_rgba[..., 3], want_rgba[..., 3])
+    dist = pkg.commit_distance(g, t0)
+    assert torch.equal(dist, t0[..., 0])
+    # every march kernel family must reproduce the oracle: the fast march (symmetric-box / fused-scale /
+    # reciprocal / divide variants) over tex0.r, the same over the compact distance volume, and the general
+    # kernel (full MirroredRepeat, the shader's nested loop)
+    env_of = {"fast": {}, "dist": {}, "general": {"SDFV_RAYMARCH_GENERAL": "1"},
+              "fast_plain": {"SDFV_RAYMARCH_NO_SYMM": "1", "SDFV_RAYMARCH_NO_POW2N": "1"},
+              "fast_div": {"SDFV_RAYMARCH_NO_SYMM": "1", "SDFV_RAYMARCH_NO_POW2": "1"}}
+    for variant, env in env_of.items():
+        os.environ.update(env)
+        try:
+            rgba, aux = pkg.raymarch(rp, t0, t1, cam, width, height, y0=y0, y1=y1, want_aux=True,
+                                     dist=dist if variant == "dist" else None)
+            torch.cuda.synchronize()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        got_rgba = rgba[0].cpu().numpy()
+        got_aux = aux_to_np(oracle, aux)[0]
+        for field in ("status", "steps"):
+            np.testing.assert_array_equal(got_aux[field], want_aux[field], err_msg=f"{variant}:{field}")
+        for field in ("hit_pos", "t", "raw0", "raw1", "normal", "depth"):
+            np.testing.assert_array_equal(got_aux[field].view(np.uint32), want_aux[field].view(np.uint32),
+                                          err_msg=f"{variant}:{field}")
+        assert np.abs(got_rgba - want_rgba).max() <= RGBA_TOL, variant
+        np.testing.assert_array_equal(got_rgba[..., 3], want_rgba[..., 3])
     return got_rgba, got_aux
 
 
@@ -87,6 +105,19 @@ def test_other_sdf_params_and_shading_options(pkg, oracle):
         rp.color_mapping = 0
 
     compare(pkg, oracle, *env, cam_kw={}, width=80, height=60, rp_edit=edit2)
+
+
+def test_tiny_bbox_disables_fast_index(pkg, oracle):
+    """A box so small that 1e-4 (the shader's absolute OOB epsilon) spans several texels: rays march outside
+    [0,1] in texture space and MirroredRepeat really mirrors; the launcher must fall back to the general kernel."""
+    bb = ((-1e-3, -1e-3, -1e-3), (1e-3, 1e-3, 1e-3))
+    prm = pkg.default_params(cube_half_side=0.95e-3, sphere_radius=1.05e-3, max_distance_custom_material=0.05e-3)
+    g = pkg.make_grid((24, 24, 24), *bb)
+    t0, t1 = pkg.alloc_textures(g)
+    pkg.fill_grid(prm, g, t0, t1)
+    torch.cuda.synchronize()
+    compare(pkg, oracle, g, t0, t1, t0.cpu().numpy(), t1.cpu().numpy(),
+            cam_kw=dict(eye=(2.5e-3, 3e-3, 5e-3), z_near=1e-5), width=64, height=64)
 
 
 def test_loading_lod_nearest_path(pkg, oracle):

@@ -10,10 +10,11 @@ t0, t1 = pkg.alloc_textures(g); pkg.fill_grid(prm, g, t0, t1)
 rp = pkg.default_render_params(g); cam = pkg.camera_look_at(aspect=W / H)
 n_waves = ((W + 15) // 16) * ((H + 15) // 16) * 4
 buf = torch.zeros((n_waves, 4), dtype=torch.int64, device="cuda")
-for _ in range(3): pkg.raymarch(rp, t0, t1, cam, W, H)
+dist = pkg.commit_distance(g, t0) if "--dist" in sys.argv else None
+for _ in range(3): pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist)
 os.environ["SDFV_RAYMARCH_WAVE_TIMING"] = hex(buf.data_ptr())
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-a.record(); pkg.raymarch(rp, t0, t1, cam, W, H); b.record(); torch.cuda.synchronize()
+a.record(); pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist); b.record(); torch.cuda.synchronize()
 d = buf.cpu().numpy()
 start, end, it = d[:, 0], d[:, 1], d[:, 2]
 t00 = start.min(); dur = end - start
