@@ -81,41 +81,39 @@ __global__ __launch_bounds__(kBlock) void fill_dense_kernel(FillArgs a) {
     store_texel<NT>(a.tex1 + o, v1);
 }
 
-struct GlobalLut {
-    __device__ __forceinline__ float operator[](uint32_t i) const { return c_srgb_lut[i]; }
-};
-
-// One LoadingManager pass: thread per visited voxel (x, y, z multiples of `step`; z is GLOBAL).
+// One LoadingManager pass: one thread per visited voxel (x, y, z multiples of `step`; z is GLOBAL), workgroups in
+// memory order like the dense kernel.  Reads tex0.r for update_required (scene/sdf/mod.rs:184-190) and, when an
+// update is required, rewrites tex0 (16 B) and tex1.rgb (12 B: tex1.a is not update()'s to touch).
 __global__ __launch_bounds__(kBlock) void fill_pass_kernel(FillArgs a, PassArgs p) {
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = c_srgb_lut[threadIdx.x];
+    __syncthreads();
+    const LdsLut lut{s_lut};
     const uint64_t n = (uint64_t)p.nx * p.ny * p.nz;
-    const GlobalLut lut{};
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-        const uint32_t ix = (uint32_t)(i % p.nx);
-        const uint64_t r = i / p.nx;
-        const uint32_t iy = (uint32_t)(r % p.ny), iz = (uint32_t)(r / p.ny);
-        const uint32_t x = ix * p.step, y = iy * p.step, z = p.z_first + iz * p.step;  // global z
-        const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
-        const float py = voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]);
-        const float pz = voxel_coord(z, a.dm1[2], a.bb_size[2], a.bb_min[2]);
-        const uint64_t flat = ((uint64_t)(z - a.z_begin) * a.H + y) * a.W + x;
-        // update_required, scene/sdf/mod.rs:184-190
-        bool update_required = a.tex0[flat].x == a.air_dist;
-        if (p.has_box) {
-            update_required = update_required ||
-                              (px >= p.box[0] && px <= p.box[3] && py >= p.box[1] && py <= p.box[4] &&
-                               pz >= p.box[2] && pz <= p.box[5]);
-        }
-        if (!update_required) continue;
-        Sample s = demo_sample(a.prm, a.sdf_id, px, py, pz, false);
-        float4 v0, v1;
-        pack_sample(s, lut, a.air_dist, v0, v1);
-        a.tex0[flat] = v0;
-        // tex1.a is not written by update(): store 12 bytes only
-        float* t1 = reinterpret_cast<float*>(a.tex1 + flat);
-        t1[0] = v1.x;
-        t1[1] = v1.y;
-        t1[2] = v1.z;
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ix = (uint32_t)(i % p.nx);
+    const uint32_t r = (uint32_t)(i / p.nx);
+    const uint32_t iz = r / p.ny, iy = r - iz * p.ny;
+    const uint32_t x = ix * p.step, y = iy * p.step, z = p.z_first + iz * p.step;  // global z
+    const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
+    const float py = voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]);
+    const float pz = voxel_coord(z, a.dm1[2], a.bb_size[2], a.bb_min[2]);
+    const uint64_t flat = ((uint64_t)(z - a.z_begin) * a.H + y) * a.W + x;
+    bool update_required = a.tex0[flat].x == a.air_dist;
+    if (p.has_box) {
+        update_required = update_required ||
+                          (px >= p.box[0] && px <= p.box[3] && py >= p.box[1] && py <= p.box[4] &&
+                           pz >= p.box[2] && pz <= p.box[5]);
     }
+    if (!update_required) return;
+    float4 v0, v1;
+    fill_voxel<RuntimeCfg>(a.prm, a.sdf_id, px, py, pz, lut, a.air_dist, v0, v1);
+    a.tex0[flat] = v0;
+    float* t1 = reinterpret_cast<float*>(a.tex1 + flat);
+    t1[0] = v1.x;
+    t1[1] = v1.y;
+    t1[2] = v1.z;
 }
 
 __global__ __launch_bounds__(kBlock) void grid_init_kernel(float4* tex0, float4* tex1, uint64_t n, float air) {
@@ -173,8 +171,8 @@ hipError_t launch_fill_dense(const FillArgs& a, const FillLaunch& cfg, hipStream
 hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& p, hipStream_t stream) {
     const uint64_t n = (uint64_t)p.nx * p.ny * p.nz;
     if (n == 0) return hipSuccess;
-    uint64_t blocks = (n + kBlock - 1) / kBlock;
-    if (blocks > 8192) blocks = 8192;
+    const uint64_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(fill_pass_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, stream, a, p);
     return hipGetLastError();
 }

@@ -103,6 +103,7 @@ class SDFViewer {
    private:
     SDFViewer(std::array<size_t, 3> voxels, const BoundingBox& bb, size_t passes);
     std::string error_;
+    bool fresh_ = true;  // both textures still hold new_voxels' AIR_DIST everywhere
 };
 
 }  // namespace sdfviewer

@@ -31,6 +31,29 @@ def test_viewer_full_load_matches_dense_oracle(host, oracle):
     np.testing.assert_array_equal(t1.view(np.uint32), r1.view(np.uint32))
 
 
+def test_viewer_dense_shortcut_equals_pass_by_pass(host, oracle):
+    """A fresh grid with a real time budget is finished with the dense kernel; the result, the iteration count
+    and the manager state equal loading pass by pass (zero budget = one pass per call)."""
+    sdf = host.SDF.demo("-s", "0.9")
+    dims = (37, 20, 29)
+    a = host.Viewer.new_voxels(dims, [-1, -1, -1, 1, 1, 1], 3)
+    b = host.Viewer.new_voxels(dims, [-1, -1, -1, 1, 1, 1], 3)
+    na = a.update(sdf, 0.030)
+    nb = 0
+    while True:
+        n = b.update(sdf, 0.0)
+        if n == 0:
+            break
+        nb += n
+    assert na == nb and a.remaining() == b.remaining() == 0
+    a.commit()
+    b.commit()
+    assert a.lod() == b.lod() == 1.0
+    for x, y in zip(a.download(), b.download()):
+        np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert a.update(sdf, 0.030) == 0
+
+
 def test_viewer_progressive_states_and_lod(host, oracle):
     """A zero time budget = exactly one pass per update(): every intermediate texture state and the
     lod_dist_between_samples = 2^passes_left published by commit() follow the reference (mod.rs:226)."""

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Timing of the progressive path (sdfv_fill_grid_pass) on a 256^3 / 512^3 grid: every LoadingManager pass
+on a fresh grid, a no-op pass over a finished grid, and a changed_box refill."""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+pkg = importlib.import_module("sdf-viewer_amd")
+
+def timed(fn, setup=None, reps=5):
+    ts = []
+    for _ in range(reps):
+        if setup: setup()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return sorted(ts)[len(ts) // 2]
+
+for side in [int(s) for s in (sys.argv[1:] or ["256"])]:
+    prm = pkg.default_params(); g = pkg.make_grid((side,) * 3)
+    t0, t1 = pkg.alloc_textures(g)
+    nv = side ** 3
+    init = lambda: pkg.grid_init(g, t0, t1)
+    print(f"== {side}^3")
+    ms = timed(init); print(f"grid_init            {ms:.3f} ms  {nv * 32 / ms / 1e6:.0f} GB/s")
+    ms = timed(lambda: pkg.fill_grid(prm, g, t0, t1)); print(f"dense fill           {ms:.3f} ms  {nv / ms / 1e3:.0f} Mvox/s")
+    for step in (4, 2, 1):
+        def setup(step=step):
+            init()
+            for s in (4, 2, 1):
+                if s > step: pkg.fill_grid_pass(prm, g, s, t0, t1)
+        visited = (-(-side // step)) ** 3
+        ms = timed(lambda: pkg.fill_grid_pass(prm, g, step, t0, t1), setup)
+        print(f"pass step {step} (fresh)  {ms:.3f} ms  {visited / ms / 1e3:.0f} Mvisits/s")
+    pkg.fill_grid(prm, g, t0, t1)
+    ms = timed(lambda: pkg.fill_grid_pass(prm, g, 1, t0, t1)); print(f"pass step 1 (no-op)   {ms:.3f} ms  {nv / ms / 1e3:.0f} Mvisits/s  {nv * 4 / ms / 1e6:.0f} GB/s algorithmic read")
+    box = (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5)
+    ms = timed(lambda: pkg.fill_grid_pass(prm, g, 1, t0, t1, changed_box=box)); print(f"pass step 1 (box 1/8) {ms:.3f} ms")
+    tot = timed(lambda: [pkg.fill_grid_pass(prm, g, s, t0, t1) for s in (2, 1)], init)
+    print(f"default 2-pass load  {tot:.3f} ms  {nv / tot / 1e3:.0f} Mvox/s (LoadingManager order, incl. skip pass)")
