@@ -67,7 +67,7 @@ def timed_region(fn, steps, torch, dist, world, device):
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device=device)
+        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, ev_ms = float(t[0]), float(t[1])
     return dt, ev_ms
@@ -161,11 +161,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libsdfgrid has no CPU path")
+    # SDFV_BENCH_BACKEND=gloo lets the N>1 code path be exercised by several ranks sharing one GPU (test boxes);
+    # the real thing is nccl = RCCL, one GPU per rank.
+    backend = os.environ.get("SDFV_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload]
     side, W, H = wl["side"], wl["width"], wl["height"]
@@ -243,6 +250,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (demo SDF defaults on the integer lattice, fixed cameras; no RNG)",
+            "backend": None if world == 1 else ("rccl" if backend == "nccl" else backend + " (test only)"),
             "config": {"workload": wl["name"], "grid_global": list(gdims), "voxels_per_gpu": voxels_per_rank,
                        "image": [W, H], "cameras_per_gpu": len(my_cams),
                        "parallelism": "single GPU" if world == 1 else f"z-slab x{world} + 1-voxel RCCL halo; 1 camera/GPU"},

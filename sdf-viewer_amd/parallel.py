@@ -65,27 +65,44 @@ def alloc_slab(dims, rank, world, device, fill_value=None):
     return SlabTextures(t0, t1, z0, z1, glo, ghi)
 
 
+def _needs_host_staging(t, group=None):
+    """gloo cannot send/recv device tensors: when the path is exercised over gloo with GPU tensors (two ranks
+    sharing the one GPU of a test box) the slices are staged through host memory.  Never taken with nccl/RCCL."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def halo_exchange(slab, rank, world, group=None):
     """One-voxel (= one z-slice) halo of both textures with ranks rank-1 / rank+1; non-periodic ends.
     Returns the number of bytes this rank sent."""
     if world == 1:
         return 0
+    staged = _needs_host_staging(slab.tex0, group)
     ops = []
+    copies = []  # (ghost slice, host buffer) to copy back after the wait when staging
     sent = 0
     n_owned = slab.z_end - slab.z_begin
+
+    def post(send_slice, recv_slice, peer):
+        nonlocal sent
+        if staged:
+            buf = torch.empty(recv_slice.shape, dtype=recv_slice.dtype)
+            ops.append(dist.P2POp(dist.isend, send_slice.cpu(), peer, group))
+            ops.append(dist.P2POp(dist.irecv, buf, peer, group))
+            copies.append((recv_slice, buf))
+        else:
+            ops.append(dist.P2POp(dist.isend, send_slice, peer, group))
+            ops.append(dist.P2POp(dist.irecv, recv_slice, peer, group))
+        sent += send_slice.numel() * 4
+
     for t in (slab.tex0, slab.tex1):
-        first_owned = t[slab.ghost_lo]
-        last_owned = t[slab.ghost_lo + n_owned - 1]
         if rank > 0:
-            ops.append(dist.P2POp(dist.isend, first_owned, rank - 1, group))
-            ops.append(dist.P2POp(dist.irecv, t[0], rank - 1, group))
-            sent += first_owned.numel() * 4
+            post(t[slab.ghost_lo], t[0], rank - 1)                                  # first owned slice down
         if rank < world - 1:
-            ops.append(dist.P2POp(dist.isend, last_owned, rank + 1, group))
-            ops.append(dist.P2POp(dist.irecv, t[t.shape[0] - 1], rank + 1, group))
-            sent += last_owned.numel() * 4
+            post(t[slab.ghost_lo + n_owned - 1], t[t.shape[0] - 1], rank + 1)      # last owned slice up
     for req in dist.batch_isend_irecv(ops):
         req.wait()
+    for dst, buf in copies:
+        dst.copy_(buf)
     return sent
 
 
@@ -95,12 +112,14 @@ def gather_replica(slab, dims, world, group=None):
     ranges = [slab_range(dims[2], r, world) for r in range(world)]
     deepest = max(z1 - z0 for z0, z1 in ranges)
     outs = []
+    staged = _needs_host_staging(slab.tex0, group)
     for owned in (slab.owned0, slab.owned1):
-        padded = torch.zeros((deepest, dims[1], dims[0], 4), dtype=owned.dtype, device=owned.device)
+        dev = torch.device("cpu") if staged else owned.device
+        padded = torch.zeros((deepest, dims[1], dims[0], 4), dtype=owned.dtype, device=dev)
         padded[:owned.shape[0]] = owned
         parts = [torch.empty_like(padded) for _ in range(world)]
         dist.all_gather(parts, padded, group=group)
-        outs.append(torch.cat([p[:z1 - z0] for p, (z0, z1) in zip(parts, ranges)], dim=0))
+        outs.append(torch.cat([p[:z1 - z0] for p, (z0, z1) in zip(parts, ranges)], dim=0).to(owned.device))
     return outs[0], outs[1]
 
 
