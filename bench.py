@@ -11,7 +11,7 @@ Inputs are deterministic (integer lattice + fixed cameras) and already resident 
 
 N = 1 workload: BASELINE.json configs[1] (256^3 grid + 1920x1080).  --workload 512 selects configs[2]
 (512^3 + 3840x2160).  N > 1 (weak scaling): the grid grows to side^3 voxels PER RANK, sharded by z-slab,
-each fill step followed by the one-voxel RCCL halo exchange; the raymarch renders one camera per rank
+each fill step includes the one-voxel RCCL halo exchange (overlapped with the interior fill); the raymarch renders one camera per rank
 (orbit) over a replica of the N = 1 grid.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
@@ -185,10 +185,10 @@ def main():
     owned0, owned1 = slab.owned0, slab.owned1
     voxels_per_rank = pkg.slab_voxels(grid)
 
+    filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world)  # N>1: halo exchange overlapped with the interior
+
     def fill_step():
-        pkg.fill_grid(prm, grid, owned0, owned1)
-        if world > 1:
-            par.halo_exchange(slab, rank, world)
+        filler.step()
 
     def fill_only():
         pkg.fill_grid(prm, grid, owned0, owned1)

@@ -106,6 +106,52 @@ def halo_exchange(slab, rank, world, group=None):
     return sent
 
 
+class SlabFiller:
+    """One fill step of a rank: fill the slab, exchange the halo, with the exchange hidden behind the fill.
+
+    The two boundary slices (the ones the neighbours need) are filled first; as soon as they are done the halo
+    exchange starts on a second HIP stream while the interior of the slab is still being filled on the main
+    stream.  Per neighbour pair the exchange moves 2 x W*H*16 B per direction over one xGMI link (~0.1 ms for
+    512^2 slices, ~0.5 ms for 1024^2), the interior fill takes W*H*depth*32 B / ~6.5 TB/s, so for slabs of a few
+    dozen slices the two are of the same order and overlapping them is what keeps weak scaling near linear.
+    """
+
+    def __init__(self, pkg, params, dims, slab, rank, world, sdf_id=0, group=None):
+        self.pkg, self.params, self.dims, self.slab = pkg, params, dims, slab
+        self.rank, self.world, self.sdf_id, self.group = rank, world, sdf_id, group
+        self.overlap = world > 1 and slab.tex0.is_cuda and (slab.z_end - slab.z_begin) >= 3
+        self.comm_stream = torch.cuda.Stream(device=slab.tex0.device) if self.overlap else None
+        z0, z1 = slab.z_begin, slab.z_end
+        self.whole = pkg.make_grid(dims, z_begin=z0, z_end=z1)
+        if self.overlap:
+            o0, o1 = slab.owned0, slab.owned1
+            # (grid, tex0 view, tex1 view) of the first slice, the last slice and the interior
+            self.parts = [(pkg.make_grid(dims, z_begin=z0, z_end=z0 + 1), o0[:1], o1[:1]),
+                          (pkg.make_grid(dims, z_begin=z1 - 1, z_end=z1), o0[-1:], o1[-1:]),
+                          (pkg.make_grid(dims, z_begin=z0 + 1, z_end=z1 - 1), o0[1:-1], o1[1:-1])]
+
+    def step(self):
+        pkg, slab = self.pkg, self.slab
+        if not self.overlap:
+            pkg.fill_grid(self.params, self.whole, slab.owned0, slab.owned1, sdf_id=self.sdf_id)
+            if self.world > 1:
+                halo_exchange(slab, self.rank, self.world, self.group)
+            return
+        main = torch.cuda.current_stream()
+        for grid, t0, t1 in self.parts[:2]:
+            pkg.fill_grid(self.params, grid, t0, t1, sdf_id=self.sdf_id)
+        boundary_done = torch.cuda.Event()
+        boundary_done.record(main)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(boundary_done)
+            halo_exchange(slab, self.rank, self.world, self.group)  # its waits block the comm stream only
+            halo_done = torch.cuda.Event()
+            halo_done.record(self.comm_stream)
+        grid, t0, t1 = self.parts[2]
+        pkg.fill_grid(self.params, grid, t0, t1, sdf_id=self.sdf_id)  # overlaps the exchange
+        main.wait_event(halo_done)
+
+
 def gather_replica(slab, dims, world, group=None):
     """Full grid on every rank from the slabs (all-gather; slabs may differ by one slice, so each is
     padded to the deepest slab for the collective and trimmed afterwards)."""
