@@ -1,0 +1,146 @@
+// cli_main.cpp -- `sdf-viewer-gpu`: the reference's `app` command line on the MI355X path, headless.
+//
+//   sdf-viewer-gpu app [--max-voxels-side N] [--loading-passes P] demo [-t M] [-c F] [-l M] [-s F] [-m F] [-d B]
+//                  [--width W] [--height H] [--out image.ppm] [--dump-textures prefix] [--frames K]
+//
+// Flag names and defaults are the reference's: CliApp (src/app/cli/mod.rs:10-22: max_voxels_side 64,
+// loading_passes 2) and the demo SDF's flags (src/sdf/demo/cube.rs:15-18, sphere.rs:11-14, demo/mod.rs:26-29).
+// Where the reference opens a window, this loads the SDF into the two device textures
+// (SDFViewer::from_bb/update/commit), renders the default scene camera (scene/mod.rs:82-95) with the raymarch
+// kernel and writes the frame as a binary PPM.  The log lines follow scene/mod.rs:180-197.
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sdf_demo.hpp"
+#include "sdf_viewer.hpp"
+
+using namespace sdfviewer;
+
+static int usage(const char* msg) {
+    if (msg) fprintf(stderr, "error: %s\n\n", msg);
+    fprintf(stderr,
+            "USAGE:\n    sdf-viewer-gpu app [--max-voxels-side <N>] [--loading-passes <P>] demo [demo flags]\n"
+            "                   [--width <W>] [--height <H>] [--out <file.ppm>] [--dump-textures <prefix>] [--frames <K>]\n"
+            "demo flags: -t/--cube-material <brick|normal>  -c/--cube-half-side <f>  -l/--sphere-material <brick|normal>\n"
+            "            -s/--sphere-radius <f>  -m/--max-distance-custom-material <f>  -d/--disable-sphere <true|false>\n");
+    return msg ? 2 : 0;
+}
+
+int main(int argc, char** argv) {
+    std::vector<std::string> args(argv + 1, argv + argc);
+    if (args.empty() || args[0] == "-h" || args[0] == "--help") return usage(nullptr);
+    if (args[0] != "app") return usage("only the `app` subcommand has a GPU path (server / mesh are out of scope)");
+    size_t max_voxels_side = 64, loading_passes = 2;  // src/app/cli/mod.rs:13-18
+    uint32_t width = 1280, height = 720;
+    int frames = 1;
+    std::string out = "sdf-viewer-gpu.ppm", dump;
+    std::vector<std::string> demo_args;
+    bool in_demo = false;
+    for (size_t i = 1; i < args.size(); ++i) {
+        const std::string& a = args[i];
+        auto next = [&](const char* what) -> const char* {
+            if (i + 1 >= args.size()) {
+                fprintf(stderr, "error: The argument '%s' requires a value but none was supplied\n", what);
+                exit(2);
+            }
+            return args[++i].c_str();
+        };
+        if (a == "--max-voxels-side") max_voxels_side = strtoul(next("--max-voxels-side <MAX_VOXELS_SIDE>"), nullptr, 10);
+        else if (a == "--loading-passes") loading_passes = strtoul(next("--loading-passes <LOADING_PASSES>"), nullptr, 10);
+        else if (a == "--width") width = (uint32_t)strtoul(next("--width"), nullptr, 10);
+        else if (a == "--height") height = (uint32_t)strtoul(next("--height"), nullptr, 10);
+        else if (a == "--frames") frames = atoi(next("--frames"));
+        else if (a == "--out") out = next("--out");
+        else if (a == "--dump-textures") dump = next("--dump-textures");
+        else if (a == "demo") in_demo = true;
+        else if (a == "url") return usage("the `url` provider (arbitrary wasm) cannot run on the GPU; use the reference");
+        else if (in_demo) demo_args.push_back(a);
+        else return usage(("Found argument '" + a + "' which wasn't expected").c_str());
+    }
+    std::string err;
+    auto sdf = SDFDemo::from_args(demo_args, &err);
+    if (!sdf) return usage(err.c_str());
+
+    if (sdfv_device_count() == 0) {
+        fprintf(stderr, "error: no HIP device visible: sdf-viewer-gpu has no CPU path\n");
+        return 1;
+    }
+    // set_root_sdf -> scene.set_sdf -> SDFViewer::from_bb (app/mod.rs:99-109, scene/mod.rs:139-156)
+    auto viewer = SDFViewer::from_bb(sdf->bounding_box(), max_voxels_side, loading_passes);
+    if (!viewer) {
+        fprintf(stderr, "error: cannot create the device textures: %s\n", sdfv_last_error());
+        return 1;
+    }
+    // SDFViewerAppScene::render's loading half (scene/mod.rs:166-200): update until nothing is left, commit
+    for (;;) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t updates = viewer->update(*sdf, std::chrono::milliseconds(30));
+        if (updates == 0) break;
+        viewer->commit();
+        (void)hipStreamSynchronize((hipStream_t)viewer->stream);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "Loaded SDF chunk (%zu updates) in %.3fms (GPU)\n", updates, ms);
+    }
+    viewer->commit();
+    fprintf(stderr, "Loaded last SDF chunk (lod %g)\n", (double)viewer->material.lod_dist_between_samples);
+
+    Camera cam;  // scene/mod.rs:82-95 defaults
+    cam.set_viewport(width, height);
+    DeviceBuffer rgba((size_t)width * height * 16);
+    if (!rgba.ok()) return 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int f = 0; f < frames; ++f) {
+        if (viewer->material.render(cam, rgba.f32(), nullptr, viewer->stream) != 0) {
+            fprintf(stderr, "error: %s\n", sdfv_last_error());
+            return 1;
+        }
+    }
+    (void)hipStreamSynchronize((hipStream_t)viewer->stream);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "Rendered %d frame(s) of %ux%u in %.3fms (%.1f Mrays/s)\n", frames, width, height, ms,
+            frames * (double)width * height / ms / 1e3);
+
+    std::vector<float> host((size_t)width * height * 4);
+    if (hipMemcpy(host.data(), rgba.get(), rgba.bytes(), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    // outColor over a black background (blend TRANSPARENCY, material.rs:75-81): rgb * a, quantised to 8 bits
+    FILE* fp = fopen(out.c_str(), "wb");
+    if (!fp) {
+        perror(out.c_str());
+        return 1;
+    }
+    fprintf(fp, "P6\n%u %u\n255\n", width, height);
+    std::vector<unsigned char> row((size_t)width * 3);
+    for (uint32_t y = 0; y < height; ++y) {
+        for (uint32_t x = 0; x < width; ++x) {
+            const float* p = &host[((size_t)y * width + x) * 4];
+            for (int c = 0; c < 3; ++c) {
+                float v = p[c] * p[3];
+                v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+                row[x * 3 + c] = (unsigned char)std::lround(v * 255.0f);
+            }
+        }
+        fwrite(row.data(), 1, row.size(), fp);
+    }
+    fclose(fp);
+    fprintf(stderr, "Wrote %s\n", out.c_str());
+    if (!dump.empty()) {
+        const size_t n = viewer->material.tex0->bytes() / 4;
+        std::vector<float> t0h(n), t1h(n);
+        if (viewer->download(t0h.data(), t1h.data()) != 0) return 1;
+        for (int k = 0; k < 2; ++k) {
+            const std::string path = dump + (k ? ".tex1.f32" : ".tex0.f32");
+            FILE* f = fopen(path.c_str(), "wb");
+            if (!f) return 1;
+            fwrite(k ? t1h.data() : t0h.data(), 4, n, f);
+            fclose(f);
+        }
+    }
+    return 0;
+}

@@ -170,3 +170,33 @@ def test_provider_abi_sample_and_normal(host, oracle):
     P.sample_free(s)
     np.testing.assert_array_equal(got.view(np.uint32),
                                   oracle.sample(oracle.default_params(disable_sphere=1), (0.2, 0.1, 0.0)).view(np.uint32))
+
+
+def test_cli_loads_and_renders(oracle, tmp_path):
+    """`sdf-viewer-gpu app --max-voxels-side 48 --loading-passes 3 demo -s 0.9 -t normal`: the textures it loads and
+    the frame it writes equal the oracle's."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sdf-viewer_amd", "sdf-viewer-gpu")
+    out = tmp_path / "frame.ppm"
+    dump = tmp_path / "grid"
+    r = subprocess.run([exe, "app", "--max-voxels-side", "48", "--loading-passes", "3", "demo", "-s", "0.9", "-t", "normal",
+                        "--width", "160", "--height", "90", "--out", str(out), "--dump-textures", str(dump)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Using 48x48x48 voxels" in r.stderr and "Loaded SDF chunk (" in r.stderr and "Loaded last SDF chunk" in r.stderr
+    dims = (48, 48, 48)
+    prm = oracle.default_params(sphere_radius=0.9, cube_material=1)
+    r0, r1 = oracle.fill_dense(prm, dims)
+    t0 = np.fromfile(str(dump) + ".tex0.f32", np.float32).reshape(r0.shape)
+    t1 = np.fromfile(str(dump) + ".tex1.f32", np.float32).reshape(r1.shape)
+    np.testing.assert_array_equal(t0.view(np.uint32), r0.view(np.uint32))
+    np.testing.assert_array_equal(t1.view(np.uint32), r1.view(np.uint32))
+    want, _ = oracle.raymarch(oracle.default_render_params(dims), r0, r1, oracle.camera_look_at(aspect=160 / 90), 160, 90,
+                              want_aux=False)
+    raw = open(out, "rb").read()
+    header = b"P6\n160 90\n255\n"
+    assert raw.startswith(header)
+    img = np.frombuffer(raw[len(header):], np.uint8).reshape(90, 160, 3).astype(np.int32)
+    ref = np.rint(np.clip(want[..., :3] * want[..., 3:4], 0, 1) * 255).astype(np.int32)
+    assert np.abs(img - ref).max() <= 1
