@@ -149,6 +149,12 @@ __device__ __forceinline__ Sample demo_sample(const sdfv_demo_params& prm, uint3
     return s;
 }
 
+// f32::clamp(0.0, 1.0) as used at scene/sdf/mod.rs:196: a NaN stays a NaN (fminf/fmaxf would turn it into 0).
+// Only reachable through the dim == 1 quirk (0/0 coordinates), but the packing is reproduced exactly.
+__device__ __forceinline__ float clamp01_rust(float v) {
+    return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+}
+
 // three-d-asset Srgba::from(Vec3): (c * 255.0) as u8 -- truncating, saturating, NaN -> 0.
 __device__ __forceinline__ uint32_t srgb_quantize(float c) {
     float v = fminf(fmaxf(c * 255.0f, 0.0f), 255.0f);  // fmaxf(NaN, 0) = 0
@@ -161,7 +167,7 @@ __device__ __forceinline__ void pack_sample(const Sample& s, const Lut& lut, flo
                                             float4& t0, float4& t1) {
     float r = s.m.r, g = s.m.g, b = s.m.b;
     if (r == 0.0f && g == 0.0f && b == 0.0f) { r = 0.5f; g = 0.5f; b = 0.5f; }
-    t0.x = fminf(fmaxf(1e-1f + s.distance, 0.0f), 1.0f);
+    t0.x = clamp01_rust(1e-1f + s.distance);
     t0.y = lut[srgb_quantize(r)];
     t0.z = lut[srgb_quantize(g)];
     t0.w = lut[srgb_quantize(b)];
@@ -303,7 +309,7 @@ __device__ __forceinline__ void fill_voxel(const sdfv_demo_params& prm, uint32_t
             m = sphere_packed<Cfg>(prm, px, py, pz, len, d_sph, lut);
         }
     }
-    t0.x = fminf(fmaxf(1e-1f + distance, 0.0f), 1.0f);
+    t0.x = clamp01_rust(1e-1f + distance);
     t0.y = m.lr; t0.z = m.lg; t0.w = m.lb;
     t1.x = m.metallic; t1.y = m.roughness; t1.z = m.occlusion; t1.w = air_dist;
 }
