@@ -10,6 +10,8 @@ oracle they are used to pin:
   2. grid_9x7x5.npz,     -- an op-by-op numpy-float32 restatement of the same source written below (every
      points_512.npz         operation on np.float32 scalars, so each one rounds to f32 like Rust's), run on a
                             small non-cubic grid and on 512 seeded points for several parameter sets.
+  3. raymarch_12cube_40x30.npz -- the same kind of restatement of material.frag (sphere tracing, texel-centre
+                            trilinear, ambient shading, ACES, sRGB) for two cameras over a 12^3 grid.
 
 Run from the repo root:  python tests/golden/make_golden.py
 """
@@ -153,7 +155,168 @@ SURVEY_KATS = [
 SURVEY_COORDS_64 = {"0": -1.0, "1": -0.96825397, "31": -0.015873015, "32": 0.015873075, "63": 1.0}
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Independent numpy-float32 restatement of the fragment shader (src/app/scene/sdf/material.frag) + the
+# three-d pieces it calls, for a second opinion on oracle/raymarch.c.  Restatement choices are the ones
+# documented in oracle/raymarch.c (slab-test fragment, texel-centre trilinear with MirroredRepeat, mix() along
+# x then y then z, normalize = v / length, ambient-only lighting, ACES, linear->sRGB).
+# ---------------------------------------------------------------------------------------------------------
+def v3(*a):
+    return [F(x) for x in a]
+
+
+def vlen(a):
+    return np.sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2])
+
+
+def vnorm(a):
+    l = vlen(a)
+    return [a[0] / l, a[1] / l, a[2] / l]
+
+
+def mixf(a, b, t):
+    return a * (F(1.0) - t) + b * t
+
+
+def look_at(eye, target, up, fovy_deg, aspect, near, far):
+    e, t, u0 = v3(*eye), v3(*target), v3(*up)
+    f = [t[i] - e[i] for i in range(3)]
+    fl = F(1.0) / vlen(f)
+    f = [c * fl for c in f]
+    s = [f[1] * u0[2] - f[2] * u0[1], f[2] * u0[0] - f[0] * u0[2], f[0] * u0[1] - f[1] * u0[0]]
+    sl = F(1.0) / vlen(s)
+    s = [c * sl for c in s]
+    u = [s[1] * f[2] - s[2] * f[1], s[2] * f[0] - s[0] * f[2], s[0] * f[1] - s[1] * f[0]]
+    half = F(fovy_deg) * (F(3.14159265358979323846) / F(180.0)) / F(2.0)
+    tan_half = F(np.tan(half))
+    # bvp is not consumed by the fixture (depth is not compared); zeros keep the POD layout
+    return dict(eye=e, right=s, up=u, forward=f, tan_half_fovy=tan_half, aspect=F(aspect), bvp=[F(0)] * 16)
+
+
+def mirror(i, n):
+    m = i % (2 * n)
+    return m if m < n else 2 * n - 1 - m
+
+
+def tex_linear(tex, p01):
+    d, h, w = tex.shape[:3]
+    u = p01[0] * F(w) - F(0.5)
+    v = p01[1] * F(h) - F(0.5)
+    ww = p01[2] * F(d) - F(0.5)
+    fu, fv, fw = np.floor(u), np.floor(v), np.floor(ww)
+    ax, ay, az = u - fu, v - fv, ww - fw
+    i0, j0, k0 = int(fu), int(fv), int(fw)
+    t = lambda i, j, k: tex[mirror(k, d), mirror(j, h), mirror(i, w)]
+    out = []
+    for c in range(4):
+        c00 = mixf(t(i0, j0, k0)[c], t(i0 + 1, j0, k0)[c], ax)
+        c10 = mixf(t(i0, j0 + 1, k0)[c], t(i0 + 1, j0 + 1, k0)[c], ax)
+        c01 = mixf(t(i0, j0, k0 + 1)[c], t(i0 + 1, j0, k0 + 1)[c], ax)
+        c11 = mixf(t(i0, j0 + 1, k0 + 1)[c], t(i0 + 1, j0 + 1, k0 + 1)[c], ax)
+        out.append(mixf(mixf(c00, c10, ay), mixf(c01, c11, ay), az))
+    return out
+
+
+def oob(p, bmin, bmax):
+    o = [max(bmin[i] - p[i], p[i] - bmax[i]) for i in range(3)]
+    return max(o[0], max(o[1], o[2]))
+
+
+def shade_px(raw0, raw1):
+    out = []
+    for c in range(3):
+        albedo = raw0[1 + c] * F(1.0)
+        lit = raw1[2] * F(1.0) * mixf(albedo, F(0.0), raw1[0])
+        lit = (lit * (F(2.51) * lit + F(0.03))) / (lit * (F(2.43) * lit + F(0.59)) + F(0.14))  # ACES
+        lit = min(max(lit, F(0.0)), F(1.0))
+        sel = F(1.0) if lit >= F(0.0031308) else F(0.0)
+        lo = lit * F(12.92)
+        hi = F(1.055) * F(np.power(np.float64(lit), np.float64(F(1.0) / F(2.4)))) - F(0.055)
+        out.append(mixf(lo, hi, sel))
+    return out + [F(1.0)]
+
+
+def march_px(tex0, tex1, cam, bmin, bmax, W, H, px, py):
+    rec = dict(status=0, steps=0, hit_pos=v3(0, 0, 0), rgba=v3(0, 0, 0) + [F(0)])
+    ndc_x = ((F(px) + F(0.5)) / F(W)) * F(2.0) - F(1.0)
+    ndc_y = F(1.0) - ((F(py) + F(0.5)) / F(H)) * F(2.0)
+    sx = ndc_x * cam["aspect"] * cam["tan_half_fovy"]
+    sy = ndc_y * cam["tan_half_fovy"]
+    eye = cam["eye"]
+    d0 = vnorm([cam["forward"][i] + cam["right"][i] * sx + cam["up"][i] * sy for i in range(3)])
+    with np.errstate(all="ignore"):
+        t1 = [(bmin[i] - eye[i]) / d0[i] for i in range(3)]
+        t2 = [(bmax[i] - eye[i]) / d0[i] for i in range(3)]
+    lo = [np.fmin(a, b) for a, b in zip(t1, t2)]
+    hi = [np.fmax(a, b) for a, b in zip(t1, t2)]
+    tnear = np.fmax(np.fmax(lo[0], lo[1]), lo[2])
+    tfar = np.fmin(np.fmin(hi[0], hi[1]), hi[2])
+    if not (tfar >= tnear and tfar > 0):
+        return rec
+    tfrag = tnear if tnear > 0 else tfar
+    pos = [eye[i] + d0[i] * tfrag for i in range(3)]
+    rd = vnorm([pos[i] - eye[i] for i in range(3)])
+    ro = pos
+    if oob([ro[i] + rd[i] * F(0.2) for i in range(3)], bmin, bmax) > 0:
+        ro = [eye[i] + rd[i] * F(0.2) for i in range(3)]
+    size = [bmax[i] - bmin[i] for i in range(3)]
+    p = ro
+    status, steps, raw0 = -1, 0, None
+    for i in range(256):
+        if i >= 255:
+            status = -1
+            break
+        if oob(p, bmin, bmax) > F(1e-4):
+            status = -2
+            break
+        s = tex_linear(tex0, [(p[c] - bmin[c]) / size[c] for c in range(3)])
+        steps += 1
+        d = s[0] - F(1e-1)
+        if d < F(1e-5):
+            status, raw0 = 1, s
+            break
+        p = [p[c] + rd[c] * d for c in range(3)]
+    rec.update(status=status, steps=steps, hit_pos=p)
+    if status == 1:
+        raw1 = tex_linear(tex1, [(p[c] - bmin[c]) / size[c] for c in range(3)])
+        rec["rgba"] = shade_px(raw0, raw1)
+    return rec
+
+
+def make_raymarch_fixture():
+    n = 12
+    bmin, bmax = v3(-1, -1, -1), v3(1, 1, 1)
+    tex0 = np.zeros((n, n, n, 4), np.float32)
+    tex1 = np.zeros_like(tex0)
+    for z in range(n):
+        for y in range(n):
+            for x in range(n):
+                p = (coord(x, n, -1, 1), coord(y, n, -1, 1), coord(z, n, -1, 1))
+                a, b = pack(sample(DEFAULT, 0, p))
+                tex0[z, y, x] = a
+                tex1[z, y, x] = b
+    W, H = 40, 30
+    out = {}
+    for k, eye in enumerate([(2.5, 3.0, 5.0), (0.2, 0.1, -0.3)]):  # the default camera, and one inside the box
+        cam = look_at(eye, (0, 0, 0) if k == 0 else (1.0, 0.8, 0.9), (0, 1, 0), 45.0, W / H, 0.1, 1000.0)
+        status = np.zeros((H, W), np.int32)
+        steps = np.zeros((H, W), np.int32)
+        hit_pos = np.zeros((H, W, 3), np.float32)
+        rgba = np.zeros((H, W, 4), np.float32)
+        for py in range(H):
+            for px in range(W):
+                r = march_px(tex0, tex1, cam, bmin, bmax, W, H, px, py)
+                status[py, px], steps[py, px] = r["status"], r["steps"]
+                hit_pos[py, px] = r["hit_pos"] if r["status"] != 0 else 0
+                rgba[py, px] = r["rgba"]
+        pod = np.array(cam["eye"] + cam["right"] + cam["up"] + cam["forward"] + [cam["tan_half_fovy"], cam["aspect"]] +
+                       cam["bvp"], np.float32)
+        out.update({f"cam_{k}": pod, f"status_{k}": status, f"steps_{k}": steps, f"hit_pos_{k}": hit_pos, f"rgba_{k}": rgba})
+    np.savez_compressed(os.path.join(HERE, "raymarch_12cube_40x30.npz"), tex0=tex0, tex1=tex1, width=W, height=H, **out)
+
+
 def main():
+    make_raymarch_fixture()
     with open(os.path.join(HERE, "demo_sdf_kat.json"), "w") as f:
         json.dump(dict(source="SURVEY.md 8(c), hand-derived from the reference source; default demo params",
                        air_dist_bits="0x3DCF53C6", kats=SURVEY_KATS, coords_n64_bb_m1_1=SURVEY_COORDS_64), f, indent=1)

@@ -173,3 +173,28 @@ def test_1080p_properties_on_256_grid(pkg, oracle):
     ocam = oracle.copy_struct(oracle.Camera, cam)
     want, _ = oracle.raymarch(orp, h0, h1, ocam, W, H, y0=536, y1=544, want_aux=False)
     assert np.abs(full[0, 536:544].cpu().numpy() - want).max() <= RGBA_TOL
+
+
+def test_golden_raymarch_fixture(pkg, oracle):
+    """The committed numpy-restatement fixture (tests/golden/raymarch_12cube_40x30.npz) straight against the GPU."""
+    import ctypes as C
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "raymarch_12cube_40x30.npz"))
+    W, H = int(g["width"]), int(g["height"])
+    grid = pkg.make_grid((12, 12, 12))
+    t0, t1 = pkg.alloc_textures(grid)
+    pkg.fill_grid(pkg.default_params(), grid, t0, t1)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(t0.cpu().numpy().view(np.uint32), g["tex0"].view(np.uint32))
+    np.testing.assert_array_equal(t1.cpu().numpy().view(np.uint32), g["tex1"].view(np.uint32))
+    rp = pkg.default_render_params(grid)
+    for k in (0, 1):
+        cam = pkg.Camera()
+        C.memmove(C.byref(cam), g[f"cam_{k}"].ctypes.data, C.sizeof(cam))
+        rgba, aux = pkg.raymarch(rp, t0, t1, cam, W, H, want_aux=True)
+        torch.cuda.synchronize()
+        a = aux_to_np(oracle, aux)[0]
+        np.testing.assert_array_equal(a["status"], g[f"status_{k}"])
+        np.testing.assert_array_equal(a["steps"], g[f"steps_{k}"])
+        covered = a["status"] != 0
+        np.testing.assert_array_equal(a["hit_pos"][covered].view(np.uint32), g[f"hit_pos_{k}"][covered].view(np.uint32))
+        assert np.abs(rgba[0].cpu().numpy() - g[f"rgba_{k}"]).max() <= RGBA_TOL

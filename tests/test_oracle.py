@@ -153,3 +153,31 @@ def test_raymarch_oracle_sanity(oracle):
     assert (rgba[hit][:, 3] == 1.0).all() and (rgba[~hit] == 0).all()
     assert (aux["steps"][hit] >= 1).all() and aux["steps"].max() <= 255
     assert np.isfinite(rgba).all() and rgba.min() >= 0.0 and rgba.max() <= 1.0
+
+
+def test_numpy_restatement_raymarch(oracle):
+    """oracle/raymarch.c against the independent numpy-float32 restatement of material.frag (two cameras, one of
+    them inside the volume): hit flags, step counts and hit positions bit for bit, shaded RGBA to pow() rounding."""
+    import ctypes as C
+    g = np.load(os.path.join(GOLD, "raymarch_12cube_40x30.npz"))
+    t0, t1 = np.ascontiguousarray(g["tex0"]), np.ascontiguousarray(g["tex1"])
+    W, H = int(g["width"]), int(g["height"])
+    # the fixture's grid is itself a restatement output: it must equal the oracle's fill
+    d0, d1 = oracle.fill_dense(oracle.default_params(), (12, 12, 12), threads=1)
+    np.testing.assert_array_equal(t0.view(np.uint32), d0.view(np.uint32))
+    np.testing.assert_array_equal(t1.view(np.uint32), d1.view(np.uint32))
+    rp = oracle.default_render_params((12, 12, 12))
+    for k in (0, 1):
+        cam = oracle.Camera()
+        C.memmove(C.byref(cam), g[f"cam_{k}"].ctypes.data, C.sizeof(cam))
+        rgba, aux = oracle.raymarch(rp, t0, t1, cam, W, H, threads=1)
+        np.testing.assert_array_equal(aux["status"], g[f"status_{k}"])
+        np.testing.assert_array_equal(aux["steps"], g[f"steps_{k}"])
+        covered = aux["status"] != 0
+        np.testing.assert_array_equal(aux["hit_pos"][covered].view(np.uint32), g[f"hit_pos_{k}"][covered].view(np.uint32))
+        assert np.abs(rgba - g[f"rgba_{k}"]).max() <= 2e-7
+        assert (aux["status"] == 1).sum() > 50
+    # the oracle's own camera builder agrees with the restated one (bvp excluded: the fixture leaves it zero)
+    cam0 = oracle.camera_look_at(aspect=W / H)
+    np.testing.assert_array_equal(np.frombuffer(bytes(cam0), np.float32)[:14].view(np.uint32),
+                                  g["cam_0"][:14].view(np.uint32))
