@@ -164,25 +164,21 @@ __device__ __forceinline__ float oob_dist(const RaymarchArgs& a, V3 p) {
     return fmaxf(ox, fmaxf(oy, oz));
 }
 
-// sdfRaycast's loop (material.frag:97-126) for the LINEAR filter, arranged for what a lone wave pays for on
-// gfx950 (tools/ubench/latency.hip: ~11 cycles per DEPENDENT VALU instruction, ~6 per independent one, ~30 for a
-// VALU->SALU->VALU round trip, ~110 for a per-iteration `ballot == 0` exit test): the loop-carried dependency
-// chain is position -> texel coordinates -> trilinear mix -> advance, and nothing else.
-//  * The position advances unconditionally; NO select sits between one sample and the next.  Lane state that
-//    changes once per ray (stopped / hit or out of bounds / final position / step count) lives in wave masks
-//    held in SGPRs and is only touched inside a uniform branch taken on the iterations in which some lane
-//    actually stops.  A stopped lane gets a zero direction, so it stays in its texel cell and triggers no fetch.
-//  * The out-of-bounds stop of iteration i+1 (material.frag:106-109) is evaluated at the end of iteration i on the
-//    freshly advanced position, off the critical path; it is not applied after the 255th sample, where the
-//    shader reports "out of steps" without looking at the position.
-//  * The exit test is a scalar compare of the alive mask (no VALU round trip).
-//  * One-cell register cache: sphere tracing takes its smallest steps exactly on the longest rays (grazing a
-//    surface), so consecutive samples usually fall in the same texel cell; the 8 corner values live in
-//    registers and are re-fetched only when floor(u,v,w) changes (the one divergent branch of the loop).
+// sdfRaycast's loop (material.frag:97-126) for the LINEAR filter, with everything the loop does not need
+// taken out of it.  Per iteration and lane: out-of-bounds test, texel coordinates, (re)fetch, trilinear
+// mix, hit test, advance.
+//  * Predicated straight-line code with ONE branch (the re-fetch): lanes that stopped no longer commit
+//    results, so the wave does not pay exec-mask bookkeeping for the shader's nested if/else.
+//  * One-cell register cache: sphere tracing takes its smallest steps exactly on the longest rays
+//    (grazing a surface), so consecutive samples usually fall in the same texel cell; the 8 corner values
+//    live in registers and are re-fetched only when floor(u,v,w) changes.
 //  * MirroredRepeat needs no modulo: a marching ray is within 1e-4 of the box, hence (the launcher checks
 //    1e-4 * N / size <= 0.25 per axis before selecting this kernel) floor(u) is in [-1, N-1], where
-//    mirror(i) == clamp(i, 0, N-1); the clamp also keeps the fetches of stopped lanes inside the texture.
+//    mirror(i) == clamp(i, 0, N-1).
 //  * XF == 2: extents AND texture sizes are powers of two, so ((p-min)*inv)*N == (p-min)*(inv*N) exactly.
+//  * No per-iteration status/step counters: a stopped lane's ray_pos no longer moves, so afterwards
+//    "out of bounds" is re-derived from it (oob(ray_pos) > 1e-4 <=> it stopped on that test), and the
+//    step count is 1 + the last iteration the lane sampled in.
 //  * STRIDE = 4 reads tex0.r in place, STRIDE = 1 the compact distance volume (sdfv_commit_distance).
 //  * T: accumulate distanceFromOrigin (only the aux record consumes it).
 // Values and operation order are exactly those of sample_r() / the oracle; only redundant work is skipped.
@@ -190,44 +186,37 @@ template <int XF, bool SYMM, int STRIDE, bool T>
 __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* __restrict__ vol, const Tex& t,
                                            V3 ray_dir, bool covered, V3& ray_pos, float& dist_from_origin,
                                            int& status, int& steps, int& iterations) {
-    const uint32_t lane = threadIdx.x & 63;
     const float fw_ = (float)t.w, fh_ = (float)t.h, fd_ = (float)t.d;
     const float kx = a.inv_bsize[0] * fw_, ky = a.inv_bsize[1] * fh_, kz = a.inv_bsize[2] * fd_;  // exact if XF == 2
     const int wm1 = t.w - 1, hm1 = t.h - 1, dm1 = t.d - 1;
     const uint32_t sy = (uint32_t)t.w, sz = (uint32_t)t.w * (uint32_t)t.h;
-
-    // iteration 0's out-of-bounds stop; lanes that never march are parked at the box corner with no direction
-    const bool start_oob = oob_dist<SYMM>(a, ray_pos) > 1e-4f;
-    unsigned long long alive = __ballot(covered && !start_oob);
-    V3 p = covered ? ray_pos : mk(a.rp.bounds_min[0], a.rp.bounds_min[1], a.rp.bounds_min[2]);
-    V3 dir = (covered && !start_oob) ? ray_dir : mk(0.0f, 0.0f, 0.0f);
-    V3 fin = p;                       // position reported for lanes that stop
-    float tacc = 0.0f, tfin = 0.0f, tscale = (covered && !start_oob) ? 1.0f : 0.0f;
-    status = covered ? (start_oob ? -2 : -1) : 0;
-    steps = (covered && !start_oob) ? 255 : 0;
-
-    float cfu = -4.0f, cfv = -4.0f, cfw = -4.0f;  // never a valid floor(u)
+    bool marching = covered;
+    int last_i = -1;
+    float cfu = -4.0f, cfv = -4.0f, cfw = -4.0f;  // never a valid floor(u) of a marching lane
     float t000 = 0.0f, t100 = 0.0f, t010 = 0.0f, t110 = 0.0f, t001 = 0.0f, t101 = 0.0f, t011 = 0.0f, t111 = 0.0f;
     for (int i = 0; i < 255; ++i) {
-        if (alive == 0ull) break;  // wave-level early termination (scalar test)
+        // Stop condition: out of bounds (material.frag:106-109)
+        marching = marching && !(oob_dist<SYMM>(a, ray_pos) > 1e-4f);
+        if (__ballot(marching) == 0ull) break;  // wave-level early termination
         ++iterations;
+        last_i = marching ? i : last_i;
         float u, v, w;
         if (XF == 2) {
-            u = (p.x - a.rp.bounds_min[0]) * kx - 0.5f;
-            v = (p.y - a.rp.bounds_min[1]) * ky - 0.5f;
-            w = (p.z - a.rp.bounds_min[2]) * kz - 0.5f;
+            u = (ray_pos.x - a.rp.bounds_min[0]) * kx - 0.5f;
+            v = (ray_pos.y - a.rp.bounds_min[1]) * ky - 0.5f;
+            w = (ray_pos.z - a.rp.bounds_min[2]) * kz - 0.5f;
         } else {
-            const V3 q = to_p01<XF>(a, p);
+            const V3 q = to_p01<XF>(a, ray_pos);
             u = q.x * fw_ - 0.5f; v = q.y * fh_ - 0.5f; w = q.z * fd_ - 0.5f;
         }
         const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
         const float ax = u - fu, ay = v - fv, az = w - fw;
-        if (fu != cfu || fv != cfv || fw != cfw) {
+        if (marching && (fu != cfu || fv != cfv || fw != cfw)) {
             cfu = fu; cfv = fv; cfw = fw;
             const int i0 = (int)fu, j0 = (int)fv, k0 = (int)fw;
-            const uint32_t i0c = (uint32_t)min(max(i0, 0), wm1), i1c = (uint32_t)max(min(i0 + 1, wm1), 0);
-            const uint32_t j0c = (uint32_t)min(max(j0, 0), hm1) * sy, j1c = (uint32_t)max(min(j0 + 1, hm1), 0) * sy;
-            const uint32_t k0c = (uint32_t)min(max(k0, 0), dm1) * sz, k1c = (uint32_t)max(min(k0 + 1, dm1), 0) * sz;
+            const uint32_t i0c = (uint32_t)max(i0, 0), i1c = (uint32_t)min(i0 + 1, wm1);
+            const uint32_t j0c = (uint32_t)max(j0, 0) * sy, j1c = (uint32_t)min(j0 + 1, hm1) * sy;
+            const uint32_t k0c = (uint32_t)max(k0, 0) * sz, k1c = (uint32_t)min(k0 + 1, dm1) * sz;
             const uint32_t r00 = k0c + j0c, r10 = k0c + j1c, r01 = k1c + j0c, r11 = k1c + j1c;
             t000 = vol[(uint64_t)(r00 + i0c) * STRIDE]; t100 = vol[(uint64_t)(r00 + i1c) * STRIDE];
             t010 = vol[(uint64_t)(r10 + i0c) * STRIDE]; t110 = vol[(uint64_t)(r10 + i1c) * STRIDE];
@@ -235,33 +224,20 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
             t011 = vol[(uint64_t)(r11 + i0c) * STRIDE]; t111 = vol[(uint64_t)(r11 + i1c) * STRIDE];
         }
         const float sample_dist = trilerp(t000, t100, t010, t110, t001, t101, t011, t111, ax, ay, az) - 1e-1f;
-        const V3 np = madd(p, dir, sample_dist);  // material.frag:124-125
-        // stop conditions: hit (material.frag:117-121) now, out of bounds at the top of the next iteration
-        const unsigned long long hit_m = __ballot(sample_dist < 1e-5f);
-        const unsigned long long oob_m = i < 254 ? __ballot(oob_dist<SYMM>(a, np) > 1e-4f) : 0ull;
-        const unsigned long long stop = alive & (hit_m | oob_m);
-        const float tnew = T ? tacc + sample_dist * tscale : 0.0f;  // tscale is 1 while marching: t + d exactly
-        if (stop != 0ull) {  // uniform, taken only when some lane ends its march in this iteration
-            const bool mine = (stop >> lane) & 1ull;
-            const bool mine_hit = ((stop & hit_m) >> lane) & 1ull;
-            if (mine) {
-                status = mine_hit ? 1 : -2;
-                steps = i + 1;
-                fin = mine_hit ? p : np;
-                if (T) {
-                    tfin = mine_hit ? tacc : tnew;  // a hit does not advance (material.frag:117-121)
-                    tscale = 0.0f;
-                }
-                dir = mk(0.0f, 0.0f, 0.0f);
-            }
-            alive &= ~stop;
+        // Stop condition: actually hit the surface (material.frag:117-121)
+        marching = marching && !(sample_dist < 1e-5f);
+        // Move the ray forward by the minimum distance to the surface (material.frag:124-125)
+        const V3 np = madd(ray_pos, ray_dir, sample_dist);
+        ray_pos.x = marching ? np.x : ray_pos.x;
+        ray_pos.y = marching ? np.y : ray_pos.y;
+        ray_pos.z = marching ? np.z : ray_pos.z;
+        if (T) {
+            const float nt = dist_from_origin + sample_dist;
+            dist_from_origin = marching ? nt : dist_from_origin;
         }
-        p = np;
-        if (T) tacc = tnew;
     }
-    const bool still = (alive >> lane) & 1ull;  // out of steps: reports the advanced position
-    ray_pos = still ? p : fin;
-    if (T) dist_from_origin = still ? tacc : tfin;
+    steps = last_i + 1;
+    if (covered) status = marching ? -1 : (oob_dist<SYMM>(a, ray_pos) > 1e-4f ? -2 : 1);
 }
 
 // three-d 0.18.2 tone_mapping / color_mapping (material.frag:167-168) [not vendored in the reference]
