@@ -222,6 +222,21 @@ def main():
     total_rays = W * H * world
     march_mrays = total_rays * args.steps / march_dt / 1e6
 
+    # ---------------- config 5 shape: a batch of 64 cameras, split over the ranks (extra, not `value`) ----------------
+    n_batch = 64
+    batch_cams = pkg.orbit_cameras(n_batch, aspect=W / H)
+    mine = [batch_cams[i] for i in par.split_cameras(n_batch, rank, world)]
+    batch_out = torch.empty((len(mine), H, W, 4), dtype=torch.float32, device=device)
+
+    def batch_step():
+        pkg.raymarch(rp, r0, r1, mine, W, H, out=batch_out)
+
+    batch_step()
+    batch_steps = max(2, min(args.steps, 5))
+    batch_dt, _ = timed_region(batch_step, batch_steps, torch, dist, world, device)
+    batch_mrays = n_batch * W * H * batch_steps / batch_dt / 1e6
+    del batch_out
+
     if world > 1:
         # outside the timed regions: the gathered slabs must equal a dense local fill of the global grid
         if gdims[0] * gdims[1] * gdims[2] * 32 <= 8 << 30:
@@ -261,6 +276,10 @@ def main():
                          "algorithmic_bytes_per_launch": FILL_BYTES_PER_VOXEL * voxels_per_rank,
                          "avg_launch_ms": round(kern_ms, 5)},
             "raymarch_kernel_ms": round(march_ev_ms / args.steps, 4),
+            "batch_raymarch": {"cameras": n_batch, "image": [W, H], "cameras_per_gpu": len(mine),
+                               "value": round(batch_mrays, 1), "unit": "Mrays/s",
+                               "ms_per_batch": round(batch_dt / batch_steps * 1e3, 4),
+                               "note": "BASELINE.json configs[4] shape (64-camera orbit) over the same grid"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_seconds)

@@ -11,6 +11,7 @@
 
 #include "loading_manager.hpp"
 #include "sdf_demo.hpp"
+#include "scene.hpp"
 #include "sdf_viewer.hpp"
 
 using namespace sdfviewer;
@@ -156,6 +157,57 @@ int sdfvh_viewer_render(void* v, uint32_t width, uint32_t height, const float ey
     int rc = V(v).material.render(cam, out.f32(), nullptr, V(v).stream);
     if (rc != 0) return rc;
     return hipMemcpy(rgba_host, out.get(), out.bytes(), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+
+// ---- SDFViewerAppScene (a manual clock, in milliseconds, makes the 500 ms commit spacing testable) ----
+struct SceneHandle {
+    long long now_ms = 0;
+    std::unique_ptr<SDFViewerAppScene> scene;
+};
+void* sdfvh_scene_new(void* sdf) {
+    auto* h = new SceneHandle();
+    auto clock = [h] { return std::chrono::steady_clock::time_point(std::chrono::milliseconds(h->now_ms)); };
+    h->scene.reset(new SDFViewerAppScene(*static_cast<std::shared_ptr<SDFSurface>*>(sdf), clock));
+    if (!h->scene->sdf_viewer) {
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+void sdfvh_scene_free(void* h) { delete static_cast<SceneHandle*>(h); }
+void sdfvh_scene_advance_clock(void* h, long long ms) { static_cast<SceneHandle*>(h)->now_ms += ms; }
+int sdfvh_scene_set_sdf(void* h, void* sdf, long long max_voxels_side, long long loading_passes) {
+    auto& sc = *static_cast<SceneHandle*>(h)->scene;
+    return sc.set_sdf(*static_cast<std::shared_ptr<SDFSurface>*>(sdf),
+                      max_voxels_side >= 0 ? std::optional<size_t>((size_t)max_voxels_side) : std::nullopt,
+                      loading_passes >= 0 ? std::optional<size_t>((size_t)loading_passes) : std::nullopt) ? 0 : -1;
+}
+void sdfvh_scene_set_budget_ms(void* h, long long budget_ms) {
+    static_cast<SceneHandle*>(h)->scene->load_budget = std::chrono::milliseconds(budget_ms);
+}
+// out[4] = {cpu_updates, committed, last_chunk, request_repaint}; rgba_host may be NULL (no drawing)
+int sdfvh_scene_render(void* h, uint32_t width, uint32_t height, float* rgba_host, unsigned long long out[4]) {
+    auto& sc = *static_cast<SceneHandle*>(h)->scene;
+    DeviceBuffer img(rgba_host ? (size_t)width * height * 16 : 0);
+    if (!img.ok()) return -1;
+    RenderReport r = sc.render(width, height, rgba_host ? img.f32() : nullptr);
+    out[0] = r.cpu_updates; out[1] = r.committed; out[2] = r.last_chunk; out[3] = r.request_repaint;
+    if (rgba_host && hipMemcpy(rgba_host, img.get(), img.bytes(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return 0;
+}
+float sdfvh_scene_lod(void* h) { return static_cast<SceneHandle*>(h)->scene->sdf_viewer->material.lod_dist_between_samples; }
+void sdfvh_scene_dims(void* h, uint32_t out[3]) {
+    for (int i = 0; i < 3; ++i) out[i] = static_cast<SceneHandle*>(h)->scene->sdf_viewer->material.tex_size[i];
+}
+// returns -1 when not loading, else writes the progress text and returns progress * 1e6
+long long sdfvh_scene_load_progress(void* h, char* text, size_t n) {
+    auto p = static_cast<SceneHandle*>(h)->scene->load_progress();
+    if (!p) return -1;
+    if (text && n) {
+        strncpy(text, p->second.c_str(), n - 1);
+        text[n - 1] = 0;
+    }
+    return (long long)(p->first * 1e6f);
 }
 
 }  // extern "C"

@@ -35,6 +35,13 @@ for name, res, args in [
     ("sdfvh_viewer_download", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("sdfvh_viewer_tex0", C.c_void_p, [C.c_void_p]), ("sdfvh_viewer_tex1", C.c_void_p, [C.c_void_p]),
     ("sdfvh_viewer_render", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("sdfvh_scene_new", C.c_void_p, [C.c_void_p]), ("sdfvh_scene_free", None, [C.c_void_p]),
+    ("sdfvh_scene_advance_clock", None, [C.c_void_p, C.c_longlong]),
+    ("sdfvh_scene_set_sdf", C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong]),
+    ("sdfvh_scene_set_budget_ms", None, [C.c_void_p, C.c_longlong]),
+    ("sdfvh_scene_render", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_ulonglong)]),
+    ("sdfvh_scene_lod", C.c_float, [C.c_void_p]), ("sdfvh_scene_dims", None, [C.c_void_p, C.c_void_p]),
+    ("sdfvh_scene_load_progress", C.c_longlong, [C.c_void_p, C.c_char_p, SZ]),
 ]:
     fn = getattr(H, name)
     fn.restype = res
@@ -191,6 +198,47 @@ class Viewer:
         e = None if eye is None else np.asarray(eye, np.float32)
         assert H.sdfvh_viewer_render(self.h, width, height, None if e is None else e.ctypes.data, out.ctypes.data) == 0
         return out
+
+
+class Scene:
+    """SDFViewerAppScene with a manual clock."""
+
+    def __init__(self, sdf):
+        self.h = H.sdfvh_scene_new(sdf.h)
+        assert self.h, "SDFViewerAppScene creation failed (no GPU?)"
+
+    def __del__(self):
+        H.sdfvh_scene_free(self.h)
+
+    def advance_clock(self, ms):
+        H.sdfvh_scene_advance_clock(self.h, ms)
+
+    def set_sdf(self, sdf, max_voxels_side=None, loading_passes=None):
+        assert H.sdfvh_scene_set_sdf(self.h, sdf.h, -1 if max_voxels_side is None else max_voxels_side,
+                                     -1 if loading_passes is None else loading_passes) == 0
+
+    def set_budget_ms(self, ms):
+        H.sdfvh_scene_set_budget_ms(self.h, ms)
+
+    def render(self, width=0, height=0, draw=False):
+        out = (C.c_ulonglong * 4)()
+        img = np.empty((height, width, 4), np.float32) if draw else None
+        assert H.sdfvh_scene_render(self.h, width, height, img.ctypes.data if draw else None, out) == 0
+        rep = dict(cpu_updates=out[0], committed=bool(out[1]), last_chunk=bool(out[2]), request_repaint=bool(out[3]))
+        return (rep, img) if draw else rep
+
+    def lod(self):
+        return H.sdfvh_scene_lod(self.h)
+
+    def dims(self):
+        out = (C.c_uint32 * 3)()
+        H.sdfvh_scene_dims(self.h, out)
+        return tuple(out)
+
+    def load_progress(self):
+        b = C.create_string_buffer(256)
+        p = H.sdfvh_scene_load_progress(self.h, b, 256)
+        return None if p < 0 else (p / 1e6, b.value.decode())
 
 
 # ---- per-point provider (reference ffi.rs ABI) ----

@@ -200,3 +200,44 @@ def test_cli_loads_and_renders(oracle, tmp_path):
     img = np.frombuffer(raw[len(header):], np.uint8).reshape(90, 160, 3).astype(np.int32)
     ref = np.rint(np.clip(want[..., :3] * want[..., 3:4], 0, 1) * 255).astype(np.int32)
     assert np.abs(img - ref).max() <= 1
+
+
+def test_scene_frame_scheduling(host, oracle):
+    """SDFViewerAppScene::render (scene/mod.rs:158-225): load within the budget every frame, commit at most every
+    500 ms while loading, one final commit when nothing is left, progress text while loading."""
+    sdf = host.SDF.demo()
+    sc = host.Scene(sdf)
+    assert sc.dims() == (32, 32, 32)                          # SDFViewer::from_bb(.., 32, 2), scene/mod.rs:102
+    sc.set_sdf(sdf, max_voxels_side=24, loading_passes=3)     # set_root_sdf(.., Some(n), Some(p))
+    assert sc.dims() == (24, 24, 24) and sc.load_progress() is None
+    sc.set_budget_ms(0)                                        # one LoadingManager pass per frame
+    passes = [6 ** 3, 12 ** 3, 24 ** 3]
+    r = sc.render()                                            # frame 1: first pass, first commit (no previous one)
+    assert r == dict(cpu_updates=passes[0], committed=True, last_chunk=False, request_repaint=True)
+    assert sc.lod() == 4.0                                     # 2^passes_left after the step-4 pass (step 2 is next)
+    prog, text = sc.load_progress()
+    total = sum(passes)
+    assert abs(prog - passes[0] / total) < 1e-6
+    assert text == f"Loading SDF {100 * passes[0] / total:.2f}% (2 levels of detail left, evaluations: {passes[0]} / {total})"
+    sc.advance_clock(100)
+    r = sc.render()                                            # frame 2: second pass, commit throttled (< 500 ms)
+    assert r == dict(cpu_updates=passes[1], committed=False, last_chunk=False, request_repaint=True)
+    assert sc.lod() == 4.0
+    sc.advance_clock(450)
+    r = sc.render()                                            # frame 3: last pass, 550 ms since the commit -> commit
+    assert r == dict(cpu_updates=passes[2], committed=True, last_chunk=False, request_repaint=True)
+    r = sc.render()                                            # frame 4: nothing left -> "Loaded last SDF chunk"
+    assert r == dict(cpu_updates=0, committed=True, last_chunk=True, request_repaint=True)
+    assert sc.lod() == 1.0 and sc.load_progress() is None
+    r, img = sc.render(96, 54, draw=True)                      # steady state: no loading, just draw
+    assert r == dict(cpu_updates=0, committed=False, last_chunk=False, request_repaint=False)
+    dims = (24, 24, 24)
+    r0, r1 = oracle.fill_dense(oracle.default_params(), dims)
+    want, _ = oracle.raymarch(oracle.default_render_params(dims), r0, r1, oracle.camera_look_at(aspect=96 / 54), 96, 54,
+                              want_aux=False)
+    assert np.abs(img - want).max() <= 1e-4
+    # a parameter edit restarts loading through changed() and the scene keeps scheduling it
+    assert sdf.set_parameter(0, 0.1) is None
+    sc.set_budget_ms(30)
+    r = sc.render()
+    assert r["cpu_updates"] > 0 and r["committed"] and sc.load_progress() is not None
