@@ -20,7 +20,7 @@ def test_bench_weak_scaling_path_two_ranks_one_gpu(world):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "64", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]  # includes bench.py's own assert: gathered slabs == dense fill
+    assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == world and d["scaling"] == "weak" and d["steps"] == 2
@@ -28,3 +28,4 @@ def test_bench_weak_scaling_path_two_ranks_one_gpu(world):
     gx, gy, gz = d["config"]["grid_global"]
     assert gx * gy * gz == world * 64 ** 3
     assert d["value"] > 0 and d["value_rays"] > 0
+    assert d["sharded_fill_verified"] is True  # gathered slabs == dense fill, ghost slices == neighbour's slices
