@@ -299,8 +299,11 @@ __device__ __forceinline__ void stamp_wave(const RaymarchArgs& a, uint32_t wave,
 //       1 = fast march over tex0.r; 2 = fast march over the compact distance volume (both LINEAR only).
 // XF:   0 = IEEE divide, 1 = exact power-of-two reciprocal, 2 = power-of-two extents and texture sizes.
 // AUX:  the per-pixel march record is stored (and distanceFromOrigin accumulated).
+#ifndef SDFV_RM_MIN_WAVES
+#define SDFV_RM_MIN_WAVES 1
+#endif
 template <int MODE, bool LINEAR, int XF, bool SYMM, bool AUX>
-__global__ __launch_bounds__(256) void raymarch_kernel(RaymarchArgs a) {
+__global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(RaymarchArgs a) {
     constexpr bool FAST = MODE != 0;
     // 8x8 pixel tile per wave, 2x2 waves per workgroup
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

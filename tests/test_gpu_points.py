@@ -59,3 +59,18 @@ def test_empty_batch(pkg):
     prm = pkg.default_params()
     out = pkg.sample_points(prm, torch.empty((0, 3), device="cuda"))
     assert out.shape == (0, 7)
+
+
+def test_unaligned_and_ragged_batches_take_the_scalar_path(pkg, oracle):
+    """Pointers that are not 16-byte aligned and batch sizes that are not a multiple of the workgroup size."""
+    rng = np.random.default_rng(23)
+    prm = pkg.default_params()
+    oprm = oracle.params_from(prm)
+    for n in (1, 255, 256, 257, 1000):
+        pts = rng.uniform(-1.2, 1.2, size=(n, 3)).astype(np.float32)
+        want = oracle.sample_many(oprm, pts)
+        flat = torch.zeros(n * 3 + 1, device="cuda")
+        flat[1:] = torch.from_numpy(pts).cuda().reshape(-1)
+        for view in (flat[1:].view(n, 3), torch.from_numpy(pts).cuda()):   # misaligned by 4 bytes, aligned
+            got = pkg.sample_points(prm, view).cpu().numpy()
+            np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))

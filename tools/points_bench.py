@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Throughput of the batched point kernels (SDFSurface::sample / ::normal over point lists)."""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+pkg = importlib.import_module("sdf-viewer_amd")
+prm = pkg.default_params()
+n = 64 * 1024 * 1024
+pts = (torch.rand((n, 3), device="cuda") * 2.4 - 1.2).contiguous()
+def timed(fn, reps=5):
+    fn(); ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    return sorted(ts)[len(ts) // 2]
+for name, fn, bytes_per in [("sample(p, false)", lambda: pkg.sample_points(prm, pts), 12 + 28),
+                            ("sample(p, true)", lambda: pkg.sample_points(prm, pts, True), 12 + 28),
+                            ("normal(p)", lambda: pkg.normal_points(prm, pts), 12 + 12),
+                            ("normal_default(p, 0.001)", lambda: pkg.normal_points(prm, pts, eps=0.001, use_default=True), 12 + 12)]:
+    ms = timed(fn)
+    print(f"{name:26s} {n / ms / 1e3:9.0f} Mpoints/s  {n * bytes_per / ms / 1e6:7.0f} GB/s algorithmic ({ms:.3f} ms for {n} points; includes the output allocation)")
