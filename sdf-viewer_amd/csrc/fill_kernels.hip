@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kBlock) void fill_dense_kernel(FillArgs a) {
 
 // One LoadingManager pass: one thread per visited voxel (x, y, z multiples of `step`; z is GLOBAL), workgroups in
 // memory order like the dense kernel.  Reads tex0.r for update_required (scene/sdf/mod.rs:184-190) and, when an
-// update is required, rewrites tex0 (16 B) and tex1.rgb (12 B: tex1.a is not update()'s to touch).
+// update is required, rewrites tex0 (16 B) and tex1 (16 B, its alpha read back and stored unchanged).
 __global__ __launch_bounds__(kBlock) void fill_pass_kernel(FillArgs a, PassArgs p) {
     __shared__ float s_lut[256];
     s_lut[threadIdx.x] = c_srgb_lut[threadIdx.x];
@@ -110,10 +110,10 @@ __global__ __launch_bounds__(kBlock) void fill_pass_kernel(FillArgs a, PassArgs 
     float4 v0, v1;
     fill_voxel<RuntimeCfg>(a.prm, a.sdf_id, px, py, pz, lut, a.air_dist, v0, v1);
     a.tex0[flat] = v0;
-    float* t1 = reinterpret_cast<float*>(a.tex1 + flat);
-    t1[0] = v1.x;
-    t1[1] = v1.y;
-    t1[2] = v1.z;
+    // tex1.a is not update()'s to touch: carry the stored value through a full 16-byte store (12-byte partial
+    // stores make the memory side read-modify-write the line; ~10 % slower on the step-1 pass)
+    v1.w = reinterpret_cast<const float*>(a.tex1 + flat)[3];
+    a.tex1[flat] = v1;
 }
 
 __global__ __launch_bounds__(kBlock) void grid_init_kernel(float4* tex0, float4* tex1, uint64_t n, float air) {
