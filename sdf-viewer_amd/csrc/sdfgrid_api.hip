@@ -114,6 +114,7 @@ struct DeviceBuf {
 
 }  // namespace
 
+#pragma GCC visibility push(default)
 extern "C" {
 
 uint32_t sdfv_abi_version(void) { return SDFV_ABI_VERSION; }
@@ -442,3 +443,4 @@ int sdfv_raymarch_host(const sdfv_render_params* rp, const float* tex0_host, con
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

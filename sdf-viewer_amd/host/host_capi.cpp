@@ -16,6 +16,7 @@
 
 using namespace sdfviewer;
 
+#pragma GCC visibility push(default)
 extern "C" {
 
 // ---- LoadingManager ----
@@ -211,3 +212,4 @@ long long sdfvh_scene_load_progress(void* h, char* text, size_t n) {
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

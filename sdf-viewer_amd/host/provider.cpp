@@ -109,6 +109,7 @@ SDFParamValue value_to_api(const SDFParamValueC& c) {  // ffi.rs:223-231 (takes 
 
 }  // namespace
 
+#pragma GCC visibility push(default)
 extern "C" {
 
 void init(void) { set_root_sdf(std::make_shared<SDFDemo>()); }  // demo/ffi.rs:5-8
@@ -254,3 +255,4 @@ SDFVec3* normal(uint32_t sdf_id, SDFVec3 p, float eps) {
 void normal_free(SDFVec3* ret) { free(ret); }
 
 }  // extern "C"
+#pragma GCC visibility pop
