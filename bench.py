@@ -261,7 +261,8 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Mvoxels/s grid fill (value) + Mrays/s sphere-trace (value_rays), demo SDF",
+            "metric": "Mvoxels/s grid fill + Mrays/s sphere-trace @1080p, demo SDF",
+            "metric_note": "the metric is a pair: value = Mvoxels/s of the grid fill, value_rays = Mrays/s of the sphere-trace",
             "value": round(fill_mvox, 1),
             "unit": "Mvoxels/s",
             "value_rays": round(march_mrays, 1),
@@ -294,7 +295,7 @@ def main():
                                "ms_per_batch": round(batch_dt / batch_steps * 1e3, 4),
                                "note": "BASELINE.json configs[4] shape (64-camera orbit) over the same grid"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0, N = 1 only
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -143,8 +143,16 @@ def test_demo_from_cli_flags(host, pkg):
 
 
 def test_provider_exports_reference_symbols(host):
+    import os
+    import re
     raw = C.CDLL(host.PROVIDER_PATH)
-    for name in host.PROVIDER_SYMBOLS:
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sdf_provider.h")).read()
+    body = hdr[hdr.index("void init(void);"):]
+    declared = set(re.findall(r"\b([a-z_]+)\s*\(", re.sub(r"/\*.*?\*/", "", body, flags=re.S)))
+    assert set(host.PROVIDER_SYMBOLS) <= declared and "init_with_args" in declared
+    for name in declared:            # every function include/sdf_provider.h declares is exported ...
+        getattr(raw, name)
+    for name in host.PROVIDER_SYMBOLS:  # ... and they are the reference's own names (ffi.rs:42-337)
         getattr(raw, name)
     assert C.sizeof(host.ParamC) == 88 and C.sizeof(host.ParamValueC) == 24 and C.sizeof(host.ParamKindC) == 24
 
