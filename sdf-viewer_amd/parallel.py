@@ -172,3 +172,21 @@ def gather_replica(slab, dims, world, group=None):
 def split_cameras(n_cameras, rank, world):
     """Cameras dealt to ranks in contiguous blocks (config 5: 64 cameras over 8 GPUs = 8 each)."""
     return range(n_cameras * rank // world, n_cameras * (rank + 1) // world)
+
+
+def gather_images(rgba, n_cameras, rank, world, dst=0, group=None):
+    """Config 5's optional last step: collect every rank's rendered cameras ([n_local, H, W, 4]) on rank `dst` in
+    camera order.  Camera counts may differ by one between ranks, so each block is padded to the largest count.
+    Returns [n_cameras, H, W, 4] on `dst`, None elsewhere."""
+    if world == 1:
+        return rgba
+    counts = [len(split_cameras(n_cameras, r, world)) for r in range(world)]
+    staged = _needs_host_staging(rgba, group)
+    dev = torch.device("cpu") if staged else rgba.device
+    padded = torch.zeros((max(counts),) + tuple(rgba.shape[1:]), dtype=rgba.dtype, device=dev)
+    padded[:rgba.shape[0]] = rgba
+    parts = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0).to(rgba.device)

@@ -48,6 +48,15 @@ def _worker(rank, world, port, dims, q):
         d0, d1 = oracle.fill_dense(prm, dims, threads=1)
         ok &= np.array_equal(r0.numpy().view(np.uint32), d0.view(np.uint32))
         ok &= np.array_equal(r1.numpy().view(np.uint32), d1.view(np.uint32))
+        # camera split + image gather (config 5): rank r's cameras carry their global index as pixel value
+        n_cams = 7
+        mine = list(par.split_cameras(n_cams, rank, world))
+        imgs = torch.stack([torch.full((3, 5, 4), float(c)) for c in mine]) if mine else torch.zeros((0, 3, 5, 4))
+        got = par.gather_images(imgs, n_cams, rank, world, dst=0)
+        if rank == 0:
+            ok &= got.shape == (n_cams, 3, 5, 4) and all(bool((got[c] == float(c)).all()) for c in range(n_cams))
+        else:
+            ok &= got is None
         q.put((rank, bool(ok), slab.z_begin, slab.z_end))
     finally:
         dist.destroy_process_group()
