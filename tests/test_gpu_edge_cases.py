@@ -106,3 +106,39 @@ def test_grid_larger_than_infinity_cache_round_trips_unchanged_elsewhere(pkg):
     s0, s1 = pkg.alloc_textures(g1)
     pkg.fill_grid(prm, g1, s0, s1)
     assert torch.equal(s0[0], buf0[3]) and torch.equal(s1[0], buf1[3])
+
+
+def test_textures_larger_than_4_gib_use_64_bit_addressing(pkg, oracle):
+    """1024 x 1024 x 288 voxels: 4.5 GiB per texture, so byte offsets pass 2^32 (the 512^3 case stays below it)."""
+    dims = (1024, 1024, 288)
+    prm = pkg.default_params()
+    g = pkg.make_grid(dims)
+    t0, t1 = pkg.alloc_textures(g)
+    assert t0.numel() * 4 > 2 ** 32
+    pkg.fill_grid(prm, g, t0, t1)
+    torch.cuda.synchronize()
+    oprm = oracle.params_from(prm)
+    for z in (0, 255, 256, 257, 287):      # slice 256 starts exactly at byte 2^32
+        r0, r1 = oracle.fill_dense(oprm, dims, z0=z, z1=z + 1)
+        np.testing.assert_array_equal(t0[z:z + 1].cpu().numpy().view(np.uint32), r0.view(np.uint32))
+        np.testing.assert_array_equal(t1[z:z + 1].cpu().numpy().view(np.uint32), r1.view(np.uint32))
+    # the progressive pass and the compact distance copy address the same range
+    pkg.fill_grid_pass(pkg.default_params(sphere_radius=0.5), g, 4, t0, t1, changed_box=(-1, -1, 0.9, 1, 1, 1))
+    dist = pkg.commit_distance(g, t0)
+    torch.cuda.synchronize()
+    assert torch.equal(dist, t0[..., 0])
+    assert not torch.equal(t0[284], torch.from_numpy(oracle.fill_dense(oprm, dims, z0=284, z1=285)[0][0]).cuda())
+    pkg.fill_grid(prm, g, t0, t1)
+    # a small image marched through the far end of the volume (camera behind the last slices) vs the oracle
+    rp = pkg.default_render_params(g)
+    cam = pkg.camera_look_at(eye=(0.4, 0.3, 4.0), aspect=1.0)
+    got, aux = pkg.raymarch(rp, t0, t1, cam, 48, 48, want_aux=True, dist=pkg.commit_distance(g, t0))
+    torch.cuda.synchronize()
+    h0, h1 = t0.cpu().numpy(), t1.cpu().numpy()
+    want, waux = oracle.raymarch(oracle.copy_struct(oracle.RenderParams, rp), h0, h1,
+                                 oracle.copy_struct(oracle.Camera, cam), 48, 48, threads=32)
+    a = aux.cpu().numpy().view(oracle.AUX_DTYPE).reshape(48, 48)
+    np.testing.assert_array_equal(a["status"], waux["status"])
+    np.testing.assert_array_equal(a["steps"], waux["steps"])
+    np.testing.assert_array_equal(a["hit_pos"].view(np.uint32), waux["hit_pos"].view(np.uint32))
+    assert np.abs(got[0].cpu().numpy() - want).max() <= 1e-4 and (waux["status"] == 1).sum() > 100
