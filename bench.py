@@ -73,6 +73,25 @@ def timed_region(fn, steps, torch, dist, world, device):
     return dt, ev_ms
 
 
+def effective_cores():
+    """Host cores this process can actually use: the affinity mask, capped by the cgroup CPU quota (a container
+    may see every core of the node but be throttled to a fraction of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = max(1, min(n, (q + p // 2) // p))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(workload, budget_s):
     """The oracle (a port: the Rust reference cannot be built here) timed on this box's host cores, on a bounded
     sample of the same workload (SURVEY.md 8d / BASELINE.md 2):
@@ -87,7 +106,7 @@ def cpu_baseline(workload, budget_s):
     side, W, H = workload["side"], workload["width"], workload["height"]
     prm = oracle.default_params()
     dims = (side, side, side)
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     n_vox = side ** 3
     # (i) faithful single-thread loop
     t0, t1 = oracle.grid_init(dims)
@@ -106,17 +125,22 @@ def cpu_baseline(workload, budget_s):
         if fill_dt > budget_s:  # one load of a big grid may exceed the budget on its own: stop there
             break
     fill_mvox = loads * n_vox / fill_dt / 1e6
-    # (ii) all host cores, dense
+    # (ii) all host cores, dense.  Fresh buffers whose pages are first touched by the OpenMP team itself (one
+    # untimed warm-up fill), so that on a multi-socket host every thread writes to its own NUMA node.
     threads = min(cores, side)
-    oracle.fill_dense(prm, dims, z0=0, z1=min(side, threads), threads=threads)  # warm the OpenMP team
+    a0 = np.empty((side, side, side, 4), np.float32)
+    a1 = np.empty_like(a0)
+    dense_args = (oracle.C.byref(prm), 0, oracle.u3(dims), oracle.f3((-1, -1, -1)), oracle.f3((1, 1, 1)), 0, side,
+                  a0.ctypes.data, a1.ctypes.data, threads)
+    oracle.L.or_fill_dense(*dense_args)
     n_all, all_dt = 0, 0.0
     while all_dt < budget_s * 0.2:
         t = time.perf_counter()
-        oracle.L.or_fill_dense(oracle.C.byref(prm), 0, oracle.u3(dims), oracle.f3((-1, -1, -1)), oracle.f3((1, 1, 1)),
-                               0, side, t0.ctypes.data, t1.ctypes.data, threads)
+        oracle.L.or_fill_dense(*dense_args)
         all_dt += time.perf_counter() - t
         n_all += 1
     all_mvox = n_all * n_vox / all_dt / 1e6
+    del a0, a1
     # raymarch: 8-row bands of the same image over the grid just filled, middle of the image outwards
     rp = oracle.default_render_params(dims)
     cam = oracle.camera_look_at(aspect=W / H)
@@ -132,7 +156,8 @@ def cpu_baseline(workload, budget_s):
             "sample": f"{loads} complete load(s) of the {side}^3 grid in LoadingManager order, 2 passes "
                       f"({loads * n_vox} voxels, {fill_dt:.1f} s), oracle/grid_fill.c gcc -O2 -ffp-contract=off, 1 thread",
             "all_cores": {"value": round(all_mvox, 3), "unit": "Mvoxels/s", "cores": threads,
-                          "sample": f"{n_all} dense fill(s) of the {side}^3 grid, OpenMP over z ({all_dt:.1f} s)"},
+                          "sample": f"{n_all} dense fill(s) of the {side}^3 grid, OpenMP over z ({all_dt:.1f} s); "
+                                    f"{threads} = usable cores (affinity {len(os.sched_getaffinity(0))}, cgroup quota applied)"},
             "value_rays": round(rays, 3), "unit_rays": "Mrays/s",
             "sample_rays": f"{rows_done} central rows of the {W}x{H} image, 1 thread"}
 

@@ -107,7 +107,7 @@ void or_fill_dense(const OrDemoParams *prm, uint32_t sdf_id, const uint32_t dims
     const float air = or_air_dist();
     (void)n_threads;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1)
+#pragma omp parallel for schedule(static) num_threads(n_threads > 0 ? n_threads : 1)
 #endif
     for (int64_t z = z0; z < (int64_t)z1; ++z) {
         for (size_t y = 0; y < H; ++y) {

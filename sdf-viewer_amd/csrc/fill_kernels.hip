@@ -118,7 +118,8 @@ __global__ __launch_bounds__(kBlock) void fill_pass_kernel(FillArgs a, PassArgs 
 
 __global__ __launch_bounds__(kBlock) void grid_init_kernel(float4* tex0, float4* tex1, uint64_t n, float air) {
     const float4 v = make_float4(air, air, air, air);
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;  // memory order, like the dense fill
+    if (i < n) {
         tex0[i] = v;
         tex1[i] = v;
     }
@@ -188,8 +189,8 @@ hipError_t launch_commit_distance(const float* tex0, float* dist, uint64_t n_vox
 
 hipError_t launch_grid_init(float* tex0, float* tex1, uint64_t n_voxels, float air, hipStream_t stream) {
     if (n_voxels == 0) return hipSuccess;
-    uint64_t blocks = (n_voxels + kBlock - 1) / kBlock;
-    if (blocks > 8192) blocks = 8192;
+    const uint64_t blocks = (n_voxels + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(grid_init_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, stream,
                        reinterpret_cast<float4*>(tex0), reinterpret_cast<float4*>(tex1), n_voxels, air);
     return hipGetLastError();
