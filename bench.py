@@ -10,7 +10,8 @@ halves are timed in two separately bracketed regions of exactly K steps each:
 Inputs are deterministic (integer lattice + fixed cameras) and already resident in HBM; outputs stay in HBM.
 
 N = 1 workload: BASELINE.json configs[1] (256^3 grid + 1920x1080).  --workload 512 selects configs[2]
-(512^3 + 3840x2160).  N > 1 (weak scaling): the grid grows to side^3 voxels PER RANK, sharded by z-slab,
+(512^3 + 3840x2160).  N > 1 (weak scaling): the grid grows to side^3 voxels PER RANK, sharded by z-slab
+(--weak-geometry slab: along z only, each rank fills the N = 1 slab; cube: towards config 4's 1024^3),
 each fill step includes the one-voxel RCCL halo exchange (overlapped with the interior fill); the raymarch renders one camera per rank
 (orbit) over a replica of the N = 1 grid.
 
@@ -44,6 +45,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="256")
+    ap.add_argument("--weak-geometry", choices=["slab", "cube"], default="slab",
+                    help="N>1: grow the grid along z only (every rank fills the N=1 slab; default) or towards a cube "
+                         "(8 ranks x --workload 512 = BASELINE.json config 4, 1024^3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     return ap.parse_args()
@@ -204,7 +208,7 @@ def main():
     prm = pkg.default_params()
 
     # ---------------- fill: side^3 voxels per rank, z-slab of the weak-scaled global grid ----------------
-    gdims = par.weak_scaling_dims(side, world)
+    gdims = par.weak_scaling_dims(side, world, args.weak_geometry)
     slab = par.alloc_slab(gdims, rank, world, device)
     grid = pkg.make_grid(gdims, z_begin=slab.z_begin, z_end=slab.z_end)
     owned0, owned1 = slab.owned0, slab.owned1
@@ -307,6 +311,7 @@ def main():
             "backend": None if world == 1 else ("rccl" if backend == "nccl" else backend + " (test only)"),
             "config": {"workload": wl["name"], "grid_global": list(gdims), "voxels_per_gpu": voxels_per_rank,
                        "image": [W, H], "cameras_per_gpu": len(my_cams),
+                       "weak_geometry": None if world == 1 else args.weak_geometry,
                        "parallelism": "single GPU" if world == 1 else f"z-slab x{world} + 1-voxel RCCL halo; 1 camera/GPU"},
             "roofline": {"kernel": "fill_dense_kernel", "bound": "hbm",
                          "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

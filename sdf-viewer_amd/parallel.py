@@ -20,9 +20,15 @@ def slab_range(depth, rank, world):
     return depth * rank // world, depth * (rank + 1) // world
 
 
-def weak_scaling_dims(side, world):
-    """Global grid with side^3 voxels per rank: doubles x, then y, then z as world doubles (1,2,4,8 -> cube of
-    2*side at 8 ranks = BASELINE.json config 4 when side = 512)."""
+def weak_scaling_dims(side, world, geometry="slab"):
+    """Global grid with side^3 voxels per rank.
+    "slab": the grid grows along the sharded axis only, (side, side, side*world): every rank fills exactly the
+            slab the single-GPU run fills (same launch shape, same rows), and the halo slice stays side^2.
+    "cube": doubles z, then y, then x as world doubles (1,2,4,8 -> a cube of 2*side at 8 ranks = BASELINE.json
+            config 4 when side = 512); the halo slice grows to (2*side)^2 while the slab gets thinner."""
+    if geometry == "slab":
+        return (side, side, side * world)
+    assert geometry == "cube", geometry
     dims = [side, side, side]
     axis, w = 2, world
     while w > 1:

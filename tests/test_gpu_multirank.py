@@ -12,13 +12,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_bench_weak_scaling_path_two_ranks_one_gpu(world):
+@pytest.mark.parametrize("world,geometry", [(2, "slab"), (4, "cube")])
+def test_bench_weak_scaling_path_two_ranks_one_gpu(world, geometry):
     env = dict(os.environ, SDFV_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     port = 29600 + world + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "64", "--no-cpu-baseline"]
+           "--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "64", "--no-cpu-baseline",
+           "--weak-geometry", geometry]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -27,5 +28,6 @@ def test_bench_weak_scaling_path_two_ranks_one_gpu(world):
     assert d["config"]["voxels_per_gpu"] == 64 ** 3
     gx, gy, gz = d["config"]["grid_global"]
     assert gx * gy * gz == world * 64 ** 3
+    assert (gx, gy, gz) == ((64, 64, 64 * world) if geometry == "slab" else (64, 128, 128))
     assert d["value"] > 0 and d["value_rays"] > 0
     assert d["sharded_fill_verified"] is True  # gathered slabs == dense fill, ghost slices == neighbour's slices

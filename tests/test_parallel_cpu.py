@@ -88,9 +88,11 @@ def test_partition_helpers():
             assert rs[0][0] == 0 and rs[-1][1] == depth
             assert all(a[1] == b[0] for a, b in zip(rs[:-1], rs[1:]))
             assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1
-    assert par.weak_scaling_dims(256, 1) == (256, 256, 256)
-    assert par.weak_scaling_dims(256, 2) == (256, 256, 512)
-    assert par.weak_scaling_dims(256, 4) == (256, 512, 512)
-    assert par.weak_scaling_dims(512, 8) == (1024, 1024, 1024)   # BASELINE.json config 4
+    assert par.weak_scaling_dims(256, 1) == par.weak_scaling_dims(256, 1, "cube") == (256, 256, 256)
+    assert par.weak_scaling_dims(256, 8) == (256, 256, 2048)             # every rank fills the N=1 slab
+    assert par.slab_range(2048, 3, 8) == (768, 1024)
+    assert par.weak_scaling_dims(256, 2, "cube") == (256, 256, 512)
+    assert par.weak_scaling_dims(256, 4, "cube") == (256, 512, 512)
+    assert par.weak_scaling_dims(512, 8, "cube") == (1024, 1024, 1024)   # BASELINE.json config 4
     cams = [list(par.split_cameras(64, r, 8)) for r in range(8)]
     assert sum(cams, []) == list(range(64)) and all(len(c) == 8 for c in cams)
