@@ -166,9 +166,9 @@ def cpu_baseline(workload, budget_s):
             "sample_rays": f"{rows_done} central rows of the {W}x{H} image, 1 thread"}
 
 
-def load_traffic(workload_key):
-    """HBM bytes per launch from the committed PMC pass (profiles/*_pmc.json), or None."""
-    path = os.path.join(ROOT, "profiles", "fill_pmc_traffic.json")
+def load_traffic(workload_key, name="fill_pmc_traffic.json"):
+    """HBM bytes per launch from the committed PMC pass (profiles/*_pmc_traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", name)
     try:
         d = json.load(open(path))
         return d.get(workload_key, {}).get("hbm_bytes_per_launch")
@@ -320,6 +320,13 @@ def main():
                          "algorithmic_bytes_per_launch": FILL_BYTES_PER_VOXEL * voxels_per_rank,
                          "avg_launch_ms": round(kern_ms, 5)},
             "raymarch_kernel_ms": round(march_ev_ms / args.steps, 4),
+            "roofline_raymarch": (lambda tr, ms: {
+                "kernel": "raymarch_kernel", "bound": "latency (<=255 dependent gathers per ray), not hbm",
+                "traffic": tr, "achieved": None if tr is None else round(tr / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": None if tr is None else round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "HBM traffic per frame from PMC counters / live launch time; informational"})(
+                    load_traffic(args.workload, "raymarch_pmc_traffic.json") if world == 1 else None,
+                    march_ev_ms / args.steps),
             "batch_raymarch": {"cameras": n_batch, "image": [W, H], "cameras_per_gpu": len(mine),
                                "value": round(batch_mrays, 1), "unit": "Mrays/s",
                                "ms_per_batch": round(batch_dt / batch_steps * 1e3, 4),
