@@ -69,8 +69,10 @@ sdfv_render_params SDFViewerMaterial::uniforms() const {
 int SDFViewerMaterial::render(const Camera& camera, float* rgba_device, sdfv_march_aux* aux_device, void* stream) const {
     const sdfv_render_params rp = uniforms();
     const sdfv_camera cam = camera.to_device();
-    return sdfv_raymarch(&rp, tex0->f32(), tex1->f32(), &cam, 1, camera.viewport_width, camera.viewport_height, 0,
-                         camera.viewport_height, rgba_device, aux_device, stream);
+    // the distance volume is only meaningful for the fully loaded grid (LINEAR filter, lod == 1)
+    const float* d = (dist && lod_dist_between_samples == 1.0f) ? dist->f32() : nullptr;
+    return sdfv_raymarch_accel(&rp, tex0->f32(), tex1->f32(), d, &cam, 1, camera.viewport_width,
+                               camera.viewport_height, 0, camera.viewport_height, rgba_device, aux_device, stream);
 }
 
 // ---- SDFViewer ----
@@ -148,6 +150,7 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
             return 0;
         }
         fresh_ = false;
+        dist_stale_ = true;
         while (loading_mgr.step_size() != 0) loading_mgr.finish_pass();
         return loading_mgr.total_iterations() - start_iter;
     }
@@ -170,6 +173,7 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
             break;
         }
         fresh_ = false;
+        dist_stale_ = true;
         loading_mgr.finish_pass();
     }
     return loading_mgr.total_iterations() - start_iter;
@@ -179,6 +183,21 @@ void SDFViewer::commit() {
     // tex0.fill / tex1.fill re-upload nothing here: the textures already live on the device.  (:222-234)
     material.lod_dist_between_samples = std::pow(2.0f, (float)(uint8_t)loading_mgr.passes_left());  // :226
     // lod == 1 switches the GL filter to LINEAR (:227-230): the kernel selects the filter from the same uniform.
+    // Where the reference uploads, derive the raymarch's acceleration data instead: a compact copy of tex0.r.
+    if (material.lod_dist_between_samples == 1.0f) {
+        if (dist_stale_) {
+            const size_t bytes = material.tex0->bytes() / 4;
+            if (!material.dist || material.dist->bytes() != bytes) material.dist = std::make_shared<DeviceBuffer>(bytes);
+            const sdfv_grid g = grid();
+            if (material.dist->ok() && sdfv_commit_distance(&g, tex0_device(), material.dist->f32(), stream) == 0)
+                dist_stale_ = false;
+            else
+                material.dist.reset();  // rendering falls back to marching tex0.r in place
+        }
+    } else {
+        material.dist.reset();
+        dist_stale_ = true;
+    }
 }
 
 int SDFViewer::download(float* tex0_host, float* tex1_host) const {

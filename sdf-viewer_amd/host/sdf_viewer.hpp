@@ -5,8 +5,9 @@
 // with the two textures living in HBM instead of a CPU Vec + GL texture pair:
 //   - update() launches LoadingManager passes as kernels (sdfv_fill_grid_pass) -- or the dense kernel when a
 //     fresh grid can be finished within the call -- instead of calling sample() once per voxel;
-//   - commit() has nothing to upload (the reference re-uploads both whole textures, :220-239): it only
-//     publishes lod_dist_between_samples = 2^passes_left to the material;
+//   - commit() has nothing to upload (the reference re-uploads both whole textures, :220-239): it publishes
+//     lod_dist_between_samples = 2^passes_left to the material and, once the grid is fully loaded, derives the
+//     raymarch's compact distance volume from tex0 (sdfv_commit_distance);
 //   - SDFViewerMaterial::render() is the fragment shader over every pixel (sdfv_raymarch).
 #pragma once
 
@@ -62,6 +63,7 @@ class DeviceBuffer {
 struct SDFViewerMaterial {
     std::shared_ptr<DeviceBuffer> tex0;  // distance (R), colour (GBA)
     std::shared_ptr<DeviceBuffer> tex1;  // material properties (RGB)
+    std::shared_ptr<DeviceBuffer> dist;  // compact copy of tex0.r built by SDFViewer::commit (may be null)
     std::array<uint32_t, 3> tex_size{0, 0, 0};
     BoundingBox voxels_bounds;
     float lod_dist_between_samples = 1.0f;
@@ -104,6 +106,7 @@ class SDFViewer {
     SDFViewer(std::array<size_t, 3> voxels, const BoundingBox& bb, size_t passes);
     std::string error_;
     bool fresh_ = true;  // both textures still hold new_voxels' AIR_DIST everywhere
+    bool dist_stale_ = true;  // the textures changed since the distance volume was derived
 };
 
 }  // namespace sdfviewer
