@@ -49,6 +49,7 @@ def parse_args():
                     help="N>1: grow the grid along z only (every rank fills the N=1 slab; default) or towards a cube "
                          "(8 ranks x --workload 512 = BASELINE.json config 4, 1024^3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch", action="store_true", help="skip the extra 64-camera batch (profiling runs)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     return ap.parse_args()
 
@@ -184,7 +185,7 @@ def raymarch_traffic_report(workload_key, launch_ms):
     return {"kernel": "raymarch_kernel", "bound": "latency (<=255 dependent gathers per ray), not hbm",
             "traffic": traffic, "achieved": None if gbs is None else round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": None if gbs is None else round(gbs / HBM_PEAK_GBS, 4),
-            "note": "PMC traffic was collected marching tex0.r in place; the bench marches the compact distance volume"}
+            "note": "HBM bytes per frame from the committed PMC pass of this same configuration"}
 
 
 def main():
@@ -271,18 +272,23 @@ def main():
 
     # ---------------- config 5 shape: a batch of 64 cameras, split over the ranks (extra, not `value`) ----------------
     n_batch = 64
-    batch_cams = pkg.orbit_cameras(n_batch, aspect=W / H)
-    mine = [batch_cams[i] for i in par.split_cameras(n_batch, rank, world)]
-    batch_out = torch.empty((len(mine), H, W, 4), dtype=torch.float32, device=device)
+    batch_report = None
+    if not args.no_batch:
+        batch_cams = pkg.orbit_cameras(n_batch, aspect=W / H)
+        mine = [batch_cams[i] for i in par.split_cameras(n_batch, rank, world)]
+        batch_out = torch.empty((len(mine), H, W, 4), dtype=torch.float32, device=device)
 
-    def batch_step():
-        pkg.raymarch(rp, r0, r1, mine, W, H, out=batch_out, dist=dist_vol)
+        def batch_step():
+            pkg.raymarch(rp, r0, r1, mine, W, H, out=batch_out, dist=dist_vol)
 
-    batch_step()
-    batch_steps = max(2, min(args.steps, 5))
-    batch_dt, _ = timed_region(batch_step, batch_steps, torch, dist, world, device)
-    batch_mrays = n_batch * W * H * batch_steps / batch_dt / 1e6
-    del batch_out
+        batch_step()
+        batch_steps = max(2, min(args.steps, 5))
+        batch_dt, _ = timed_region(batch_step, batch_steps, torch, dist, world, device)
+        batch_report = {"cameras": n_batch, "image": [W, H], "cameras_per_gpu": len(mine),
+                        "value": round(n_batch * W * H * batch_steps / batch_dt / 1e6, 1), "unit": "Mrays/s",
+                        "ms_per_batch": round(batch_dt / batch_steps * 1e3, 4),
+                        "note": "BASELINE.json configs[4] shape (64-camera orbit) over the same grid"}
+        del batch_out
 
     verified = None
     if world > 1:
@@ -342,10 +348,7 @@ def main():
             "commit_note": "device-side SDFViewer::commit (compact distance volume for the march), once per load; "
                            "not part of ms_per_step",
             "roofline_raymarch": raymarch_traffic_report(args.workload if world == 1 else None, march_ev_ms / args.steps),
-            "batch_raymarch": {"cameras": n_batch, "image": [W, H], "cameras_per_gpu": len(mine),
-                               "value": round(batch_mrays, 1), "unit": "Mrays/s",
-                               "ms_per_batch": round(batch_dt / batch_steps * 1e3, 4),
-                               "note": "BASELINE.json configs[4] shape (64-camera orbit) over the same grid"},
+            "batch_raymarch": batch_report,
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0, N = 1 only
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_seconds)
