@@ -180,3 +180,30 @@ def test_host_buffer_entry_point(pkg, oracle):
     r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims)
     np.testing.assert_array_equal(t0.view(np.uint32), r0.view(np.uint32))
     np.testing.assert_array_equal(t1.view(np.uint32), r1.view(np.uint32))
+
+
+def test_randomised_parameters_and_grids(pkg, oracle):
+    """Seeded sweep over the demo's whole parameter space (the GUI sliders' ranges, demo/mod.rs:94-118,
+    cube.rs:117-127, sphere.rs:75-85), odd grid shapes and off-centre boxes: dense fill and one progressive pass."""
+    rng = np.random.default_rng(20250404)
+    for trial in range(24):
+        kw = dict(cube_half_side=float(rng.integers(0, 101)) / 100.0,             # Int 0..=100 mapped to [0, 1]
+                  sphere_radius=float(np.float32(rng.uniform(0.0, 1.25))),
+                  max_distance_custom_material=float(np.float32(rng.uniform(0.0, 0.25))),
+                  cube_material=int(rng.integers(0, 2)), sphere_material=int(rng.integers(0, 2)),
+                  disable_sphere=int(rng.integers(0, 4) == 0))
+        prm = pkg.default_params(**kw)
+        dims = tuple(int(d) for d in rng.integers(2, 40, size=3))
+        lo = rng.uniform(-1.5, -0.2, size=3)
+        hi = lo + rng.uniform(0.3, 2.5, size=3)
+        sdf_id = int(rng.integers(0, 3))
+        t0, t1 = gpu_fill(pkg, prm, dims, lo, hi, sdf_id=sdf_id)
+        r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, lo, hi, sdf_id=sdf_id, threads=2)
+        assert_bits_equal(t0, r0)
+        assert_bits_equal(t1, r1)
+        g = pkg.make_grid(dims, lo, hi)
+        p0, p1 = pkg.alloc_textures(g)
+        pkg.grid_init(g, p0, p1)
+        pkg.fill_grid_pass(prm, g, 1, p0, p1, sdf_id=sdf_id)
+        torch.cuda.synchronize()
+        assert torch.equal(p0, t0) and torch.equal(p1, t1), (trial, kw, dims)
