@@ -12,6 +12,9 @@
  * copies what it needs and hands the SAME pointer to the matching *_free.  Errors (ffi.rs:46-49):
  * unknown ids print "Failed to find SDF with ID <id>" on stderr and return zeros / NULL payloads.
  * The registry is thread-local (ffi.rs:15-17): call init() on the thread that uses the SDF.
+ * One deliberate difference: a String payload handed to set_parameter() is COPIED and stays the caller's; the
+ * reference reclaims it as a Rust Vec (ffi.rs:228-229), which is only sound when caller and callee share an
+ * allocator (its wasm host writes the bytes at a fixed scratch address instead, wasm/native.rs:408-411).
  *
  * All arithmetic runs on the GPU (one-point batches of the libsdfgrid kernels): this ABI is the
  * compatibility path; the hot path is the batched API in sdfgrid.h.
