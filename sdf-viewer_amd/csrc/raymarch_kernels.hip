@@ -132,6 +132,17 @@ __device__ __forceinline__ float sample_r(const RaymarchArgs& a, const Tex& t, V
     return base[(uint64_t)nearest_offset(a, t, q) * 4];
 }
 
+// LINEAR tex0.r read from either tex0 itself (STRIDE 4) or the compact distance volume (STRIDE 1).
+template <int XF, bool FAST, int STRIDE>
+__device__ __forceinline__ float sample_r_linear(const RaymarchArgs& a, const float* __restrict__ vol, const Tex& t, V3 p) {
+    const Footprint f = footprint<FAST>(t, to_p01<XF>(a, p));
+    const float t000 = vol[(uint64_t)f.o000 * STRIDE], t100 = vol[(uint64_t)f.o100 * STRIDE];
+    const float t010 = vol[(uint64_t)f.o010 * STRIDE], t110 = vol[(uint64_t)f.o110 * STRIDE];
+    const float t001 = vol[(uint64_t)f.o001 * STRIDE], t101 = vol[(uint64_t)f.o101 * STRIDE];
+    const float t011 = vol[(uint64_t)f.o011 * STRIDE], t111 = vol[(uint64_t)f.o111 * STRIDE];
+    return trilerp(t000, t100, t010, t110, t001, t101, t011, t111, f.ax, f.ay, f.az);
+}
+
 template <bool LINEAR, int XF, bool FAST>
 __device__ __forceinline__ float4 sample_rgba(const RaymarchArgs& a, const Tex& t, V3 p) {
     V3 q = to_p01<XF>(a, p);
@@ -179,7 +190,8 @@ __device__ __forceinline__ float oob_dist(const RaymarchArgs& a, V3 p) {
 //  * No per-iteration status/step counters: a stopped lane's ray_pos no longer moves, so afterwards
 //    "out of bounds" is re-derived from it (oob(ray_pos) > 1e-4 <=> it stopped on that test), and the
 //    step count is 1 + the last iteration the lane sampled in.
-//  * STRIDE = 4 reads tex0.r in place, STRIDE = 1 the compact distance volume (sdfv_commit_distance).
+//  * STRIDE = 4 reads tex0.r in place, STRIDE = 1 the compact distance volume (sdfv_commit_distance), where
+//    x-neighbours are adjacent floats and each (y, z) pair of corners is ONE 8-byte load.
 //  * T: accumulate distanceFromOrigin (only the aux record consumes it).
 // Values and operation order are exactly those of sample_r() / the oracle; only redundant work is skipped.
 template <int XF, bool SYMM, int STRIDE, bool T>
@@ -218,10 +230,26 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
             const uint32_t j0c = (uint32_t)max(j0, 0) * sy, j1c = (uint32_t)min(j0 + 1, hm1) * sy;
             const uint32_t k0c = (uint32_t)max(k0, 0) * sz, k1c = (uint32_t)min(k0 + 1, dm1) * sz;
             const uint32_t r00 = k0c + j0c, r10 = k0c + j1c, r01 = k1c + j0c, r11 = k1c + j1c;
-            t000 = vol[(uint64_t)(r00 + i0c) * STRIDE]; t100 = vol[(uint64_t)(r00 + i1c) * STRIDE];
-            t010 = vol[(uint64_t)(r10 + i0c) * STRIDE]; t110 = vol[(uint64_t)(r10 + i1c) * STRIDE];
-            t001 = vol[(uint64_t)(r01 + i0c) * STRIDE]; t101 = vol[(uint64_t)(r01 + i1c) * STRIDE];
-            t011 = vol[(uint64_t)(r11 + i0c) * STRIDE]; t111 = vol[(uint64_t)(r11 + i1c) * STRIDE];
+            if (STRIDE == 1 && wm1 >= 1) {
+                // x-neighbours are adjacent floats in the distance volume: one 8-byte load per (y, z) pair.
+                // b = clamp(i0, 0, W-2) makes {b, b+1} cover {i0c, i1c} also where the clamp folds them together.
+                const uint32_t b = (uint32_t)min(max(i0, 0), wm1 - 1);
+                const bool lo_is_x = i0c == b, hi_is_y = i1c == b + 1;
+                typedef float f2 __attribute__((ext_vector_type(2), aligned(4)));
+                const f2 q00 = *reinterpret_cast<const f2*>(vol + (uint64_t)(r00 + b));
+                const f2 q10 = *reinterpret_cast<const f2*>(vol + (uint64_t)(r10 + b));
+                const f2 q01 = *reinterpret_cast<const f2*>(vol + (uint64_t)(r01 + b));
+                const f2 q11 = *reinterpret_cast<const f2*>(vol + (uint64_t)(r11 + b));
+                t000 = lo_is_x ? q00.x : q00.y; t100 = hi_is_y ? q00.y : q00.x;
+                t010 = lo_is_x ? q10.x : q10.y; t110 = hi_is_y ? q10.y : q10.x;
+                t001 = lo_is_x ? q01.x : q01.y; t101 = hi_is_y ? q01.y : q01.x;
+                t011 = lo_is_x ? q11.x : q11.y; t111 = hi_is_y ? q11.y : q11.x;
+            } else {
+                t000 = vol[(uint64_t)(r00 + i0c) * STRIDE]; t100 = vol[(uint64_t)(r00 + i1c) * STRIDE];
+                t010 = vol[(uint64_t)(r10 + i0c) * STRIDE]; t110 = vol[(uint64_t)(r10 + i1c) * STRIDE];
+                t001 = vol[(uint64_t)(r01 + i0c) * STRIDE]; t101 = vol[(uint64_t)(r01 + i1c) * STRIDE];
+                t011 = vol[(uint64_t)(r11 + i0c) * STRIDE]; t111 = vol[(uint64_t)(r11 + i1c) * STRIDE];
+            }
         }
         const float sample_dist = trilerp(t000, t100, t010, t110, t001, t101, t011, t111, ax, ay, az) - 1e-1f;
         // Stop condition: actually hit the surface (material.frag:117-121)
@@ -433,7 +461,12 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
             const V3 p3 = mk(ray_pos.x - h, ray_pos.y + h, ray_pos.z - h);  // k.yxy
             const V3 p4 = mk(ray_pos.x + h, ray_pos.y + h, ray_pos.z + h);  // k.xxx
             float d1, d2, d3, d4;
-            if (FAST && a.fast_normal) {
+            if (MODE == 2 && a.fast_normal) {  // the taps read the compact distance volume too
+                d1 = sample_r_linear<XF, true, 1>(a, a.dist, tex0, p1) - 1e-1f;
+                d2 = sample_r_linear<XF, true, 1>(a, a.dist, tex0, p2) - 1e-1f;
+                d3 = sample_r_linear<XF, true, 1>(a, a.dist, tex0, p3) - 1e-1f;
+                d4 = sample_r_linear<XF, true, 1>(a, a.dist, tex0, p4) - 1e-1f;
+            } else if (FAST && a.fast_normal) {
                 d1 = sample_r<LINEAR, XF, true>(a, tex0, p1) - 1e-1f;
                 d2 = sample_r<LINEAR, XF, true>(a, tex0, p2) - 1e-1f;
                 d3 = sample_r<LINEAR, XF, true>(a, tex0, p3) - 1e-1f;
