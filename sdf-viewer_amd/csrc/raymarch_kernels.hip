@@ -304,6 +304,14 @@ __device__ __forceinline__ float4 shade(const RaymarchArgs& a, float4 raw0, floa
     return make_float4(out[0], out[1], out[2], a.rp.tint[3]);
 }
 
+// outColor is written once and never re-read by this kernel: a streaming store keeps it from evicting the
+// texels the march is re-reading out of L2.
+__device__ __forceinline__ void store_rgba(float4* dst, float4 v) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(dst));
+}
+
 __device__ __forceinline__ void aux_clear(sdfv_march_aux& aux) {
     aux.status = 0; aux.steps = 0;
     aux.hit_pos[0] = aux.hit_pos[1] = aux.hit_pos[2] = 0.0f;
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
         const bool miss = mm > r2 && (md >= 0.0f || mm * dd - md * md > r2 * dd);
         if (__ballot(in_image && !miss) == 0ull) {
             if (in_image) {
-                a.rgba[out_index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                store_rgba(a.rgba + out_index, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                 if (AUX) {
                     sdfv_march_aux aux;
                     aux_clear(aux);
@@ -496,7 +504,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
 
     if (a.wave_timing && lane == 0) stamp_wave(a, wave, t_start, iterations, __ballot(covered));
     if (in_image) {
-        a.rgba[out_index] = rgba;
+        store_rgba(a.rgba + out_index, rgba);
         if (AUX) a.aux[out_index] = aux;
     }
 }
