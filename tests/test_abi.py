@@ -95,3 +95,35 @@ def test_no_cpu_fallback(pkg):
     assert (t0 == 0).all()
     with pytest.raises(TypeError):
         pkg.fill_grid(p, g, torch.zeros(4, 4, 4, 4), torch.zeros(4, 4, 4, 4))
+
+
+def test_power_of_two_modulus_identity():
+    """The kernels replace `x % 0.5` / `x % 0.25` (cube.rs:192) by a - trunc(a * (1/m)) * m and `v / 0.25`,
+    `floor(r) / 4` by multiplications.  Every step is exact for a power-of-two modulus; checked here against
+    fmod / true division on float32 bit patterns from every binade (the arithmetic is the same on the device)."""
+    rng = np.random.default_rng(1)
+    bits = rng.integers(0, 0x7F800000, size=4_000_000, dtype=np.uint32)           # all finite non-negative floats
+    a = np.concatenate([bits.view(np.float32),
+                        np.array([0.0, 0.25, 0.5, 0.75, 1.0, 2.0 ** 23, 2.0 ** 24, 3.4e38, 1e-45, 1.17549435e-38,
+                                  0.49999997, 0.24999999, 0.50000006], np.float32)])
+    for m, inv in ((np.float32(0.5), np.float32(2.0)), (np.float32(0.25), np.float32(4.0))):
+        with np.errstate(over="ignore", invalid="ignore"):
+            got = a - np.trunc(a * inv) * m
+            want = np.fmod(a, m)
+            ok = np.isfinite(a * inv)                  # a * inv overflows only above 1.7e38 (never a texture coordinate)
+        np.testing.assert_array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32))
+    s = np.concatenate([a, -a])
+    with np.errstate(over="ignore"):
+        times4, div025 = s * np.float32(4.0), s / np.float32(0.25)
+    np.testing.assert_array_equal(times4.view(np.uint32), div025.view(np.uint32))   # including the overflow to inf
+    r = np.floor(s[np.abs(s) < 1e30])
+    np.testing.assert_array_equal((r * np.float32(0.25)).view(np.uint32), (r / np.float32(4.0)).view(np.uint32))
+    # (p - min) / 2^k == (p - min) * 2^-k, and for power-of-two texture sizes ((p - min) * 2^-k) * N == (p - min) * (2^-k * N)
+    d = rng.uniform(-3.0, 3.0, size=1_000_000).astype(np.float32)
+    for size, n in ((np.float32(2.0), np.float32(256.0)), (np.float32(0.5), np.float32(64.0)), (np.float32(8.0), np.float32(1024.0))):
+        inv = np.float32(1.0) / size
+        np.testing.assert_array_equal((d / size).view(np.uint32), (d * inv).view(np.uint32))
+        np.testing.assert_array_equal(((d * inv) * n).view(np.uint32), (d * (inv * n)).view(np.uint32))
+    # symmetric box: max(-m - p, p - m) == |p| - m
+    mx = np.float32(1.0)
+    np.testing.assert_array_equal(np.maximum(-mx - d, d - mx).view(np.uint32), (np.abs(d) - mx).view(np.uint32))
