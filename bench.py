@@ -157,6 +157,14 @@ def cpu_baseline(workload, budget_s):
         k += 1
     rows_done = k * band
     rays = rows_done * W / (time.perf_counter() - t) / 1e6
+    # the same image on every usable core (OpenMP over rows), whole frames until a small budget is used
+    frames, all_rays_dt = 0, 0.0
+    while all_rays_dt < budget_s * 0.1:
+        t = time.perf_counter()
+        oracle.raymarch(rp, t0, t1, cam, W, H, threads=threads, want_aux=False)
+        all_rays_dt += time.perf_counter() - t
+        frames += 1
+    all_rays = frames * W * H / all_rays_dt / 1e6
     return {"value": round(fill_mvox, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
             "sample": f"{loads} complete load(s) of the {side}^3 grid in LoadingManager order, 2 passes "
                       f"({loads * n_vox} voxels, {fill_dt:.1f} s), oracle/grid_fill.c gcc -O2 -ffp-contract=off, 1 thread",
@@ -164,7 +172,9 @@ def cpu_baseline(workload, budget_s):
                           "sample": f"{n_all} dense fill(s) of the {side}^3 grid, OpenMP over z ({all_dt:.1f} s); "
                                     f"{threads} = usable cores (affinity {len(os.sched_getaffinity(0))}, cgroup quota applied)"},
             "value_rays": round(rays, 3), "unit_rays": "Mrays/s",
-            "sample_rays": f"{rows_done} central rows of the {W}x{H} image, 1 thread"}
+            "sample_rays": f"{rows_done} central rows of the {W}x{H} image, 1 thread",
+            "all_cores_rays": {"value": round(all_rays, 3), "unit": "Mrays/s", "cores": threads,
+                               "sample": f"{frames} whole {W}x{H} frame(s), OpenMP over rows ({all_rays_dt:.1f} s)"}}
 
 
 def load_traffic(workload_key, name="fill_pmc_traffic.json"):
