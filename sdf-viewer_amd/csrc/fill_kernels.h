@@ -19,6 +19,7 @@ struct FillArgs {
     float bb_min[3];
     float air_dist;
     uint32_t x_chunks;       // set by the launcher: ceil(W / TX)
+    unsigned long long w_magic;  // set by the launcher (flat form): floor(2^64 / W) + 1
     float4* tex0;
     float4* tex1;
 };
@@ -33,6 +34,7 @@ struct PassArgs {
 
 struct FillLaunch {
     bool nontemporal;  // global_store_dwordx4 ... nt (measured: within noise of plain stores)
+    bool force_flat = false, force_rows = false;  // A/B runs: pin the kernel form
 };
 
 hipError_t launch_fill_dense(const FillArgs& a, const FillLaunch& cfg, hipStream_t stream);

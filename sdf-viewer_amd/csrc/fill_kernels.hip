@@ -81,6 +81,47 @@ __global__ __launch_bounds__(kBlock) void fill_dense_kernel(FillArgs a) {
     store_texel<NT>(a.tex1 + o, v1);
 }
 
+// Flat form of the dense kernel for widths that do not fill the row-chunk form's lanes (W not a multiple of the
+// 64 / 128 / 256 chunk): thread <-> voxel over the slab's flat index, so every wave is full and every store burst
+// is 1 KiB whatever W is.  x and row come from an exact division by W done as a 64-bit multiply-high with
+// M = floor(2^64 / W) + 1 (exact for dividends below 2^32); the (y, z) coordinates of the few rows a workgroup
+// touches are staged in LDS by its first lanes.
+template <bool NT, typename Cfg>
+__global__ __launch_bounds__(kBlock) void fill_dense_flat_kernel(FillArgs a) {
+    __shared__ float s_lut[256];
+    __shared__ float2 s_yz[kBlock + 1];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_vox = a.W * a.H * a.slab_d;  // < 2^32, checked by the launcher
+    const uint32_t v0 = blockIdx.x * kBlock;
+    auto div_w = [&](uint32_t v) -> uint32_t {
+        if (a.W == 1) return v;
+        const unsigned long long t = ((unsigned long long)v * (uint32_t)a.w_magic) >> 32;
+        return (uint32_t)(((unsigned long long)v * (uint32_t)(a.w_magic >> 32) + t) >> 32);
+    };
+    const uint32_t row_first = div_w(v0);
+    const uint32_t v_last = min(v0 + kBlock - 1, n_vox - 1);
+    const uint32_t n_rows_here = div_w(v_last) - row_first + 1;  // <= kBlock + 1
+    s_lut[tid] = c_srgb_lut[tid];
+    for (uint32_t r = tid; r < n_rows_here; r += kBlock) {
+        const uint32_t row = row_first + r;
+        const uint32_t zl = row / a.H, y = row - zl * a.H;
+        s_yz[r] = make_float2(voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]),
+                              voxel_coord(a.z_begin + zl, a.dm1[2], a.bb_size[2], a.bb_min[2]));
+    }
+    __syncthreads();
+    const uint32_t v = v0 + tid;
+    if (v >= n_vox) return;
+    const uint32_t row = div_w(v);
+    const uint32_t x = v - row * a.W;
+    const LdsLut lut{s_lut};
+    const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
+    const float2 yz = s_yz[row - row_first];
+    float4 v0t, v1t;
+    fill_voxel<Cfg>(a.prm, a.sdf_id, px, yz.x, yz.y, lut, a.air_dist, v0t, v1t);
+    store_texel<NT>(a.tex0 + v, v0t);
+    store_texel<NT>(a.tex1 + v, v1t);
+}
+
 // One LoadingManager pass: one thread per visited voxel (x, y, z multiples of `step`; z is GLOBAL), workgroups in
 // memory order like the dense kernel.  Reads tex0.r for update_required (scene/sdf/mod.rs:184-190) and, when an
 // update is required, rewrites tex0 (16 B) and tex1 (16 B, its alpha read back and stored unchanged).
@@ -162,8 +203,28 @@ hipError_t launch_dense_tx(const FillArgs& a, const FillLaunch& cfg, hipStream_t
 
 }  // namespace
 
+template <bool NT>
+hipError_t launch_dense_flat(const FillArgs& args, hipStream_t stream) {
+    FillArgs a = args;
+    const uint64_t n_vox = (uint64_t)a.W * a.H * a.slab_d;
+    // floor((2^64 - 1) / W) + 1: floor(2^64 / W) + 1 when W does not divide 2^64, exactly 2^64 / W when it does
+    a.w_magic = a.W > 1 ? (~0ull / a.W) + 1ull : 0ull;
+    const uint32_t blocks = (uint32_t)((n_vox + kBlock - 1) / kBlock);
+    if (is_default_config(a))
+        hipLaunchKernelGGL((fill_dense_flat_kernel<NT, DefaultCfg>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    else
+        hipLaunchKernelGGL((fill_dense_flat_kernel<NT, RuntimeCfg>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill_dense(const FillArgs& a, const FillLaunch& cfg, hipStream_t stream) {
     if (a.W == 0 || a.H == 0 || a.slab_d == 0) return hipSuccess;
+    // Row-chunk form when the width fills its lanes, flat form otherwise (and always when forced for A/B runs).
+    const uint32_t chunk = a.W <= 64 ? 64 : (a.W <= 128 ? 128 : 256);
+    const bool lanes_full = a.W % chunk == 0;
+    const uint64_t n_vox = (uint64_t)a.W * a.H * a.slab_d;
+    if (n_vox < (1ull << 32) && (cfg.force_flat || (!lanes_full && !cfg.force_rows)))
+        return cfg.nontemporal ? launch_dense_flat<true>(a, stream) : launch_dense_flat<false>(a, stream);
     if (a.W <= 64) return launch_dense_tx<64>(a, cfg, stream);
     if (a.W <= 128) return launch_dense_tx<128>(a, cfg, stream);
     return launch_dense_tx<256>(a, cfg, stream);

@@ -102,6 +102,10 @@ sdfv::FillLaunch fill_launch_config() {
     sdfv::FillLaunch c;
     c.nontemporal = false;
     if (const char* s = getenv("SDFV_FILL_NT")) c.nontemporal = atoi(s) != 0;
+    if (const char* s = getenv("SDFV_FILL_FORM")) {
+        c.force_flat = strcmp(s, "flat") == 0;
+        c.force_rows = strcmp(s, "rows") == 0;
+    }
     return c;
 }
 

@@ -52,6 +52,20 @@ def test_dense_fill_matches_oracle(pkg, oracle, dims):
     assert_bits_equal(t1, r1)
 
 
+@pytest.mark.parametrize("form", ["flat", "rows"])
+@pytest.mark.parametrize("dims", [(64, 16, 8), (7, 13, 300), (257, 3, 5), (1, 9, 4), (1000, 6, 2)])
+def test_both_index_forms_of_the_dense_fill(pkg, oracle, monkeypatch, form, dims):
+    """The row-chunk and the flat form of the dense kernel produce the same texels on every width, whichever the
+    launcher would have picked (SDFV_FILL_FORM overrides the choice; slab offsets included)."""
+    monkeypatch.setenv("SDFV_FILL_FORM", form)
+    for prm in (pkg.default_params(), pkg.default_params(cube_material=1, disable_sphere=1)):
+        z0 = dims[2] // 3
+        t0, t1 = gpu_fill(pkg, prm, dims, z0=z0, z1=dims[2])
+        r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, z0=z0, z1=dims[2])
+        assert_bits_equal(t0, r0)
+        assert_bits_equal(t1, r1)
+
+
 @pytest.mark.parametrize("kw", [dict(cube_material=1, sphere_material=0), dict(disable_sphere=1),
                                 dict(cube_half_side=0.5, sphere_radius=0.6, max_distance_custom_material=0.0),
                                 dict(cube_half_side=0.8, sphere_radius=0.3, max_distance_custom_material=0.25),
