@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--weak-geometry", choices=["slab", "cube"], default="slab",
                     help="N>1: grow the grid along z only (every rank fills the N=1 slab; default) or towards a cube "
                          "(8 ranks x --workload 512 = BASELINE.json config 4, 1024^3)")
+    ap.add_argument("--halo-transport", choices=["auto", "rccl", "torch"], default="auto",
+                    help="N>1: rccl = sdfv_slab_fill_step over the library's own RCCL communicator (default under "
+                         "nccl), torch = torch.distributed P2P ops")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the extra 64-camera batch (profiling runs)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
@@ -236,7 +239,25 @@ def main():
     owned0, owned1 = slab.owned0, slab.owned1
     voxels_per_rank = pkg.slab_voxels(grid)
 
-    filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world)  # N>1: halo exchange overlapped with the interior
+    # N>1: halo exchange overlapped with the interior fill.  Under nccl the library's own RCCL communicator carries
+    # it (one C call per step); should any rank fail to create one, every rank falls back to torch.distributed P2P.
+    transport = args.halo_transport
+    if transport == "auto":
+        transport = "rccl" if (world > 1 and backend == "nccl") else "torch"
+    filler = None
+    if transport == "rccl":
+        try:
+            filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="rccl")
+        except Exception as e:  # noqa: BLE001 -- reported, then decided collectively below
+            print(f"[bench rank {rank}] library communicator unavailable: {e}", file=sys.stderr, flush=True)
+        if world > 1:
+            ok = torch.tensor([1 if filler is not None else 0], device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                filler, transport = None, "torch"
+    if filler is None:
+        transport = "torch"
+        filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="torch")
 
     def fill_step():
         filler.step()
@@ -343,6 +364,8 @@ def main():
             "data": "synthetic (demo SDF defaults on the integer lattice, fixed cameras; no RNG)",
             "sharded_fill_verified": verified,
             "backend": None if world == 1 else ("rccl" if backend == "nccl" else backend + " (test only)"),
+            "halo_transport": None if world == 1 else {"rccl": "sdfv_slab_fill_step (library RCCL communicator)",
+                                                       "torch": "torch.distributed batch_isend_irecv"}[transport],
             "config": {"workload": wl["name"], "grid_global": list(gdims), "voxels_per_gpu": voxels_per_rank,
                        "image": [W, H], "cameras_per_gpu": len(my_cams),
                        "weak_geometry": None if world == 1 else args.weak_geometry,

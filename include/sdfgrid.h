@@ -38,7 +38,8 @@ typedef enum sdfv_status {
     SDFV_ERR_INVALID_ARGUMENT = -1,
     SDFV_ERR_UNKNOWN_SDF = -2, /* ffi.rs:46-49 "Failed to find SDF with ID" */
     SDFV_ERR_HIP = -3,
-    SDFV_ERR_NO_DEVICE = -4
+    SDFV_ERR_NO_DEVICE = -4,
+    SDFV_ERR_COMM = -5 /* RCCL could not be loaded, or one of its calls failed */
 } sdfv_status;
 
 /* src/sdf/mod.rs:104-118: #[repr(C)] struct SDFSample, 28 bytes */
@@ -184,6 +185,35 @@ int sdfv_normal_points_host(const sdfv_demo_params *params, uint32_t sdf_id, con
 int sdfv_raymarch_host(const sdfv_render_params *rp, const float *tex0_host, const float *tex1_host,
                        const sdfv_camera *cameras, uint32_t n_cameras, uint32_t width, uint32_t height,
                        float *rgba_host, sdfv_march_aux *aux_host);
+
+/* ---- multi-GPU: z-slab sharding with a one-voxel halo over RCCL (one process per GPU) ----------------------
+ * The reference has no sharding (its loop carries "TODO: Cross-platform parallel iteration?", scene/sdf/mod.rs:174).
+ * Rank r of `world` owns slices [z_begin, z_end) of the global grid.  Its textures carry one ghost slice per
+ * existing z-neighbour:   [ghost_lo (rank > 0)] [owned z_begin .. z_end) [ghost_hi (rank < world-1)]
+ * and the tex0/tex1 pointers handed to the two calls below address the START of that allocation.  After the
+ * exchange ghost_lo holds the last slice of rank-1 and ghost_hi the first slice of rank+1, so trilinear
+ * sampling (material.frag:42-45) across a slab boundary reads local memory.  Ends are not periodic.
+ * SDFV_COMM_PERIODIC wraps rank 0 / world-1 around (both ghosts always present); with world = 1 every send is
+ * matched by a receive of the same rank, which is how the single-GPU tests drive the RCCL path.
+ * RCCL is loaded at run time (librccl.so.1), so hosts that never create a communicator do not need it. */
+#define SDFV_COMM_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+#define SDFV_COMM_PERIODIC 1u
+typedef struct sdfv_slab_comm sdfv_slab_comm;
+
+/* Rank 0 makes the id; the HOST hands the 128 bytes to every rank by whatever channel it has. */
+int sdfv_slab_comm_unique_id(unsigned char id_out[SDFV_COMM_ID_BYTES]);
+/* Collective over all ranks (ncclCommInitRank on the current HIP device).  Owns a second HIP stream + events. */
+int sdfv_slab_comm_create(const unsigned char id[SDFV_COMM_ID_BYTES], int rank, int world, uint32_t flags,
+                          sdfv_slab_comm **out);
+int sdfv_slab_comm_destroy(sdfv_slab_comm *comm);
+/* The halo exchange alone, enqueued on `stream` (one ncclGroup of up to 4 sends + 4 receives). DEVICE pointers. */
+int sdfv_slab_halo_exchange(sdfv_slab_comm *comm, const sdfv_grid *slab, float *tex0, float *tex1, void *stream);
+/* One fill step of this rank = sdfv_fill_grid over the owned slab + the halo exchange, with the exchange hidden
+ * behind the fill: the two boundary slices are filled first, the exchange runs on the communicator's own stream
+ * while `stream` fills the interior, and `stream` then waits for the exchange.  On return everything is enqueued;
+ * work later put on `stream` sees owned and ghost slices complete. */
+int sdfv_slab_fill_step(sdfv_slab_comm *comm, const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *slab,
+                        float *tex0, float *tex1, void *stream);
 
 #ifdef __cplusplus
 }

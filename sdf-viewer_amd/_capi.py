@@ -89,7 +89,15 @@ PROTOTYPES = {
                                           C.c_int, C.c_void_p]),
     "sdfv_raymarch_host": (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(Camera),
                                      C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "sdfv_slab_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
+    "sdfv_slab_comm_create": (C.c_int, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "sdfv_slab_comm_destroy": (C.c_int, [C.c_void_p]),
+    "sdfv_slab_halo_exchange": (C.c_int, [C.c_void_p, C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdfv_slab_fill_step": (C.c_int, [C.c_void_p, C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
 }
+COMM_ID_BYTES = 128
+COMM_PERIODIC = 1
 
 
 def load(path=LIB_PATH):

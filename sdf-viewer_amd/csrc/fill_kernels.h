@@ -20,6 +20,8 @@ struct FillArgs {
     float air_dist;
     uint32_t x_chunks;       // set by the launcher: ceil(W / TX)
     unsigned long long w_magic;  // set by the launcher (flat form): floor(2^64 / W) + 1
+    uint32_t z_step;         // strided flat form only: local slice k is global slice z_begin + k * z_step and
+                             // lives k * z_step slices into the textures (1 everywhere else)
     float4* tex0;
     float4* tex1;
 };
@@ -38,6 +40,8 @@ struct FillLaunch {
 };
 
 hipError_t launch_fill_dense(const FillArgs& a, const FillLaunch& cfg, hipStream_t stream);
+// slab_d slices z_begin + k * z_step in ONE launch (the two boundary slices of a slab: slab_d = 2).
+hipError_t launch_fill_slices(const FillArgs& a, hipStream_t stream);
 hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& p, hipStream_t stream);
 hipError_t launch_commit_distance(const float* tex0, float* dist, uint64_t n_voxels, hipStream_t stream);
 hipError_t launch_grid_init(float* tex0, float* tex1, uint64_t n_voxels, float air, hipStream_t stream);

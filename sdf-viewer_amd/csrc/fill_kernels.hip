@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void fill_dense_kernel(FillArgs a) {
 // is 1 KiB whatever W is.  x and row come from an exact division by W done as a 64-bit multiply-high with
 // M = floor(2^64 / W) + 1 (exact for dividends below 2^32); the (y, z) coordinates of the few rows a workgroup
 // touches are staged in LDS by its first lanes.
-template <bool NT, typename Cfg>
+template <bool NT, typename Cfg, bool STRIDED = false>
 __global__ __launch_bounds__(kBlock) void fill_dense_flat_kernel(FillArgs a) {
     __shared__ float s_lut[256];
     __shared__ float2 s_yz[kBlock + 1];
@@ -105,8 +105,9 @@ __global__ __launch_bounds__(kBlock) void fill_dense_flat_kernel(FillArgs a) {
     for (uint32_t r = tid; r < n_rows_here; r += kBlock) {
         const uint32_t row = row_first + r;
         const uint32_t zl = row / a.H, y = row - zl * a.H;
+        const uint32_t z = a.z_begin + (STRIDED ? zl * a.z_step : zl);
         s_yz[r] = make_float2(voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]),
-                              voxel_coord(a.z_begin + zl, a.dm1[2], a.bb_size[2], a.bb_min[2]));
+                              voxel_coord(z, a.dm1[2], a.bb_size[2], a.bb_min[2]));
     }
     __syncthreads();
     const uint32_t v = v0 + tid;
@@ -118,8 +119,10 @@ __global__ __launch_bounds__(kBlock) void fill_dense_flat_kernel(FillArgs a) {
     const float2 yz = s_yz[row - row_first];
     float4 v0t, v1t;
     fill_voxel<Cfg>(a.prm, a.sdf_id, px, yz.x, yz.y, lut, a.air_dist, v0t, v1t);
-    store_texel<NT>(a.tex0 + v, v0t);
-    store_texel<NT>(a.tex1 + v, v1t);
+    size_t at = v;
+    if (STRIDED) at += (size_t)(row / a.H) * (a.z_step - 1) * a.H * a.W;  // the slices skipped in between
+    store_texel<NT>(a.tex0 + at, v0t);
+    store_texel<NT>(a.tex1 + at, v1t);
 }
 
 // One LoadingManager pass: one thread per visited voxel (x, y, z multiples of `step`; z is GLOBAL), workgroups in
@@ -214,6 +217,20 @@ hipError_t launch_dense_flat(const FillArgs& args, hipStream_t stream) {
         hipLaunchKernelGGL((fill_dense_flat_kernel<NT, DefaultCfg>), dim3(blocks), dim3(kBlock), 0, stream, a);
     else
         hipLaunchKernelGGL((fill_dense_flat_kernel<NT, RuntimeCfg>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_slices(const FillArgs& args, hipStream_t stream) {
+    FillArgs a = args;
+    const uint64_t n_vox = (uint64_t)a.W * a.H * a.slab_d;
+    if (n_vox == 0) return hipSuccess;
+    if (n_vox >= (1ull << 32) || a.z_step == 0) return hipErrorInvalidValue;
+    a.w_magic = a.W > 1 ? (~0ull / a.W) + 1ull : 0ull;
+    const uint32_t blocks = (uint32_t)((n_vox + kBlock - 1) / kBlock);
+    if (is_default_config(a))
+        hipLaunchKernelGGL((fill_dense_flat_kernel<false, DefaultCfg, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    else
+        hipLaunchKernelGGL((fill_dense_flat_kernel<false, RuntimeCfg, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "../../include/sdfgrid.h"
+#include "api_internal.h"
 #include "fill_kernels.h"
 #include "points_kernels.h"
 #include "raymarch_kernels.h"
@@ -92,6 +93,7 @@ sdfv::FillArgs make_fill_args(const sdfv_demo_params& p, uint32_t sdf_id, const 
         a.bb_min[i] = g.bb_min[i];
     }
     a.air_dist = air_dist();
+    a.z_step = 1;
     a.tex0 = reinterpret_cast<float4*>(tex0);
     a.tex1 = reinterpret_cast<float4*>(tex1);
     return a;
@@ -117,6 +119,28 @@ struct DeviceBuf {
 };
 
 }  // namespace
+
+namespace sdfv {
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int fill_boundary_slices(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* slab, float* o0, float* o1,
+                         void* stream) {
+    if (int rc = check_params(params, sdf_id)) return rc;
+    if (int rc = check_grid(slab)) return rc;
+    if (slab->z_end - slab->z_begin < 2) return fail(SDFV_ERR_INVALID_ARGUMENT, "a slab of one slice has one boundary");
+    if (int rc = need_device()) return rc;
+    FillArgs a = make_fill_args(*params, sdf_id, *slab, o0, o1);
+    a.z_step = a.slab_d - 1;
+    a.slab_d = 2;
+    SDFV_HIP(launch_fill_slices(a, (hipStream_t)stream));
+    return SDFV_OK;
+}
+}  // namespace sdfv
 
 #pragma GCC visibility push(default)
 extern "C" {

@@ -8,7 +8,13 @@ and receives the neighbour's into a ghost slice, so trilinear sampling (material
 boundary reads local memory.  On GPUs `torch.distributed` backend "nccl" is RCCL: the grouped
 isend/irecv below become one ncclGroupStart/End of ncclSend/ncclRecv pairs, each neighbour pair riding one
 xGMI link per direction.  On CPU (tests) the same code runs over gloo.
+
+Two transports carry the halo: `SlabComm` (the library's own RCCL communicator, include/sdfgrid.h sdfv_slab_*: one
+C call enqueues a whole fill step, ~10 us of host time) and torch.distributed P2P ops (c10d spends ~120 us of
+host time per exchange, more than the 256^3 fill takes on the GPU -- tools/halo_loopback.py).  `SlabFiller` uses
+the first on GPUs with the nccl backend and the second everywhere else (gloo tests).
 """
+import ctypes as C
 from dataclasses import dataclass
 
 import torch
@@ -58,10 +64,10 @@ class SlabTextures:
         return self.tex1[self.ghost_lo:self.ghost_lo + (self.z_end - self.z_begin)]
 
 
-def alloc_slab(dims, rank, world, device, fill_value=None):
+def alloc_slab(dims, rank, world, device, fill_value=None, periodic=False):
     z0, z1 = slab_range(dims[2], rank, world)
-    glo = 1 if rank > 0 else 0
-    ghi = 1 if rank < world - 1 else 0
+    glo = 1 if (periodic or rank > 0) else 0
+    ghi = 1 if (periodic or rank < world - 1) else 0
     shape = (glo + (z1 - z0) + ghi, dims[1], dims[0], 4)
     t0 = torch.empty(shape, dtype=torch.float32, device=device)
     t1 = torch.empty(shape, dtype=torch.float32, device=device)
@@ -112,6 +118,62 @@ def halo_exchange(slab, rank, world, group=None):
     return sent
 
 
+class SlabComm:
+    """The library's RCCL communicator for the slab halo (sdfv_slab_comm_*).  Rank 0 draws the id and
+    torch.distributed only carries its 128 bytes to the other ranks; after that no torch call is on the step path.
+    `periodic` wraps the end ranks around -- with world 1 a rank exchanges with itself (single-GPU tests)."""
+
+    def __init__(self, pkg, rank, world, group=None, periodic=False):
+        capi = pkg._capi
+        self.pkg, self.rank, self.world, self.periodic = pkg, rank, world, periodic
+        ident = (C.c_ubyte * capi.COMM_ID_BYTES)()
+        if rank == 0:
+            pkg.check(pkg.lib.sdfv_slab_comm_unique_id(ident))
+        if world > 1:
+            on_gpu = dist.get_backend(group) == "nccl"
+            t = torch.tensor(list(ident), dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = (C.c_ubyte * capi.COMM_ID_BYTES)(*t.cpu().tolist())
+        handle = C.c_void_p()
+        pkg.check(pkg.lib.sdfv_slab_comm_create(ident, rank, world, capi.COMM_PERIODIC if periodic else 0,
+                                                C.byref(handle)))
+        self.handle = handle
+
+    @property
+    def ghost_lo(self):
+        return 1 if (self.periodic or self.rank > 0) else 0
+
+    @property
+    def ghost_hi(self):
+        return 1 if (self.periodic or self.rank < self.world - 1) else 0
+
+    def _args(self, grid, slab, stream):
+        n_owned = int(grid.z_end) - int(grid.z_begin)
+        assert slab.ghost_lo == self.ghost_lo and slab.ghost_hi == self.ghost_hi
+        assert slab.tex0.shape[0] == self.ghost_lo + n_owned + self.ghost_hi
+        stream = torch.cuda.current_stream() if stream is None else stream
+        return (C.byref(grid), C.c_void_p(slab.tex0.data_ptr()), C.c_void_p(slab.tex1.data_ptr()),
+                C.c_void_p(stream.cuda_stream))
+
+    def halo_exchange(self, grid, slab, stream=None):
+        self.pkg.check(self.pkg.lib.sdfv_slab_halo_exchange(self.handle, *self._args(grid, slab, stream)))
+
+    def fill_step(self, params, grid, slab, sdf_id=0, stream=None):
+        g, t0, t1, st = self._args(grid, slab, stream)
+        self.pkg.check(self.pkg.lib.sdfv_slab_fill_step(self.handle, C.byref(params), sdf_id, g, t0, t1, st))
+
+    def close(self):
+        if self.handle:
+            self.pkg.lib.sdfv_slab_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
 class SlabFiller:
     """One fill step of a rank: fill the slab, exchange the halo, with the exchange hidden behind the fill.
 
@@ -122,10 +184,17 @@ class SlabFiller:
     dozen slices the two are of the same order and overlapping them is what keeps weak scaling near linear.
     """
 
-    def __init__(self, pkg, params, dims, slab, rank, world, sdf_id=0, group=None):
+    def __init__(self, pkg, params, dims, slab, rank, world, sdf_id=0, group=None, transport="auto"):
+        """transport: "rccl" = the library's communicator (one C call per step), "torch" = torch.distributed P2P
+        ops on a second stream, "auto" = rccl on GPUs under the nccl backend, torch otherwise."""
         self.pkg, self.params, self.dims, self.slab = pkg, params, dims, slab
         self.rank, self.world, self.sdf_id, self.group = rank, world, sdf_id, group
-        self.overlap = world > 1 and slab.tex0.is_cuda and (slab.z_end - slab.z_begin) >= 3
+        if transport == "auto":
+            transport = "rccl" if (world > 1 and slab.tex0.is_cuda and dist.get_backend(group) == "nccl") else "torch"
+        self.transport = transport
+        self.comm = SlabComm(pkg, rank, world, group) if transport == "rccl" else None
+        self.overlap = (transport == "torch" and world > 1 and slab.tex0.is_cuda
+                        and (slab.z_end - slab.z_begin) >= 3)
         self.comm_stream = torch.cuda.Stream(device=slab.tex0.device) if self.overlap else None
         z0, z1 = slab.z_begin, slab.z_end
         self.whole = pkg.make_grid(dims, z_begin=z0, z_end=z1)
@@ -138,6 +207,9 @@ class SlabFiller:
 
     def step(self):
         pkg, slab = self.pkg, self.slab
+        if self.comm is not None:
+            self.comm.fill_step(self.params, self.whole, slab, sdf_id=self.sdf_id)
+            return
         if not self.overlap:
             pkg.fill_grid(self.params, self.whole, slab.owned0, slab.owned1, sdf_id=self.sdf_id)
             if self.world > 1:

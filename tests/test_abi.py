@@ -97,6 +97,20 @@ def test_no_cpu_fallback(pkg):
         pkg.fill_grid(p, g, torch.zeros(4, 4, 4, 4), torch.zeros(4, 4, 4, 4))
 
 
+def test_slab_communicator_argument_checks_and_no_device(pkg):
+    """sdfv_slab_comm_create validates before it touches RCCL, and without a GPU reports "no device" (no hang)."""
+    lib = pkg.lib
+    ident = (C.c_ubyte * 128)()
+    out = C.c_void_p(123)
+    assert lib.sdfv_slab_comm_create(ident, 2, 2, 0, C.byref(out)) == -1 and out.value is None
+    assert lib.sdfv_slab_comm_create(ident, 0, 1, 6, C.byref(out)) == -1
+    assert lib.sdfv_slab_comm_create(None, 0, 1, 0, C.byref(out)) == -1
+    assert lib.sdfv_slab_comm_destroy(None) == 0
+    if not torch.cuda.is_available():
+        assert lib.sdfv_slab_comm_create(ident, 0, 1, 0, C.byref(out)) == -4
+        assert b"no HIP device" in lib.sdfv_last_error()
+
+
 def test_power_of_two_modulus_identity():
     """The kernels replace `x % 0.5` / `x % 0.25` (cube.rs:192) by a - trunc(a * (1/m)) * m and `v / 0.25`,
     `floor(r) / 4` by multiplications.  Every step is exact for a power-of-two modulus; checked here against

@@ -1,0 +1,119 @@
+"""The library's own RCCL halo path (include/sdfgrid.h sdfv_slab_*) on ONE GPU: a periodic communicator of world
+size 1 makes the rank its own z-neighbour, so every ncclSend is matched by an ncclRecv of the same rank and the
+whole enqueue path (boundary fills, second stream, events, the RCCL group) runs exactly as it does between GPUs.
+Expected ghosts then follow from the wrap: ghost_lo = last owned slice, ghost_hi = first owned slice."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def par(pkg):
+    return importlib.import_module("sdf-viewer_amd.parallel")
+
+
+@pytest.fixture(scope="module")
+def loop_comm(pkg, par):
+    comm = par.SlabComm(pkg, 0, 1, periodic=True)
+    yield comm
+    comm.close()
+
+
+def bits(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def check_slab(oracle, pkg, prm, dims, z0, z1, slab, sdf_id=0):
+    r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, z0=z0, z1=z1, sdf_id=sdf_id)
+    np.testing.assert_array_equal(bits(slab.owned0), r0.view(np.uint32))
+    np.testing.assert_array_equal(bits(slab.owned1), r1.view(np.uint32))
+    for tex, ref in ((slab.tex0, r0), (slab.tex1, r1)):
+        np.testing.assert_array_equal(bits(tex[0]), ref[-1].view(np.uint32))   # ghost_lo <- last owned (wrap)
+        np.testing.assert_array_equal(bits(tex[-1]), ref[0].view(np.uint32))   # ghost_hi <- first owned (wrap)
+
+
+@pytest.mark.parametrize("dims,z0,z1", [((40, 24, 16), 0, 16), ((40, 24, 16), 5, 12), ((33, 7, 9), 0, 2),
+                                        ((33, 7, 9), 4, 5), ((64, 64, 64), 0, 64), ((130, 5, 3), 0, 3)])
+def test_fill_step_fills_slab_and_ghosts(pkg, par, oracle, loop_comm, dims, z0, z1):
+    prm = pkg.default_params()
+    slab = par.alloc_slab((dims[0], dims[1], z1 - z0), 0, 1, "cuda", fill_value=-7.0, periodic=True)
+    slab.z_begin, slab.z_end = z0, z1
+    grid = pkg.make_grid(dims, z_begin=z0, z_end=z1)
+    loop_comm.fill_step(prm, grid, slab)
+    torch.cuda.synchronize()
+    check_slab(oracle, pkg, prm, dims, z0, z1, slab)
+
+
+def test_repeated_steps_on_a_side_stream(pkg, par, oracle, loop_comm):
+    """Events and the communicator stream are reused step after step; parameters change between steps."""
+    dims = (48, 40, 12)
+    slab = par.alloc_slab(dims, 0, 1, "cuda", fill_value=-7.0, periodic=True)
+    grid = pkg.make_grid(dims)
+    side = torch.cuda.Stream()
+    prm = None
+    with torch.cuda.stream(side):
+        for k in range(12):
+            prm = pkg.default_params(cube_half_side=0.5 + 0.03 * k, sphere_radius=0.6 + 0.02 * k)
+            loop_comm.fill_step(prm, grid, slab, stream=side)
+    side.synchronize()
+    check_slab(oracle, pkg, prm, dims, 0, dims[2], slab)
+
+
+def test_halo_exchange_alone(pkg, par, oracle, loop_comm):
+    dims = (20, 10, 6)
+    prm = pkg.default_params(cube_material=1)
+    slab = par.alloc_slab(dims, 0, 1, "cuda", fill_value=-7.0, periodic=True)
+    grid = pkg.make_grid(dims)
+    pkg.fill_grid(prm, grid, slab.owned0, slab.owned1)
+    assert float(slab.tex0[0, 0, 0, 0]) == -7.0
+    loop_comm.halo_exchange(grid, slab)
+    torch.cuda.synchronize()
+    check_slab(oracle, pkg, prm, dims, 0, dims[2], slab)
+
+
+def test_world_of_one_without_wrap_is_a_plain_fill(pkg, par, oracle):
+    dims = (24, 12, 10)
+    comm = par.SlabComm(pkg, 0, 1)
+    slab = par.alloc_slab(dims, 0, 1, "cuda", fill_value=-7.0)
+    assert slab.ghost_lo == 0 and slab.ghost_hi == 0
+    prm = pkg.default_params()
+    comm.fill_step(prm, pkg.make_grid(dims), slab)
+    torch.cuda.synchronize()
+    r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims)
+    np.testing.assert_array_equal(bits(slab.tex0), r0.view(np.uint32))
+    np.testing.assert_array_equal(bits(slab.tex1), r1.view(np.uint32))
+    comm.close()
+
+
+def test_slab_filler_uses_the_library_communicator_when_asked(pkg, par, oracle):
+    """SlabFiller(transport="rccl") is the path bench.py takes for N > 1 under the nccl backend."""
+    dims = (32, 16, 8)
+    slab = par.alloc_slab(dims, 0, 1, "cuda", fill_value=-7.0)
+    prm = pkg.default_params()
+    filler = par.SlabFiller(pkg, prm, dims, slab, 0, 1, transport="rccl")
+    assert filler.comm is not None
+    filler.step()
+    torch.cuda.synchronize()
+    r0, _ = oracle.fill_dense(oracle.params_from(prm), dims)
+    np.testing.assert_array_equal(bits(slab.tex0), r0.view(np.uint32))
+
+
+def test_errors_are_status_codes(pkg, par, loop_comm):
+    lib = pkg.lib
+    ident = (C.c_ubyte * 128)()
+    out = C.c_void_p()
+    assert lib.sdfv_slab_comm_create(ident, 3, 2, 0, C.byref(out)) == -1
+    assert b"rank 3" in lib.sdfv_last_error()
+    assert lib.sdfv_slab_comm_create(ident, 0, 1, 0x80, C.byref(out)) == -1
+    g = pkg.make_grid((4, 4, 4))
+    assert lib.sdfv_slab_halo_exchange(None, C.byref(g), None, None, None) == -1
+    empty = pkg.make_grid((4, 4, 4), z_begin=2, z_end=2)
+    t = torch.zeros(64, device="cuda")
+    assert lib.sdfv_slab_fill_step(loop_comm.handle, C.byref(pkg.default_params()), 0, C.byref(empty),
+                                   C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), None) == -1
+    assert lib.sdfv_slab_comm_destroy(None) == 0
