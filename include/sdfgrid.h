@@ -155,6 +155,28 @@ int sdfv_sample_points(const sdfv_demo_params *params, uint32_t sdf_id, const fl
 int sdfv_normal_points(const sdfv_demo_params *params, uint32_t sdf_id, const float *points, size_t n,
                        float eps, int use_default, float *out, void *stream);
 
+/* ---- mesher front end (src/sdf/meshers): what the isosurface extractors and Mesh::postproc ask of the SDF ---- */
+/* Vertex, meshers/mesh.rs:135-143 (12 floats, 48 bytes) */
+typedef struct sdfv_vertex {
+    float position[3];
+    float normal[3];
+    float color[3];
+    float metallic;
+    float roughness;
+    float occlusion;
+} sdfv_vertex;
+/* ScalarSource::sample_scalar for n points of the UNIT cube (meshers/isosurface.rs:78-84): each point goes through
+ * vert_pos_to (p * (bb_max - bb_min) + bb_min, isosurface.rs:95-99), then sample(p, true).distance.
+ * unit_points: DEVICE n x 3 floats; dist_out: DEVICE n floats. */
+int sdfv_source_sample_scalar(const sdfv_demo_params *params, uint32_t sdf_id, const float bb_min[3],
+                              const float bb_max[3], const float *unit_points, size_t n, float *dist_out, void *stream);
+/* HermiteSource::sample_normal (meshers/isosurface.rs:87-92): normal(vert_pos_to(p), None).  out: DEVICE n x 3. */
+int sdfv_source_sample_normal(const sdfv_demo_params *params, uint32_t sdf_id, const float bb_min[3],
+                              const float bb_max[3], const float *unit_points, size_t n, float *normal_out, void *stream);
+/* Mesh::postproc (meshers/mesh.rs:22-33) in place: colour/metallic/roughness/occlusion from sample(position, false);
+ * normal from normal(position, None) where the mesher left |normal|^2 < 1e-4.  vertices: DEVICE, n x sdfv_vertex. */
+int sdfv_mesh_postproc(const sdfv_demo_params *params, uint32_t sdf_id, sdfv_vertex *vertices, size_t n, void *stream);
+
 /* ---- raymarch ---- */
 /* material.frag main() for every pixel of rows [y0, y1) of n_cameras W x H images (row 0 = top).
  * tex0/tex1: DEVICE, the FULL grid rp->tex_size.  cameras: HOST array.  rgba: DEVICE,
@@ -182,6 +204,7 @@ int sdfv_sample_points_host(const sdfv_demo_params *params, uint32_t sdf_id, con
                             int distance_only, sdfv_sample *out_host);
 int sdfv_normal_points_host(const sdfv_demo_params *params, uint32_t sdf_id, const float *points_host, size_t n,
                             float eps, int use_default, float *out_host);
+int sdfv_mesh_postproc_host(const sdfv_demo_params *params, uint32_t sdf_id, sdfv_vertex *vertices_host, size_t n);
 int sdfv_raymarch_host(const sdfv_render_params *rp, const float *tex0_host, const float *tex1_host,
                        const sdfv_camera *cameras, uint32_t n_cameras, uint32_t width, uint32_t height,
                        float *rgba_host, sdfv_march_aux *aux_host);

@@ -60,6 +60,21 @@ void or_normal(const OrDemoParams *prm, uint32_t sdf_id, const float p[3], float
 /* normal_default_impl, defaults.rs:49-56 (4-tap tetrahedral over sample(.., true)) */
 void or_normal_default(const OrDemoParams *prm, uint32_t sdf_id, const float p[3], float eps, float out[3]);
 
+/* ---- mesher front end (src/sdf/meshers): the reference's Vertex and the calls its meshers make ---- */
+typedef struct OrVertex { /* meshers/mesh.rs:135-143 */
+    float position[3], normal[3], color[3], metallic, roughness, occlusion;
+} OrVertex;
+/* SDFSurfaceWrapper::vert_pos_to, meshers/isosurface.rs:95-99: unit cube -> bounding box */
+void or_vert_pos_to(const float bb_min[3], const float bb_max[3], const float p[3], float out[3]);
+/* ScalarSource::sample_scalar, meshers/isosurface.rs:78-84 */
+float or_source_scalar(const OrDemoParams *prm, uint32_t sdf_id, const float bb_min[3], const float bb_max[3], const float p[3]);
+/* HermiteSource::sample_normal, meshers/isosurface.rs:87-92 */
+void or_source_normal(const OrDemoParams *prm, uint32_t sdf_id, const float bb_min[3], const float bb_max[3], const float p[3], float out[3]);
+/* Mesh::postproc, meshers/mesh.rs:22-33 */
+void or_mesh_postproc(const OrDemoParams *prm, uint32_t sdf_id, OrVertex *vertices, size_t n);
+/* (v.color[i] * 255.9999) as u8, meshers/mesh.rs:106-108 */
+uint8_t or_ply_color_u8(float c);
+
 /* ---- grid ---- */
 /* AIR_DIST, scene/sdf/mod.rs:42 */
 float or_air_dist(void);

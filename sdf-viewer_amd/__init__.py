@@ -108,6 +108,39 @@ def normal_points(params, points, eps=None, use_default=False, sdf_id=SDF_DEMO, 
     return out
 
 
+VERTEX_FLOATS = 12  # sdfv_vertex: position, normal, color, metallic, roughness, occlusion (meshers/mesh.rs:135-143)
+
+
+def source_sample_scalar(params, unit_points, bb_min=(-1.0, -1.0, -1.0), bb_max=(1.0, 1.0, 1.0), sdf_id=SDF_DEMO,
+                         stream=None):
+    """ScalarSource::sample_scalar over unit-cube points (meshers/isosurface.rs:78-84) -> [n] distances."""
+    n = unit_points.shape[0]
+    out = torch.empty((n,), dtype=torch.float32, device=unit_points.device)
+    check(lib.sdfv_source_sample_scalar(C.byref(params), sdf_id, f3(bb_min), f3(bb_max),
+                                        _dev_ptr(unit_points, "unit_points"), n, C.c_void_p(out.data_ptr()),
+                                        _stream_ptr(stream)))
+    return out
+
+
+def source_sample_normal(params, unit_points, bb_min=(-1.0, -1.0, -1.0), bb_max=(1.0, 1.0, 1.0), sdf_id=SDF_DEMO,
+                         stream=None):
+    """HermiteSource::sample_normal over unit-cube points (meshers/isosurface.rs:87-92) -> [n, 3]."""
+    n = unit_points.shape[0]
+    out = torch.empty((n, 3), dtype=torch.float32, device=unit_points.device)
+    check(lib.sdfv_source_sample_normal(C.byref(params), sdf_id, f3(bb_min), f3(bb_max),
+                                        _dev_ptr(unit_points, "unit_points"), n, C.c_void_p(out.data_ptr()),
+                                        _stream_ptr(stream)))
+    return out
+
+
+def mesh_postproc(params, vertices, sdf_id=SDF_DEMO, stream=None):
+    """Mesh::postproc (meshers/mesh.rs:22-33), in place over an [n, 12] vertex tensor."""
+    assert vertices.dim() == 2 and vertices.shape[1] == VERTEX_FLOATS
+    check(lib.sdfv_mesh_postproc(C.byref(params), sdf_id, _dev_ptr(vertices, "vertices"), vertices.shape[0],
+                                 _stream_ptr(stream)))
+    return vertices
+
+
 def default_render_params(grid):
     rp = RenderParams()
     lib.sdfv_render_params_default(C.byref(rp), C.byref(grid))

@@ -89,6 +89,12 @@ PROTOTYPES = {
                                           C.c_int, C.c_void_p]),
     "sdfv_raymarch_host": (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(Camera),
                                      C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "sdfv_source_sample_scalar": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(C.c_float),
+                                            C.POINTER(C.c_float), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "sdfv_source_sample_normal": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(C.c_float),
+                                            C.POINTER(C.c_float), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "sdfv_mesh_postproc": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sdfv_mesh_postproc_host": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.c_void_p, C.c_size_t]),
     "sdfv_slab_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "sdfv_slab_comm_create": (C.c_int, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
     "sdfv_slab_comm_destroy": (C.c_int, [C.c_void_p]),

@@ -64,40 +64,110 @@ __device__ __forceinline__ void normalize3(float x, float y, float z, float& nx,
     nx = x * inv; ny = y * inv; nz = z * inv;
 }
 
-__global__ __launch_bounds__(kBlock) void normal_points_kernel(sdfv_demo_params prm, uint32_t sdf_id,
+// SDFSurface::normal(p, eps) for the demo tree: the overrides (demo/mod.rs:147-156, cube.rs:164-177,
+// sphere.rs:122-124) ignore eps; use_default = the trait's default body (defaults.rs:49-56).
+__device__ __forceinline__ void demo_normal(const sdfv_demo_params& prm, uint32_t sdf_id, float px, float py, float pz,
+                                            float eps, bool use_default, float& nx, float& ny, float& nz) {
+    if (use_default) {
+        // normal_default_impl, defaults.rs:49-56: eps.unwrap_or(0.001), 4 taps of sample(.., true)
+        const float e = eps > 0.0f ? eps : 0.001f;
+        float d1 = demo_sample(prm, sdf_id, px + e, py + -1.0f * e, pz + -1.0f * e, true).distance;
+        float d2 = demo_sample(prm, sdf_id, px + -1.0f * e, py + e, pz + -1.0f * e, true).distance;
+        float d3 = demo_sample(prm, sdf_id, px + -1.0f * e, py + -1.0f * e, pz + e, true).distance;
+        float d4 = demo_sample(prm, sdf_id, px + e, py + e, pz + e, true).distance;
+        normalize3(d1 + -d2 + -d3 + d4, -d1 + d2 + -d3 + d4, -d1 + -d2 + d3 + d4, nx, ny, nz);
+    } else if (sdf_id == SDFV_SDF_CUBE) {
+        cube_normal(prm, px, py, pz, nx, ny, nz);
+    } else if (sdf_id == SDFV_SDF_SPHERE) {
+        normalize3(px, py, pz, nx, ny, nz);  // sphere.rs:122-124
+    } else {
+        // SDFDemo::normal, demo/mod.rs:147-156: normal of the closest surface, sphere negated
+        float d_box = cube_distance(prm, px, py, pz);
+        float d_sph = vec_length(px, py, pz) - prm.sphere_radius;
+        if (fabsf(d_box) < fabsf(d_sph)) {
+            cube_normal(prm, px, py, pz, nx, ny, nz);
+        } else {
+            normalize3(px, py, pz, nx, ny, nz);
+            nx = -nx; ny = -ny; nz = -nz;
+        }
+    }
+}
+
+// SDFSurfaceWrapper::vert_pos_to, meshers/isosurface.rs:95-99: the meshers work in the unit cube.
+struct SourceBox {
+    float bb_min[3], bb_size[3];
+    bool unit_cube;  // false: points are already in world space
+    __device__ __forceinline__ void to_world(float& x, float& y, float& z) const {
+        if (!unit_cube) return;
+        x = x * bb_size[0] + bb_min[0];
+        y = y * bb_size[1] + bb_min[1];
+        z = z * bb_size[2] + bb_min[2];
+    }
+};
+
+__global__ __launch_bounds__(kBlock) void normal_points_kernel(sdfv_demo_params prm, uint32_t sdf_id, SourceBox box,
                                                                const float* __restrict__ points, size_t n,
                                                                float eps, bool use_default,
                                                                float* __restrict__ out) {
-    {
-        const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-        if (i >= n) return;
-        const float px = points[i * 3 + 0], py = points[i * 3 + 1], pz = points[i * 3 + 2];
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float px = points[i * 3 + 0], py = points[i * 3 + 1], pz = points[i * 3 + 2];
+    box.to_world(px, py, pz);
+    float nx, ny, nz;
+    demo_normal(prm, sdf_id, px, py, pz, eps, use_default, nx, ny, nz);
+    out[i * 3 + 0] = nx; out[i * 3 + 1] = ny; out[i * 3 + 2] = nz;
+}
+
+// ScalarSource::sample_scalar, meshers/isosurface.rs:78-84: distance only, 12 B in, 4 B out per point.
+__global__ __launch_bounds__(kBlock) void source_scalar_kernel(sdfv_demo_params prm, uint32_t sdf_id, SourceBox box,
+                                                               const float* __restrict__ points, size_t n,
+                                                               float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float px = points[i * 3 + 0], py = points[i * 3 + 1], pz = points[i * 3 + 2];
+    box.to_world(px, py, pz);
+    out[i] = demo_sample(prm, sdf_id, px, py, pz, true).distance;
+}
+
+// Mesh::postproc, meshers/mesh.rs:22-33, in place over #[repr(Rust)]-free 48-byte vertices (sdfv_vertex):
+// material from sample(position, false); normal from sdf.normal(position, None) where the mesher left |n|^2 < 1e-4.
+__device__ __forceinline__ void postproc_vertex(const sdfv_demo_params& prm, uint32_t sdf_id, float* v) {
+    const float px = v[0], py = v[1], pz = v[2];
+    Sample s = demo_sample(prm, sdf_id, px, py, pz, false);
+    const float dx = v[3] - 0.0f, dy = v[4] - 0.0f, dz = v[5] - 0.0f;  // distance2(Vector3::zero())
+    if (dx * dx + dy * dy + dz * dz < 0.0001f) {
         float nx, ny, nz;
-        if (use_default) {
-            // normal_default_impl, defaults.rs:49-56: eps.unwrap_or(0.001), 4 taps of sample(.., true)
-            const float e = eps > 0.0f ? eps : 0.001f;
-            float d1 = demo_sample(prm, sdf_id, px + e, py + -1.0f * e, pz + -1.0f * e, true).distance;
-            float d2 = demo_sample(prm, sdf_id, px + -1.0f * e, py + e, pz + -1.0f * e, true).distance;
-            float d3 = demo_sample(prm, sdf_id, px + -1.0f * e, py + -1.0f * e, pz + e, true).distance;
-            float d4 = demo_sample(prm, sdf_id, px + e, py + e, pz + e, true).distance;
-            normalize3(d1 + -d2 + -d3 + d4, -d1 + d2 + -d3 + d4, -d1 + -d2 + d3 + d4, nx, ny, nz);
-        } else if (sdf_id == SDFV_SDF_CUBE) {
-            cube_normal(prm, px, py, pz, nx, ny, nz);
-        } else if (sdf_id == SDFV_SDF_SPHERE) {
-            normalize3(px, py, pz, nx, ny, nz);  // sphere.rs:122-124
-        } else {
-            // SDFDemo::normal, demo/mod.rs:147-156: normal of the closest surface, sphere negated
-            float d_box = cube_distance(prm, px, py, pz);
-            float d_sph = vec_length(px, py, pz) - prm.sphere_radius;
-            if (fabsf(d_box) < fabsf(d_sph)) {
-                cube_normal(prm, px, py, pz, nx, ny, nz);
-            } else {
-                normalize3(px, py, pz, nx, ny, nz);
-                nx = -nx; ny = -ny; nz = -nz;
-            }
-        }
-        out[i * 3 + 0] = nx; out[i * 3 + 1] = ny; out[i * 3 + 2] = nz;
+        demo_normal(prm, sdf_id, px, py, pz, 0.0f, false, nx, ny, nz);
+        v[3] = nx; v[4] = ny; v[5] = nz;
     }
+    v[6] = s.m.r; v[7] = s.m.g; v[8] = s.m.b;
+    v[9] = s.m.metallic; v[10] = s.m.roughness; v[11] = s.m.occlusion;
+}
+
+__global__ __launch_bounds__(kBlock) void mesh_postproc_kernel(sdfv_demo_params prm, uint32_t sdf_id,
+                                                               float* __restrict__ vertices, size_t first, size_t n) {
+    const size_t i = first + (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float v[12];
+    for (int k = 0; k < 12; ++k) v[k] = vertices[i * 12 + k];
+    postproc_vertex(prm, sdf_id, v);
+    for (int k = 3; k < 12; ++k) vertices[i * 12 + k] = v[k];
+}
+
+// Whole workgroups: 256 vertices = 12 KiB contiguous, moved as dwordx4 and re-sliced per vertex in LDS.
+__global__ __launch_bounds__(kBlock) void mesh_postproc_staged_kernel(sdfv_demo_params prm, uint32_t sdf_id,
+                                                                      float4* __restrict__ vertices) {
+    __shared__ __attribute__((aligned(16))) float s_v[kBlock * 12];
+    const uint32_t t = threadIdx.x;
+    float4* base = vertices + (size_t)blockIdx.x * (kBlock * 3);
+    for (int k = 0; k < 3; ++k) reinterpret_cast<float4*>(s_v)[k * kBlock + t] = base[k * kBlock + t];
+    __syncthreads();
+    float v[12];
+    for (int k = 0; k < 12; ++k) v[k] = s_v[t * 12 + k];
+    postproc_vertex(prm, sdf_id, v);
+    for (int k = 3; k < 12; ++k) s_v[t * 12 + k] = v[k];
+    __syncthreads();
+    for (int k = 0; k < 3; ++k) base[k * kBlock + t] = reinterpret_cast<const float4*>(s_v)[k * kBlock + t];
 }
 
 uint32_t blocks_for(size_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
@@ -124,12 +194,53 @@ hipError_t launch_sample_points(const sdfv_demo_params& prm, uint32_t sdf_id, co
     return hipGetLastError();
 }
 
-hipError_t launch_normal_points(const sdfv_demo_params& prm, uint32_t sdf_id, const float* points, size_t n,
-                                float eps, bool use_default, float* out, hipStream_t stream) {
+namespace {
+SourceBox make_box(const float* bb_min, const float* bb_max) {
+    SourceBox b{};
+    b.unit_cube = bb_min != nullptr && bb_max != nullptr;
+    for (int i = 0; i < 3 && b.unit_cube; ++i) {
+        b.bb_min[i] = bb_min[i];
+        b.bb_size[i] = bb_max[i] - bb_min[i];
+    }
+    return b;
+}
+}  // namespace
+
+hipError_t launch_normal_points(const sdfv_demo_params& prm, uint32_t sdf_id, const float* bb_min,
+                                const float* bb_max, const float* points, size_t n, float eps, bool use_default,
+                                float* out, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     if ((n + kBlock - 1) / kBlock > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(normal_points_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, prm, sdf_id, points, n,
-                       eps, use_default, out);
+    hipLaunchKernelGGL(normal_points_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, prm, sdf_id,
+                       make_box(bb_min, bb_max), points, n, eps, use_default, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_source_scalar(const sdfv_demo_params& prm, uint32_t sdf_id, const float* bb_min,
+                                const float* bb_max, const float* points, size_t n, float* out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if ((n + kBlock - 1) / kBlock > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(source_scalar_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, prm, sdf_id,
+                       make_box(bb_min, bb_max), points, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_mesh_postproc(const sdfv_demo_params& prm, uint32_t sdf_id, sdfv_vertex* vertices, size_t n,
+                                hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    float* v = reinterpret_cast<float*>(vertices);
+    size_t done = 0;
+    const size_t whole = n / kBlock;
+    if (whole > 0 && whole <= 0x7fffffffull && ((uintptr_t)vertices & 15) == 0) {
+        hipLaunchKernelGGL(mesh_postproc_staged_kernel, dim3((uint32_t)whole), dim3(kBlock), 0, stream, prm, sdf_id,
+                           reinterpret_cast<float4*>(v));
+        done = whole * kBlock;
+    }
+    if (done < n) {
+        const size_t blocks = (n - done + kBlock - 1) / kBlock;
+        if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(mesh_postproc_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, stream, prm, sdf_id, v, done, n);
+    }
     return hipGetLastError();
 }
 

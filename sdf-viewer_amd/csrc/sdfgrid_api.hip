@@ -313,7 +313,39 @@ int sdfv_normal_points(const sdfv_demo_params* params, uint32_t sdf_id, const fl
     if (int rc = check_params(params, sdf_id)) return rc;
     if (n && (!points || !out)) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL buffer");
     if (int rc = need_device()) return rc;
-    SDFV_HIP(sdfv::launch_normal_points(*params, sdf_id, points, n, eps, use_default != 0, out, (hipStream_t)stream));
+    SDFV_HIP(sdfv::launch_normal_points(*params, sdf_id, nullptr, nullptr, points, n, eps, use_default != 0, out,
+                                        (hipStream_t)stream));
+    return SDFV_OK;
+}
+
+int sdfv_source_sample_scalar(const sdfv_demo_params* params, uint32_t sdf_id, const float bb_min[3],
+                              const float bb_max[3], const float* unit_points, size_t n, float* dist_out, void* stream) {
+    if (int rc = check_params(params, sdf_id)) return rc;
+    if (!bb_min || !bb_max) return fail(SDFV_ERR_INVALID_ARGUMENT, "bounding box is NULL");
+    if (n && (!unit_points || !dist_out)) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (int rc = need_device()) return rc;
+    SDFV_HIP(sdfv::launch_source_scalar(*params, sdf_id, bb_min, bb_max, unit_points, n, dist_out, (hipStream_t)stream));
+    return SDFV_OK;
+}
+
+int sdfv_source_sample_normal(const sdfv_demo_params* params, uint32_t sdf_id, const float bb_min[3],
+                              const float bb_max[3], const float* unit_points, size_t n, float* normal_out,
+                              void* stream) {
+    if (int rc = check_params(params, sdf_id)) return rc;
+    if (!bb_min || !bb_max) return fail(SDFV_ERR_INVALID_ARGUMENT, "bounding box is NULL");
+    if (n && (!unit_points || !normal_out)) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (int rc = need_device()) return rc;
+    SDFV_HIP(sdfv::launch_normal_points(*params, sdf_id, bb_min, bb_max, unit_points, n, 0.0f, false, normal_out,
+                                        (hipStream_t)stream));
+    return SDFV_OK;
+}
+
+int sdfv_mesh_postproc(const sdfv_demo_params* params, uint32_t sdf_id, sdfv_vertex* vertices, size_t n, void* stream) {
+    if (int rc = check_params(params, sdf_id)) return rc;
+    if (n && !vertices) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if ((uintptr_t)vertices & 3) return fail(SDFV_ERR_INVALID_ARGUMENT, "vertices must be 4-byte aligned");
+    if (int rc = need_device()) return rc;
+    SDFV_HIP(sdfv::launch_mesh_postproc(*params, sdf_id, vertices, n, (hipStream_t)stream));
     return SDFV_OK;
 }
 
@@ -444,6 +476,19 @@ int sdfv_normal_points_host(const sdfv_demo_params* params, uint32_t sdf_id, con
     SDFV_HIP(hipMemcpy(dp.p, points_host, n * 12, hipMemcpyHostToDevice));
     if (int rc = sdfv_normal_points(params, sdf_id, (const float*)dp.p, n, eps, use_default, (float*)dn.p, nullptr)) return rc;
     SDFV_HIP(hipMemcpy(out_host, dn.p, n * 12, hipMemcpyDeviceToHost));
+    return SDFV_OK;
+}
+
+int sdfv_mesh_postproc_host(const sdfv_demo_params* params, uint32_t sdf_id, sdfv_vertex* vertices_host, size_t n) {
+    if (n && !vertices_host) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (int rc = check_params(params, sdf_id)) return rc;
+    if (int rc = need_device()) return rc;
+    if (n == 0) return SDFV_OK;
+    DeviceBuf dv;
+    SDFV_HIP(hipMalloc(&dv.p, n * sizeof(sdfv_vertex)));
+    SDFV_HIP(hipMemcpy(dv.p, vertices_host, n * sizeof(sdfv_vertex), hipMemcpyHostToDevice));
+    if (int rc = sdfv_mesh_postproc(params, sdf_id, (sdfv_vertex*)dv.p, n, nullptr)) return rc;
+    SDFV_HIP(hipMemcpy(vertices_host, dv.p, n * sizeof(sdfv_vertex), hipMemcpyDeviceToHost));
     return SDFV_OK;
 }
 

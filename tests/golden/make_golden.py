@@ -10,6 +10,8 @@ oracle they are used to pin:
   2. grid_9x7x5.npz,     -- an op-by-op numpy-float32 restatement of the same source written below (every
      points_512.npz         operation on np.float32 scalars, so each one rounds to f32 like Rust's), run on a
                             small non-cubic grid and on 512 seeded points for several parameter sets.
+     mesh_front_200.npz  -- the same restatement behind the mesher front end (src/sdf/meshers/isosurface.rs:78-99,
+                            mesh.rs:22-33): ScalarSource, HermiteSource and Mesh::postproc on 200 seeded points.
   3. raymarch_12cube_40x30.npz -- the same kind of restatement of material.frag (sphere tracing, texel-centre
                             trilinear, ambient shading, ACES, sRGB) for two cameras over a 12^3 grid.
 
@@ -104,6 +106,60 @@ def demo(prm, p, distance_only=False):  # demo/mod.rs:51-75
 
 def sample(prm, sdf_id, p, distance_only=False):
     return (demo, cube, sphere)[sdf_id](prm, p, distance_only)
+
+
+def normal(prm, sdf_id, p):  # SDFSurface::normal(p, None): demo/mod.rs:147-156, cube.rs:164-177, sphere.rs:122-124
+    def cube_n():
+        h = F(prm["cube_half_side"])
+        return tuple((F(-1.0) if np.signbit(c) else F(1.0)) if abs(c) > h else F(0) for c in p)
+
+    def sphere_n():
+        with np.errstate(all="ignore"):
+            inv = F(1.0) / np.sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2])
+            return (p[0] * inv, p[1] * inv, p[2] * inv)
+    if sdf_id == 1:
+        return cube_n()
+    if sdf_id == 2:
+        return sphere_n()
+    if abs(cube(prm, p, True)[0]) < abs(sphere(prm, p, True)[0]):
+        return cube_n()
+    return tuple(-c for c in sphere_n())
+
+
+def vert_pos_to(bb_min, bb_max, p):  # meshers/isosurface.rs:95-99
+    return tuple(F(p[i]) * (F(bb_max[i]) - F(bb_min[i])) + F(bb_min[i]) for i in range(3))
+
+
+def postproc(prm, sdf_id, v):  # Mesh::postproc, meshers/mesh.rs:22-33; v = 12 floats
+    v = [F(c) for c in v]
+    pos = tuple(v[0:3])
+    s = sample(prm, sdf_id, pos, False)
+    if v[3] * v[3] + v[4] * v[4] + v[5] * v[5] < F(0.0001):
+        v[3:6] = normal(prm, sdf_id, pos)
+    v[6:12] = s[1:7]
+    return v
+
+
+def make_mesh_front_fixture():
+    rng = np.random.default_rng(20250405)
+    unit = rng.uniform(0.0, 1.0, size=(200, 3)).astype(np.float32)
+    unit[:4] = [(0, 0, 0), (1, 1, 1), (0.5, 0.5, 0.5), (0.25, 1.0, 0.0)]
+    bb_min, bb_max = (-1.0, -0.75, -1.25), (1.0, 1.0, 0.5)
+    verts = np.zeros((200, 12), np.float32)
+    verts[:, 0:3] = rng.uniform(-1.1, 1.1, size=(200, 3)).astype(np.float32)
+    verts[:70, 3:6] = rng.normal(size=(70, 3)).astype(np.float32)
+    verts[140:, 3] = np.float32(0.01) * (1 + rng.uniform(-1e-3, 1e-3, size=60)).astype(np.float32)
+    out = {}
+    with np.errstate(all="ignore"):
+        for k, prm in enumerate(PARAM_SETS):
+            for sdf_id in (0, 1, 2):
+                world = [vert_pos_to(bb_min, bb_max, p) for p in unit]
+                out[f"scalar_{k}_{sdf_id}"] = np.array([sample(prm, sdf_id, w, True)[0] for w in world], np.float32)
+                out[f"normal_{k}_{sdf_id}"] = np.array([normal(prm, sdf_id, w) for w in world], np.float32)
+                out[f"postproc_{k}_{sdf_id}"] = np.array([postproc(prm, sdf_id, v) for v in verts], np.float32)
+    np.savez_compressed(os.path.join(HERE, "mesh_front_200.npz"), unit_points=unit, bb_min=np.array(bb_min, np.float32),
+                        bb_max=np.array(bb_max, np.float32), vertices=verts,
+                        params=np.array([[p[k] for k in DEFAULT] for p in PARAM_SETS], np.float64), **out)
 
 
 def quant(c):  # (c * 255.0) as u8
@@ -317,6 +373,7 @@ def make_raymarch_fixture():
 
 def main():
     make_raymarch_fixture()
+    make_mesh_front_fixture()
     with open(os.path.join(HERE, "demo_sdf_kat.json"), "w") as f:
         json.dump(dict(source="SURVEY.md 8(c), hand-derived from the reference source; default demo params",
                        air_dist_bits="0x3DCF53C6", kats=SURVEY_KATS, coords_n64_bb_m1_1=SURVEY_COORDS_64), f, indent=1)

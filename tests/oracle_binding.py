@@ -193,3 +193,39 @@ def raymarch(rp, t0, t1, cam, width, height, y0=0, y1=None, threads=8, want_aux=
     L.or_raymarch(C.byref(rp), t0.ctypes.data, t1.ctypes.data, C.byref(cam), width, height, y0, y1, rgba.ctypes.data,
                   aux.ctypes.data if want_aux else None, threads)
     return rgba, aux
+
+
+# ---- mesher front end (oracle/mesh_front.c) ----
+VERTEX_FLOATS = 12
+L.or_source_scalar.restype = C.c_float
+L.or_source_scalar.argtypes = [C.c_void_p, C.c_uint32, FP, FP, FP]
+L.or_source_normal.argtypes = [C.c_void_p, C.c_uint32, FP, FP, FP, FP]
+L.or_vert_pos_to.argtypes = [FP, FP, FP, FP]
+L.or_mesh_postproc.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+L.or_ply_color_u8.restype = C.c_uint8
+L.or_ply_color_u8.argtypes = [C.c_float]
+
+
+def source_scalar_many(params, unit_pts, bb_min=(-1, -1, -1), bb_max=(1, 1, 1), sdf_id=0):
+    out = np.empty(len(unit_pts), np.float32)
+    lo, hi = f3(bb_min), f3(bb_max)
+    for i, p in enumerate(unit_pts):
+        out[i] = L.or_source_scalar(C.byref(params), sdf_id, lo, hi, f3(p))
+    return out
+
+
+def source_normal_many(params, unit_pts, bb_min=(-1, -1, -1), bb_max=(1, 1, 1), sdf_id=0):
+    out = np.empty((len(unit_pts), 3), np.float32)
+    lo, hi = f3(bb_min), f3(bb_max)
+    n = (C.c_float * 3)()
+    for i, p in enumerate(unit_pts):
+        L.or_source_normal(C.byref(params), sdf_id, lo, hi, f3(p), n)
+        out[i] = n[:]
+    return out
+
+
+def mesh_postproc(params, vertices, sdf_id=0):
+    """vertices: [n, 12] float32 (sdfv_vertex layout); returns the post-processed copy."""
+    v = np.ascontiguousarray(vertices, np.float32).copy()
+    L.or_mesh_postproc(C.byref(params), sdf_id, v.ctypes.data, len(v))
+    return v

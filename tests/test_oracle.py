@@ -181,3 +181,25 @@ def test_numpy_restatement_raymarch(oracle):
     cam0 = oracle.camera_look_at(aspect=W / H)
     np.testing.assert_array_equal(np.frombuffer(bytes(cam0), np.float32)[:14].view(np.uint32),
                                   g["cam_0"][:14].view(np.uint32))
+
+
+def test_numpy_restatement_mesh_front(oracle):
+    """ScalarSource / HermiteSource / Mesh::postproc (src/sdf/meshers) against the numpy restatement's fixture."""
+    g = np.load(os.path.join(GOLD, "mesh_front_200.npz"))
+    unit, verts = g["unit_points"], g["vertices"]
+    for k, row in enumerate(g["params"]):
+        prm = params_from_row(oracle, row)
+        for sdf_id in (0, 1, 2):
+            got = oracle.source_scalar_many(prm, unit, g["bb_min"], g["bb_max"], sdf_id)
+            np.testing.assert_array_equal(got.view(np.uint32), g[f"scalar_{k}_{sdf_id}"].view(np.uint32))
+            got = oracle.source_normal_many(prm, unit, g["bb_min"], g["bb_max"], sdf_id)
+            np.testing.assert_array_equal(got.view(np.uint32), g[f"normal_{k}_{sdf_id}"].view(np.uint32))
+            got = oracle.mesh_postproc(prm, verts, sdf_id)
+            np.testing.assert_array_equal(got.view(np.uint32), g[f"postproc_{k}_{sdf_id}"].view(np.uint32))
+
+
+def test_ply_colour_quantisation(oracle):
+    """(c * 255.9999) as u8, meshers/mesh.rs:106-108: truncating and saturating."""
+    q = oracle.L.or_ply_color_u8
+    assert [q(0.0), q(1.0), q(0.5), q(2.0), q(-0.3), q(float("nan"))] == [0, 255, 127, 255, 0, 0]
+    assert q(1.0 / 255.9999 * 3) in (2, 3) and q(0.999) == 255 and q(0.99) == 253
