@@ -177,6 +177,25 @@ int sdfv_source_sample_normal(const sdfv_demo_params *params, uint32_t sdf_id, c
  * normal from normal(position, None) where the mesher left |normal|^2 < 1e-4.  vertices: DEVICE, n x sdfv_vertex. */
 int sdfv_mesh_postproc(const sdfv_demo_params *params, uint32_t sdf_id, sdfv_vertex *vertices, size_t n, void *stream);
 
+/* An indexed triangle mesh in DEVICE memory, allocated by sdfv_mesh_extract and owned by the library until
+ * sdfv_mesh_free (the reference's callee-allocates + *_free convention, ffi.rs:52-55).  Mesh, meshers/mesh.rs:11-17. */
+typedef struct sdfv_mesh {
+    sdfv_vertex *vertices; /* DEVICE, n_vertices */
+    uint32_t    *indices;  /* DEVICE, n_indices = 3 * triangles, counter-clockwise seen from outside */
+    size_t       n_vertices;
+    size_t       n_indices;
+} sdfv_mesh;
+#define SDFV_MESHER_MARCHING_CUBES 0u /* Meshers::MarchingCubes, meshers/mod.rs:118-119 (the default, :130-134) */
+/* Meshers::mesh (meshers/mod.rs:136-149 -> isosurface.rs:16-66) on the device: max_voxels_per_axis^3 cells over the
+ * unit cube mapped onto the bounding box, distances from ScalarSource, one vertex per crossing lattice edge with
+ * its HermiteSource normal, material fields zero (Vertex::default) until sdfv_mesh_postproc.  The extraction
+ * algorithm itself is the build's own (the reference delegates to the un-vendored `isosurface` crate); algorithms
+ * other than marching cubes are rejected like the reference's "Unsupported algorithm" (isosurface.rs:49).
+ * Synchronises `stream` (the output size is data dependent). */
+int sdfv_mesh_extract(const sdfv_demo_params *params, uint32_t sdf_id, const float bb_min[3], const float bb_max[3],
+                      uint32_t max_voxels_per_axis, uint32_t algorithm, sdfv_mesh *out, void *stream);
+int sdfv_mesh_free(sdfv_mesh *mesh);
+
 /* ---- raymarch ---- */
 /* material.frag main() for every pixel of rows [y0, y1) of n_cameras W x H images (row 0 = top).
  * tex0/tex1: DEVICE, the FULL grid rp->tex_size.  cameras: HOST array.  rgba: DEVICE,

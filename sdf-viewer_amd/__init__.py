@@ -141,6 +141,37 @@ def mesh_postproc(params, vertices, sdf_id=SDF_DEMO, stream=None):
     return vertices
 
 
+class _DeviceArray:
+    """A library-owned device buffer seen through __cuda_array_interface__ (torch.as_tensor wraps it without a copy)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": tuple(shape), "typestr": typestr,
+                                         "version": 2, "strides": None}
+
+
+def mesh_extract(params, max_voxels_per_axis=64, bb_min=(-1.0, -1.0, -1.0), bb_max=(1.0, 1.0, 1.0), sdf_id=SDF_DEMO,
+                 algorithm=0, stream=None):
+    """Meshers::mesh (meshers/mod.rs:136-149): -> (vertices [n, 12] float32, indices [3 * triangles] int32), copied
+    out of the library's buffers into torch tensors (the library's copy is freed before returning)."""
+    m = _capi.Mesh()
+    check(lib.sdfv_mesh_extract(C.byref(params), sdf_id, f3(bb_min), f3(bb_max), int(max_voxels_per_axis),
+                                int(algorithm), C.byref(m), _stream_ptr(stream)))
+    try:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if m.n_vertices:
+            v = torch.as_tensor(_DeviceArray(m.vertices, (m.n_vertices, VERTEX_FLOATS), "<f4"), device=dev).clone()
+        else:
+            v = torch.empty((0, VERTEX_FLOATS), dtype=torch.float32, device=dev)
+        if m.n_indices:
+            i = torch.as_tensor(_DeviceArray(m.indices, (m.n_indices,), "<i4"), device=dev).clone()
+        else:
+            i = torch.empty((0,), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+    finally:
+        lib.sdfv_mesh_free(C.byref(m))
+    return v, i
+
+
 def default_render_params(grid):
     rp = RenderParams()
     lib.sdfv_render_params_default(C.byref(rp), C.byref(grid))

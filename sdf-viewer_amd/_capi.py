@@ -56,6 +56,10 @@ SDF_DEMO, SDF_CUBE, SDF_SPHERE = 0, 1, 2
 MATERIAL_BRICK, MATERIAL_NORMAL = 0, 1
 
 # name -> (restype, argtypes); every symbol include/sdfgrid.h declares
+class Mesh(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("indices", C.c_void_p), ("n_vertices", C.c_size_t), ("n_indices", C.c_size_t)]
+
+
 PROTOTYPES = {
     "sdfv_abi_version": (C.c_uint32, []),
     "sdfv_last_error": (C.c_char_p, []),
@@ -95,6 +99,9 @@ PROTOTYPES = {
                                             C.POINTER(C.c_float), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "sdfv_mesh_postproc": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sdfv_mesh_postproc_host": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.c_void_p, C.c_size_t]),
+    "sdfv_mesh_extract": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                    C.c_uint32, C.c_uint32, C.POINTER(Mesh), C.c_void_p]),
+    "sdfv_mesh_free": (C.c_int, [C.POINTER(Mesh)]),
     "sdfv_slab_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "sdfv_slab_comm_create": (C.c_int, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
     "sdfv_slab_comm_destroy": (C.c_int, [C.c_void_p]),

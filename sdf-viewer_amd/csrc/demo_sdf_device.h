@@ -323,4 +323,62 @@ __device__ __forceinline__ float voxel_coord(uint32_t idx, float dim_minus_1, fl
     return p;
 }
 
+// ---- SDFSurface::normal and the meshers' unit-cube mapping (shared by points_kernels.hip, mesh_kernels.hip) ----
+
+// SDFDemoCube::normal, cube.rs:164-177
+__device__ __forceinline__ void cube_normal(const sdfv_demo_params& prm, float px, float py, float pz,
+                                            float& nx, float& ny, float& nz) {
+    float side = prm.cube_half_side;
+    nx = fabsf(px) > side ? signum_f32(px) : 0.0f;
+    ny = fabsf(py) > side ? signum_f32(py) : 0.0f;
+    nz = fabsf(pz) > side ? signum_f32(pz) : 0.0f;
+}
+
+// cgmath normalize: v * (1 / |v|)
+__device__ __forceinline__ void normalize3(float x, float y, float z, float& nx, float& ny, float& nz) {
+    float inv = 1.0f / vec_length(x, y, z);
+    nx = x * inv; ny = y * inv; nz = z * inv;
+}
+
+// SDFSurface::normal(p, eps) for the demo tree: the overrides (demo/mod.rs:147-156, cube.rs:164-177,
+// sphere.rs:122-124) ignore eps; use_default = the trait's default body (defaults.rs:49-56).
+__device__ __forceinline__ void demo_normal(const sdfv_demo_params& prm, uint32_t sdf_id, float px, float py, float pz,
+                                            float eps, bool use_default, float& nx, float& ny, float& nz) {
+    if (use_default) {
+        // normal_default_impl, defaults.rs:49-56: eps.unwrap_or(0.001), 4 taps of sample(.., true)
+        const float e = eps > 0.0f ? eps : 0.001f;
+        float d1 = demo_sample(prm, sdf_id, px + e, py + -1.0f * e, pz + -1.0f * e, true).distance;
+        float d2 = demo_sample(prm, sdf_id, px + -1.0f * e, py + e, pz + -1.0f * e, true).distance;
+        float d3 = demo_sample(prm, sdf_id, px + -1.0f * e, py + -1.0f * e, pz + e, true).distance;
+        float d4 = demo_sample(prm, sdf_id, px + e, py + e, pz + e, true).distance;
+        normalize3(d1 + -d2 + -d3 + d4, -d1 + d2 + -d3 + d4, -d1 + -d2 + d3 + d4, nx, ny, nz);
+    } else if (sdf_id == SDFV_SDF_CUBE) {
+        cube_normal(prm, px, py, pz, nx, ny, nz);
+    } else if (sdf_id == SDFV_SDF_SPHERE) {
+        normalize3(px, py, pz, nx, ny, nz);  // sphere.rs:122-124
+    } else {
+        // SDFDemo::normal, demo/mod.rs:147-156: normal of the closest surface, sphere negated
+        float d_box = cube_distance(prm, px, py, pz);
+        float d_sph = vec_length(px, py, pz) - prm.sphere_radius;
+        if (fabsf(d_box) < fabsf(d_sph)) {
+            cube_normal(prm, px, py, pz, nx, ny, nz);
+        } else {
+            normalize3(px, py, pz, nx, ny, nz);
+            nx = -nx; ny = -ny; nz = -nz;
+        }
+    }
+}
+
+// SDFSurfaceWrapper::vert_pos_to, meshers/isosurface.rs:95-99: the meshers work in the unit cube.
+struct SourceBox {
+    float bb_min[3], bb_size[3];
+    bool unit_cube;  // false: points are already in world space
+    __device__ __forceinline__ void to_world(float& x, float& y, float& z) const {
+        if (!unit_cube) return;
+        x = x * bb_size[0] + bb_min[0];
+        y = y * bb_size[1] + bb_min[1];
+        z = z * bb_size[2] + bb_min[2];
+    }
+};
+
 }  // namespace sdfv

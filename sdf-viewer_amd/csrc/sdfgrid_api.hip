@@ -11,6 +11,7 @@
 #include "../../include/sdfgrid.h"
 #include "api_internal.h"
 #include "fill_kernels.h"
+#include "mesh_kernels.h"
 #include "points_kernels.h"
 #include "raymarch_kernels.h"
 
@@ -346,6 +347,74 @@ int sdfv_mesh_postproc(const sdfv_demo_params* params, uint32_t sdf_id, sdfv_ver
     if ((uintptr_t)vertices & 3) return fail(SDFV_ERR_INVALID_ARGUMENT, "vertices must be 4-byte aligned");
     if (int rc = need_device()) return rc;
     SDFV_HIP(sdfv::launch_mesh_postproc(*params, sdf_id, vertices, n, (hipStream_t)stream));
+    return SDFV_OK;
+}
+
+int sdfv_mesh_extract(const sdfv_demo_params* params, uint32_t sdf_id, const float bb_min[3], const float bb_max[3],
+                      uint32_t max_voxels_per_axis, uint32_t algorithm, sdfv_mesh* out, void* stream) {
+    if (!out) return fail(SDFV_ERR_INVALID_ARGUMENT, "out is NULL");
+    memset(out, 0, sizeof(*out));
+    if (int rc = check_params(params, sdf_id)) return rc;
+    if (!bb_min || !bb_max) return fail(SDFV_ERR_INVALID_ARGUMENT, "bounding box is NULL");
+    if (algorithm != SDFV_MESHER_MARCHING_CUBES)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "Unsupported algorithm %u", algorithm);  // isosurface.rs:49
+    if (max_voxels_per_axis < 1 || max_voxels_per_axis > 1024)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "max_voxels_per_axis %u is outside [1, 1024]", max_voxels_per_axis);
+    if (int rc = need_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    sdfv::MeshGrid g;
+    for (int i = 0; i < 3; ++i) {
+        g.cells[i] = max_voxels_per_axis;
+        g.bb_min[i] = bb_min[i];
+        g.bb_size[i] = bb_max[i] - bb_min[i];
+    }
+    const size_t n_points = (size_t)(g.cells[0] + 1) * (g.cells[1] + 1) * (g.cells[2] + 1);
+    const size_t n_cells = (size_t)g.cells[0] * g.cells[1] * g.cells[2];
+    DeviceBuf dist, first, mask, cfirst, tmp, totals;
+    sdfv::MeshWork w{};
+    w.scan_tmp_bytes = sdfv::mesh_scan_tmp_bytes(n_points);
+    SDFV_HIP(hipMalloc(&dist.p, n_points * 4));
+    SDFV_HIP(hipMalloc(&first.p, n_points * 4));
+    SDFV_HIP(hipMalloc(&mask.p, n_points));
+    SDFV_HIP(hipMalloc(&cfirst.p, n_cells * 4));
+    SDFV_HIP(hipMalloc(&tmp.p, w.scan_tmp_bytes ? w.scan_tmp_bytes : 16));
+    SDFV_HIP(hipMalloc(&totals.p, 8));
+    w.dist = (float*)dist.p;
+    w.point_first = (uint32_t*)first.p;
+    w.point_mask = (uint8_t*)mask.p;
+    w.cell_first = (uint32_t*)cfirst.p;
+    w.scan_tmp = tmp.p;
+    SDFV_HIP(sdfv::launch_mesh_count(*params, sdf_id, g, w, (uint32_t*)totals.p, st));
+    uint32_t n[2] = {0, 0};
+    SDFV_HIP(hipMemcpyAsync(n, totals.p, 8, hipMemcpyDeviceToHost, st));
+    SDFV_HIP(hipStreamSynchronize(st));
+    sdfv_mesh m{};
+    m.n_vertices = n[0];
+    m.n_indices = (size_t)n[1] * 3;
+    if (m.n_vertices) SDFV_HIP(hipMalloc((void**)&m.vertices, m.n_vertices * sizeof(sdfv_vertex)));
+    if (m.n_indices) {
+        hipError_t e = hipMalloc((void**)&m.indices, m.n_indices * 4);
+        if (e != hipSuccess) {
+            (void)hipFree(m.vertices);
+            return hip_fail(e, "hipMalloc(indices)");
+        }
+    }
+    hipError_t e = sdfv::launch_mesh_emit(*params, sdf_id, g, w, m.vertices, m.indices, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // the scratch buffers go out of scope below
+    if (e != hipSuccess) {
+        (void)hipFree(m.vertices);
+        (void)hipFree(m.indices);
+        return hip_fail(e, "mesh emit");
+    }
+    *out = m;
+    return SDFV_OK;
+}
+
+int sdfv_mesh_free(sdfv_mesh* mesh) {
+    if (!mesh) return SDFV_OK;
+    if (mesh->vertices) (void)hipFree(mesh->vertices);
+    if (mesh->indices) (void)hipFree(mesh->indices);
+    memset(mesh, 0, sizeof(*mesh));
     return SDFV_OK;
 }
 

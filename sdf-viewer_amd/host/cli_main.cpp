@@ -5,6 +5,11 @@
 //
 // Flag names and defaults are the reference's: CliApp (src/app/cli/mod.rs:10-22: max_voxels_side 64,
 // loading_passes 2) and the demo SDF's flags (src/sdf/demo/cube.rs:15-18, sphere.rs:11-14, demo/mod.rs:26-29).
+//   sdf-viewer-gpu mesh [-o mesh.ply] [-v 64] [marching-cubes] [demo flags after `demo`]
+//
+// `mesh` is the reference's CliMesher (src/sdf/meshers/mod.rs:22-89): -o/--output (default mesh.ply, "-" = stdout,
+// refuses to overwrite), -v/--max-voxels-per-axis (default 64), the mesher subcommand (default marching-cubes); the
+// input is the embedded demo SDF instead of -i <wasm>.  Mesh -> postproc -> serialize_ply, as run_custom_out does.
 // Where the reference opens a window, this loads the SDF into the two device textures
 // (SDFViewer::from_bb/update/commit), renders the default scene camera (scene/mod.rs:82-95) with the raymarch
 // kernel and writes the frame as a binary PPM.  The log lines follow scene/mod.rs:180-197.
@@ -18,6 +23,10 @@
 #include <string>
 #include <vector>
 
+#include <fstream>
+#include <iostream>
+
+#include "mesh.hpp"
 #include "sdf_demo.hpp"
 #include "sdf_viewer.hpp"
 
@@ -28,15 +37,84 @@ static int usage(const char* msg) {
     fprintf(stderr,
             "USAGE:\n    sdf-viewer-gpu app [--max-voxels-side <N>] [--loading-passes <P>] demo [demo flags]\n"
             "                   [--width <W>] [--height <H>] [--out <file.ppm>] [--dump-textures <prefix>] [--frames <K>]\n"
+            "    sdf-viewer-gpu mesh [-o <mesh.ply|->] [-v <max-voxels-per-axis>] [marching-cubes] [demo [demo flags]]\n"
             "demo flags: -t/--cube-material <brick|normal>  -c/--cube-half-side <f>  -l/--sphere-material <brick|normal>\n"
             "            -s/--sphere-radius <f>  -m/--max-distance-custom-material <f>  -d/--disable-sphere <true|false>\n");
     return msg ? 2 : 0;
 }
 
+// CliMesher::run_cli / run_custom_out, src/sdf/meshers/mod.rs:40-89
+static int run_mesh(const std::vector<std::string>& args) {
+    std::string output = "mesh.ply";   // meshers/mod.rs:30-31
+    MesherConfig cfg;                   // -v default 64, meshers/mod.rs:96-97
+    Meshers mesher = Meshers::MarchingCubes;  // Default for Meshers, meshers/mod.rs:130-134
+    std::vector<std::string> demo_args;
+    bool in_demo = false;
+    for (size_t i = 1; i < args.size(); ++i) {
+        const std::string& a = args[i];
+        auto next = [&](const char* what) -> std::string {
+            if (i + 1 >= args.size()) {
+                fprintf(stderr, "error: The argument '%s' requires a value but none was supplied\n", what);
+                exit(2);
+            }
+            return args[++i];
+        };
+        if (in_demo) demo_args.push_back(a);
+        else if (a == "-o" || a == "--output") output = next("--output <OUTPUT_FILE>");
+        else if (a == "-v" || a == "--max-voxels-per-axis") cfg.max_voxels_per_axis = strtoul(next("--max-voxels-per-axis").c_str(), nullptr, 10);
+        else if (a == "-i" || a == "--input") return usage("-i <wasm>: arbitrary wasm cannot run on the GPU; the input is the embedded demo SDF");
+        else if (a == "demo") in_demo = true;
+        else if (auto m = mesher_from_name(a)) mesher = *m;
+        else return usage(("Found argument '" + a + "' which wasn't expected").c_str());
+    }
+    std::string err;
+    auto sdf = SDFDemo::from_args(demo_args, &err);
+    if (!sdf) return usage(err.c_str());
+    if (sdfv_device_count() == 0) {
+        fprintf(stderr, "error: no HIP device visible: sdf-viewer-gpu has no CPU path\n");
+        return 1;
+    }
+    const bool to_stdout = output.empty() || output == "-";
+    if (!to_stdout && std::ifstream(output).good()) {
+        fprintf(stderr, "Error: Output file already exists\n");  // meshers/mod.rs:52-54
+        return 1;
+    }
+    fprintf(stderr, "Running the meshing algorithm with Config { max_voxels_per_axis: %zu }...\n", cfg.max_voxels_per_axis);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto mesh = mesh_sdf(mesher, *sdf, cfg, &err);
+    if (!mesh) {
+        fprintf(stderr, "error: %s\n", err.c_str());
+        return 1;
+    }
+    fprintf(stderr, "Post-processing the mesh (%zu vertices, %zu triangles)...\n", mesh->vertices.size(), mesh->indices.size() / 3);
+    if (mesh->postproc(*sdf) != 0) {
+        fprintf(stderr, "error: %s\n", sdfv_last_error());
+        return 1;
+    }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "Serializing output mesh... (meshed and post-processed in %.3fms on the GPU)\n", ms);
+    const std::string version = "sdf-viewer-gpu 0.1.0 (MI355X)";  // metadata.rs:13-16 short_version_info()
+    size_t bytes;
+    if (to_stdout) {
+        bytes = mesh->serialize_ply(std::cout, version);
+        std::cout.flush();
+    } else {
+        std::ofstream f(output, std::ios::binary | std::ios::trunc);
+        if (!f) {
+            perror(output.c_str());
+            return 1;
+        }
+        bytes = mesh->serialize_ply(f, version);
+    }
+    fprintf(stderr, "Wrote %zu bytes\n", bytes);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     std::vector<std::string> args(argv + 1, argv + argc);
     if (args.empty() || args[0] == "-h" || args[0] == "--help") return usage(nullptr);
-    if (args[0] != "app") return usage("only the `app` subcommand has a GPU path (server / mesh are out of scope)");
+    if (args[0] == "mesh") return run_mesh(args);
+    if (args[0] != "app") return usage("only the `app` and `mesh` subcommands have a GPU path (server is out of scope)");
     size_t max_voxels_side = 64, loading_passes = 2;  // src/app/cli/mod.rs:13-18
     uint32_t width = 1280, height = 720;
     int frames = 1;

@@ -9,7 +9,10 @@
 #include <string>
 #include <vector>
 
+#include <sstream>
+
 #include "loading_manager.hpp"
+#include "mesh.hpp"
 #include "sdf_demo.hpp"
 #include "scene.hpp"
 #include "sdf_viewer.hpp"
@@ -209,6 +212,62 @@ long long sdfvh_scene_load_progress(void* h, char* text, size_t n) {
         text[n - 1] = 0;
     }
     return (long long)(p->first * 1e6f);
+}
+
+// ---- Mesh (meshers/mesh.rs) ----
+size_t sdfvh_format_f32(float v, char* out, size_t n) {
+    const std::string s = format_f32(v);
+    if (out && n) {
+        strncpy(out, s.c_str(), n - 1);
+        out[n - 1] = 0;
+    }
+    return s.size();
+}
+uint32_t sdfvh_ply_color_u8(float c) { return ply_color_u8(c); }
+// Mesher::mesh + (optionally) Mesh::postproc of an SDF handle; returns a Mesh handle or NULL (err filled).
+void* sdfvh_mesh_sdf(void* sdf, const char* mesher, size_t max_voxels_per_axis, int postproc, char* err, size_t err_len) {
+    auto fail = [&](const std::string& m) -> void* {
+        if (err && err_len) {
+            strncpy(err, m.c_str(), err_len - 1);
+            err[err_len - 1] = 0;
+        }
+        return nullptr;
+    };
+    auto which = mesher_from_name(mesher ? mesher : "");
+    if (!which) return fail(std::string("unknown mesher '") + (mesher ? mesher : "") + "'");
+    std::string e;
+    MesherConfig cfg;
+    cfg.max_voxels_per_axis = max_voxels_per_axis;
+    auto m = mesh_sdf(*which, S(sdf), cfg, &e);
+    if (!m) return fail(e);
+    if (postproc && m->postproc(S(sdf)) != 0) return fail(sdfv_last_error());
+    return new Mesh(std::move(*m));
+}
+// Builds a Mesh from caller arrays (serialisation tests need no GPU).
+void* sdfvh_mesh_from_arrays(const float* vertices12, size_t n_vertices, const uint32_t* indices, size_t n_indices) {
+    auto* m = new Mesh;
+    m->vertices.resize(n_vertices);
+    if (n_vertices) memcpy(static_cast<void*>(m->vertices.data()), vertices12, n_vertices * sizeof(Vertex));
+    m->indices.assign(indices, indices + n_indices);
+    return m;
+}
+void sdfvh_mesh_free(void* m) { delete static_cast<Mesh*>(m); }
+size_t sdfvh_mesh_counts(void* m, size_t* n_indices) {
+    *n_indices = static_cast<Mesh*>(m)->indices.size();
+    return static_cast<Mesh*>(m)->vertices.size();
+}
+void sdfvh_mesh_copy(void* m, float* vertices12, uint32_t* indices) {
+    auto& mesh = *static_cast<Mesh*>(m);
+    if (!mesh.vertices.empty()) memcpy(vertices12, mesh.vertices.data(), mesh.vertices.size() * sizeof(Vertex));
+    if (!mesh.indices.empty()) memcpy(indices, mesh.indices.data(), mesh.indices.size() * 4);
+}
+// Mesh::serialize_ply into out (capacity n); returns the bytes the PLY needs.
+size_t sdfvh_mesh_serialize_ply(void* m, const char* version_info, char* out, size_t n) {
+    std::ostringstream os;
+    const size_t bytes = static_cast<Mesh*>(m)->serialize_ply(os, version_info ? version_info : "");
+    const std::string s = os.str();
+    if (out && n) memcpy(out, s.data(), s.size() < n ? s.size() : n);
+    return bytes;
 }
 
 }  // extern "C"

@@ -35,6 +35,11 @@ for name, res, args in [
     ("sdfvh_viewer_download", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("sdfvh_viewer_tex0", C.c_void_p, [C.c_void_p]), ("sdfvh_viewer_tex1", C.c_void_p, [C.c_void_p]),
     ("sdfvh_viewer_render", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("sdfvh_format_f32", SZ, [C.c_float, C.c_char_p, SZ]), ("sdfvh_ply_color_u8", C.c_uint32, [C.c_float]),
+    ("sdfvh_mesh_sdf", C.c_void_p, [C.c_void_p, C.c_char_p, SZ, C.c_int, C.c_char_p, SZ]),
+    ("sdfvh_mesh_from_arrays", C.c_void_p, [C.c_void_p, SZ, C.c_void_p, SZ]), ("sdfvh_mesh_free", None, [C.c_void_p]),
+    ("sdfvh_mesh_counts", SZ, [C.c_void_p, C.POINTER(SZ)]), ("sdfvh_mesh_copy", None, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("sdfvh_mesh_serialize_ply", SZ, [C.c_void_p, C.c_char_p, C.c_char_p, SZ]),
     ("sdfvh_scene_new", C.c_void_p, [C.c_void_p]), ("sdfvh_scene_free", None, [C.c_void_p]),
     ("sdfvh_scene_advance_clock", None, [C.c_void_p, C.c_longlong]),
     ("sdfvh_scene_set_sdf", C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong]),
@@ -239,6 +244,53 @@ class Scene:
         b = C.create_string_buffer(256)
         p = H.sdfvh_scene_load_progress(self.h, b, 256)
         return None if p < 0 else (p / 1e6, b.value.decode())
+
+
+class Mesh:
+    """sdfviewer::Mesh (host/mesh.hpp = meshers/mesh.rs)."""
+
+    def __init__(self, handle):
+        assert handle
+        self.h = handle
+
+    def __del__(self):
+        H.sdfvh_mesh_free(self.h)
+
+    @staticmethod
+    def from_sdf(sdf, mesher="marching-cubes", max_voxels_per_axis=64, postproc=True):
+        err = C.create_string_buffer(512)
+        h = H.sdfvh_mesh_sdf(sdf.h, mesher.encode(), max_voxels_per_axis, int(postproc), err, 512)
+        if not h:
+            raise RuntimeError(err.value.decode())
+        return Mesh(h)
+
+    @staticmethod
+    def from_arrays(vertices, indices):
+        import numpy as np
+        v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 12)
+        i = np.ascontiguousarray(indices, np.uint32)
+        return Mesh(H.sdfvh_mesh_from_arrays(v.ctypes.data, len(v), i.ctypes.data, len(i)))
+
+    def arrays(self):
+        import numpy as np
+        ni = SZ()
+        nv = H.sdfvh_mesh_counts(self.h, C.byref(ni))
+        v = np.empty((nv, 12), np.float32)
+        i = np.empty(ni.value, np.uint32)
+        H.sdfvh_mesh_copy(self.h, v.ctypes.data, i.ctypes.data)
+        return v, i
+
+    def serialize_ply(self, version_info="test"):
+        need = H.sdfvh_mesh_serialize_ply(self.h, version_info.encode(), None, 0)
+        buf = C.create_string_buffer(need)
+        H.sdfvh_mesh_serialize_ply(self.h, version_info.encode(), buf, need)
+        return buf.raw[:need].decode()
+
+
+def format_f32(v):
+    b = C.create_string_buffer(128)
+    H.sdfvh_format_f32(v, b, 128)
+    return b.value.decode()
 
 
 # ---- per-point provider (reference ffi.rs ABI) ----

@@ -241,3 +241,63 @@ def test_scene_frame_scheduling(host, oracle):
     sc.set_budget_ms(30)
     r = sc.render()
     assert r["cpu_updates"] > 0 and r["committed"] and sc.load_progress() is not None
+
+
+def parse_ply(text):
+    lines = text.split("\n")
+    nv = int([ln for ln in lines if ln.startswith("element vertex")][0].split()[-1])
+    nf = int([ln for ln in lines if ln.startswith("element face")][0].split()[-1])
+    body = lines[lines.index("end_header") + 1:]
+    verts = np.array([[float(x) for x in ln.split()] for ln in body[:nv]], np.float64).reshape(nv, 12)
+    faces = np.array([[int(x) for x in ln.split()] for ln in body[nv:nv + nf]], np.int64).reshape(nf, 4)
+    return verts, faces
+
+
+def test_host_mesh_equals_device_mesh_then_postproc(host, pkg, oracle):
+    """sdfviewer::mesh_sdf + Mesh::postproc (host/mesh.hpp = meshers/mod.rs:136-149, mesh.rs:22-33) go through the
+    same device calls as the Python harness; the post-processed vertices equal the oracle's postproc."""
+    sdf = host.SDF.demo("-s", "0.9")
+    raw_v, raw_i = host.Mesh.from_sdf(sdf, max_voxels_per_axis=24, postproc=False).arrays()
+    prm = pkg.default_params(sphere_radius=0.9)
+    v, i = pkg.mesh_extract(prm, 24)
+    np.testing.assert_array_equal(raw_v.view(np.uint32), v.cpu().numpy().view(np.uint32))
+    np.testing.assert_array_equal(raw_i.astype(np.int64), i.cpu().numpy().astype(np.int64))
+    post_v, post_i = host.Mesh.from_sdf(sdf, max_voxels_per_axis=24).arrays()
+    want = oracle.mesh_postproc(oracle.params_from(prm), raw_v)
+    np.testing.assert_array_equal(post_v.view(np.uint32), want.view(np.uint32))
+    np.testing.assert_array_equal(post_i, raw_i)
+    with pytest.raises(RuntimeError, match="Unsupported algorithm"):
+        host.Mesh.from_sdf(sdf, mesher="dual-contouring-minimize-qef")
+    # a child of the hierarchy meshes on its own (app/mod.rs:200-208 renders any child)
+    cube_v, _ = host.Mesh.from_sdf(sdf.children()[0], max_voxels_per_axis=16).arrays()
+    assert np.abs(np.abs(cube_v[:, :3]).max(axis=1) - 0.95).max() < 1e-6
+
+
+def test_cli_mesh_writes_the_ply_the_library_mesh_describes(pkg, oracle, tmp_path):
+    """`sdf-viewer-gpu mesh -o out.ply -v 20 marching-cubes demo -c 0.8`: CliMesher (meshers/mod.rs:22-89)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sdf-viewer_amd", "sdf-viewer-gpu")
+    out = tmp_path / "mesh.ply"
+    cmd = [exe, "mesh", "-o", str(out), "-v", "20", "marching-cubes", "demo", "-c", "0.8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Post-processing the mesh (" in r.stderr and "Serializing output mesh..." in r.stderr
+    verts, faces = parse_ply(open(out).read())
+    prm = pkg.default_params(cube_half_side=0.8)
+    v, i = pkg.mesh_extract(prm, 20)
+    pkg.mesh_postproc(prm, v)
+    v = v.cpu().numpy()
+    assert verts.shape[0] == v.shape[0] and faces.shape[0] * 3 == i.shape[0]
+    # floats are printed with the shortest digits that round-trip: parsing gives the same f32 back
+    np.testing.assert_array_equal(verts[:, :6].astype(np.float32), v[:, :6])
+    np.testing.assert_array_equal(verts[:, 9:].astype(np.float32), v[:, 9:])
+    want_rgb = np.array([[oracle.L.or_ply_color_u8(float(c)) for c in row] for row in v[:, 6:9]])
+    np.testing.assert_array_equal(verts[:, 6:9].astype(np.int64), want_rgb)
+    assert (faces[:, 0] == 3).all()
+    np.testing.assert_array_equal(faces[:, 1:].reshape(-1), i.cpu().numpy().astype(np.int64))
+    # refuses to overwrite (meshers/mod.rs:52-54); "-" streams the same bytes to stdout
+    r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and "Output file already exists" in r2.stderr
+    r3 = subprocess.run([exe, "mesh", "-o", "-", "-v", "20", "demo", "-c", "0.8"], capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 0 and r3.stdout == open(out).read()

@@ -220,3 +220,51 @@ def test_cli_flag_surface_and_no_cpu_path():
     if not torch.cuda.is_available():
         r = subprocess.run([exe, "app", "--max-voxels-side", "8", "demo"], capture_output=True, text=True)
         assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+# ---- Mesh serialisation (meshers/mesh.rs:37-129): host-only, no GPU ----
+def test_f32_display_like_rust(host):
+    """ply-rs prints floats with `{}`: shortest digits that round-trip, never an exponent, "1" for 1.0."""
+    cases = [(1.0, "1"), (0.5, "0.5"), (-2.0, "-2"), (0.1, "0.1"), (1e-7, "0.0000001"), (16777216.0, "16777216"),
+             (0.95, "0.95"), (3.4028235e38, "340282350000000000000000000000000000000"), (float("inf"), "inf"),
+             (float("-inf"), "-inf"), (0.0, "0"), (-0.0, "-0"), (123.456, "123.456"), (1.5e10, "15000000000")]
+    for v, want in cases:
+        assert host.format_f32(v) == want, v
+    assert host.format_f32(float("nan")) == "NaN"
+    rng = np.random.default_rng(3)
+    for v in rng.normal(size=300).astype(np.float32) * np.float32(10.0) ** rng.integers(-6, 7, size=300).astype(np.float32):
+        txt = host.format_f32(float(v))
+        assert np.float32(txt) == v and "e" not in txt.lower()
+        assert txt == np.format_float_positional(v, unique=True, trim="-")  # numpy's shortest repr agrees
+
+
+def test_ply_colour_quantisation_matches_oracle(host, oracle):
+    for c in [0.0, 1.0, 0.5, 0.999, 0.99, 2.0, -1.0, 1e-3, 0.2196, float("nan")]:
+        assert host.H.sdfvh_ply_color_u8(c) == oracle.L.or_ply_color_u8(c)
+
+
+def test_serialize_ply_structure(host):
+    """Header element/property list and order are the reference's (mesh.rs:47-96); one line per vertex and face."""
+    v = np.zeros((3, 12), np.float32)
+    v[:, 0:3] = [(0, 0, 0), (1, 0, 0), (0, 1.5, 0)]
+    v[:, 3:6] = (0, 0, 1)
+    v[:, 6:9] = [(1, 0, 0), (0.5, 0.5, 0.5), (0.2, 0.4, 0.6)]
+    v[:, 9:12] = (0.25, 0.5, 1.0)
+    ply = host.Mesh.from_arrays(v, [0, 1, 2]).serialize_ply("sdf-viewer x.y (test)")
+    lines = ply.split("\n")
+    assert lines[:4] == ["ply", "format ascii 1.0", "comment Created with sdf-viewer x.y (test)", "element vertex 3"]
+    props = [ln for ln in lines if ln.startswith("property")]
+    assert props == [f"property float {n}" for n in ("x", "y", "z", "nx", "ny", "nz")] + \
+        [f"property uchar {n}" for n in ("red", "green", "blue")] + \
+        [f"property float {n}" for n in ("metallic", "roughness", "occlusion")] + \
+        ["property list uchar int vertex_index"]
+    assert "element face 1" in lines and ply.endswith("\n")
+    body = lines[lines.index("end_header") + 1:]
+    assert body[0] == "0 0 0 0 0 1 255 0 0 0.25 0.5 1"
+    assert body[1] == "1 0 0 0 0 1 127 127 127 0.25 0.5 1"
+    assert body[2] == "0 1.5 0 0 0 1 51 102 153 0.25 0.5 1"
+    assert body[3] == "3 0 1 2" and body[4] == ""
+    # an empty mesh is still a valid file; a trailing partial triangle is dropped (chunks_exact(3), mesh.rs:116)
+    empty = host.Mesh.from_arrays(np.zeros((0, 12), np.float32), []).serialize_ply()
+    assert "element vertex 0" in empty and "element face 0" in empty
+    assert "element face 1" in host.Mesh.from_arrays(v, [0, 1, 2, 1]).serialize_ply()
