@@ -322,6 +322,7 @@ def main():
         del batch_out
 
     verified = None
+    sharded_march = None
     if world > 1:
         # outside the timed regions: the gathered slabs must equal a dense local fill of the global grid, and the
         # ghost slices must equal what the neighbour computed (= a local recompute: the SDF is analytic)
@@ -337,7 +338,30 @@ def main():
                 flag = torch.tensor([1.0 if ok else 0.0], device=device if backend == "nccl" else "cpu")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 verified = bool(flag.item() == 1.0)
-                del full0, full1, chk0, chk1
+                del full0, full1
+                # the consumer of the halo: raymarch the grid where it lies (sharded, rays handed between ranks)
+                # and compare with a march over the whole grid, bit for bit
+                try:
+                    ggrid = pkg.make_grid(gdims)
+                    grp = pkg.default_render_params(ggrid)
+                    sw, sh = 320, 180
+                    scam = pkg.camera_look_at(eye=(1.5, 2.0, 3.5), aspect=sw / sh)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    got = par.raymarch_sharded(pkg, grp, grid, slab, scam, sw, sh, rank, world)
+                    torch.cuda.synchronize()
+                    sharded_march_ms = (time.perf_counter() - t0) * 1e3
+                    want = pkg.raymarch(grp, chk0, chk1, scam, sw, sh)[0]
+                    same = torch.equal(got.view(torch.int32), want.view(torch.int32)) and bool((want[..., 3] > 0).any())
+                    flag = torch.tensor([1.0 if same else 0.0], device=device if backend == "nccl" else "cpu")
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    sharded_march = {"verified": bool(flag.item() == 1.0), "image": [sw, sh], "rounds": world,
+                                     "ms": round(sharded_march_ms, 3),
+                                     "note": "sdfv_raymarch_slab over the sharded grid vs sdfv_raymarch over the whole "
+                                             "grid, bit for bit; not part of the timed regions"}
+                except Exception as e:  # noqa: BLE001
+                    sharded_march = {"verified": f"error: {type(e).__name__}: {e}"}
+                del chk0, chk1
             except Exception as e:  # never lose the measurement over the self-check
                 verified = f"error: {type(e).__name__}: {e}"
         else:
@@ -363,6 +387,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic (demo SDF defaults on the integer lattice, fixed cameras; no RNG)",
             "sharded_fill_verified": verified,
+            "sharded_march": sharded_march,
             "backend": None if world == 1 else ("rccl" if backend == "nccl" else backend + " (test only)"),
             "halo_transport": None if world == 1 else {"rccl": "sdfv_slab_fill_step (library RCCL communicator)",
                                                        "torch": "torch.distributed batch_isend_irecv"}[transport],

@@ -216,6 +216,34 @@ int sdfv_raymarch_accel(const sdfv_render_params *rp, const float *tex0, const f
                         uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                         float *rgba, sdfv_march_aux *aux, void *stream);
 
+/* ---- raymarch over a z-sharded grid (multi-GPU; the consumer of the slab halo) ----
+ * The grid stays sharded: rank r holds [ghost_lo][owned z_begin..z_end)[ghost_hi] as laid out for sdfv_slab_*.
+ * A ray is marched by the rank that owns the cell it is in (clamp(floor(w), 0, D-1) in [z_begin, z_end); the
+ * trilinear fetch then needs at most slice z_end = ghost_hi) and is handed to the z-neighbour, state and all, when
+ * it leaves the slab.  z is monotonic along a ray, so after `world` rounds every ray has ended on exactly one rank;
+ * that rank writes the pixel, all others leave it all-zero bits, and the image is their merge (OR, or integer sum, of the bit patterns).
+ * The arithmetic and its order are those of sdfv_raymarch: the merged image is bit-identical to the single-GPU one.
+ * Restrictions: loaded grids only (lod_dist_between_samples == 1), boxes large enough that a marching ray's
+ * floor(w) stays in [-1, D-1] (1e-4 * N / size <= 0.25), one camera per call; aux.normal is left (0,0,0) (its
+ * taps can reach one slice past the halo). */
+typedef struct sdfv_ray_state {
+    uint32_t pixel;     /* y * width + x */
+    uint32_t iteration; /* sdfRaycast's loop counter i = tex0 fetches done so far */
+    float    pos[3];    /* rayPos */
+    float    t;         /* distanceFromOrigin */
+} sdfv_ray_state;
+/* One round on this rank.  in_states == NULL: first round (every pixel's primary ray; rays that start in another
+ * rank's slab are left to that rank, and every pixel of rgba/aux is initialised).  Otherwise: continue the n_in rays
+ * received from the neighbours.  Rays that leave the slab are appended to out_down / out_up (DEVICE, `capacity`
+ * entries each; width*height always suffices) and counted in counters[0] / counters[1] (DEVICE, zeroed by the
+ * caller).  rp describes the GLOBAL grid; slab gives dims and [z_begin, z_end); tex0/tex1 address the start of the
+ * slab allocation (ghost_lo slices before z_begin, ghost_hi after z_end).  rgba: DEVICE height x width x 4. */
+int sdfv_raymarch_slab(const sdfv_render_params *rp, const sdfv_grid *slab, uint32_t ghost_lo, uint32_t ghost_hi,
+                       const float *tex0, const float *tex1, const sdfv_camera *camera, uint32_t width,
+                       uint32_t height, const sdfv_ray_state *in_states, uint32_t n_in, float *rgba,
+                       sdfv_march_aux *aux, sdfv_ray_state *out_down, sdfv_ray_state *out_up, uint32_t capacity,
+                       uint32_t *counters, void *stream);
+
 /* ---- host-buffer conveniences (allocate, run, copy back, synchronise; PCIe-inclusive) ---- */
 int sdfv_fill_grid_host(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid,
                         float *tex0_host, float *tex1_host);

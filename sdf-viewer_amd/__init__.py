@@ -198,6 +198,24 @@ def orbit_cameras(n, aspect, eye0=(2.5, 3.0, 5.0)):
     return cams
 
 
+RAY_STATE_WORDS = C.sizeof(_capi.RayState) // 4  # pixel, iteration, pos[3], t
+
+
+def raymarch_slab(rp, grid, ghost_lo, ghost_hi, tex0, tex1, camera, width, height, rgba, out_down, out_up, counters,
+                  in_states=None, aux=None, stream=None):
+    """One round of the sharded march on this rank (sdfv_raymarch_slab).  in_states None = first round.
+    out_down/out_up: [capacity, 6] int32 device tensors, counters: [2] int32 device tensor (zeroed by the caller)."""
+    n_in = 0 if in_states is None else int(in_states.shape[0])
+    if in_states is not None and n_in == 0:
+        return  # a continuation round in which nothing arrived (an empty tensor has no address to pass)
+    check(lib.sdfv_raymarch_slab(C.byref(rp), C.byref(grid), int(ghost_lo), int(ghost_hi), _dev_ptr(tex0, "tex0"),
+                                 _dev_ptr(tex1, "tex1"), C.byref(camera), width, height,
+                                 None if in_states is None else C.c_void_p(in_states.data_ptr()), n_in,
+                                 _dev_ptr(rgba, "rgba"), None if aux is None else C.c_void_p(aux.data_ptr()),
+                                 C.c_void_p(out_down.data_ptr()), C.c_void_p(out_up.data_ptr()),
+                                 int(out_down.shape[0]), C.c_void_p(counters.data_ptr()), _stream_ptr(stream)))
+
+
 def commit_distance(grid, tex0, dist=None, stream=None):
     """Device-side commit: compact copy of tex0.r for the raymarch (sdfv_commit_distance)."""
     if dist is None:

@@ -56,6 +56,10 @@ SDF_DEMO, SDF_CUBE, SDF_SPHERE = 0, 1, 2
 MATERIAL_BRICK, MATERIAL_NORMAL = 0, 1
 
 # name -> (restype, argtypes); every symbol include/sdfgrid.h declares
+class RayState(C.Structure):
+    _fields_ = [("pixel", C.c_uint32), ("iteration", C.c_uint32), ("pos", C.c_float * 3), ("t", C.c_float)]
+
+
 class Mesh(C.Structure):
     _fields_ = [("vertices", C.c_void_p), ("indices", C.c_void_p), ("n_vertices", C.c_size_t), ("n_indices", C.c_size_t)]
 
@@ -102,6 +106,9 @@ PROTOTYPES = {
     "sdfv_mesh_extract": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                     C.c_uint32, C.c_uint32, C.POINTER(Mesh), C.c_void_p]),
     "sdfv_mesh_free": (C.c_int, [C.POINTER(Mesh)]),
+    "sdfv_raymarch_slab": (C.c_int, [C.POINTER(RenderParams), C.POINTER(Grid), C.c_uint32, C.c_uint32, C.c_void_p,
+                                     C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "sdfv_slab_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "sdfv_slab_comm_create": (C.c_int, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
     "sdfv_slab_comm_destroy": (C.c_int, [C.c_void_p]),

@@ -34,6 +34,19 @@ struct RaymarchArgs {
 
 constexpr uint32_t kMaxCamerasPerLaunch = 16;
 
+// One round of the march over a z-slab of the grid (multi-GPU: the grid stays sharded, rays move between ranks).
+struct SlabMarchArgs {
+    uint32_t z_lo, z_count;        // resident slices [z_lo, z_lo + z_count) (owned + ghosts); tex0/tex1 address z_lo
+    uint32_t own_begin, own_end;   // owned slices: this rank marches a ray while clamp(floor(w), 0, D-1) is in here
+    const sdfv_ray_state* in;      // continuation round: rays handed over by the neighbours; nullptr = first round
+    uint32_t n_in;
+    sdfv_ray_state* out_down;      // rays leaving through the low / high face of the slab
+    sdfv_ray_state* out_up;
+    uint32_t* counters;            // [0] rays in out_down, [1] rays in out_up (atomically appended)
+    uint32_t capacity;             // entries each out list can hold
+};
+hipError_t launch_raymarch_slab(const RaymarchArgs& a, const SlabMarchArgs& s, hipStream_t stream);
+
 hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream);
 
 }  // namespace sdfv

@@ -331,6 +331,36 @@ __device__ __forceinline__ void stamp_wave(const RaymarchArgs& a, uint32_t wave,
     a.wave_timing[wave_id * 4 + 3] = covered_mask;
 }
 
+// Primary ray through the centre of pixel (px, py) (image row 0 = top), not yet normalised.
+__device__ __forceinline__ V3 pixel_ray_raw(const RaymarchArgs& a, const sdfv_camera& cam, uint32_t px, uint32_t py) {
+    const float ndc_x = (((float)px + 0.5f) / (float)a.width) * 2.0f - 1.0f;
+    const float ndc_y = 1.0f - (((float)py + 0.5f) / (float)a.height) * 2.0f;
+    const float sx = ndc_x * cam.aspect * cam.tan_half_fovy;
+    const float sy = ndc_y * cam.tan_half_fovy;
+    return mk(cam.forward[0] + cam.right[0] * sx + cam.up[0] * sy,
+              cam.forward[1] + cam.right[1] * sx + cam.up[1] * sy,
+              cam.forward[2] + cam.right[2] * sx + cam.up[2] * sy);
+}
+
+// The bbox fragment of that ray (slab test standing in for the rasterised cube, scene/sdf/mod.rs:254-282) and
+// main()'s ray set-up, material.frag:133-139.  Returns whether the pixel is covered by the box.
+__device__ __forceinline__ bool box_fragment_ray(const RaymarchArgs& a, V3 eye, V3 d_raw, bool in_image,
+                                                 V3& ray_origin, V3& ray_dir) {
+    const V3 d0 = normalize(d_raw);
+    const float tx1 = (a.rp.bounds_min[0] - eye.x) / d0.x, tx2 = (a.rp.bounds_max[0] - eye.x) / d0.x;
+    const float ty1 = (a.rp.bounds_min[1] - eye.y) / d0.y, ty2 = (a.rp.bounds_max[1] - eye.y) / d0.y;
+    const float tz1 = (a.rp.bounds_min[2] - eye.z) / d0.z, tz2 = (a.rp.bounds_max[2] - eye.z) / d0.z;
+    const float tnear = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+    const float tfar = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+    const bool covered = in_image && (tfar >= tnear && tfar > 0.0f);
+    const float tfrag = tnear > 0.0f ? tnear : tfar;
+    const V3 pos = madd(eye, d0, tfrag);
+    ray_origin = pos;
+    ray_dir = normalize(sub(ray_origin, eye));
+    if (oob_dist<false>(a, madd(ray_origin, ray_dir, 0.2f)) > 0.0f) ray_origin = madd(eye, ray_dir, 0.2f);
+    return covered;
+}
+
 // MODE: 0 = general kernel (any filter, any extents: the shader's nested loop with full MirroredRepeat);
 //       1 = fast march over tex0.r; 2 = fast march over the compact distance volume (both LINEAR only).
 // XF:   0 = IEEE divide, 1 = exact power-of-two reciprocal, 2 = power-of-two extents and texture sizes.
@@ -352,15 +382,8 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
     const uint64_t out_index = ((uint64_t)cam_idx * (a.y1 - a.y0) + row) * a.width + px;
     const unsigned long long t_start = a.wave_timing ? __builtin_readcyclecounter() : 0ull;
 
-    // primary ray through the pixel centre (image row 0 = top)
-    const float ndc_x = (((float)px + 0.5f) / (float)a.width) * 2.0f - 1.0f;
-    const float ndc_y = 1.0f - (((float)py + 0.5f) / (float)a.height) * 2.0f;
-    const float sx = ndc_x * cam.aspect * cam.tan_half_fovy;
-    const float sy = ndc_y * cam.tan_half_fovy;
     const V3 eye = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
-    const V3 d_raw = mk(cam.forward[0] + cam.right[0] * sx + cam.up[0] * sy,
-                        cam.forward[1] + cam.right[1] * sx + cam.up[1] * sy,
-                        cam.forward[2] + cam.right[2] * sx + cam.up[2] * sy);
+    const V3 d_raw = pixel_ray_raw(a, cam, px, py);
 
     // Conservative tile cull (the reference gets it from rasterising the box).  A ray that misses the box's
     // bounding sphere inflated by 1 % cannot be covered; if no lane of the wave can be covered, the wave
@@ -388,22 +411,8 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
 
     const Tex tex0{a.tex0, (int)a.rp.tex_size[0], (int)a.rp.tex_size[1], (int)a.rp.tex_size[2]};
     const Tex tex1{a.tex1, tex0.w, tex0.h, tex0.d};
-    const V3 d0 = normalize(d_raw);
-
-    // bbox fragment via slab test
-    const float tx1 = (a.rp.bounds_min[0] - eye.x) / d0.x, tx2 = (a.rp.bounds_max[0] - eye.x) / d0.x;
-    const float ty1 = (a.rp.bounds_min[1] - eye.y) / d0.y, ty2 = (a.rp.bounds_max[1] - eye.y) / d0.y;
-    const float tz1 = (a.rp.bounds_min[2] - eye.z) / d0.z, tz2 = (a.rp.bounds_max[2] - eye.z) / d0.z;
-    const float tnear = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
-    const float tfar = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
-    const bool covered = in_image && (tfar >= tnear && tfar > 0.0f);
-    const float tfrag = tnear > 0.0f ? tnear : tfar;
-    const V3 pos = madd(eye, d0, tfrag);
-
-    // main(), material.frag:133-139
-    V3 ray_origin = pos;
-    const V3 ray_dir = normalize(sub(ray_origin, eye));
-    if (oob_dist<false>(a, madd(ray_origin, ray_dir, 0.2f)) > 0.0f) ray_origin = madd(eye, ray_dir, 0.2f);
+    V3 ray_origin, ray_dir;
+    const bool covered = box_fragment_ray(a, eye, d_raw, in_image, ray_origin, ray_dir);
 
     // sdfRaycast(rayOrigin, rayDir, 256), material.frag:92-128
     V3 ray_pos = ray_origin;
@@ -509,6 +518,175 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
     }
 }
 
+// ---- march over a z-slab: the grid stays sharded across GPUs and rays are handed between ranks ----------------
+// Same arithmetic, same order as the MODE 0 loop above (hence as the oracle); what differs is WHO executes an
+// iteration: the rank whose slab holds the ray's cell.  Texel z-indices are clamped (the launcher requires the
+// fast_index condition) and rebased to the first resident slice.
+struct SlabTex {
+    const float4* data;
+    int w, h, d;    // GLOBAL texture size
+    int z_lo;       // first resident slice
+};
+
+__device__ __forceinline__ Footprint footprint_slab(const SlabTex& t, V3 p01, int& k0c) {
+    float u = p01.x * (float)t.w - 0.5f, v = p01.y * (float)t.h - 0.5f, w = p01.z * (float)t.d - 0.5f;
+    float fu = floorf(u), fv = floorf(v), fw = floorf(w);
+    Footprint f;
+    f.ax = u - fu; f.ay = v - fv; f.az = w - fw;
+    const int i0 = (int)fu, j0 = (int)fv, k0 = (int)fw;
+    const uint32_t sy = (uint32_t)t.w, sz = (uint32_t)t.w * (uint32_t)t.h;
+    const uint32_t i0m = (uint32_t)max(i0, 0), i1m = (uint32_t)min(i0 + 1, t.w - 1);
+    const uint32_t j0m = (uint32_t)max(j0, 0) * sy, j1m = (uint32_t)min(j0 + 1, t.h - 1) * sy;
+    k0c = min(max(k0, 0), t.d - 1);
+    const uint32_t k0m = (uint32_t)(max(k0, 0) - t.z_lo) * sz, k1m = (uint32_t)(min(k0 + 1, t.d - 1) - t.z_lo) * sz;
+    f.o000 = k0m + j0m + i0m; f.o100 = k0m + j0m + i1m;
+    f.o010 = k0m + j1m + i0m; f.o110 = k0m + j1m + i1m;
+    f.o001 = k1m + j0m + i0m; f.o101 = k1m + j0m + i1m;
+    f.o011 = k1m + j1m + i0m; f.o111 = k1m + j1m + i1m;
+    return f;
+}
+
+__device__ __forceinline__ float4 fetch_rgba(const float4* data, const Footprint& f) {
+    const float4 t000 = data[f.o000], t100 = data[f.o100], t010 = data[f.o010], t110 = data[f.o110];
+    const float4 t001 = data[f.o001], t101 = data[f.o101], t011 = data[f.o011], t111 = data[f.o111];
+    float4 r;
+    r.x = trilerp(t000.x, t100.x, t010.x, t110.x, t001.x, t101.x, t011.x, t111.x, f.ax, f.ay, f.az);
+    r.y = trilerp(t000.y, t100.y, t010.y, t110.y, t001.y, t101.y, t011.y, t111.y, f.ax, f.ay, f.az);
+    r.z = trilerp(t000.z, t100.z, t010.z, t110.z, t001.z, t101.z, t011.z, t111.z, f.ax, f.ay, f.az);
+    r.w = trilerp(t000.w, t100.w, t010.w, t110.w, t001.w, t101.w, t011.w, t111.w, f.ax, f.ay, f.az);
+    return r;
+}
+
+template <int XF, bool AUX>
+__global__ __launch_bounds__(256) void raymarch_slab_kernel(RaymarchArgs a, SlabMarchArgs s) {
+    const bool first_round = s.in == nullptr;
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    const sdfv_camera& cam = a.cameras[0];
+    uint32_t px, py;
+    bool live;            // this thread carries a ray (first round: a pixel of the image)
+    int i = 0;
+    V3 ray_pos = mk(0.0f, 0.0f, 0.0f);
+    float dist_from_origin = 0.0f;
+    if (first_round) {
+        // 8x8 pixel tiles per wave, like the single-GPU kernel
+        const uint32_t tiles_x = (a.width + 7) / 8, tile = gid >> 6, lane = gid & 63;
+        px = (tile % tiles_x) * 8 + (lane & 7);
+        py = (tile / tiles_x) * 8 + (lane >> 3);
+        live = px < a.width && py < a.height;
+    } else {
+        live = gid < s.n_in;
+        const sdfv_ray_state st = s.in[live ? gid : 0];
+        px = st.pixel % a.width;
+        py = st.pixel / a.width;
+        i = (int)st.iteration;
+        ray_pos = mk(st.pos[0], st.pos[1], st.pos[2]);
+        dist_from_origin = st.t;
+    }
+    const uint32_t pixel = py * a.width + px;
+    const V3 eye = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
+    V3 ray_origin, ray_dir;
+    const bool covered = box_fragment_ray(a, eye, pixel_ray_raw(a, cam, px, py), live, ray_origin, ray_dir);
+    const SlabTex tex{a.tex0, (int)a.rp.tex_size[0], (int)a.rp.tex_size[1], (int)a.rp.tex_size[2], (int)s.z_lo};
+    const float* dist_r = reinterpret_cast<const float*>(a.tex0);
+
+    bool marching = live && covered;
+    if (first_round) {
+        ray_pos = ray_origin;
+        // every pixel of this rank's image starts transparent; the rank a ray ends on overwrites it
+        if (live) {
+            a.rgba[pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (AUX) {
+                sdfv_march_aux z;
+                aux_clear(z);
+                z.depth = 0.0f;  // summed over ranks; the caller restores 1.0 where no rank reports a status
+                a.aux[pixel] = z;
+            }
+        }
+        // a ray that starts in another rank's slab is that rank's to begin
+        int k0c;
+        (void)footprint_slab(tex, to_p01<XF>(a, ray_pos), k0c);
+        marching = marching && k0c >= (int)s.own_begin && k0c < (int)s.own_end;
+    }
+    const bool mine = marching;  // this rank reports the ray's end unless it hands the ray over
+    int status = 0, steps = 0;
+    bool exported = false;
+    Footprint hit_fp{};
+    for (;;) {
+        marching = marching && i < 255;  // sdfRaycast's `for (i < 255)`; a ray that runs out keeps status 0 for now
+        if (__ballot(marching) == 0ull) break;
+        if (!marching) continue;
+        if (oob_dist<false>(a, ray_pos) > 1e-4f) {  // material.frag:106-109
+            status = -2;
+            steps = i;
+            marching = false;
+            continue;
+        }
+        int k0c;
+        const Footprint f = footprint_slab(tex, to_p01<XF>(a, ray_pos), k0c);
+        if (k0c < (int)s.own_begin || k0c >= (int)s.own_end) {
+            // the cell belongs to a z-neighbour: hand the ray over exactly as it is
+            const int dir = k0c < (int)s.own_begin ? 0 : 1;
+            const uint32_t at = atomicAdd(&s.counters[dir], 1u);
+            if (at < s.capacity) {
+                sdfv_ray_state st;
+                st.pixel = pixel;
+                st.iteration = (uint32_t)i;
+                st.pos[0] = ray_pos.x; st.pos[1] = ray_pos.y; st.pos[2] = ray_pos.z;
+                st.t = dist_from_origin;
+                (dir == 0 ? s.out_down : s.out_up)[at] = st;
+            }
+            exported = true;
+            marching = false;
+            continue;
+        }
+        const float sample_dist =
+            trilerp(dist_r[(uint64_t)f.o000 * 4], dist_r[(uint64_t)f.o100 * 4], dist_r[(uint64_t)f.o010 * 4],
+                    dist_r[(uint64_t)f.o110 * 4], dist_r[(uint64_t)f.o001 * 4], dist_r[(uint64_t)f.o101 * 4],
+                    dist_r[(uint64_t)f.o011 * 4], dist_r[(uint64_t)f.o111 * 4], f.ax, f.ay, f.az) - 1e-1f;
+        ++i;  // one more tex0 fetch done
+        if (sample_dist < 1e-5f) {  // material.frag:117-121
+            status = 1;
+            steps = i;
+            hit_fp = f;
+            marching = false;
+        } else {  // material.frag:124-125
+            dist_from_origin += sample_dist;
+            ray_pos = madd(ray_pos, ray_dir, sample_dist);
+        }
+    }
+    if (!mine || exported) return;
+    if (status == 0) {  // out of steps, material.frag:99-101
+        status = -1;
+        steps = i;
+    }
+
+    float4 rgba = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 raw0 = rgba, raw1 = rgba;
+    if (status == 1) {
+        raw0 = fetch_rgba(a.tex0, hit_fp);  // == the march's last sample
+        raw1 = fetch_rgba(a.tex1, hit_fp);  // material.frag:154
+        rgba = shade(a, raw0, raw1);
+    }
+    a.rgba[pixel] = rgba;
+    if (AUX) {
+        sdfv_march_aux aux;
+        aux_clear(aux);
+        aux.status = status;
+        aux.steps = steps;
+        aux.hit_pos[0] = ray_pos.x; aux.hit_pos[1] = ray_pos.y; aux.hit_pos[2] = ray_pos.z;
+        aux.t = dist_from_origin;
+        if (status == 1) {
+            const float* m = cam.bvp;  // gl_FragDepth, material.frag:180-181
+            const float hz = m[2] * ray_pos.x + m[6] * ray_pos.y + m[10] * ray_pos.z + m[14];
+            const float hw = m[3] * ray_pos.x + m[7] * ray_pos.y + m[11] * ray_pos.z + m[15];
+            aux.raw0[0] = raw0.x; aux.raw0[1] = raw0.y; aux.raw0[2] = raw0.z; aux.raw0[3] = raw0.w;
+            aux.raw1[0] = raw1.x; aux.raw1[1] = raw1.y; aux.raw1[2] = raw1.z; aux.raw1[3] = raw1.w;
+            aux.depth = hz / hw;
+        }
+        a.aux[pixel] = aux;
+    }
+}
+
 template <int MODE, bool LINEAR, int XF, bool SYMM>
 void launch_aux(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
     if (a.aux)
@@ -529,6 +707,21 @@ void launch_fast(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
 }
 
 }  // namespace
+
+hipError_t launch_raymarch_slab(const RaymarchArgs& a, const SlabMarchArgs& s, hipStream_t stream) {
+    const uint64_t threads = s.in ? (uint64_t)s.n_in
+                                  : (uint64_t)((a.width + 7) / 8) * ((a.height + 7) / 8) * 64;  // whole 8x8 tiles
+    if (threads == 0) return hipSuccess;
+    const dim3 grid((uint32_t)((threads + 255) / 256));
+    if (a.pow2_extent) {
+        if (a.aux) hipLaunchKernelGGL((raymarch_slab_kernel<1, true>), grid, dim3(256), 0, stream, a, s);
+        else hipLaunchKernelGGL((raymarch_slab_kernel<1, false>), grid, dim3(256), 0, stream, a, s);
+    } else {
+        if (a.aux) hipLaunchKernelGGL((raymarch_slab_kernel<0, true>), grid, dim3(256), 0, stream, a, s);
+        else hipLaunchKernelGGL((raymarch_slab_kernel<0, false>), grid, dim3(256), 0, stream, a, s);
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream) {
     const uint32_t rows = a.y1 - a.y0;

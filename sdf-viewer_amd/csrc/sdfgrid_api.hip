@@ -119,6 +119,43 @@ struct DeviceBuf {
     }
 };
 
+// Everything RaymarchArgs derives from the render parameters alone (exactness flags, tap sizes, cull sphere).
+void derive_raymarch_args(const sdfv_render_params* rp, sdfv::RaymarchArgs& a) {
+    memset(&a, 0, sizeof(a));
+    a.rp = *rp;
+    a.pow2_extent = getenv("SDFV_RAYMARCH_NO_POW2") ? 0u : 1u;
+    a.fast_index = getenv("SDFV_RAYMARCH_GENERAL") ? 0u : 1u;
+    a.pow2_size = 1;
+    a.symmetric_box = 1;
+    a.fast_normal = 1;
+    float inv_h2 = 0.0f, radius2 = 0.0f;
+    for (int i = 0; i < 3; ++i) {
+        const float s = (float)rp->tex_size[i] / rp->lod_dist_between_samples;
+        inv_h2 += s * s;
+    }
+    const float h_world = 1.0f / sqrtf(inv_h2);  // sdfNormal's tap offset, material.frag:74
+    for (int i = 0; i < 3; ++i) {
+        a.bsize[i] = rp->bounds_max[i] - rp->bounds_min[i];
+        a.inv_bsize[i] = 1.0f / a.bsize[i];
+        const float n = (float)rp->tex_size[i];
+        // a marching ray stays within 1e-4 of the box (material.frag:106): floor(u) in [-1, N-1] needs
+        // 1e-4 * N / size well below 0.5; the normal's taps sit h_world further out
+        if (!(a.bsize[i] > 0.0f) || !(1e-4f * n / a.bsize[i] <= 0.25f)) a.fast_index = 0;
+        if (!(a.bsize[i] > 0.0f) || !((1e-4f + h_world) * n / a.bsize[i] <= 0.45f)) a.fast_normal = 0;
+        int e = 0;
+        // x / 2^k == x * 2^-k exactly (both correctly rounded), provided 2^-k is itself normal
+        if (!(a.bsize[i] > 0.0f) || frexpf(a.bsize[i], &e) != 0.5f || e < -100 || e > 100) a.pow2_extent = 0;
+        if (rp->tex_size[i] & (rp->tex_size[i] - 1)) a.pow2_size = 0;
+        if (rp->bounds_min[i] != -rp->bounds_max[i]) a.symmetric_box = 0;
+        a.cull_center[i] = 0.5f * (rp->bounds_min[i] + rp->bounds_max[i]);
+        radius2 += 0.25f * a.bsize[i] * a.bsize[i];
+    }
+    a.cull_radius2 = radius2 * 1.0201f + 1e-12f;  // (1.01 r)^2
+    if (!(a.cull_radius2 > 0.0f) || !std::isfinite(a.cull_radius2)) a.cull_radius2 = INFINITY;  // never cull
+    if (getenv("SDFV_RAYMARCH_NO_SYMM")) a.symmetric_box = 0;
+    if (getenv("SDFV_RAYMARCH_NO_POW2N")) a.pow2_size = 0;
+}
+
 }  // namespace
 
 namespace sdfv {
@@ -446,40 +483,8 @@ int sdfv_raymarch_accel(const sdfv_render_params* rp, const float* tex0, const f
         return fail(SDFV_ERR_INVALID_ARGUMENT, "texture too large for 32-bit texel indexing");
     if (int rc = need_device()) return rc;
     sdfv::RaymarchArgs a;
-    memset(&a, 0, sizeof(a));
-    a.rp = *rp;
-    a.pow2_extent = getenv("SDFV_RAYMARCH_NO_POW2") ? 0u : 1u;
-    a.fast_index = getenv("SDFV_RAYMARCH_GENERAL") ? 0u : 1u;
-    a.pow2_size = 1;
-    a.symmetric_box = 1;
-    a.fast_normal = 1;
+    derive_raymarch_args(rp, a);
     a.dist = dist;
-    float inv_h2 = 0.0f, radius2 = 0.0f;
-    for (int i = 0; i < 3; ++i) {
-        const float s = (float)rp->tex_size[i] / rp->lod_dist_between_samples;
-        inv_h2 += s * s;
-    }
-    const float h_world = 1.0f / sqrtf(inv_h2);  // sdfNormal's tap offset, material.frag:74
-    for (int i = 0; i < 3; ++i) {
-        a.bsize[i] = rp->bounds_max[i] - rp->bounds_min[i];
-        a.inv_bsize[i] = 1.0f / a.bsize[i];
-        const float n = (float)rp->tex_size[i];
-        // a marching ray stays within 1e-4 of the box (material.frag:106): floor(u) in [-1, N-1] needs
-        // 1e-4 * N / size well below 0.5; the normal's taps sit h_world further out
-        if (!(a.bsize[i] > 0.0f) || !(1e-4f * n / a.bsize[i] <= 0.25f)) a.fast_index = 0;
-        if (!(a.bsize[i] > 0.0f) || !((1e-4f + h_world) * n / a.bsize[i] <= 0.45f)) a.fast_normal = 0;
-        int e = 0;
-        // x / 2^k == x * 2^-k exactly (both correctly rounded), provided 2^-k is itself normal
-        if (!(a.bsize[i] > 0.0f) || frexpf(a.bsize[i], &e) != 0.5f || e < -100 || e > 100) a.pow2_extent = 0;
-        if (rp->tex_size[i] & (rp->tex_size[i] - 1)) a.pow2_size = 0;
-        if (rp->bounds_min[i] != -rp->bounds_max[i]) a.symmetric_box = 0;
-        a.cull_center[i] = 0.5f * (rp->bounds_min[i] + rp->bounds_max[i]);
-        radius2 += 0.25f * a.bsize[i] * a.bsize[i];
-    }
-    a.cull_radius2 = radius2 * 1.0201f + 1e-12f;  // (1.01 r)^2
-    if (!(a.cull_radius2 > 0.0f) || !std::isfinite(a.cull_radius2)) a.cull_radius2 = INFINITY;  // never cull
-    if (getenv("SDFV_RAYMARCH_NO_SYMM")) a.symmetric_box = 0;
-    if (getenv("SDFV_RAYMARCH_NO_POW2N")) a.pow2_size = 0;
     a.tex0 = reinterpret_cast<const float4*>(tex0);
     a.tex1 = reinterpret_cast<const float4*>(tex1);
     a.width = width;
@@ -498,6 +503,60 @@ int sdfv_raymarch_accel(const sdfv_render_params* rp, const float* tex0, const f
         a.aux = aux ? aux + c0 * pixels_per_cam : nullptr;
         SDFV_HIP(sdfv::launch_raymarch(a, (hipStream_t)stream));
     }
+    return SDFV_OK;
+}
+
+int sdfv_raymarch_slab(const sdfv_render_params* rp, const sdfv_grid* slab, uint32_t ghost_lo, uint32_t ghost_hi,
+                       const float* tex0, const float* tex1, const sdfv_camera* camera, uint32_t width, uint32_t height,
+                       const sdfv_ray_state* in_states, uint32_t n_in, float* rgba, sdfv_march_aux* aux,
+                       sdfv_ray_state* out_down, sdfv_ray_state* out_up, uint32_t capacity, uint32_t* counters,
+                       void* stream) {
+    if (!rp || !slab || !tex0 || !tex1 || !camera || !rgba || !out_down || !out_up || !counters)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (int rc = check_grid(slab)) return rc;
+    for (int i = 0; i < 3; ++i)
+        if (rp->tex_size[i] != slab->dims[i])
+            return fail(SDFV_ERR_INVALID_ARGUMENT, "render parameters describe a %ux%ux%u grid, the slab a %ux%ux%u one",
+                        rp->tex_size[0], rp->tex_size[1], rp->tex_size[2], slab->dims[0], slab->dims[1], slab->dims[2]);
+    if (slab->z_begin >= slab->z_end) return fail(SDFV_ERR_INVALID_ARGUMENT, "empty slab");
+    if (ghost_lo > slab->z_begin || slab->z_end + ghost_hi > slab->dims[2])
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "ghost slices reach outside the grid");
+    if (slab->z_end < slab->dims[2] && ghost_hi == 0)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "an interior slab needs its upper ghost slice (run the halo exchange)");
+    if (rp->lod_dist_between_samples != 1.0f)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "the sharded march renders loaded grids only (lod_dist_between_samples == 1)");
+    if ((uint64_t)width * height >= (1ull << 32)) return fail(SDFV_ERR_INVALID_ARGUMENT, "image too large");
+    const uint64_t resident = (uint64_t)slab->dims[0] * slab->dims[1] * (ghost_lo + (slab->z_end - slab->z_begin) + ghost_hi);
+    if (resident >= (1ull << 32)) return fail(SDFV_ERR_INVALID_ARGUMENT, "slab too large for 32-bit texel indexing");
+    if (in_states == nullptr && n_in != 0) return fail(SDFV_ERR_INVALID_ARGUMENT, "n_in without in_states");
+    if (int rc = need_device()) return rc;
+    sdfv::RaymarchArgs a;
+    derive_raymarch_args(rp, a);
+    if (!a.fast_index)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "box too small for the sharded march: 1e-4 * N / size must be <= 0.25");
+    a.tex0 = reinterpret_cast<const float4*>(tex0);
+    a.tex1 = reinterpret_cast<const float4*>(tex1);
+    a.width = width;
+    a.height = height;
+    a.y0 = 0;
+    a.y1 = height;
+    a.n_cameras = 1;
+    a.cameras[0] = *camera;
+    a.rgba = reinterpret_cast<float4*>(rgba);
+    a.aux = aux;
+    sdfv::SlabMarchArgs s{};
+    s.z_lo = slab->z_begin - ghost_lo;
+    s.z_count = ghost_lo + (slab->z_end - slab->z_begin) + ghost_hi;
+    s.own_begin = slab->z_begin;
+    s.own_end = slab->z_end;
+    s.in = in_states;
+    s.n_in = n_in;
+    s.out_down = out_down;
+    s.out_up = out_up;
+    s.counters = counters;
+    s.capacity = capacity;
+    if (in_states && n_in == 0) return SDFV_OK;  // nothing arrived this round
+    SDFV_HIP(sdfv::launch_raymarch_slab(a, s, (hipStream_t)stream));
     return SDFV_OK;
 }
 

@@ -230,6 +230,101 @@ class SlabFiller:
         main.wait_event(halo_done)
 
 
+class ShardedMarch:
+    """One rank's side of the raymarch over a z-sharded grid (sdfv_raymarch_slab): the grid stays where the fill put
+    it, rays are handed between z-neighbours.  `round(incoming)` runs one round and returns the rays leaving through
+    the low and the high face of the slab; after `world` rounds every ray has ended on exactly one rank and the image
+    is the merge of the ranks' images (all-zero bits except on the rank the ray ended on) (`raymarch_sharded` below drives it over torch.distributed)."""
+
+    def __init__(self, pkg, rp, grid, slab, camera, width, height, want_aux=False):
+        self.pkg, self.rp, self.grid, self.slab, self.camera = pkg, rp, grid, slab, camera
+        self.width, self.height = width, height
+        dev = slab.tex0.device
+        cap = width * height
+        self.rgba = torch.empty((height, width, 4), dtype=torch.float32, device=dev)
+        self.aux = torch.empty((height, width, pkg.AUX_FLOATS), dtype=torch.int32, device=dev) if want_aux else None
+        self.out = [torch.empty((cap, pkg.RAY_STATE_WORDS), dtype=torch.int32, device=dev) for _ in range(2)]
+        self.counters = torch.zeros(2, dtype=torch.int32, device=dev)
+
+    def round(self, incoming=None):
+        """incoming None = first round; otherwise an [n, 6] int32 tensor of ray states (n may be 0).  Returns (down, up)."""
+        self.counters.zero_()
+        self.pkg.raymarch_slab(self.rp, self.grid, self.slab.ghost_lo, self.slab.ghost_hi, self.slab.tex0, self.slab.tex1,
+                               self.camera, self.width, self.height, self.rgba, self.out[0], self.out[1], self.counters,
+                               in_states=incoming, aux=self.aux)
+        n_down, n_up = (int(v) for v in self.counters.tolist())  # synchronises
+        return self.out[0][:n_down], self.out[1][:n_up]
+
+
+def _exchange_rays(down, up, rank, world, group):
+    """Rays leaving downwards go to rank-1, upwards to rank+1; returns what the two neighbours sent here, concatenated.
+    Counts travel first (the lists are data dependent), then the payloads."""
+    dev = down.device
+    staged = _needs_host_staging(down, group)
+    cdev = torch.device("cpu") if staged else dev
+    peers = [(rank - 1, down), (rank + 1, up)]
+    peers = [(p, t) for p, t in peers if 0 <= p < world]
+    send_n = [torch.tensor([t.shape[0]], dtype=torch.int64, device=cdev) for _, t in peers]
+    recv_n = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in peers]
+    ops = []
+    for (p, _), sn, rn in zip(peers, send_n, recv_n):
+        ops += [dist.P2POp(dist.isend, sn, p, group), dist.P2POp(dist.irecv, rn, p, group)]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    ops, bufs = [], []
+    for (p, t), rn in zip(peers, recv_n):
+        n = int(rn.item())
+        if t.shape[0]:
+            ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t.contiguous(), p, group))
+        if n:
+            buf = torch.empty((n, t.shape[1]), dtype=t.dtype, device=cdev)
+            ops.append(dist.P2POp(dist.irecv, buf, p, group))
+            bufs.append(buf)
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if not bufs:
+        return torch.empty((0, down.shape[1]), dtype=down.dtype, device=dev)
+    return torch.cat([b.to(dev) for b in bufs], dim=0)
+
+
+def merge_sharded_aux(aux_sum):
+    """Merge of the ranks' aux images (summed bit patterns) -> the single-GPU record: pixels no rank reports (status 0) get the
+    cleared record's depth of 1.0 back (aux words: status, steps, hit_pos[3], t, raw0[4], raw1[4], normal[3], depth)."""
+    out = aux_sum.clone()
+    depth = out[..., -1].view(torch.float32)
+    depth[out[..., 0] == 0] = 1.0
+    return out
+
+
+def raymarch_sharded(pkg, rp, grid, slab, camera, width, height, rank, world, group=None, want_aux=False):
+    """Raymarch of a grid that stays z-sharded across the ranks (slab + ghosts as left by the halo exchange).
+    Every rank gets the full image (all-reduce of the per-rank images' bit patterns: each pixel is written by one rank).
+    Returns rgba [H, W, 4] (+ the merged aux image); bit-identical to pkg.raymarch over the whole grid, except that
+    aux.normal stays (0, 0, 0)."""
+    m = ShardedMarch(pkg, rp, grid, slab, camera, width, height, want_aux)
+    incoming = None
+    for _ in range(world):
+        down, up = m.round(incoming)
+        incoming = _exchange_rays(down, up, rank, world, group) if world > 1 else down[:0]
+    staged = world > 1 and _needs_host_staging(m.rgba, group)
+
+    def merge(t):
+        """Each pixel is written by one rank and is all-zero bits elsewhere, so adding the BIT PATTERNS as integers
+        over the ranks reproduces them exactly (a float sum would turn -0.0 into +0.0; RCCL has no bitwise OR)."""
+        if world == 1:
+            return t
+        bits = t.view(torch.int32)
+        h = bits.cpu() if staged else bits
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        return (h.to(t.device) if staged else h).view(t.dtype)
+
+    rgba = merge(m.rgba)
+    if not want_aux:
+        return rgba
+    return rgba, merge_sharded_aux(merge(m.aux))
+
+
 def gather_replica(slab, dims, world, group=None):
     """Full grid on every rank from the slabs (all-gather; slabs may differ by one slice, so each is
     padded to the deepest slab for the collective and trimmed afterwards)."""

@@ -31,3 +31,5 @@ def test_bench_weak_scaling_path_two_ranks_one_gpu(world, geometry):
     assert (gx, gy, gz) == ((64, 64, 64 * world) if geometry == "slab" else (64, 128, 128))
     assert d["value"] > 0 and d["value_rays"] > 0
     assert d["sharded_fill_verified"] is True  # gathered slabs == dense fill, ghost slices == neighbour's slices
+    # the grid raymarched where it lies (rays handed between the ranks over gloo) == the march over the whole grid
+    assert d["sharded_march"]["verified"] is True, d["sharded_march"]

@@ -57,6 +57,20 @@ def _worker(rank, world, port, dims, q):
             ok &= got.shape == (n_cams, 3, 5, 4) and all(bool((got[c] == float(c)).all()) for c in range(n_cams))
         else:
             ok &= got is None
+        # ray hand-over of the sharded march: lists of data-dependent length to both neighbours, some empty.
+        # Rank r sends r + 1 rays down and 2 * r rays up (rank 0 none up); every word carries (sender, direction, k).
+        def rays(n, direction):
+            t = torch.zeros((n, 6), dtype=torch.int32)
+            t[:, 0], t[:, 1], t[:, 2] = rank, direction, torch.arange(n, dtype=torch.int32)
+            return t
+        inc = par._exchange_rays(rays(rank + 1 if rank > 0 else 0, 0), rays(2 * rank if rank < world - 1 else 0, 1),
+                                 rank, world, None)
+        want = []
+        if rank > 0 and 2 * (rank - 1) > 0:                     # what the lower neighbour sent up
+            want += [(rank - 1, 1, k) for k in range(2 * (rank - 1))]
+        if rank < world - 1:                                     # what the upper neighbour sent down
+            want += [(rank + 1, 0, k) for k in range(rank + 2)]
+        ok &= sorted(map(tuple, inc[:, :3].tolist())) == sorted(want) and inc.shape == (len(want), 6)
         q.put((rank, bool(ok), slab.z_begin, slab.z_end))
     finally:
         dist.destroy_process_group()
