@@ -53,6 +53,9 @@ def parse_args():
                          "nccl), torch = torch.distributed P2P ops")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the extra 64-camera batch (profiling runs)")
+    ap.add_argument("--batch-split", choices=["cameras", "rows"], default="cameras",
+                    help="N>1, 64-camera batch: deal whole cameras to the ranks (default) or give every rank a band of "
+                         "rows of every camera (BASELINE.json config 5's image-tile split)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     return ap.parse_args()
 
@@ -306,16 +309,22 @@ def main():
     batch_report = None
     if not args.no_batch:
         batch_cams = pkg.orbit_cameras(n_batch, aspect=W / H)
-        mine = [batch_cams[i] for i in par.split_cameras(n_batch, rank, world)]
-        batch_out = torch.empty((len(mine), H, W, 4), dtype=torch.float32, device=device)
+        if args.batch_split == "rows":
+            mine = batch_cams
+            by0, by1 = par.split_rows(H, rank, world)
+        else:
+            mine = [batch_cams[i] for i in par.split_cameras(n_batch, rank, world)]
+            by0, by1 = 0, H
+        batch_out = torch.empty((len(mine), by1 - by0, W, 4), dtype=torch.float32, device=device)
 
         def batch_step():
-            pkg.raymarch(rp, r0, r1, mine, W, H, out=batch_out, dist=dist_vol)
+            pkg.raymarch(rp, r0, r1, mine, W, H, y0=by0, y1=by1, out=batch_out, dist=dist_vol)
 
         batch_step()
         batch_steps = max(2, min(args.steps, 5))
         batch_dt, _ = timed_region(batch_step, batch_steps, torch, dist, world, device)
         batch_report = {"cameras": n_batch, "image": [W, H], "cameras_per_gpu": len(mine),
+                        "rows_per_gpu": by1 - by0, "split": args.batch_split if world > 1 else None,
                         "value": round(n_batch * W * H * batch_steps / batch_dt / 1e6, 1), "unit": "Mrays/s",
                         "ms_per_batch": round(batch_dt / batch_steps * 1e3, 4),
                         "note": "BASELINE.json configs[4] shape (64-camera orbit) over the same grid"}

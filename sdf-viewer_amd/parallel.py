@@ -347,6 +347,30 @@ def split_cameras(n_cameras, rank, world):
     return range(n_cameras * rank // world, n_cameras * (rank + 1) // world)
 
 
+def split_rows(height, rank, world, tile=16):
+    """Image-tile split of ONE image over the ranks (config 5's "image-tile split"): contiguous bands of rows, cut on
+    multiples of the kernel's 16-row workgroup tile so no workgroup straddles two ranks; -> (y0, y1)."""
+    tiles = (height + tile - 1) // tile
+    return min(height, tiles * rank // world * tile), min(height, tiles * (rank + 1) // world * tile)
+
+
+def gather_rows(band, height, rank, world, dst=0, group=None, tile=16):
+    """Collect the row bands of split_rows ([n_cam, rows, W, 4] each) on rank `dst` -> [n_cam, height, W, 4]."""
+    if world == 1:
+        return band
+    ranges = [split_rows(height, r, world, tile) for r in range(world)]
+    deepest = max(y1 - y0 for y0, y1 in ranges)
+    staged = _needs_host_staging(band, group)
+    dev = torch.device("cpu") if staged else band.device
+    padded = torch.zeros((band.shape[0], deepest) + tuple(band.shape[2:]), dtype=band.dtype, device=dev)
+    padded[:, :band.shape[1]] = band
+    parts = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([p[:, :y1 - y0] for p, (y0, y1) in zip(parts, ranges)], dim=1).to(band.device)
+
+
 def gather_images(rgba, n_cameras, rank, world, dst=0, group=None):
     """Config 5's optional last step: collect every rank's rendered cameras ([n_local, H, W, 4]) on rank `dst` in
     camera order.  Camera counts may differ by one between ranks, so each block is padded to the largest count.

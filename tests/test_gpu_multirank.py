@@ -19,7 +19,7 @@ def test_bench_weak_scaling_path_two_ranks_one_gpu(world, geometry):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "64", "--no-cpu-baseline",
-           "--weak-geometry", geometry]
+           "--weak-geometry", geometry, "--batch-split", "rows" if geometry == "cube" else "cameras"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -30,6 +30,8 @@ def test_bench_weak_scaling_path_two_ranks_one_gpu(world, geometry):
     assert gx * gy * gz == world * 64 ** 3
     assert (gx, gy, gz) == ((64, 64, 64 * world) if geometry == "slab" else (64, 128, 128))
     assert d["value"] > 0 and d["value_rays"] > 0
+    b = d["batch_raymarch"]
+    assert b["value"] > 0 and (b["rows_per_gpu"] == 512 // world if geometry == "cube" else b["cameras_per_gpu"] == 64 // world)
     assert d["sharded_fill_verified"] is True  # gathered slabs == dense fill, ghost slices == neighbour's slices
     # the grid raymarched where it lies (rays handed between the ranks over gloo) == the march over the whole grid
     assert d["sharded_march"]["verified"] is True, d["sharded_march"]

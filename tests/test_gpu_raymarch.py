@@ -236,3 +236,20 @@ def test_randomised_cameras_grids_and_boxes(pkg, oracle):
         compare(pkg, oracle, g, t0, t1, t0.cpu().numpy(), t1.cpu().numpy(),
                 cam_kw=dict(eye=tuple(float(x) for x in eye), target=tuple(float(x) for x in target),
                             fovy_degrees=float(rng.uniform(10.0, 120.0))), width=w, height=h)
+
+
+def test_row_bands_of_the_image_tile_split_tile_the_frame(pkg):
+    """parallel.split_rows (config 5's image-tile split): the bands rendered by the "ranks" concatenate to the frame."""
+    import importlib
+    par = importlib.import_module("sdf-viewer_amd.parallel")
+    dims, W, H = (32, 32, 32), 120, 100
+    g = pkg.make_grid(dims)
+    t0, t1 = pkg.alloc_textures(g)
+    pkg.fill_grid(pkg.default_params(), g, t0, t1)
+    rp = pkg.default_render_params(g)
+    cams = pkg.orbit_cameras(3, aspect=W / H)
+    whole = pkg.raymarch(rp, t0, t1, cams, W, H)
+    for world in (2, 3, 7):
+        bands = [pkg.raymarch(rp, t0, t1, cams, W, H, *par.split_rows(H, r, world)) for r in range(world)
+                 if par.split_rows(H, r, world)[1] > par.split_rows(H, r, world)[0]]
+        assert torch.equal(torch.cat(bands, dim=1).view(torch.int32), whole.view(torch.int32))

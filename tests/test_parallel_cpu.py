@@ -57,6 +57,18 @@ def _worker(rank, world, port, dims, q):
             ok &= got.shape == (n_cams, 3, 5, 4) and all(bool((got[c] == float(c)).all()) for c in range(n_cams))
         else:
             ok &= got is None
+        # image-tile split (config 5): rank r's band of rows carries r + 1 in every pixel
+        Himg = 50
+        y0, y1 = par.split_rows(Himg, rank, world)
+        band = torch.full((2, y1 - y0, 6, 4), float(rank + 1))
+        whole = par.gather_rows(band, Himg, rank, world, dst=0)
+        if rank == 0:
+            ok &= whole.shape == (2, Himg, 6, 4)
+            for r in range(world):
+                a, b = par.split_rows(Himg, r, world)
+                ok &= bool((whole[:, a:b] == float(r + 1)).all())
+        else:
+            ok &= whole is None
         # ray hand-over of the sharded march: lists of data-dependent length to both neighbours, some empty.
         # Rank r sends r + 1 rays down and 2 * r rays up (rank 0 none up); every word carries (sender, direction, k).
         def rays(n, direction):
@@ -108,5 +120,11 @@ def test_partition_helpers():
     assert par.weak_scaling_dims(256, 2, "cube") == (256, 256, 512)
     assert par.weak_scaling_dims(256, 4, "cube") == (256, 512, 512)
     assert par.weak_scaling_dims(512, 8, "cube") == (1024, 1024, 1024)   # BASELINE.json config 4
+    for h in (1, 15, 16, 17, 1080, 2160):
+        for world in (1, 2, 3, 8):
+            bands = [par.split_rows(h, r, world) for r in range(world)]
+            assert bands[0][0] == 0 and bands[-1][1] == h and all(a[1] == b[0] for a, b in zip(bands[:-1], bands[1:]))
+            assert all(y0 % 16 == 0 for y0, _ in bands)
+    assert par.split_rows(1080, 3, 8) == (400, 544)
     cams = [list(par.split_cameras(64, r, 8)) for r in range(8)]
     assert sum(cams, []) == list(range(64)) and all(len(c) == 8 for c in cams)
