@@ -12,7 +12,7 @@ principles, so the conventions are this file's own.
                       off on its own -- a rule that depends on the face's signs only, so the two cells sharing a
                       face agree and the mesh is watertight.
   loops             : every crossing point has one incoming and one outgoing segment; following them gives closed
-                      polygons, triangulated as fans.  Triangles are counter-clockwise seen from the outside
+                      polygons, triangulated so that no diagonal lies in a cube face (triangulate_loop).  Triangles are counter-clockwise seen from the outside
                       (positive distance), checked below against the trilinear interpolant of the corner signs.
 Run: python tools/gen_mc_table.py            (rewrites the .inc; the committed copy must match -- tests check)
 """
@@ -113,6 +113,45 @@ def case_loops(case):
     return loops
 
 
+def faces_of_edge(e):
+    """The two cube faces (axis, side) a cube edge lies in."""
+    c0, c1 = edge_ends(e)
+    p0, p1 = corner_xyz(c0), corner_xyz(c1)
+    return {(ax, p0[ax]) for ax in range(3) if p0[ax] == p1[ax]}
+
+
+def triangulations(n):
+    """All triangulations of a convex n-gon with vertices 0..n-1, as lists of index triples."""
+    def rec(lo, hi):  # polygon lo, lo+1, ..., hi
+        if hi - lo < 2:
+            return [[]]
+        out = []
+        for mid in range(lo + 1, hi):
+            for left in rec(lo, mid):
+                for right in rec(mid, hi):
+                    out.append(left + [(lo, mid, hi)] + right)
+        return out
+    return rec(0, n - 1)
+
+
+def triangulate_loop(loop):
+    """Triangles (as edge-id triples, loop orientation kept) such that no diagonal joins two crossing points of one cube
+    face: such a diagonal lies IN that face, where the neighbouring cell may lay the same segment -- four triangles on
+    one mesh edge.  Every loop of every case admits such a triangulation (asserted)."""
+    n = len(loop)
+    for tris in triangulations(n):
+        ok = True
+        for a, b, c in tris:
+            for u, v in ((a, b), (b, c), (c, a)):
+                if (v - u) % n in (1, n - 1):
+                    continue  # a side of the loop (a face segment), not a diagonal
+                if faces_of_edge(loop[u]) & faces_of_edge(loop[v]):
+                    ok = False
+        if ok:
+            return [(loop[a], loop[b], loop[c]) for a, b, c in tris]
+    raise AssertionError(f"no face-free triangulation for loop {loop}")
+
+
 def edge_mid(e):
     c0, c1 = edge_ends(e)
     return (np.array(corner_xyz(c0), float) + np.array(corner_xyz(c1), float)) / 2
@@ -146,8 +185,7 @@ def build():
             assert flip == want_flip, "segment direction rule must orient every loop the same way"
             if flip:
                 loop = loop[::-1]
-            for i in range(1, len(loop) - 1):
-                tris.append((loop[0], loop[i], loop[i + 1]))
+            tris.extend(triangulate_loop(loop))
         table.append(tris)
     return table
 
@@ -155,13 +193,15 @@ def build():
 def render(table):
     width = 3 * max(len(t) for t in table)
     lines = ["// mc_table.inc -- GENERATED by tools/gen_mc_table.py (conventions documented there); do not edit.",
+             "// The includer defines SDFV_MC_TABLE (e.g. `__constant__ const`): statically initialised device tables are",
+             "// loaded with the code object on every device, no upload call needed.",
              f"constexpr int kMcMaxIndices = {width};",
-             "constexpr unsigned char kMcTriCount[256] = {"]
+             "SDFV_MC_TABLE unsigned char kMcTriCount[256] = {"]
     for r in range(0, 256, 32):
         lines.append("    " + ", ".join(str(len(t)) for t in table[r:r + 32]) + ",")
     lines.append("};")
     lines.append("// edge ids (4*axis + u + 2*v) of each triangle's corners, -1 padded")
-    lines.append(f"constexpr signed char kMcTriEdges[256][{width}] = {{")
+    lines.append(f"SDFV_MC_TABLE signed char kMcTriEdges[256][{width}] = {{")
     for case, tris in enumerate(table):
         flat = [e for t in tris for e in t]
         flat += [-1] * (width - len(flat))
