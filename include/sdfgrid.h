@@ -195,6 +195,9 @@ typedef struct sdfv_mesh {
 int sdfv_mesh_extract(const sdfv_demo_params *params, uint32_t sdf_id, const float bb_min[3], const float bb_max[3],
                       uint32_t max_voxels_per_axis, uint32_t algorithm, sdfv_mesh *out, void *stream);
 int sdfv_mesh_free(sdfv_mesh *mesh);
+/* sdfv_mesh_extract keeps its scratch (about 13 bytes per lattice point) for the calling thread's next extraction;
+ * this releases it. */
+int sdfv_mesh_trim(void);
 
 /* ---- raymarch ---- */
 /* material.frag main() for every pixel of rows [y0, y1) of n_cameras W x H images (row 0 = top).

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "sdfv_mesh_extract": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                     C.c_uint32, C.c_uint32, C.POINTER(Mesh), C.c_void_p]),
     "sdfv_mesh_free": (C.c_int, [C.POINTER(Mesh)]),
+    "sdfv_mesh_trim": (C.c_int, []),
     "sdfv_raymarch_slab": (C.c_int, [C.POINTER(RenderParams), C.POINTER(Grid), C.c_uint32, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),

@@ -112,6 +112,12 @@ sdfv::FillLaunch fill_launch_config() {
     return c;
 }
 
+struct MeshScratch {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+thread_local MeshScratch g_mesh_scratch;  // freed by sdfv_mesh_trim(); a thread that exits without it leaks the block
+
 struct DeviceBuf {
     void* p = nullptr;
     ~DeviceBuf() {
@@ -407,20 +413,27 @@ int sdfv_mesh_extract(const sdfv_demo_params* params, uint32_t sdf_id, const flo
     }
     const size_t n_points = (size_t)(g.cells[0] + 1) * (g.cells[1] + 1) * (g.cells[2] + 1);
     const size_t n_cells = (size_t)g.cells[0] * g.cells[1] * g.cells[2];
-    DeviceBuf dist, first, mask, cfirst, tmp, totals;
+    // One scratch block per host thread, grown on demand and kept between calls (allocating ~13 B per lattice point
+    // afresh costs more than the extraction itself); sdfv_mesh_trim() gives it back.
     sdfv::MeshWork w{};
     w.scan_tmp_bytes = sdfv::mesh_scan_tmp_bytes(n_points);
-    SDFV_HIP(hipMalloc(&dist.p, n_points * 4));
-    SDFV_HIP(hipMalloc(&first.p, n_points * 4));
-    SDFV_HIP(hipMalloc(&mask.p, n_points));
-    SDFV_HIP(hipMalloc(&cfirst.p, n_cells * 4));
-    SDFV_HIP(hipMalloc(&tmp.p, w.scan_tmp_bytes ? w.scan_tmp_bytes : 16));
-    SDFV_HIP(hipMalloc(&totals.p, 8));
-    w.dist = (float*)dist.p;
-    w.point_first = (uint32_t*)first.p;
-    w.point_mask = (uint8_t*)mask.p;
-    w.cell_first = (uint32_t*)cfirst.p;
-    w.scan_tmp = tmp.p;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_dist = 0, o_first = o_dist + up(n_points * 4), o_cfirst = o_first + up(n_points * 4),
+                 o_mask = o_cfirst + up(n_cells * 4), o_tmp = o_mask + up(n_points), o_totals = o_tmp + up(w.scan_tmp_bytes),
+                 need = o_totals + 256;
+    if (g_mesh_scratch.bytes < need) {
+        if (g_mesh_scratch.p) (void)hipFree(g_mesh_scratch.p);
+        g_mesh_scratch = MeshScratch{};
+        SDFV_HIP(hipMalloc(&g_mesh_scratch.p, need));
+        g_mesh_scratch.bytes = need;
+    }
+    char* base = static_cast<char*>(g_mesh_scratch.p);
+    w.dist = (float*)(base + o_dist);
+    w.point_first = (uint32_t*)(base + o_first);
+    w.cell_first = (uint32_t*)(base + o_cfirst);
+    w.point_mask = (uint8_t*)(base + o_mask);
+    w.scan_tmp = base + o_tmp;
+    struct { void* p; } totals{base + o_totals};
     SDFV_HIP(sdfv::launch_mesh_count(*params, sdf_id, g, w, (uint32_t*)totals.p, st));
     uint32_t n[2] = {0, 0};
     SDFV_HIP(hipMemcpyAsync(n, totals.p, 8, hipMemcpyDeviceToHost, st));
@@ -437,13 +450,19 @@ int sdfv_mesh_extract(const sdfv_demo_params* params, uint32_t sdf_id, const flo
         }
     }
     hipError_t e = sdfv::launch_mesh_emit(*params, sdf_id, g, w, m.vertices, m.indices, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);  // the scratch buffers go out of scope below
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // the next extraction on this thread reuses the scratch
     if (e != hipSuccess) {
         (void)hipFree(m.vertices);
         (void)hipFree(m.indices);
         return hip_fail(e, "mesh emit");
     }
     *out = m;
+    return SDFV_OK;
+}
+
+int sdfv_mesh_trim(void) {
+    if (g_mesh_scratch.p) (void)hipFree(g_mesh_scratch.p);
+    g_mesh_scratch = MeshScratch{};
     return SDFV_OK;
 }
 

@@ -153,3 +153,16 @@ def test_large_lattice_counts(pkg):
     assert v.shape[0] - tri * 3 // 2 + tri == 2  # closed triangle mesh: E = 3F/2
     area_cells = 4 * np.pi * (0.8 * 256) ** 2
     assert 1.5 * area_cells < tri < 3.0 * area_cells
+
+
+def test_scratch_is_reused_and_can_be_trimmed(pkg):
+    prm = pkg.default_params()
+    a = pkg.mesh_extract(prm, 40)
+    free_before = torch.cuda.mem_get_info()[0]
+    b = pkg.mesh_extract(prm, 24)          # smaller: runs inside the kept scratch
+    assert torch.cuda.mem_get_info()[0] >= free_before - (8 << 20)
+    c = pkg.mesh_extract(prm, 40)
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and b[0].shape[0] < a[0].shape[0]
+    assert pkg.lib.sdfv_mesh_trim() == 0 and pkg.lib.sdfv_mesh_trim() == 0
+    d = pkg.mesh_extract(prm, 40)
+    assert torch.equal(a[0], d[0]) and torch.equal(a[1], d[1])
