@@ -142,3 +142,37 @@ def test_textures_larger_than_4_gib_use_64_bit_addressing(pkg, oracle):
     np.testing.assert_array_equal(a["steps"], waux["steps"])
     np.testing.assert_array_equal(a["hit_pos"].view(np.uint32), waux["hit_pos"].view(np.uint32))
     assert np.abs(got[0].cpu().numpy() - want).max() <= 1e-4 and (waux["status"] == 1).sum() > 100
+
+
+def test_enqueue_calls_are_graph_capture_safe(pkg):
+    """fill + commit + raymarch captured into a hipGraph (no allocation, no synchronisation inside the library's
+    enqueue calls) and replayed: same bits as the eager frame."""
+    side, W, H = 32, 96, 64
+    prm = pkg.default_params()
+    g = pkg.make_grid((side, side, side))
+    t0, t1 = pkg.alloc_textures(g)
+    dist = torch.empty((side, side, side), dtype=torch.float32, device="cuda")
+    rp = pkg.default_render_params(g)
+    cam = pkg.camera_look_at(aspect=W / H)
+    out = torch.empty((1, H, W, 4), dtype=torch.float32, device="cuda")
+
+    def frame():
+        pkg.fill_grid(prm, g, t0, t1)
+        pkg.commit_distance(g, t0, dist=dist)
+        pkg.raymarch(rp, t0, t1, cam, W, H, out=out, dist=dist)
+
+    frame()
+    torch.cuda.synchronize()
+    ref = out.clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        frame()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        frame()
+    for t in (t0, t1, dist, out):
+        t.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int32), ref.view(torch.int32)) and bool((ref[..., 3] > 0).any())
