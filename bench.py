@@ -421,6 +421,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
+        if getattr(filler, "comm", None) is not None:
+            torch.cuda.synchronize()
+            filler.comm.close()  # the library's RCCL communicator, while every peer is still alive
         dist.barrier()
         dist.destroy_process_group()
 
