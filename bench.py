@@ -409,7 +409,10 @@ def main():
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
                          "traffic": load_traffic(args.workload),
                          "algorithmic_bytes_per_launch": FILL_BYTES_PER_VOXEL * voxels_per_rank,
-                         "avg_launch_ms": round(kern_ms, 5)},
+                         "avg_launch_ms": round(kern_ms, 5),
+                         "avg_launch_note": "HIP events around K back-to-back launches / K: includes the ~6 us gap "
+                                            "between launches, which rocprofv3's kernel-only average leaves out "
+                                            "(8 % at 256^3, under 1 % at 512^3)"},
             "raymarch_kernel_ms": round(march_ev_ms / args.steps, 4),
             "commit_ms": round(commit_ms, 4),
             "commit_note": "device-side SDFViewer::commit (compact distance volume for the march), once per load; "
