@@ -199,8 +199,9 @@ def test_host_buffer_entry_point(pkg, oracle):
 def test_randomised_parameters_and_grids(pkg, oracle):
     """Seeded sweep over the demo's whole parameter space (the GUI sliders' ranges, demo/mod.rs:94-118,
     cube.rs:117-127, sphere.rs:75-85), odd grid shapes and off-centre boxes: dense fill and one progressive pass."""
-    rng = np.random.default_rng(20250404)
-    for trial in range(24):
+    import os
+    rng = np.random.default_rng(int(os.environ.get("SDFV_SOAK_SEED", 20250404)))  # tools/soak.sh varies the seed
+    for trial in range(int(os.environ.get("SDFV_SOAK_TRIALS", 24))):
         kw = dict(cube_half_side=float(rng.integers(0, 101)) / 100.0,             # Int 0..=100 mapped to [0, 1]
                   sphere_radius=float(np.float32(rng.uniform(0.0, 1.25))),
                   max_distance_custom_material=float(np.float32(rng.uniform(0.0, 0.25))),

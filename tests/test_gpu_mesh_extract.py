@@ -166,3 +166,22 @@ def test_scratch_is_reused_and_can_be_trimmed(pkg):
     assert pkg.lib.sdfv_mesh_trim() == 0 and pkg.lib.sdfv_mesh_trim() == 0
     d = pkg.mesh_extract(prm, 40)
     assert torch.equal(a[0], d[0]) and torch.equal(a[1], d[1])
+
+
+def test_randomised_extractions_match_numpy_restatement(pkg, oracle, table):
+    """Seeded sweep (tools/soak.sh varies the seed): random demo parameters, sub-trees, boxes and lattice sizes."""
+    rng = np.random.default_rng(int(os.environ.get("SDFV_SOAK_SEED", 11)))
+    for _ in range(int(os.environ.get("SDFV_SOAK_TRIALS", 4))):
+        kw = dict(cube_half_side=float(np.float32(rng.uniform(0.2, 1.0))), sphere_radius=float(np.float32(rng.uniform(0.2, 1.2))),
+                  disable_sphere=int(rng.integers(0, 4) == 0))
+        lo = rng.uniform(-1.4, -0.6, size=3).astype(np.float32)
+        hi = (lo + rng.uniform(1.2, 2.8, size=3)).astype(np.float32)
+        box = (tuple(float(x) for x in lo), tuple(float(x) for x in hi))
+        n, sdf_id = int(rng.integers(3, 14)), int(rng.integers(0, 3))
+        prm = pkg.default_params(**kw)
+        v, idx = pkg.mesh_extract(prm, n, *box, sdf_id=sdf_id)
+        want_v, want_i, _ = numpy_extract(table, oracle, oracle.params_from(prm), n, box, sdf_id)
+        assert v.shape[0] == want_v.shape[0], (kw, box, n, sdf_id)
+        if v.shape[0]:
+            np.testing.assert_array_equal(v.cpu().numpy()[:, :3].view(np.uint32), want_v.view(np.uint32))
+            np.testing.assert_array_equal(idx.cpu().numpy().astype(np.int64), want_i)

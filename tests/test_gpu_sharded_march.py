@@ -134,3 +134,32 @@ def test_argument_checks(pkg, par):
     assert call(loading, g, 0, 1) == -1 and b"loaded grids only" in pkg.lib.sdfv_last_error()
     other = pkg.default_render_params(pkg.make_grid((8, 8, 9)))
     assert call(other, g, 0, 1) == -1
+
+
+def test_randomised_slabs_and_cameras(pkg, par):
+    """Seeded sweep (tools/soak.sh varies the seed): random grids, world sizes, boxes and cameras in and around the box."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("SDFV_SOAK_SEED", 5)))
+    for _ in range(int(os.environ.get("SDFV_SOAK_TRIALS", 4))):
+        dims = tuple(int(d) for d in rng.integers(6, 40, size=3))
+        world = int(rng.integers(2, min(9, dims[2] + 1)))
+        lo = rng.uniform(-1.5, -0.5, size=3)
+        hi = lo + rng.uniform(1.0, 3.0, size=3)
+        bb = (tuple(float(x) for x in lo), tuple(float(x) for x in hi))
+        centre, half = (lo + hi) / 2, (hi - lo) / 2
+        eye = centre + rng.normal(size=3) * half * rng.uniform(0.3, 3.0)
+        W, H = int(rng.integers(16, 80)), int(rng.integers(16, 60))
+        prm = pkg.default_params(cube_half_side=float(0.9 * half.min()), sphere_radius=float(half.min()))
+        full = pkg.make_grid(dims, *bb)
+        f0, f1 = pkg.alloc_textures(full)
+        pkg.fill_grid(prm, full, f0, f1)
+        rp = pkg.default_render_params(full)
+        cam = pkg.camera_look_at(eye=tuple(float(x) for x in eye), target=tuple(float(x) for x in centre), aspect=W / H,
+                                 fovy_degrees=float(rng.uniform(20, 100)))
+        want_rgba, want_aux = pkg.raymarch(rp, f0, f1, cam, W, H, want_aux=True)
+        slabs, grids = build_slabs(pkg, par, prm, dims, world, bb)
+        got_rgba, got_aux, _ = run_lockstep(pkg, par, rp, slabs, grids, cam, W, H)
+        np.testing.assert_array_equal(got_rgba.cpu().numpy().view(np.uint32), want_rgba[0].cpu().numpy().view(np.uint32))
+        ga, wa = got_aux.cpu().numpy(), want_aux[0].cpu().numpy()
+        np.testing.assert_array_equal(ga[..., :14], wa[..., :14])
+        np.testing.assert_array_equal(ga[..., 17], wa[..., 17])
