@@ -176,3 +176,48 @@ def test_enqueue_calls_are_graph_capture_safe(pkg):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out.view(torch.int32), ref.view(torch.int32)) and bool((ref[..., 3] > 0).any())
+
+
+def test_two_host_threads_on_their_own_streams(pkg, oracle):
+    """The library keeps no shared mutable state besides thread-local error text and per-thread scratch: two host
+    threads driving different grids on different streams at the same time get the results they would get alone."""
+    import threading
+    results, errors = {}, []
+
+    def work(tag, dims, kw, sdf_id):
+        try:
+            stream = torch.cuda.Stream()
+            prm = pkg.default_params(**kw)
+            g = pkg.make_grid(dims)
+            with torch.cuda.stream(stream):
+                t0, t1 = pkg.alloc_textures(g)
+                for _ in range(20):
+                    pkg.fill_grid(prm, g, t0, t1, sdf_id=sdf_id, stream=stream)
+                    rgba = pkg.raymarch(pkg.default_render_params(g), t0, t1, pkg.camera_look_at(aspect=1.5), 96, 64,
+                                        stream=stream)
+                    v, i = pkg.mesh_extract(prm, 12, sdf_id=sdf_id, stream=stream)
+                    bad = pkg.lib.sdfv_fill_grid(None, 0, None, None, None, None)  # sets THIS thread's error text
+                    assert bad == -1
+            stream.synchronize()
+            results[tag] = (t0.cpu().numpy(), rgba.cpu().numpy(), v.cpu().numpy(), i.cpu().numpy(), prm, dims, sdf_id)
+        except Exception as e:  # noqa: BLE001
+            errors.append((tag, repr(e)))
+
+    threads = [threading.Thread(target=work, args=("a", (40, 36, 28), dict(), 0)),
+               threading.Thread(target=work, args=("b", (33, 17, 45), dict(cube_material=1, sphere_radius=0.8), 2))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for tag, (t0, rgba, v, i, prm, dims, sdf_id) in results.items():
+        r0, _ = oracle.fill_dense(oracle.params_from(prm), dims, sdf_id=sdf_id)
+        np.testing.assert_array_equal(t0.view(np.uint32), r0.view(np.uint32))
+        g = pkg.make_grid(dims)
+        s0, s1 = pkg.alloc_textures(g)
+        pkg.fill_grid(prm, g, s0, s1, sdf_id=sdf_id)
+        alone = pkg.raymarch(pkg.default_render_params(g), s0, s1, pkg.camera_look_at(aspect=1.5), 96, 64)
+        np.testing.assert_array_equal(rgba.view(np.uint32), alone.cpu().numpy().view(np.uint32))
+        va, ia = pkg.mesh_extract(prm, 12, sdf_id=sdf_id)
+        np.testing.assert_array_equal(v.view(np.uint32), va.cpu().numpy().view(np.uint32))
+        np.testing.assert_array_equal(i, ia.cpu().numpy())
