@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Whole-workload parity at BASELINE.json's configs[1] and configs[2] (not a unit test: the oracle needs the host's
+cores for tens of seconds).  Every voxel of both textures against the oracle's dense fill, bit for bit, in z-chunks;
+then every pixel of the frame: the pre-shading march record bit for bit, RGBA within 1e-4.
+Usage (GPU box): python tools/full_parity.py [256 512]"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+pkg = importlib.import_module("sdf-viewer_amd")
+import oracle_binding as oracle  # noqa: E402  (checker only)
+
+WORKLOADS = {256: (1920, 1080), 512: (3840, 2160)}
+
+
+def cores():
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
+
+
+def check(side, threads=None, log=print):
+    """-> (differing texture words, {aux field: differing words}, max |RGBA - oracle|)"""
+    threads = threads or cores()
+    if True:
+        W, H = WORKLOADS[side]
+        dims = (side, side, side)
+        prm = pkg.default_params()
+        oprm = oracle.params_from(prm)
+        g = pkg.make_grid(dims)
+        t0, t1 = pkg.alloc_textures(g)
+        pkg.fill_grid(prm, g, t0, t1)
+        torch.cuda.synchronize()
+        h0, h1 = t0.cpu().numpy(), t1.cpu().numpy()
+        t = time.time()
+        bad = 0
+        chunk = 32
+        for z in range(0, side, chunk):
+            r0, r1 = oracle.fill_dense(oprm, dims, z0=z, z1=z + chunk, threads=threads)
+            bad += int((h0[z:z + chunk].view(np.uint32) != r0.view(np.uint32)).sum())
+            bad += int((h1[z:z + chunk].view(np.uint32) != r1.view(np.uint32)).sum())
+        log(f"{side}^3 fill: {side ** 3} voxels x 8 words compared with the oracle in {time.time() - t:.1f} s "
+            f"({threads} threads): {bad} differing words")
+        rp = pkg.default_render_params(g)
+        cam = pkg.camera_look_at(aspect=W / H)
+        dist = pkg.commit_distance(g, t0)
+        rgba, aux = pkg.raymarch(rp, t0, t1, cam, W, H, want_aux=True, dist=dist)
+        torch.cuda.synchronize()
+        t = time.time()
+        want_rgba, want_aux = oracle.raymarch(oracle.copy_struct(oracle.RenderParams, rp), h0, h1,
+                                              oracle.copy_struct(oracle.Camera, cam), W, H, threads=threads)
+        got_aux = aux[0].cpu().numpy().view(oracle.AUX_DTYPE).reshape(H, W)
+        fields = ["status", "steps", "hit_pos", "t", "raw0", "raw1", "normal", "depth"]
+        diff = {f: int((got_aux[f].view(np.uint32) != want_aux[f].view(np.uint32)).sum()) for f in fields}
+        err = float(np.abs(rgba[0].cpu().numpy() - want_rgba).max())
+        hits = int((want_aux["status"] == 1).sum())
+        log(f"{W}x{H} march over {side}^3: {W * H} pixels ({hits} hits, {int(want_aux['steps'].sum())} march steps) "
+            f"compared in {time.time() - t:.1f} s: differing words per aux field {diff}; max |RGBA - oracle| = {err:.3g}")
+        return bad, diff, err
+
+
+def main():
+    for side in [int(a) for a in sys.argv[1:]] or [256, 512]:
+        check(side, log=lambda m: print(m, flush=True))
+
+
+if __name__ == "__main__":
+    main()
