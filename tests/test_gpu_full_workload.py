@@ -11,12 +11,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RGBA_TOL = 1e-4
 
 
-@pytest.mark.parametrize("side", [256, 512])
-def test_whole_grid_and_whole_frame(pkg, oracle, side):
+def load_tool():
     spec = importlib.util.spec_from_file_location("full_parity", os.path.join(ROOT, "tools", "full_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    bad_words, aux_diff, rgba_err = mod.check(side, log=lambda m: None)
+    return mod
+
+
+@pytest.mark.parametrize("side", [256, 512])
+def test_whole_grid_and_whole_frame(pkg, oracle, side):
+    bad_words, aux_diff, rgba_err = load_tool().check(side, log=lambda m: None)
     assert bad_words == 0
     assert all(v == 0 for v in aux_diff.values()), aux_diff
     assert rgba_err <= RGBA_TOL
+
+
+def test_config4_grid_as_eight_slabs_on_one_gpu(pkg, oracle):
+    """1024^3 (68.7 GB of textures) filled slab by slab as the 8 ranks of config 4 would, every voxel against the oracle."""
+    import torch
+    if torch.cuda.mem_get_info()[0] < 80 << 30:
+        pytest.skip("needs 80 GB of free HBM")
+    assert load_tool().check_config4(log=lambda m: None) == 0

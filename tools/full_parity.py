@@ -71,9 +71,40 @@ def check(side, threads=None, log=print):
         return bad, diff, err
 
 
+def check_config4(world=8, side=1024, threads=None, log=print):
+    """BASELINE.json config 4's grid (1024^3 as 8 z-slabs) rehearsed on ONE GPU: every rank's slab filled by the slab
+    path (z_begin/z_end) into its place, all 68.7 GB compared with the oracle on the device, chunk by chunk.
+    -> number of differing 32-slice chunks."""
+    threads = threads or cores()
+    dims = (side, side, side)
+    prm = pkg.default_params()
+    oprm = oracle.params_from(prm)
+    t0 = torch.empty((side, side, side, 4), dtype=torch.float32, device="cuda")
+    t1 = torch.empty_like(t0)
+    t = time.time()
+    for r in range(world):
+        z0, z1 = side * r // world, side * (r + 1) // world
+        pkg.fill_grid(prm, pkg.make_grid(dims, z_begin=z0, z_end=z1), t0[z0:z1], t1[z0:z1])
+    torch.cuda.synchronize()
+    fill_s = time.time() - t
+    t = time.time()
+    bad, chunk = 0, 32
+    for z in range(0, side, chunk):
+        r0, r1 = oracle.fill_dense(oprm, dims, z0=z, z1=z + chunk, threads=threads)
+        same = torch.equal(t0[z:z + chunk].view(torch.int32), torch.from_numpy(r0).cuda().view(torch.int32)) and \
+            torch.equal(t1[z:z + chunk].view(torch.int32), torch.from_numpy(r1).cuda().view(torch.int32))
+        bad += 0 if same else 1
+    log(f"{side}^3 as {world} z-slabs: {side ** 3} voxels filled in {fill_s * 1e3:.1f} ms ({world} launches), compared with "
+        f"the oracle in {time.time() - t:.1f} s ({threads} threads): {bad} of {side // chunk} chunks differ")
+    return bad
+
+
 def main():
-    for side in [int(a) for a in sys.argv[1:]] or [256, 512]:
-        check(side, log=lambda m: print(m, flush=True))
+    for side in [int(a) for a in sys.argv[1:]] or [256, 512, 1024]:
+        if side == 1024:
+            check_config4(log=lambda m: print(m, flush=True))
+        else:
+            check(side, log=lambda m: print(m, flush=True))
 
 
 if __name__ == "__main__":
