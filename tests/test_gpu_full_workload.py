@@ -32,3 +32,33 @@ def test_config4_grid_as_eight_slabs_on_one_gpu(pkg, oracle):
     if torch.cuda.mem_get_info()[0] < 80 << 30:
         pytest.skip("needs 80 GB of free HBM")
     assert load_tool().check_config4(log=lambda m: None) == 0
+
+
+def test_config5_batch_of_64_cameras(pkg, oracle):
+    """BASELINE.json config 5's shape on one GPU: 64 orbit cameras x 1080p over the 256^3 grid in ONE call; every
+    frame within tolerance of the oracle's, four of them also bit for bit before shading."""
+    import numpy as np
+    import torch
+    W, H, n = 1920, 1080, 64
+    prm = pkg.default_params()
+    g = pkg.make_grid((256, 256, 256))
+    t0, t1 = pkg.alloc_textures(g)
+    pkg.fill_grid(prm, g, t0, t1)
+    dist = pkg.commit_distance(g, t0)
+    rp = pkg.default_render_params(g)
+    cams = pkg.orbit_cameras(n, aspect=W / H)
+    rgba = pkg.raymarch(rp, t0, t1, cams, W, H, dist=dist)
+    torch.cuda.synchronize()
+    h0, h1 = t0.cpu().numpy(), t1.cpu().numpy()
+    orp = oracle.copy_struct(oracle.RenderParams, rp)
+    worst = 0.0
+    for k in range(n):
+        want, want_aux = oracle.raymarch(orp, h0, h1, oracle.copy_struct(oracle.Camera, cams[k]), W, H, threads=16,
+                                         want_aux=(k % 16 == 0))
+        worst = max(worst, float(np.abs(rgba[k].cpu().numpy() - want).max()))
+        if k % 16 == 0:
+            _, aux = pkg.raymarch(rp, t0, t1, cams[k], W, H, want_aux=True, dist=dist)
+            got = aux[0].cpu().numpy().view(oracle.AUX_DTYPE).reshape(H, W)
+            for f in ("status", "steps", "hit_pos", "t", "raw0", "raw1", "normal", "depth"):
+                assert (got[f].view(np.uint32) == want_aux[f].view(np.uint32)).all(), (k, f)
+    assert worst <= RGBA_TOL
