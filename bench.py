@@ -294,6 +294,10 @@ def main():
     commit_dt, _ = timed_region(lambda: pkg.commit_distance(rgrid, r0, dist=dist_vol), max(2, min(args.steps, 10)),
                                 torch, dist, world, device)
     commit_ms = commit_dt / max(2, min(args.steps, 10)) * 1e3
+    # the same load as ONE pass: the dense fill also stores the distance volume (sdfv_fill_grid_commit)
+    fused_dt, _ = timed_region(lambda: pkg.fill_grid(prm, rgrid, r0, r1, dist=dist_vol), max(2, min(args.steps, 10)),
+                               torch, dist, world, device)
+    fused_ms = fused_dt / max(2, min(args.steps, 10)) * 1e3
 
     def march_step():
         pkg.raymarch(rp, r0, r1, my_cams, W, H, out=rgba, dist=dist_vol)
@@ -417,6 +421,9 @@ def main():
             "commit_ms": round(commit_ms, 4),
             "commit_note": "device-side SDFViewer::commit (compact distance volume for the march), once per load; "
                            "not part of ms_per_step",
+            "fill_commit_fused_ms": round(fused_ms, 4),
+            "fill_commit_fused_note": "fill + commit of the N=1 grid as one pass (sdfv_fill_grid_commit, 36 B/voxel "
+                                      "stored), what SDFViewer::update uses for a fresh grid; not part of ms_per_step",
             "roofline_raymarch": raymarch_traffic_report(args.workload if world == 1 else None, march_ev_ms / args.steps),
             "batch_raymarch": batch_report,
         }

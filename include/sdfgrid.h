@@ -138,6 +138,11 @@ int sdfv_grid_init(const sdfv_grid *grid, float *tex0, float *tex1, void *stream
 int sdfv_fill_grid(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid,
                    float *tex0, float *tex1, void *stream);
 
+/* sdfv_fill_grid and sdfv_commit_distance in ONE pass: the dense fill also writes the compact distance volume
+ * (dist: DEVICE, one float per voxel of the slab, or NULL = plain sdfv_fill_grid).  +4 B/voxel of stores instead of a
+ * second pass that re-reads tex0 (SDFViewer::update to completion followed by SDFViewer::commit, scene/sdf/mod.rs:128-239). */
+int sdfv_fill_grid_commit(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid, float *tex0,
+                          float *tex1, float *dist, void *stream);
 /* One LoadingManager pass (loading.rs:50-76) with step `step` (a power of two >= 1) over the slab:
  * visits voxels whose x, y and GLOBAL z are multiples of step and applies update_required
  * (scene/sdf/mod.rs:184-190): tex0.r == AIR_DIST, or position inside changed_box (HOST, 6 floats

@@ -75,11 +75,14 @@ def grid_init(grid, tex0, tex1, stream=None):
     check(lib.sdfv_grid_init(C.byref(grid), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"), _stream_ptr(stream)))
 
 
-def fill_grid(params, grid, tex0, tex1, sdf_id=SDF_DEMO, stream=None):
-    """Dense fill = final state of SDFViewer::update (scene/sdf/mod.rs:128-217)."""
+def fill_grid(params, grid, tex0, tex1, sdf_id=SDF_DEMO, stream=None, dist=None):
+    """Dense fill = final state of SDFViewer::update (scene/sdf/mod.rs:128-217).  `dist`: optional [D, H, W] tensor that
+    receives the compact distance volume in the same pass (sdfv_fill_grid_commit)."""
     assert tex0.numel() == slab_voxels(grid) * 4 and tex1.numel() == slab_voxels(grid) * 4
-    check(lib.sdfv_fill_grid(C.byref(params), sdf_id, C.byref(grid), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"),
-                             _stream_ptr(stream)))
+    assert dist is None or dist.numel() == slab_voxels(grid)
+    check(lib.sdfv_fill_grid_commit(C.byref(params), sdf_id, C.byref(grid), _dev_ptr(tex0, "tex0"),
+                                    _dev_ptr(tex1, "tex1"), None if dist is None else _dev_ptr(dist, "dist"),
+                                    _stream_ptr(stream)))
 
 
 def fill_grid_pass(params, grid, step, tex0, tex1, changed_box=None, sdf_id=SDF_DEMO, stream=None):

@@ -77,6 +77,8 @@ PROTOTYPES = {
     "sdfv_grid_init": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_fill_grid": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
+    "sdfv_fill_grid_commit": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
     "sdfv_fill_grid_pass": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_uint32,
                                       C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_sample_points": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_int,

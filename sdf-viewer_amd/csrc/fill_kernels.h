@@ -24,6 +24,7 @@ struct FillArgs {
                              // lives k * z_step slices into the textures (1 everywhere else)
     float4* tex0;
     float4* tex1;
+    float* dist;             // optional compact copy of tex0.r written in the same pass (fused SDFViewer::commit)
 };
 
 struct PassArgs {

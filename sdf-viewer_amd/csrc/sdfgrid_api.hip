@@ -308,18 +308,25 @@ int sdfv_grid_init(const sdfv_grid* grid, float* tex0, float* tex1, void* stream
     return SDFV_OK;
 }
 
-int sdfv_fill_grid(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, float* tex0, float* tex1,
-                   void* stream) {
+int sdfv_fill_grid_commit(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, float* tex0,
+                          float* tex1, float* dist, void* stream) {
     if (int rc = check_params(params, sdf_id)) return rc;
     if (int rc = check_grid(grid)) return rc;
     if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
     if (((uintptr_t)tex0 | (uintptr_t)tex1) & 15) return fail(SDFV_ERR_INVALID_ARGUMENT, "textures must be 16-byte aligned");
+    if ((uintptr_t)dist & 3) return fail(SDFV_ERR_INVALID_ARGUMENT, "dist must be 4-byte aligned");
     if (int rc = need_device()) return rc;
     sdfv::FillArgs a = make_fill_args(*params, sdf_id, *grid, tex0, tex1);
+    a.dist = dist;
     if ((uint64_t)a.H * a.slab_d > 0x7fffffffull || a.W > 0x7fffffffu)
         return fail(SDFV_ERR_INVALID_ARGUMENT, "slab of %u x %u rows is too large for one launch", a.H, a.slab_d);
     SDFV_HIP(sdfv::launch_fill_dense(a, fill_launch_config(), (hipStream_t)stream));
     return SDFV_OK;
+}
+
+int sdfv_fill_grid(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, float* tex0, float* tex1,
+                   void* stream) {
+    return sdfv_fill_grid_commit(params, sdf_id, grid, tex0, tex1, nullptr, stream);
 }
 
 int sdfv_fill_grid_pass(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, uint32_t step,

@@ -145,12 +145,19 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
     // inside one update() call; the LoadingManager is advanced exactly as the passes would have advanced it.
     if (fresh_ && !changed_box && loading_mgr.total_iterations() == 0 && loading_mgr.step_size() != 0 &&
         max_delta_time >= std::chrono::milliseconds(1)) {
-        if (sdfv_fill_grid(&dev->params, dev->sdf_id, &g, tex0_device(), tex1_device(), stream) != 0) {
+        // The grid is complete after this call, so the commit that follows will switch to LINEAR (lod 1) and want the
+        // compact distance volume: let the fill write it in the same pass (+4 B/voxel instead of re-reading tex0).
+        // Until commit() the material still carries the old lod, for which the volume is ignored.
+        const size_t dist_bytes = material.tex0->bytes() / 4;
+        if (!material.dist || material.dist->bytes() != dist_bytes) material.dist = std::make_shared<DeviceBuffer>(dist_bytes);
+        float* dist_out = material.dist->ok() ? material.dist->f32() : nullptr;
+        if (sdfv_fill_grid_commit(&dev->params, dev->sdf_id, &g, tex0_device(), tex1_device(), dist_out, stream) != 0) {
             error_ = sdfv_last_error();
             return 0;
         }
         fresh_ = false;
-        dist_stale_ = true;
+        dist_stale_ = dist_out == nullptr;
+        if (!dist_out) material.dist.reset();
         while (loading_mgr.step_size() != 0) loading_mgr.finish_pass();
         return loading_mgr.total_iterations() - start_iter;
     }

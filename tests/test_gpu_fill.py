@@ -222,3 +222,19 @@ def test_randomised_parameters_and_grids(pkg, oracle):
         pkg.fill_grid_pass(prm, g, 1, p0, p1, sdf_id=sdf_id)
         torch.cuda.synchronize()
         assert torch.equal(p0, t0) and torch.equal(p1, t1), (trial, kw, dims)
+
+
+@pytest.mark.parametrize("dims", [(64, 64, 64), (33, 5, 70), (130, 3, 9), (1, 5, 7), (256, 8, 4)])
+def test_fused_fill_and_commit_writes_the_same_distance_volume(pkg, oracle, dims):
+    """sdfv_fill_grid_commit = sdfv_fill_grid + sdfv_commit_distance in one pass (both index forms, slab offsets)."""
+    prm = pkg.default_params()
+    z0 = dims[2] // 3
+    g = pkg.make_grid(dims, z_begin=z0, z_end=dims[2])
+    t0, t1 = pkg.alloc_textures(g)
+    dist = torch.full(tuple(t0.shape[:-1]), -7.0, dtype=torch.float32, device="cuda")
+    pkg.fill_grid(prm, g, t0, t1, dist=dist)
+    torch.cuda.synchronize()
+    r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, z0=z0, z1=dims[2])
+    assert_bits_equal(t0, r0)
+    assert_bits_equal(t1, r1)
+    assert torch.equal(dist, t0[..., 0]) and torch.equal(dist, pkg.commit_distance(g, t0))
