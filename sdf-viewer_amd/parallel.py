@@ -195,7 +195,9 @@ class SlabFiller:
         self.comm = SlabComm(pkg, rank, world, group) if transport == "rccl" else None
         self.overlap = (transport == "torch" and world > 1 and slab.tex0.is_cuda
                         and (slab.z_end - slab.z_begin) >= 3)
-        self.comm_stream = torch.cuda.Stream(device=slab.tex0.device) if self.overlap else None
+        # highest priority: HIP keeps streams of different priorities on different hardware queues; with equal
+        # priorities the exchange and the interior fill can land on one queue and run back to back
+        self.comm_stream = torch.cuda.Stream(device=slab.tex0.device, priority=-1) if self.overlap else None
         z0, z1 = slab.z_begin, slab.z_end
         self.whole = pkg.make_grid(dims, z_begin=z0, z_end=z1)
         if self.overlap:
