@@ -141,3 +141,17 @@ def test_power_of_two_modulus_identity():
     # symmetric box: max(-m - p, p - m) == |p| - m
     mx = np.float32(1.0)
     np.testing.assert_array_equal(np.maximum(-mx - d, d - mx).view(np.uint32), (np.abs(d) - mx).view(np.uint32))
+
+
+def test_headers_compile_as_plain_c_and_the_library_links(tmp_path):
+    """include/*.h are C headers (the reference's FFI side is `extern "C"` Rust): a C99 program, -pedantic, no C++."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "abi_smoke"
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+           os.path.join(root, "tests", "c", "abi_smoke.c"), "-o", str(exe),
+           "-L", os.path.join(root, "sdf-viewer_amd"), "-lsdfgrid", "-Wl,-rpath," + os.path.join(root, "sdf-viewer_amd")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
