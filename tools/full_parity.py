@@ -31,13 +31,13 @@ def cores():
     return n
 
 
-def check(side, threads=None, log=print):
+def check(side, threads=None, log=print, eye=(2.5, 3.0, 5.0), **param_overrides):
     """-> (differing texture words, {aux field: differing words}, max |RGBA - oracle|)"""
     threads = threads or cores()
     if True:
         W, H = WORKLOADS[side]
         dims = (side, side, side)
-        prm = pkg.default_params()
+        prm = pkg.default_params(**param_overrides)
         oprm = oracle.params_from(prm)
         g = pkg.make_grid(dims)
         t0, t1 = pkg.alloc_textures(g)
@@ -54,7 +54,7 @@ def check(side, threads=None, log=print):
         log(f"{side}^3 fill: {side ** 3} voxels x 8 words compared with the oracle in {time.time() - t:.1f} s "
             f"({threads} threads): {bad} differing words")
         rp = pkg.default_render_params(g)
-        cam = pkg.camera_look_at(aspect=W / H)
+        cam = pkg.camera_look_at(eye=eye, aspect=W / H)
         dist = pkg.commit_distance(g, t0)
         rgba, aux = pkg.raymarch(rp, t0, t1, cam, W, H, want_aux=True, dist=dist)
         torch.cuda.synchronize()
@@ -99,7 +99,31 @@ def check_config4(world=8, side=1024, threads=None, log=print):
     return bad
 
 
+def random_sweep(n, seed=1, log=print):
+    """n random parameter sets and cameras at configs[1]'s full size; -> number of runs with any difference."""
+    rng = np.random.default_rng(seed)
+    failures = 0
+    for k in range(n):
+        kw = dict(cube_half_side=float(rng.integers(20, 101)) / 100.0, sphere_radius=float(np.float32(rng.uniform(0.2, 1.25))),
+                  max_distance_custom_material=float(np.float32(rng.uniform(0.0, 0.25))),
+                  cube_material=int(rng.integers(0, 2)), sphere_material=int(rng.integers(0, 2)),
+                  disable_sphere=int(rng.integers(0, 5) == 0))
+        v = rng.normal(size=3)
+        eye = tuple(float(x) for x in v / np.linalg.norm(v) * rng.uniform(0.3, 6.0))
+        bad, diff, err = check(256, log=lambda m: None, eye=eye, **kw)
+        ok = bad == 0 and not any(diff.values()) and err <= 1e-4
+        failures += 0 if ok else 1
+        log(f"run {k}: {kw} eye {tuple(round(e, 2) for e in eye)} -> texture words {bad}, aux {sum(diff.values())}, rgba {err:.2g}"
+            + ("" if ok else "   <-- MISMATCH"))
+    return failures
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "sweep":
+        n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+        bad = random_sweep(n, log=lambda m: print(m, flush=True))
+        print(f"sweep: {n} random full-size runs, {bad} with differences", flush=True)
+        return
     for side in [int(a) for a in sys.argv[1:]] or [256, 512, 1024]:
         if side == 1024:
             check_config4(log=lambda m: print(m, flush=True))
