@@ -138,8 +138,15 @@ __global__ __launch_bounds__(kBlock) void fill_pass_kernel(FillArgs a, PassArgs 
     const uint64_t n = (uint64_t)p.nx * p.ny * p.nz;
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const uint32_t ix = (uint32_t)(i % p.nx);
-    const uint32_t r = (uint32_t)(i / p.nx);
+    uint32_t ix, r;
+    if (n <= 0xffffffffull) {  // wave-uniform; 32-bit divisions cost a handful of instructions, 64-bit ones ~100
+        const uint32_t i32 = (uint32_t)i;
+        r = i32 / p.nx;
+        ix = i32 - r * p.nx;
+    } else {
+        r = (uint32_t)(i / p.nx);
+        ix = (uint32_t)(i - (uint64_t)r * p.nx);
+    }
     const uint32_t iz = r / p.ny, iy = r - iz * p.ny;
     const uint32_t x = ix * p.step, y = iy * p.step, z = p.z_first + iz * p.step;  // global z
     const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
