@@ -150,6 +150,14 @@ int sdfv_fill_grid_commit(const sdfv_demo_params *params, uint32_t sdf_id, const
 int sdfv_fill_grid_pass(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid,
                         uint32_t step, const float *changed_box,
                         float *tex0, float *tex1, void *stream);
+/* The same pass over textures that come with their compact distance volume (`dist`: DEVICE, one float per voxel, equal
+ * to tex0.r on entry -- as sdfv_fill_grid_commit or sdfv_commit_distance leave it, also right after sdfv_grid_init).
+ * update_required then reads 4 bytes instead of a 16-byte texel, updated voxels rewrite their dist entry, and
+ * tex1.a is written as the AIR_DIST it holds in any grid this library initialised or filled (the reference never
+ * writes it, scene/sdf/mod.rs:205-208) instead of being read back.  Same texels as sdfv_fill_grid_pass; a no-op pass
+ * over a loaded 256^3 grid moves 67 MB instead of 268 MB.  dist == NULL is sdfv_fill_grid_pass. */
+int sdfv_fill_grid_pass_dist(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid, uint32_t step,
+                             const float *changed_box, float *tex0, float *tex1, float *dist, void *stream);
 
 /* ---- batched point sampling (the "Batched sampling" TODO, src/sdf/mod.rs:39) ---- */
 /* points: DEVICE, n x 3 floats.  out: DEVICE, n x sdfv_sample.  SDFSurface::sample(p, distance_only). */

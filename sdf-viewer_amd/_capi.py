@@ -81,6 +81,8 @@ PROTOTYPES = {
                                         C.c_void_p, C.c_void_p]),
     "sdfv_fill_grid_pass": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_uint32,
                                       C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdfv_fill_grid_pass_dist": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_uint32,
+                                           C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_sample_points": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_int,
                                      C.c_void_p, C.c_void_p]),
     "sdfv_normal_points": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_float,

@@ -33,6 +33,10 @@ struct PassArgs {
     uint32_t z_first;        // first visited GLOBAL z (multiple of step, >= z_begin)
     uint32_t has_box;
     float box[6];
+    float approx_scale[3];   // set by the launcher: bb_size / (dim - 1), for the cheap coordinate estimate
+    float approx_margin[3];  // set by the launcher: bound on |estimate - exact voxel coordinate|, with slack
+    float* dist;             // optional compact copy of tex0.r, in sync with tex0: read for update_required
+                             // instead of the 16-byte texel and rewritten with it (nullptr = read tex0 itself)
 };
 
 struct FillLaunch {

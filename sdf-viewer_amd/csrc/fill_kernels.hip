@@ -127,14 +127,57 @@ __global__ __launch_bounds__(kBlock) void fill_dense_flat_kernel(FillArgs a) {
     if (a.dist) a.dist[at] = v0t.x;
 }
 
+// One visited voxel of a LoadingManager pass: update_required (scene/sdf/mod.rs:184-190) and, when it holds, the
+// rewrite of both texels.  `is_air` = the stored tex0.r equals AIR_DIST (read by the caller from tex0 or from the
+// distance volume).
+__device__ __forceinline__ void pass_voxel(const FillArgs& a, const PassArgs& p, uint32_t x, uint32_t y, uint32_t z,
+                                           uint64_t flat, bool is_air) {
+    if (!is_air) {
+        // Most visited voxels of a loaded grid need nothing: leave before paying three correctly rounded divides.
+        if (!p.has_box) return;
+        // Cheap estimate of the voxel's coordinates (one multiply-add per axis); the exact ones differ from it by
+        // less than approx_margin, so a voxel whose estimate is further than that outside the box is outside it.
+        const float ex = (float)x * p.approx_scale[0] + a.bb_min[0];
+        const float ey = (float)y * p.approx_scale[1] + a.bb_min[1];
+        const float ez = (float)z * p.approx_scale[2] + a.bb_min[2];
+        if (ex < p.box[0] - p.approx_margin[0] || ex > p.box[3] + p.approx_margin[0] ||
+            ey < p.box[1] - p.approx_margin[1] || ey > p.box[4] + p.approx_margin[1] ||
+            ez < p.box[2] - p.approx_margin[2] || ez > p.box[5] + p.approx_margin[2])
+            return;
+    }
+    const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
+    const float py = voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]);
+    const float pz = voxel_coord(z, a.dm1[2], a.bb_size[2], a.bb_min[2]);
+    bool update_required = is_air;
+    if (p.has_box) {
+        update_required = update_required ||
+                          (px >= p.box[0] && px <= p.box[3] && py >= p.box[1] && py <= p.box[4] &&
+                           pz >= p.box[2] && pz <= p.box[5]);
+    }
+    if (!update_required) return;
+    // No LDS staging of the colour table in the pass kernels: most workgroups of a pass over a loaded grid have
+    // nothing to update and would pay the staging and its barrier for nothing; the few lookups read the 1 KiB table
+    // through the caches.
+    const LdsLut lut{c_srgb_lut};
+    float4 v0, v1;
+    fill_voxel<RuntimeCfg>(a.prm, a.sdf_id, px, py, pz, lut, a.air_dist, v0, v1);
+    a.tex0[flat] = v0;
+    if (p.dist) {
+        // The volume's contract: the textures were initialised / filled by this library, so tex1.a holds AIR_DIST
+        // everywhere (update() never writes it, scene/sdf/mod.rs:205-208) and need not be read back.
+        p.dist[flat] = v0.x;
+        v1.w = a.air_dist;
+    } else {
+        // tex1.a is not update()'s to touch: carry the stored value through a full 16-byte store (12-byte partial
+        // stores make the memory side read-modify-write the line; ~10 % slower on the step-1 pass)
+        v1.w = reinterpret_cast<const float*>(a.tex1 + flat)[3];
+    }
+    a.tex1[flat] = v1;
+}
+
 // One LoadingManager pass: one thread per visited voxel (x, y, z multiples of `step`; z is GLOBAL), workgroups in
-// memory order like the dense kernel.  Reads tex0.r for update_required (scene/sdf/mod.rs:184-190) and, when an
-// update is required, rewrites tex0 (16 B) and tex1 (16 B, its alpha read back and stored unchanged).
+// memory order like the dense kernel.  Reads tex0.r (or the distance volume's entry) for update_required.
 __global__ __launch_bounds__(kBlock) void fill_pass_kernel(FillArgs a, PassArgs p) {
-    __shared__ float s_lut[256];
-    s_lut[threadIdx.x] = c_srgb_lut[threadIdx.x];
-    __syncthreads();
-    const LdsLut lut{s_lut};
     const uint64_t n = (uint64_t)p.nx * p.ny * p.nz;
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -149,24 +192,38 @@ __global__ __launch_bounds__(kBlock) void fill_pass_kernel(FillArgs a, PassArgs 
     }
     const uint32_t iz = r / p.ny, iy = r - iz * p.ny;
     const uint32_t x = ix * p.step, y = iy * p.step, z = p.z_first + iz * p.step;  // global z
-    const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
-    const float py = voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]);
-    const float pz = voxel_coord(z, a.dm1[2], a.bb_size[2], a.bb_min[2]);
     const uint64_t flat = ((uint64_t)(z - a.z_begin) * a.H + y) * a.W + x;
-    bool update_required = a.tex0[flat].x == a.air_dist;
-    if (p.has_box) {
-        update_required = update_required ||
-                          (px >= p.box[0] && px <= p.box[3] && py >= p.box[1] && py <= p.box[4] &&
-                           pz >= p.box[2] && pz <= p.box[5]);
+    const bool is_air = (p.dist ? p.dist[flat] : a.tex0[flat].x) == a.air_dist;
+    pass_voxel(a, p, x, y, z, flat, is_air);
+}
+
+// The step-1 pass over a grid with its distance volume.  A pass over a loaded grid is bound by per-wave latency (one
+// load, then exit), not by bytes, so each lane answers update_required for FOUR x-neighbours with one 16-byte load of
+// the volume and a wave with nothing to do leaves after that single load (a quarter of the waves, a quarter of the
+// time).  Where there is work, the wave's 256 voxels are processed in four rounds of 64 CONSECUTIVE voxels (lane l
+// takes voxel 64*j + l of the span, its flag fetched from the lane that loaded it), so texel stores stay coalesced.
+// Needs W % 4 == 0, a 16-byte aligned volume and fewer than 2^32 visited voxels.
+__global__ __launch_bounds__(kBlock) void fill_pass_quad_kernel(FillArgs a, PassArgs p) {
+    const uint32_t n_vox = a.W * p.ny * p.nz;  // visited voxels of the slab (step 1: all of them)
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;  // this lane's quad of voxels [4q, 4q + 4)
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t air_bits = 0;
+    if (4 * (uint64_t)q < n_vox) {
+        const float4 d = *reinterpret_cast<const float4*>(p.dist + (size_t)q * 4);
+        air_bits = (d.x == a.air_dist ? 1u : 0u) | (d.y == a.air_dist ? 2u : 0u) | (d.z == a.air_dist ? 4u : 0u) |
+                   (d.w == a.air_dist ? 8u : 0u);
     }
-    if (!update_required) return;
-    float4 v0, v1;
-    fill_voxel<RuntimeCfg>(a.prm, a.sdf_id, px, py, pz, lut, a.air_dist, v0, v1);
-    a.tex0[flat] = v0;
-    // tex1.a is not update()'s to touch: carry the stored value through a full 16-byte store (12-byte partial
-    // stores make the memory side read-modify-write the line; ~10 % slower on the step-1 pass)
-    v1.w = reinterpret_cast<const float*>(a.tex1 + flat)[3];
-    a.tex1[flat] = v1;
+    if (!p.has_box && __ballot(air_bits != 0) == 0ull) return;  // wave-uniform: nothing to update in these 256 voxels
+    const uint32_t span0 = (q - lane) * 4;  // first voxel of the wave's span (flat index within the slab)
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t bits = (uint32_t)__shfl((int)air_bits, (int)(j * 16 + (lane >> 2)));
+        const uint32_t v = span0 + j * 64 + lane;
+        if (v >= n_vox) continue;
+        const uint32_t r = v / a.W, x = v - r * a.W;
+        const uint32_t zl = r / a.H, y = r - zl * a.H;
+        pass_voxel(a, p, x, y, p.z_first + zl, v, ((bits >> (lane & 3)) & 1u) != 0);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void grid_init_kernel(float4* tex0, float4* tex1, uint64_t n, float air) {
@@ -256,12 +313,25 @@ hipError_t launch_fill_dense(const FillArgs& a, const FillLaunch& cfg, hipStream
     return launch_dense_tx<256>(a, cfg, stream);
 }
 
-hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& p, hipStream_t stream) {
-    const uint64_t n = (uint64_t)p.nx * p.ny * p.nz;
+hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& pass, hipStream_t stream) {
+    PassArgs p = pass;
+    for (int i = 0; i < 3; ++i) {
+        // |idx * (size / dm1) + min  -  ((idx / dm1) * size + min)| is a few ulp of the largest intermediate
+        // (<= |size| + |min|); 64 ulp of that is a safe bound, and tiny next to a voxel's extent.
+        p.approx_scale[i] = a.dm1[i] > 0.0f ? a.bb_size[i] / a.dm1[i] : 0.0f;
+        p.approx_margin[i] = 64.0f * 1.1920929e-7f * (fabsf(a.bb_size[i]) + fabsf(a.bb_min[i]));
+        if (!(a.dm1[i] > 0.0f) || !(p.approx_margin[i] >= 0.0f)) p.approx_margin[i] = INFINITY;  // never filter
+    }
+    uint64_t n = (uint64_t)p.nx * p.ny * p.nz;
     if (n == 0) return hipSuccess;
+    const bool quad = p.step == 1 && p.dist && a.W % 4 == 0 && ((uintptr_t)p.dist & 15) == 0 && n < (1ull << 32);
+    if (quad) n = (n + 3) / 4;
     const uint64_t blocks = (n + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fill_pass_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, stream, a, p);
+    if (quad)
+        hipLaunchKernelGGL(fill_pass_quad_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, stream, a, p);
+    else
+        hipLaunchKernelGGL(fill_pass_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, stream, a, p);
     return hipGetLastError();
 }
 

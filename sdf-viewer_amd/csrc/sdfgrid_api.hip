@@ -329,8 +329,8 @@ int sdfv_fill_grid(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_g
     return sdfv_fill_grid_commit(params, sdf_id, grid, tex0, tex1, nullptr, stream);
 }
 
-int sdfv_fill_grid_pass(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, uint32_t step,
-                        const float* changed_box, float* tex0, float* tex1, void* stream) {
+int sdfv_fill_grid_pass_dist(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, uint32_t step,
+                             const float* changed_box, float* tex0, float* tex1, float* dist, void* stream) {
     if (int rc = check_params(params, sdf_id)) return rc;
     if (int rc = check_grid(grid)) return rc;
     if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
@@ -345,9 +345,15 @@ int sdfv_fill_grid_pass(const sdfv_demo_params* params, uint32_t sdf_id, const s
     p.z_first = ((grid->z_begin + step - 1) / step) * step;
     p.nz = p.z_first < grid->z_end ? (grid->z_end - p.z_first + step - 1) / step : 0;
     p.has_box = changed_box != nullptr;
+    p.dist = dist;
     if (changed_box) memcpy(p.box, changed_box, sizeof(p.box));
     SDFV_HIP(sdfv::launch_fill_pass(a, p, (hipStream_t)stream));
     return SDFV_OK;
+}
+
+int sdfv_fill_grid_pass(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, uint32_t step,
+                        const float* changed_box, float* tex0, float* tex1, void* stream) {
+    return sdfv_fill_grid_pass_dist(params, sdf_id, grid, step, changed_box, tex0, tex1, nullptr, stream);
 }
 
 int sdfv_sample_points(const sdfv_demo_params* params, uint32_t sdf_id, const float* points, size_t n,

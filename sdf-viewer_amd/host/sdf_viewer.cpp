@@ -99,6 +99,12 @@ std::unique_ptr<SDFViewer> SDFViewer::new_voxels(std::array<size_t, 3> voxels, c
     if (!v->material.tex0->ok() || !v->material.tex1->ok()) return nullptr;
     const sdfv_grid g = v->grid();
     if (sdfv_grid_init(&g, v->tex0_device(), v->tex1_device(), v->stream) != 0) return nullptr;  // [AIR_DIST; 4]
+    // The compact distance volume (tex0.r, 4 B/voxel) lives next to the textures from the start and every fill keeps
+    // it in sync: passes read it for update_required instead of tex0's 16-byte texels, commit() has nothing to derive.
+    v->material.dist = std::make_shared<DeviceBuffer>(v->material.tex0->bytes() / 4);
+    v->dist_synced_ = v->material.dist->ok() &&
+                      sdfv_commit_distance(&g, v->tex0_device(), v->material.dist->f32(), v->stream) == 0;
+    if (!v->dist_synced_) v->material.dist.reset();  // out of memory: march tex0.r in place, passes read tex0
     return v;
 }
 
@@ -145,19 +151,13 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
     // inside one update() call; the LoadingManager is advanced exactly as the passes would have advanced it.
     if (fresh_ && !changed_box && loading_mgr.total_iterations() == 0 && loading_mgr.step_size() != 0 &&
         max_delta_time >= std::chrono::milliseconds(1)) {
-        // The grid is complete after this call, so the commit that follows will switch to LINEAR (lod 1) and want the
-        // compact distance volume: let the fill write it in the same pass (+4 B/voxel instead of re-reading tex0).
-        // Until commit() the material still carries the old lod, for which the volume is ignored.
-        const size_t dist_bytes = material.tex0->bytes() / 4;
-        if (!material.dist || material.dist->bytes() != dist_bytes) material.dist = std::make_shared<DeviceBuffer>(dist_bytes);
-        float* dist_out = material.dist->ok() ? material.dist->f32() : nullptr;
+        // The fill writes the distance volume in the same pass (+4 B/voxel instead of a second pass over tex0).
+        float* dist_out = dist_synced_ ? material.dist->f32() : nullptr;
         if (sdfv_fill_grid_commit(&dev->params, dev->sdf_id, &g, tex0_device(), tex1_device(), dist_out, stream) != 0) {
             error_ = sdfv_last_error();
             return 0;
         }
         fresh_ = false;
-        dist_stale_ = dist_out == nullptr;
-        if (!dist_out) material.dist.reset();
         while (loading_mgr.step_size() != 0) loading_mgr.finish_pass();
         return loading_mgr.total_iterations() - start_iter;
     }
@@ -174,13 +174,12 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
             box[3] = (*changed_box)[1].x; box[4] = (*changed_box)[1].y; box[5] = (*changed_box)[1].z;
             box_ptr = box;
         }
-        if (sdfv_fill_grid_pass(&dev->params, dev->sdf_id, &g, (uint32_t)step, box_ptr, tex0_device(), tex1_device(),
-                                stream) != 0) {
+        if (sdfv_fill_grid_pass_dist(&dev->params, dev->sdf_id, &g, (uint32_t)step, box_ptr, tex0_device(),
+                                     tex1_device(), dist_synced_ ? material.dist->f32() : nullptr, stream) != 0) {
             error_ = sdfv_last_error();
             break;
         }
         fresh_ = false;
-        dist_stale_ = true;
         loading_mgr.finish_pass();
     }
     return loading_mgr.total_iterations() - start_iter;
@@ -190,21 +189,9 @@ void SDFViewer::commit() {
     // tex0.fill / tex1.fill re-upload nothing here: the textures already live on the device.  (:222-234)
     material.lod_dist_between_samples = std::pow(2.0f, (float)(uint8_t)loading_mgr.passes_left());  // :226
     // lod == 1 switches the GL filter to LINEAR (:227-230): the kernel selects the filter from the same uniform.
-    // Where the reference uploads, derive the raymarch's acceleration data instead: a compact copy of tex0.r.
-    if (material.lod_dist_between_samples == 1.0f) {
-        if (dist_stale_) {
-            const size_t bytes = material.tex0->bytes() / 4;
-            if (!material.dist || material.dist->bytes() != bytes) material.dist = std::make_shared<DeviceBuffer>(bytes);
-            const sdfv_grid g = grid();
-            if (material.dist->ok() && sdfv_commit_distance(&g, tex0_device(), material.dist->f32(), stream) == 0)
-                dist_stale_ = false;
-            else
-                material.dist.reset();  // rendering falls back to marching tex0.r in place
-        }
-    } else {
-        material.dist.reset();
-        dist_stale_ = true;
-    }
+    // Where the reference uploads both textures there is nothing to move, and nothing to derive either: the compact
+    // distance volume the LINEAR march reads has been kept in sync by every fill.  Without one (allocation failed at
+    // creation) the march reads tex0.r in place.
 }
 
 int SDFViewer::download(float* tex0_host, float* tex1_host) const {

@@ -106,7 +106,7 @@ class SDFViewer {
     SDFViewer(std::array<size_t, 3> voxels, const BoundingBox& bb, size_t passes);
     std::string error_;
     bool fresh_ = true;  // both textures still hold new_voxels' AIR_DIST everywhere
-    bool dist_stale_ = true;  // the textures changed since the distance volume was derived
+    bool dist_synced_ = false;  // material.dist exists and mirrors tex0.r (kept so by every fill)
 };
 
 }  // namespace sdfviewer

@@ -222,6 +222,20 @@ def test_randomised_parameters_and_grids(pkg, oracle):
         pkg.fill_grid_pass(prm, g, 1, p0, p1, sdf_id=sdf_id)
         torch.cuda.synchronize()
         assert torch.equal(p0, t0) and torch.equal(p1, t1), (trial, kw, dims)
+        # the same load through the distance-volume passes (quad kernel when the width allows), then a boxed refill
+        pkg.grid_init(g, p0, p1)
+        dvol = pkg.commit_distance(g, p0)
+        for step in (2, 1):
+            pkg.fill_grid_pass(prm, g, step, p0, p1, sdf_id=sdf_id, dist=dvol)
+        torch.cuda.synchronize()
+        assert torch.equal(p0, t0) and torch.equal(p1, t1) and torch.equal(dvol, t0[..., 0]), (trial, kw, dims)
+        other = pkg.default_params(**dict(kw, cube_half_side=min(1.0, kw["cube_half_side"] + 0.07)))
+        box = tuple(float(v) for v in np.concatenate([lo + (hi - lo) * rng.uniform(0.0, 0.5, 3), lo + (hi - lo) * rng.uniform(0.5, 1.0, 3)]))
+        q0, q1 = t0.clone(), t1.clone()
+        pkg.fill_grid_pass(other, g, 1, q0, q1, changed_box=box, sdf_id=sdf_id)
+        pkg.fill_grid_pass(other, g, 1, p0, p1, changed_box=box, sdf_id=sdf_id, dist=dvol)
+        torch.cuda.synchronize()
+        assert torch.equal(p0, q0) and torch.equal(p1, q1) and torch.equal(dvol, p0[..., 0]), (trial, kw, dims, box)
 
 
 @pytest.mark.parametrize("dims", [(64, 64, 64), (33, 5, 70), (130, 3, 9), (1, 5, 7), (256, 8, 4)])
@@ -238,3 +252,64 @@ def test_fused_fill_and_commit_writes_the_same_distance_volume(pkg, oracle, dims
     assert_bits_equal(t0, r0)
     assert_bits_equal(t1, r1)
     assert torch.equal(dist, t0[..., 0]) and torch.equal(dist, pkg.commit_distance(g, t0))
+
+
+def test_progressive_passes_over_the_distance_volume(pkg, oracle):
+    """sdfv_fill_grid_pass_dist: same texels as the plain pass after every pass (fresh load, then a changed_box refill
+    with other parameters), the volume stays equal to tex0.r, tex1.a stays AIR_DIST."""
+    dims = (37, 20, 29)
+    g = pkg.make_grid(dims, (-1.0, -0.75, -1.0), (1.0, 1.0, 0.5))
+    prm = pkg.default_params()
+    a0, a1 = pkg.alloc_textures(g)
+    b0, b1 = pkg.alloc_textures(g)
+    pkg.grid_init(g, a0, a1)
+    pkg.grid_init(g, b0, b1)
+    dist = pkg.commit_distance(g, b0)  # the volume of a freshly initialised grid: AIR_DIST everywhere
+    assert bool((dist == pkg.AIR_DIST).all())
+    for step in (4, 2, 1):
+        pkg.fill_grid_pass(prm, g, step, a0, a1)
+        pkg.fill_grid_pass(prm, g, step, b0, b1, dist=dist)
+        torch.cuda.synchronize()
+        assert torch.equal(a0, b0) and torch.equal(a1, b1) and torch.equal(dist, b0[..., 0])
+    r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, (-1.0, -0.75, -1.0), (1.0, 1.0, 0.5))
+    assert_bits_equal(b0, r0)
+    assert_bits_equal(b1, r1)
+    edited = pkg.default_params(sphere_radius=0.8, cube_material=1)
+    box = (-0.6, -0.5, -0.7, 0.3, 0.9, 0.2)
+    for step in (4, 2, 1):
+        pkg.fill_grid_pass(edited, g, step, a0, a1, changed_box=box)
+        pkg.fill_grid_pass(edited, g, step, b0, b1, changed_box=box, dist=dist)
+        torch.cuda.synchronize()
+        assert torch.equal(a0, b0) and torch.equal(a1, b1) and torch.equal(dist, b0[..., 0])
+    assert not torch.equal(b0, torch.from_numpy(r0).cuda())  # the edit did change voxels inside the box
+    assert bool((b1[..., 3] == pkg.AIR_DIST).all())
+
+
+def test_changed_box_whose_faces_lie_exactly_on_voxel_coordinates(pkg, oracle):
+    """The pass kernel leaves early for voxels that are clearly outside the box (a cheap coordinate estimate with a
+    proven margin) and decides the rest with the exact coordinates: a box bounded by exact voxel coordinates, where
+    `>=` / `<=` (scene/sdf/mod.rs:186-188) flip from one voxel to the next, must refill exactly the oracle's voxels."""
+    dims = (23, 31, 19)
+    bb = ((-1.0, -0.9, -1.3), (0.7, 1.0, 0.4))
+    g = pkg.make_grid(dims, *bb)
+    prm, edited = pkg.default_params(), pkg.default_params(cube_half_side=0.5, sphere_radius=0.6)
+
+    def coord(i, axis):
+        return float(oracle.L.or_voxel_coord(i, dims[axis], bb[0][axis], bb[1][axis]))
+    box = (coord(5, 0), coord(7, 1), coord(3, 2), coord(17, 0), coord(22, 1), coord(11, 2))
+    for use_dist in (False, True):
+        t0, t1 = pkg.alloc_textures(g)
+        dist = torch.empty(tuple(t0.shape[:-1]), dtype=torch.float32, device="cuda") if use_dist else None
+        pkg.fill_grid(prm, g, t0, t1, dist=dist)
+        pkg.fill_grid_pass(edited, g, 1, t0, t1, changed_box=box, dist=dist)
+        torch.cuda.synchronize()
+        # oracle: dense fill with the old parameters, then one viewer update pass with the new ones and the box
+        r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, *bb)
+        lm = oracle.lm_new(dims, 1)
+        oracle.viewer_update(oracle.params_from(edited), dims, lm, r0, r1, changed_box=box, bb_min=bb[0], bb_max=bb[1])
+        assert_bits_equal(t0, r0)
+        assert_bits_equal(t1, r1)
+        n_changed = int((t0.cpu().numpy() != oracle.fill_dense(oracle.params_from(prm), dims, *bb)[0]).any(axis=-1).sum())
+        assert n_changed > 0
+        if use_dist:
+            assert torch.equal(dist, t0[..., 0])

@@ -35,5 +35,14 @@ for side in [int(s) for s in (sys.argv[1:] or ["256"])]:
     ms = timed(lambda: pkg.fill_grid_pass(prm, g, 1, t0, t1)); print(f"pass step 1 (no-op)   {ms:.3f} ms  {nv / ms / 1e3:.0f} Mvisits/s  {nv * 4 / ms / 1e6:.0f} GB/s algorithmic read")
     box = (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5)
     ms = timed(lambda: pkg.fill_grid_pass(prm, g, 1, t0, t1, changed_box=box)); print(f"pass step 1 (box 1/8) {ms:.3f} ms")
+    dist = pkg.commit_distance(g, t0)
+    ms = timed(lambda: pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=dist)); print(f"  with the distance volume: no-op {ms:.3f} ms")
+    ms = timed(lambda: pkg.fill_grid_pass(prm, g, 1, t0, t1, changed_box=box, dist=dist)); print(f"  with the distance volume: box 1/8 {ms:.3f} ms")
+    def fresh():
+        init(); pkg.commit_distance(g, t0, dist=dist)
+    ms = timed(lambda: pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=dist), fresh); print(f"  with the distance volume: step 1 over a fresh grid {ms:.3f} ms")
+    ms = timed(lambda: [pkg.fill_grid_pass(prm, g, s, t0, t1, changed_box=box, dist=dist) for s in (4, 2, 1)]); print(f"  with the distance volume: 3-pass edit of 1/8 of the grid {ms:.3f} ms")
+    pkg.fill_grid(prm, g, t0, t1)
+    ms = timed(lambda: [pkg.fill_grid_pass(prm, g, s, t0, t1, changed_box=box) for s in (4, 2, 1)] + [pkg.commit_distance(g, t0, dist=dist)]); print(f"  without: 3-pass edit + commit {ms:.3f} ms")
     tot = timed(lambda: [pkg.fill_grid_pass(prm, g, s, t0, t1) for s in (2, 1)], init)
     print(f"default 2-pass load  {tot:.3f} ms  {nv / tot / 1e3:.0f} Mvox/s (LoadingManager order, incl. skip pass)")
