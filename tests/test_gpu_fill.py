@@ -254,11 +254,13 @@ def test_fused_fill_and_commit_writes_the_same_distance_volume(pkg, oracle, dims
     assert torch.equal(dist, t0[..., 0]) and torch.equal(dist, pkg.commit_distance(g, t0))
 
 
-def test_progressive_passes_over_the_distance_volume(pkg, oracle):
+@pytest.mark.parametrize("dims,z_range", [((37, 20, 29), (0, 29)), ((40, 12, 29), (0, 29)), ((40, 12, 29), (7, 22)),
+                                          ((8, 3, 5), (1, 4))])
+def test_progressive_passes_over_the_distance_volume(pkg, oracle, dims, z_range):
     """sdfv_fill_grid_pass_dist: same texels as the plain pass after every pass (fresh load, then a changed_box refill
-    with other parameters), the volume stays equal to tex0.r, tex1.a stays AIR_DIST."""
-    dims = (37, 20, 29)
-    g = pkg.make_grid(dims, (-1.0, -0.75, -1.0), (1.0, 1.0, 0.5))
+    with other parameters), the volume stays equal to tex0.r, tex1.a stays AIR_DIST.  Widths that take the quad
+    kernel (W % 4 == 0) and widths that do not, whole grids and z-slabs."""
+    g = pkg.make_grid(dims, (-1.0, -0.75, -1.0), (1.0, 1.0, 0.5), *z_range)
     prm = pkg.default_params()
     a0, a1 = pkg.alloc_textures(g)
     b0, b1 = pkg.alloc_textures(g)
@@ -271,7 +273,7 @@ def test_progressive_passes_over_the_distance_volume(pkg, oracle):
         pkg.fill_grid_pass(prm, g, step, b0, b1, dist=dist)
         torch.cuda.synchronize()
         assert torch.equal(a0, b0) and torch.equal(a1, b1) and torch.equal(dist, b0[..., 0])
-    r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, (-1.0, -0.75, -1.0), (1.0, 1.0, 0.5))
+    r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, (-1.0, -0.75, -1.0), (1.0, 1.0, 0.5), *z_range)
     assert_bits_equal(b0, r0)
     assert_bits_equal(b1, r1)
     edited = pkg.default_params(sphere_radius=0.8, cube_material=1)
