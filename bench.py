@@ -270,10 +270,14 @@ def main():
 
     for _ in range(args.warmup):
         fill_step()
-    fill_dt, _ = timed_region(fill_step, args.steps, torch, dist, world, device)
-    # dominant kernel alone (no halo), HIP events on the launch stream
-    _, kern_ms_total = timed_region(fill_only, args.steps, torch, dist, world, device)
-    kern_ms = kern_ms_total / args.steps
+    fill_dt, fill_ev_ms = timed_region(fill_step, args.steps, torch, dist, world, device)
+    # dominant kernel alone, HIP events on the launch stream.  At N = 1 a step IS one launch of that kernel, so the
+    # events of the timed region itself are used; at N > 1 (boundary/interior launches + halo) it gets its own region.
+    if world == 1:
+        kern_ms = fill_ev_ms / args.steps
+    else:
+        _, kern_ms_total = timed_region(fill_only, args.steps, torch, dist, world, device)
+        kern_ms = kern_ms_total / args.steps
     total_voxels = voxels_per_rank * world  # identical per rank by construction
     fill_mvox = total_voxels * args.steps / fill_dt / 1e6
     achieved_gbs = FILL_BYTES_PER_VOXEL * voxels_per_rank / (kern_ms * 1e-3) / 1e9
