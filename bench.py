@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--halo-transport", choices=["auto", "rccl", "torch"], default="auto",
                     help="N>1: rccl = sdfv_slab_fill_step over the library's own RCCL communicator (default under "
                          "nccl), torch = torch.distributed P2P ops")
+    ap.add_argument("--prewarm-ms", type=float, default=250.0,
+                    help="untimed busy period before the warm-up steps of each timed region (device clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the extra 64-camera batch (profiling runs)")
     ap.add_argument("--batch-split", choices=["cameras", "rows"], default="cameras",
@@ -58,6 +60,34 @@ def parse_args():
                          "rows of every camera (BASELINE.json config 5's image-tile split)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     return ap.parse_args()
+
+
+PREWARM_S = 0.25  # --prewarm-ms
+
+
+def prewarm(fn, torch, dist=None, world=1, device=None, seconds=None):
+    """Untimed: keep the device busy with `fn` for ~0.25 s so that the timed steps run at the clocks a busy GPU runs at.
+    The MI355X idles at a few hundred MHz and needs ~10 ms of load to ramp (tools/clock_ramp.py: the first 8 ms of
+    256^3 fills after an idle period are 9 % slower than the steady state, and on some boxes the rate keeps drifting
+    for about a second: tools/tex_skew_sweep.py); a few warm-up steps of 0.1 ms each do not get it there.  At N > 1 the steps contain exchanges, so every rank must make the SAME number of calls: the
+    count is agreed on (MAX over ranks) before the loop."""
+    seconds = PREWARM_S if seconds is None else seconds
+    if seconds <= 0:
+        return
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    one = max(time.perf_counter() - t0, 1e-5)
+    n = min(2000, int(seconds / one) + 1)
+    if world > 1:
+        t = torch.tensor([n], dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n = int(t.item())
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
 
 
 def timed_region(fn, steps, torch, dist, world, device):
@@ -205,7 +235,9 @@ def raymarch_traffic_report(workload_key, launch_ms):
 
 
 def main():
+    global PREWARM_S
     args = parse_args()
+    PREWARM_S = args.prewarm_ms / 1e3
     import torch
     import torch.distributed as dist
     pkg = importlib.import_module("sdf-viewer_amd")
@@ -268,6 +300,7 @@ def main():
     def fill_only():
         pkg.fill_grid(prm, grid, owned0, owned1)
 
+    prewarm(fill_step, torch, dist, world, device)
     for _ in range(args.warmup):
         fill_step()
     fill_dt, fill_ev_ms = timed_region(fill_step, args.steps, torch, dist, world, device)
@@ -306,6 +339,7 @@ def main():
     def march_step():
         pkg.raymarch(rp, r0, r1, my_cams, W, H, out=rgba, dist=dist_vol)
 
+    prewarm(march_step, torch, dist, world, device)
     for _ in range(args.warmup):
         march_step()
     march_dt, march_ev_ms = timed_region(march_step, args.steps, torch, dist, world, device)
@@ -395,6 +429,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_ms": args.prewarm_ms,
             "ms_per_step": round((fill_dt + march_dt) / args.steps * 1e3, 4),
             "ms_per_step_fill": round(fill_dt / args.steps * 1e3, 4),
             "ms_per_step_raymarch": round(march_dt / args.steps * 1e3, 4),
