@@ -118,12 +118,51 @@ struct MeshScratch {
 };
 thread_local MeshScratch g_mesh_scratch;  // freed by sdfv_mesh_trim(); a thread that exits without it leaks the block
 
+// Per-point callers (the reference's ffi.rs ABI: one sample() per call) would otherwise pay two hipMalloc/hipFree per
+// point.  Small requests of the *_host conveniences run through a per-thread staging area instead: a device block
+// and a pinned host block allocated once, asynchronous copies on the null stream, one synchronisation.
+struct SmallStage {
+    static constexpr size_t kBytes = 64 << 10;  // in + out of up to 1024 points
+    char* dev = nullptr;
+    char* host = nullptr;
+    bool ensure() {
+        if (dev && host) return true;
+        if (!dev && hipMalloc((void**)&dev, kBytes) != hipSuccess) dev = nullptr;
+        if (!host && hipHostMalloc((void**)&host, kBytes, hipHostMallocDefault) != hipSuccess) host = nullptr;
+        return dev && host;
+    }
+};
+thread_local SmallStage g_stage;  // never freed: lives as long as the thread's device context
+
 struct DeviceBuf {
     void* p = nullptr;
     ~DeviceBuf() {
         if (p) (void)hipFree(p);
     }
 };
+
+// Runs `enqueue(dev_in, dev_out)` over host buffers: in_bytes up, out_bytes down.  Small requests use the per-thread
+// staging area, large ones a pair of temporary device buffers.
+template <typename Enqueue>
+int run_over_host_buffers(const void* in_host, size_t in_bytes, void* out_host, size_t out_bytes, Enqueue enqueue) {
+    const size_t in_up = (in_bytes + 255) & ~(size_t)255;
+    if (in_up + out_bytes <= SmallStage::kBytes && g_stage.ensure()) {
+        memcpy(g_stage.host, in_host, in_bytes);
+        SDFV_HIP(hipMemcpyAsync(g_stage.dev, g_stage.host, in_bytes, hipMemcpyHostToDevice, nullptr));
+        if (int rc = enqueue(g_stage.dev, g_stage.dev + in_up)) return rc;
+        SDFV_HIP(hipMemcpyAsync(g_stage.host + in_up, g_stage.dev + in_up, out_bytes, hipMemcpyDeviceToHost, nullptr));
+        SDFV_HIP(hipStreamSynchronize(nullptr));
+        memcpy(out_host, g_stage.host + in_up, out_bytes);
+        return SDFV_OK;
+    }
+    DeviceBuf din, dout;
+    SDFV_HIP(hipMalloc(&din.p, in_bytes));
+    SDFV_HIP(hipMalloc(&dout.p, out_bytes));
+    SDFV_HIP(hipMemcpy(din.p, in_host, in_bytes, hipMemcpyHostToDevice));
+    if (int rc = enqueue(din.p, dout.p)) return rc;
+    SDFV_HIP(hipMemcpy(out_host, dout.p, out_bytes, hipMemcpyDeviceToHost));
+    return SDFV_OK;
+}
 
 // Everything RaymarchArgs derives from the render parameters alone (exactness flags, tap sizes, cull sphere).
 void derive_raymarch_args(const sdfv_render_params* rp, sdfv::RaymarchArgs& a) {
@@ -614,14 +653,9 @@ int sdfv_sample_points_host(const sdfv_demo_params* params, uint32_t sdf_id, con
     if (int rc = check_params(params, sdf_id)) return rc;
     if (int rc = need_device()) return rc;
     if (n == 0) return SDFV_OK;
-    DeviceBuf dp, ds;
-    SDFV_HIP(hipMalloc(&dp.p, n * 12));
-    SDFV_HIP(hipMalloc(&ds.p, n * sizeof(sdfv_sample)));
-    SDFV_HIP(hipMemcpy(dp.p, points_host, n * 12, hipMemcpyHostToDevice));
-    if (int rc = sdfv_sample_points(params, sdf_id, (const float*)dp.p, n, distance_only, (sdfv_sample*)ds.p, nullptr))
-        return rc;
-    SDFV_HIP(hipMemcpy(out_host, ds.p, n * sizeof(sdfv_sample), hipMemcpyDeviceToHost));
-    return SDFV_OK;
+    return run_over_host_buffers(points_host, n * 12, out_host, n * sizeof(sdfv_sample), [&](void* in, void* out) {
+        return sdfv_sample_points(params, sdf_id, (const float*)in, n, distance_only, (sdfv_sample*)out, nullptr);
+    });
 }
 
 int sdfv_normal_points_host(const sdfv_demo_params* params, uint32_t sdf_id, const float* points_host, size_t n,
@@ -630,13 +664,9 @@ int sdfv_normal_points_host(const sdfv_demo_params* params, uint32_t sdf_id, con
     if (int rc = check_params(params, sdf_id)) return rc;
     if (int rc = need_device()) return rc;
     if (n == 0) return SDFV_OK;
-    DeviceBuf dp, dn;
-    SDFV_HIP(hipMalloc(&dp.p, n * 12));
-    SDFV_HIP(hipMalloc(&dn.p, n * 12));
-    SDFV_HIP(hipMemcpy(dp.p, points_host, n * 12, hipMemcpyHostToDevice));
-    if (int rc = sdfv_normal_points(params, sdf_id, (const float*)dp.p, n, eps, use_default, (float*)dn.p, nullptr)) return rc;
-    SDFV_HIP(hipMemcpy(out_host, dn.p, n * 12, hipMemcpyDeviceToHost));
-    return SDFV_OK;
+    return run_over_host_buffers(points_host, n * 12, out_host, n * 12, [&](void* in, void* out) {
+        return sdfv_normal_points(params, sdf_id, (const float*)in, n, eps, use_default, (float*)out, nullptr);
+    });
 }
 
 int sdfv_mesh_postproc_host(const sdfv_demo_params* params, uint32_t sdf_id, sdfv_vertex* vertices_host, size_t n) {
