@@ -53,6 +53,9 @@ def parse_args():
                          "nccl), torch = torch.distributed P2P ops")
     ap.add_argument("--prewarm-ms", type=float, default=250.0,
                     help="untimed busy period before the warm-up steps of each timed region (device clock ramp)")
+    ap.add_argument("--no-tuned-placement", action="store_true",
+                    help="allocate tex0 and tex1 separately instead of letting sdfv_tune_texture_placement choose the "
+                         "distance between them inside one block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the extra 64-camera batch (profiling runs)")
     ap.add_argument("--batch-split", choices=["cameras", "rows"], default="cameras",
@@ -269,7 +272,7 @@ def main():
 
     # ---------------- fill: side^3 voxels per rank, z-slab of the weak-scaled global grid ----------------
     gdims = par.weak_scaling_dims(side, world, args.weak_geometry)
-    slab = par.alloc_slab(gdims, rank, world, device)
+    slab = par.alloc_slab(gdims, rank, world, device, pkg=None if args.no_tuned_placement else pkg)
     grid = pkg.make_grid(gdims, z_begin=slab.z_begin, z_end=slab.z_end)
     owned0, owned1 = slab.owned0, slab.owned1
     voxels_per_rank = pkg.slab_voxels(grid)
@@ -430,6 +433,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "prewarm_ms": args.prewarm_ms,
+            "texture_placement": "separate allocations" if args.no_tuned_placement else
+                                 f"one block, tex1 {slab.tex1.data_ptr() - slab.tex0.data_ptr() - slab.tex0.numel() * 4} B "
+                                 "after tex0's end (sdfv_tune_texture_placement)",
             "ms_per_step": round((fill_dt + march_dt) / args.steps * 1e3, 4),
             "ms_per_step_fill": round(fill_dt / args.steps * 1e3, 4),
             "ms_per_step_raymarch": round(march_dt / args.steps * 1e3, 4),

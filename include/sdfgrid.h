@@ -138,6 +138,18 @@ int sdfv_grid_init(const sdfv_grid *grid, float *tex0, float *tex1, void *stream
 int sdfv_fill_grid(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid,
                    float *tex0, float *tex1, void *stream);
 
+/* Placement of the two textures inside ONE caller-owned device block.  The dense fill advances two store streams in
+ * lockstep (tex0 and tex1, the same offset into each); how fast the memory system takes them depends on the distance
+ * between the two bases -- reproducibly, by up to 12 % (256^3: tex1 starting 0 / 4 / 12 KiB after tex0's end:
+ * 0.0886 / 0.0826 / 0.0783 ms; 512^3 prefers 0) -- in a way that follows the device's address hashing, not a rule a
+ * caller could know.  This helper measures: it times the dense fill of `grid` (default demo parameters, a handful of
+ * launches per candidate) for a few small skews and returns the byte offsets of the fastest placement.  `block`:
+ * DEVICE, 16-byte aligned, at least 2 * texture_bytes + SDFV_PLACEMENT_SLACK bytes; its contents are overwritten.
+ * Synchronises `stream`.  Optional: any 16-byte aligned pair of pointers is a valid placement. */
+#define SDFV_PLACEMENT_SLACK (64u << 10)
+int sdfv_tune_texture_placement(const sdfv_grid *grid, void *block, size_t block_bytes, size_t *tex0_offset,
+                                size_t *tex1_offset, void *stream);
+
 /* sdfv_fill_grid and sdfv_commit_distance in ONE pass: the dense fill also writes the compact distance volume
  * (dist: DEVICE, one float per voxel of the slab, or NULL = plain sdfv_fill_grid).  +4 B/voxel of stores instead of a
  * second pass that re-reads tex0 (SDFViewer::update to completion followed by SDFViewer::commit, scene/sdf/mod.rs:128-239). */

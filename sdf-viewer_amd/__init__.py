@@ -52,11 +52,22 @@ def slab_voxels(grid):
     return int(grid.dims[0]) * int(grid.dims[1]) * (int(grid.z_end) - int(grid.z_begin))
 
 
-def alloc_textures(grid, device="cuda"):
-    """Two RGBA32F textures for the slab described by `grid` (uninitialised device memory)."""
+def alloc_textures(grid, device="cuda", tuned=False):
+    """Two RGBA32F textures for the slab described by `grid` (uninitialised device memory).
+    tuned=True: both live in one block and sdfv_tune_texture_placement picks the distance between them (the dense
+    fill's two store streams run up to 12 % faster or slower depending on it); the probe overwrites their contents."""
     shape = (int(grid.z_end) - int(grid.z_begin), int(grid.dims[1]), int(grid.dims[0]), 4)
-    return (torch.empty(shape, dtype=torch.float32, device=device),
-            torch.empty(shape, dtype=torch.float32, device=device))
+    n = shape[0] * shape[1] * shape[2] * 4
+    if not tuned or n == 0:
+        return (torch.empty(shape, dtype=torch.float32, device=device),
+                torch.empty(shape, dtype=torch.float32, device=device))
+    block = torch.empty(2 * n + _capi.PLACEMENT_SLACK // 4, dtype=torch.float32, device=device)
+    o0, o1 = C.c_size_t(), C.c_size_t()
+    with torch.cuda.device(block.device):
+        check(lib.sdfv_tune_texture_placement(C.byref(grid), C.c_void_p(block.data_ptr()), block.numel() * 4,
+                                              C.byref(o0), C.byref(o1), _stream_ptr()))
+    a, b = o0.value // 4, o1.value // 4
+    return block[a:a + n].view(shape), block[b:b + n].view(shape)
 
 
 def _stream_ptr(stream=None):

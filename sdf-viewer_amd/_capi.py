@@ -77,6 +77,8 @@ PROTOTYPES = {
     "sdfv_grid_init": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_fill_grid": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
+    "sdfv_tune_texture_placement": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                              C.POINTER(C.c_size_t), C.c_void_p]),
     "sdfv_fill_grid_commit": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
     "sdfv_fill_grid_pass": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_uint32,
@@ -121,6 +123,7 @@ PROTOTYPES = {
     "sdfv_slab_fill_step": (C.c_int, [C.c_void_p, C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
 }
+PLACEMENT_SLACK = 64 << 10
 COMM_ID_BYTES = 128
 COMM_PERIODIC = 1
 

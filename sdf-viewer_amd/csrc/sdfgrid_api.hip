@@ -363,6 +363,72 @@ int sdfv_fill_grid_commit(const sdfv_demo_params* params, uint32_t sdf_id, const
     return SDFV_OK;
 }
 
+int sdfv_tune_texture_placement(const sdfv_grid* grid, void* block, size_t block_bytes, size_t* tex0_offset,
+                                size_t* tex1_offset, void* stream) {
+    if (!tex0_offset || !tex1_offset) return fail(SDFV_ERR_INVALID_ARGUMENT, "offset pointer is NULL");
+    if (int rc = check_grid(grid)) return rc;
+    if (!block || ((uintptr_t)block & 15)) return fail(SDFV_ERR_INVALID_ARGUMENT, "block must be a 16-byte aligned device pointer");
+    const size_t tex_bytes = (size_t)grid->dims[0] * grid->dims[1] * (grid->z_end - grid->z_begin) * 16;
+    *tex0_offset = 0;
+    *tex1_offset = tex_bytes;
+    if (block_bytes < 2 * tex_bytes + SDFV_PLACEMENT_SLACK)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "block of %zu bytes is smaller than 2 x %zu + %u", block_bytes, tex_bytes,
+                    SDFV_PLACEMENT_SLACK);
+    if (tex_bytes == 0) return SDFV_OK;
+    if (int rc = need_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    sdfv_demo_params prm;
+    sdfv_demo_params_default(&prm);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    SDFV_HIP(hipEventCreate(&e0));
+    hipError_t err = hipEventCreate(&e1);
+    if (err != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return hip_fail(err, "hipEventCreate");
+    }
+    constexpr int kCandidates = 8;
+    const size_t skews[kCandidates] = {0, 4096, 8192, 12288, 20480, 28672, 36864, 53248};
+    float total_ms[kCandidates] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int rc = SDFV_OK;
+    int timed = 8;  // launches per measurement; raised below so that one measurement lasts about 3 ms
+    // Two interleaved rounds over the candidates (drift of the device's clocks then hits all of them alike); the first
+    // measurement of all also warms the device up and sizes the others, and is not counted.
+    for (int round = -1; round < 2 && rc == SDFV_OK && err == hipSuccess; ++round) {
+        for (int c = 0; c < (round < 0 ? 1 : kCandidates) && rc == SDFV_OK && err == hipSuccess; ++c) {
+            float* t0 = reinterpret_cast<float*>(block);
+            float* t1 = reinterpret_cast<float*>(static_cast<char*>(block) + tex_bytes + skews[c]);
+            const int warm = 3;
+            for (int i = 0; i < warm + timed && rc == SDFV_OK; ++i) {
+                if (i == warm) err = hipEventRecord(e0, st);
+                rc = sdfv_fill_grid(&prm, SDFV_SDF_DEMO, grid, t0, t1, st);
+            }
+            if (rc != SDFV_OK) break;
+            if (err == hipSuccess) err = hipEventRecord(e1, st);
+            if (err == hipSuccess) err = hipEventSynchronize(e1);
+            float ms = 0.0f;
+            if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+            if (err != hipSuccess) break;
+            if (round < 0) {
+                const float per_launch = ms / (float)timed;
+                if (per_launch > 0.0f) timed = (int)fminf(64.0f, fmaxf(8.0f, 3.0f / per_launch));
+            } else {
+                total_ms[c] += ms;
+            }
+        }
+    }
+    if (rc == SDFV_OK && err == hipSuccess) {
+        int best = 0;
+        for (int c = 1; c < kCandidates; ++c)
+            if (total_ms[c] < total_ms[best]) best = c;
+        *tex1_offset = tex_bytes + skews[best];
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != SDFV_OK) return rc;
+    if (err != hipSuccess) return hip_fail(err, "placement probe");
+    return SDFV_OK;
+}
+
 int sdfv_fill_grid(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, float* tex0, float* tex1,
                    void* stream) {
     return sdfv_fill_grid_commit(params, sdf_id, grid, tex0, tex1, nullptr, stream);

@@ -64,13 +64,19 @@ class SlabTextures:
         return self.tex1[self.ghost_lo:self.ghost_lo + (self.z_end - self.z_begin)]
 
 
-def alloc_slab(dims, rank, world, device, fill_value=None, periodic=False):
+def alloc_slab(dims, rank, world, device, fill_value=None, periodic=False, pkg=None):
+    """pkg given (and a GPU device): the two textures share one block and sdfv_tune_texture_placement chooses the
+    distance between them (see pkg.alloc_textures(tuned=True))."""
     z0, z1 = slab_range(dims[2], rank, world)
     glo = 1 if (periodic or rank > 0) else 0
     ghi = 1 if (periodic or rank < world - 1) else 0
     shape = (glo + (z1 - z0) + ghi, dims[1], dims[0], 4)
-    t0 = torch.empty(shape, dtype=torch.float32, device=device)
-    t1 = torch.empty(shape, dtype=torch.float32, device=device)
+    if pkg is not None and torch.device(device).type == "cuda":
+        with torch.cuda.device(torch.device(device)):
+            t0, t1 = pkg.alloc_textures(pkg.make_grid((dims[0], dims[1], shape[0])), device=device, tuned=True)
+    else:
+        t0 = torch.empty(shape, dtype=torch.float32, device=device)
+        t1 = torch.empty(shape, dtype=torch.float32, device=device)
     if fill_value is not None:
         t0.fill_(fill_value)
         t1.fill_(fill_value)

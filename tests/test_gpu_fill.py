@@ -315,3 +315,25 @@ def test_changed_box_whose_faces_lie_exactly_on_voxel_coordinates(pkg, oracle):
         assert n_changed > 0
         if use_dist:
             assert torch.equal(dist, t0[..., 0])
+
+
+def test_tuned_texture_placement(pkg, oracle):
+    """sdfv_tune_texture_placement only chooses WHERE tex1 starts inside a shared block: 16-byte aligned, no overlap,
+    inside the block; a fill into the tuned pair gives the usual texels."""
+    import ctypes as C
+    dims = (64, 48, 40)
+    g = pkg.make_grid(dims)
+    t0, t1 = pkg.alloc_textures(g, tuned=True)
+    n_bytes = dims[0] * dims[1] * dims[2] * 16
+    gap = t1.data_ptr() - t0.data_ptr() - n_bytes
+    assert 0 <= gap <= pkg._capi.PLACEMENT_SLACK and gap % 16 == 0 and t1.data_ptr() % 16 == 0
+    prm = pkg.default_params(cube_material=1)
+    pkg.fill_grid(prm, g, t0, t1)
+    torch.cuda.synchronize()
+    r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims)
+    assert_bits_equal(t0, r0)
+    assert_bits_equal(t1, r1)
+    small = torch.empty(1024, device="cuda")
+    o0, o1 = C.c_size_t(), C.c_size_t()
+    assert pkg.lib.sdfv_tune_texture_placement(C.byref(g), C.c_void_p(small.data_ptr()), 4096, C.byref(o0), C.byref(o1), None) == -1
+    assert b"smaller than" in pkg.lib.sdfv_last_error()
