@@ -79,8 +79,25 @@ int SDFViewerMaterial::render(const Camera& camera, float* rgba_device, sdfv_mar
 SDFViewer::SDFViewer(std::array<size_t, 3> voxels, const BoundingBox& bb, size_t passes)
     : loading_mgr(voxels, passes), bounding_box(bb) {
     const size_t bytes = voxels[0] * voxels[1] * voxels[2] * 16;
-    material.tex0 = std::make_shared<DeviceBuffer>(bytes);
-    material.tex1 = std::make_shared<DeviceBuffer>(bytes);
+    // Both textures in one block, tex1 where sdfv_tune_texture_placement finds the dense fill's two store streams
+    // run fastest (they differ by up to 9-12 % with the distance between the bases).  If the block cannot be had,
+    // two plain allocations do.
+    block_ = std::make_shared<DeviceBuffer>(2 * bytes + SDFV_PLACEMENT_SLACK);
+    size_t o0 = 0, o1 = bytes;
+    if (bytes > 0 && block_->ok()) {
+        sdfv_grid g{};
+        for (int i = 0; i < 3; ++i) g.dims[i] = (uint32_t)voxels[i];
+        g.bb_min[0] = g.bb_min[1] = g.bb_min[2] = -1.0f;
+        g.bb_max[0] = g.bb_max[1] = g.bb_max[2] = 1.0f;
+        g.z_end = g.dims[2];
+        (void)sdfv_tune_texture_placement(&g, block_->get(), block_->bytes(), &o0, &o1, stream);  // failure keeps 0 / bytes
+        material.tex0 = std::make_shared<DeviceBuffer>(static_cast<char*>(block_->get()) + o0, bytes);
+        material.tex1 = std::make_shared<DeviceBuffer>(static_cast<char*>(block_->get()) + o1, bytes);
+    } else {
+        block_.reset();
+        material.tex0 = std::make_shared<DeviceBuffer>(bytes);
+        material.tex1 = std::make_shared<DeviceBuffer>(bytes);
+    }
     material.tex_size = {(uint32_t)voxels[0], (uint32_t)voxels[1], (uint32_t)voxels[2]};
     material.voxels_bounds = bb;
 }

@@ -107,6 +107,7 @@ class SDFViewer {
     std::string error_;
     bool fresh_ = true;  // both textures still hold new_voxels' AIR_DIST everywhere
     bool dist_synced_ = false;  // material.dist exists and mirrors tex0.r (kept so by every fill)
+    std::shared_ptr<DeviceBuffer> block_;  // owns tex0 and tex1 when they share one tuned allocation
 };
 
 }  // namespace sdfviewer

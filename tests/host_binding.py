@@ -5,6 +5,11 @@ import os
 
 import numpy as np
 
+try:  # the GPU tests mix this library with torch in one process: torch bundles its own HIP/HSA runtime, and whichever
+    import torch  # noqa: F401  runtime is loaded first serves both -- ROCm's first leaves torch without devices
+except ImportError:  # pragma: no cover
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 H = C.CDLL(os.path.join(ROOT, "sdf-viewer_amd", "libsdfviewer_host.so"))
 PROVIDER_PATH = os.path.join(ROOT, "sdf-viewer_amd", "libsdfdemo_provider.so")
