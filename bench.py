@@ -286,7 +286,10 @@ def main():
     if transport == "rccl":
         try:
             filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="rccl")
+            filler.step()  # a first step, so that a communicator that cannot exchange shows up here, not mid-run
+            torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001 -- reported, then decided collectively below
+            filler = None
             print(f"[bench rank {rank}] library communicator unavailable: {e}", file=sys.stderr, flush=True)
         if world > 1:
             ok = torch.tensor([1 if filler is not None else 0], device=device if backend == "nccl" else "cpu")
