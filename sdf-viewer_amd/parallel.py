@@ -242,7 +242,8 @@ class ShardedMarch:
     """One rank's side of the raymarch over a z-sharded grid (sdfv_raymarch_slab): the grid stays where the fill put
     it, rays are handed between z-neighbours.  `round(incoming)` runs one round and returns the rays leaving through
     the low and the high face of the slab; after `world` rounds every ray has ended on exactly one rank and the image
-    is the merge of the ranks' images (all-zero bits except on the rank the ray ended on) (`raymarch_sharded` below drives it over torch.distributed)."""
+    is the merge of the ranks' images (all-zero bits except on the rank the ray ended on).  `raymarch_sharded` below
+    drives it over torch.distributed."""
 
     def __init__(self, pkg, rp, grid, slab, camera, width, height, want_aux=False):
         self.pkg, self.rp, self.grid, self.slab, self.camera = pkg, rp, grid, slab, camera
