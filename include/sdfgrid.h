@@ -252,8 +252,9 @@ int sdfv_raymarch_accel(const sdfv_render_params *rp, const float *tex0, const f
  * that rank writes the pixel, all others leave it all-zero bits, and the image is their merge (OR, or integer sum, of the bit patterns).
  * The arithmetic and its order are those of sdfv_raymarch: the merged image is bit-identical to the single-GPU one.
  * Restrictions: loaded grids only (lod_dist_between_samples == 1), boxes large enough that a marching ray's
- * floor(w) stays in [-1, D-1] (1e-4 * N / size <= 0.25), one camera per call; aux.normal is left (0,0,0) (its
- * taps can reach one slice past the halo). */
+ * floor(w) stays in [-1, D-1] (1e-4 * N / size <= 0.25), one camera per call.  aux.normal needs the slices around its
+ * four taps, which can be one further up than the march's own fetch: it is filled where a SECOND upper ghost slice
+ * (ghost_hi = 2) makes them resident, and left (0,0,0) otherwise -- the one-voxel halo suffices for RGBA. */
 typedef struct sdfv_ray_state {
     uint32_t pixel;     /* y * width + x */
     uint32_t iteration; /* sdfRaycast's loop counter i = tex0 fetches done so far */

@@ -682,6 +682,39 @@ __global__ __launch_bounds__(256) void raymarch_slab_kernel(RaymarchArgs a, Slab
             aux.raw0[0] = raw0.x; aux.raw0[1] = raw0.y; aux.raw0[2] = raw0.z; aux.raw0[3] = raw0.w;
             aux.raw1[0] = raw1.x; aux.raw1[1] = raw1.y; aux.raw1[2] = raw1.z; aux.raw1[3] = raw1.w;
             aux.depth = hz / hw;
+            // sdfNormal (material.frag:73-80): four taps h away from the hit; each needs the two slices around its own
+            // floor(w), which can be one slice further than the march's fetch -- resident only with a second upper ghost
+            // slice (or at the ends of the grid).  Without it the normal stays (0, 0, 0).
+            if (a.fast_normal) {
+                const float sxn = (float)tex.w / a.rp.lod_dist_between_samples;
+                const float syn = (float)tex.h / a.rp.lod_dist_between_samples;
+                const float szn = (float)tex.d / a.rp.lod_dist_between_samples;
+                const float h = 1.0f / sqrtf(sxn * sxn + syn * syn + szn * szn);
+                const V3 taps[4] = {mk(ray_pos.x + h, ray_pos.y - h, ray_pos.z - h), mk(ray_pos.x - h, ray_pos.y - h, ray_pos.z + h),
+                                    mk(ray_pos.x - h, ray_pos.y + h, ray_pos.z - h), mk(ray_pos.x + h, ray_pos.y + h, ray_pos.z + h)};
+                float d[4];
+                bool resident = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int kc;
+                    const V3 q = to_p01<XF>(a, taps[k]);
+                    const float w = q.z * (float)tex.d - 0.5f;
+                    const int k0 = (int)floorf(w);
+                    const int lo = max(k0, 0), hi = min(k0 + 1, tex.d - 1);
+                    resident = resident && lo >= (int)s.z_lo && hi < (int)(s.z_lo + s.z_count);
+                    d[k] = 0.0f;
+                    if (resident) {  // only then are the eight texels inside this rank's allocation
+                        const Footprint f = footprint_slab(tex, q, kc);
+                        d[k] = trilerp(dist_r[(uint64_t)f.o000 * 4], dist_r[(uint64_t)f.o100 * 4], dist_r[(uint64_t)f.o010 * 4],
+                                       dist_r[(uint64_t)f.o110 * 4], dist_r[(uint64_t)f.o001 * 4], dist_r[(uint64_t)f.o101 * 4],
+                                       dist_r[(uint64_t)f.o011 * 4], dist_r[(uint64_t)f.o111 * 4], f.ax, f.ay, f.az) - 1e-1f;
+                    }
+                }
+                if (resident) {
+                    const V3 n = normalize(mk(d[0] + -d[1] + -d[2] + d[3], -d[0] + -d[1] + d[2] + d[3], -d[0] + d[1] + -d[2] + d[3]));
+                    aux.normal[0] = n.x; aux.normal[1] = n.y; aux.normal[2] = n.z;
+                }
+            }
         }
         a.aux[pixel] = aux;
     }

@@ -658,6 +658,7 @@ int sdfv_raymarch_slab(const sdfv_render_params* rp, const sdfv_grid* slab, uint
     if (slab->z_begin >= slab->z_end) return fail(SDFV_ERR_INVALID_ARGUMENT, "empty slab");
     if (ghost_lo > slab->z_begin || slab->z_end + ghost_hi > slab->dims[2])
         return fail(SDFV_ERR_INVALID_ARGUMENT, "ghost slices reach outside the grid");
+    if (ghost_lo > 1 || ghost_hi > 2) return fail(SDFV_ERR_INVALID_ARGUMENT, "at most 1 lower and 2 upper ghost slices");
     if (slab->z_end < slab->dims[2] && ghost_hi == 0)
         return fail(SDFV_ERR_INVALID_ARGUMENT, "an interior slab needs its upper ghost slice (run the halo exchange)");
     if (rp->lod_dist_between_samples != 1.0f)

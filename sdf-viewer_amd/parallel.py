@@ -53,7 +53,8 @@ class SlabTextures:
     z_begin: int
     z_end: int
     ghost_lo: int  # 1 if a lower neighbour exists
-    ghost_hi: int
+    ghost_hi: int  # upper ghost slices actually present (0 at the top of the grid)
+    halo_hi: int = 1  # upper halo depth of the layout: every rank sends this many slices down
 
     @property
     def owned0(self):
@@ -64,12 +65,14 @@ class SlabTextures:
         return self.tex1[self.ghost_lo:self.ghost_lo + (self.z_end - self.z_begin)]
 
 
-def alloc_slab(dims, rank, world, device, fill_value=None, periodic=False, pkg=None):
+def alloc_slab(dims, rank, world, device, fill_value=None, periodic=False, pkg=None, halo_hi=1):
     """pkg given (and a GPU device): the two textures share one block and sdfv_tune_texture_placement chooses the
-    distance between them (see pkg.alloc_textures(tuned=True))."""
+    distance between them (see pkg.alloc_textures(tuned=True)).
+    halo_hi = 2: two ghost slices on the upper side (what sdfNormal's taps need in the sharded march; the library's
+    own communicator and the fill step use the one-voxel halo, halo_exchange() below handles either)."""
     z0, z1 = slab_range(dims[2], rank, world)
     glo = 1 if (periodic or rank > 0) else 0
-    ghi = 1 if (periodic or rank < world - 1) else 0
+    ghi = halo_hi if periodic else min(halo_hi, dims[2] - z1)
     shape = (glo + (z1 - z0) + ghi, dims[1], dims[0], 4)
     if pkg is not None and torch.device(device).type == "cuda":
         with torch.cuda.device(torch.device(device)):
@@ -80,7 +83,7 @@ def alloc_slab(dims, rank, world, device, fill_value=None, periodic=False, pkg=N
     if fill_value is not None:
         t0.fill_(fill_value)
         t1.fill_(fill_value)
-    return SlabTextures(t0, t1, z0, z1, glo, ghi)
+    return SlabTextures(t0, t1, z0, z1, glo, ghi, halo_hi)
 
 
 def _needs_host_staging(t, group=None):
@@ -90,33 +93,42 @@ def _needs_host_staging(t, group=None):
 
 
 def halo_exchange(slab, rank, world, group=None):
-    """One-voxel (= one z-slice) halo of both textures with ranks rank-1 / rank+1; non-periodic ends.
-    Returns the number of bytes this rank sent."""
+    """Halo of both textures with ranks rank-1 / rank+1; non-periodic ends.  Downwards a rank sends its first
+    `slab.halo_hi` owned slices (the lower neighbour's upper ghosts: 1 = the one-voxel halo, 2 = what sdfNormal's taps
+    need in the sharded march), upwards its last owned slice.  Returns the number of bytes this rank sent."""
     if world == 1:
         return 0
     staged = _needs_host_staging(slab.tex0, group)
-    ops = []
-    copies = []  # (ghost slice, host buffer) to copy back after the wait when staging
+    ops, copies = [], []  # copies: (ghost slices, host buffer) to copy back after the wait when staging
     sent = 0
     n_owned = slab.z_end - slab.z_begin
+    depth = slab.halo_hi
+    assert n_owned >= depth, "a halo deeper than a neighbour's slab would need a second hop"
 
-    def post(send_slice, recv_slice, peer):
+    def send(block, peer):
         nonlocal sent
-        if staged:
-            buf = torch.empty(recv_slice.shape, dtype=recv_slice.dtype)
-            ops.append(dist.P2POp(dist.isend, send_slice.cpu(), peer, group))
-            ops.append(dist.P2POp(dist.irecv, buf, peer, group))
-            copies.append((recv_slice, buf))
-        else:
-            ops.append(dist.P2POp(dist.isend, send_slice, peer, group))
-            ops.append(dist.P2POp(dist.irecv, recv_slice, peer, group))
-        sent += send_slice.numel() * 4
+        ops.append(dist.P2POp(dist.isend, block.cpu() if staged else block, peer, group))
+        sent += block.numel() * 4
 
+    def recv(block, peer):
+        if staged:
+            buf = torch.empty(block.shape, dtype=block.dtype)
+            ops.append(dist.P2POp(dist.irecv, buf, peer, group))
+            copies.append((block, buf))
+        else:
+            ops.append(dist.P2POp(dist.irecv, block, peer, group))
+
+    lo = slab.ghost_lo
     for t in (slab.tex0, slab.tex1):
+        # sends down then up, receives from above then from below: messages between a pair match in posting order
         if rank > 0:
-            post(t[slab.ghost_lo], t[0], rank - 1)                                  # first owned slice down
+            send(t[lo:lo + depth], rank - 1)
         if rank < world - 1:
-            post(t[slab.ghost_lo + n_owned - 1], t[t.shape[0] - 1], rank + 1)      # last owned slice up
+            send(t[lo + n_owned - 1:lo + n_owned], rank + 1)
+        if rank < world - 1:
+            recv(t[lo + n_owned:lo + n_owned + slab.ghost_hi], rank + 1)
+        if rank > 0:
+            recv(t[0:lo], rank - 1)
     for req in dist.batch_isend_irecv(ops):
         req.wait()
     for dst, buf in copies:

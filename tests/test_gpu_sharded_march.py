@@ -1,7 +1,8 @@
 """Raymarch over a grid that stays z-sharded (sdfv_raymarch_slab / parallel.ShardedMarch): all "ranks" are run in
 lockstep inside one process on the one GPU of the test box, handing ray states to each other exactly as
 parallel.raymarch_sharded does over torch.distributed.  The merged image and aux records must equal the single-GPU
-sdfv_raymarch over the whole grid bit for bit (aux.normal excepted: the sharded march leaves it zero)."""
+sdfv_raymarch over the whole grid bit for bit (aux.normal: wherever its taps are resident -- everywhere with a second
+upper ghost slice)."""
 import importlib
 
 import numpy as np
@@ -89,7 +90,11 @@ def test_sharded_march_equals_single_gpu_march(pkg, par, dims, world, bb, eye, i
     ga, wa = got_aux.cpu().numpy(), want_aux[0].cpu().numpy()
     np.testing.assert_array_equal(ga[..., :14], wa[..., :14])   # status, steps, hit_pos, t, raw0, raw1
     np.testing.assert_array_equal(ga[..., 17], wa[..., 17])     # depth
-    assert (ga[..., 14:17] == 0).all()                           # normal: not computed by the sharded march
+    # normal: filled where the four taps' slices are resident on the rank that owns the hit (always, with a second
+    # upper ghost slice -- tested below), left zero for hits in a slab's top cell layer under the one-voxel halo
+    filled = (ga[..., 14:17] != 0).any(axis=-1)
+    np.testing.assert_array_equal(ga[..., 14:17][filled], wa[..., 14:17][filled])
+    assert filled.any() and ((wa[..., 0] == 1) & ~filled).sum() < (wa[..., 0] == 1).sum()
     assert (wa[..., 0] == 1).any() and (wa[..., 0] == -2).any()  # the view has hits and rays that leave the box
     assert handed > 0                                            # and rays did cross slab boundaries
 
@@ -163,3 +168,36 @@ def test_randomised_slabs_and_cameras(pkg, par):
         ga, wa = got_aux.cpu().numpy(), want_aux[0].cpu().numpy()
         np.testing.assert_array_equal(ga[..., :14], wa[..., :14])
         np.testing.assert_array_equal(ga[..., 17], wa[..., 17])
+
+
+@pytest.mark.parametrize("dims,world,eye", [((32, 32, 32), 4, (2.5, 3.0, 5.0)), ((24, 20, 37), 3, (-3.0, 1.0, -2.0)),
+                                            ((32, 32, 32), 8, (0.2, 0.1, -4.0))])
+def test_second_upper_ghost_slice_gives_the_normals(pkg, par, dims, world, eye):
+    """sdfNormal's taps reach one slice further up than the march's fetch: with halo_hi = 2 every hit's taps are
+    resident on the rank that owns the hit and aux.normal equals the single-GPU kernel's, bit for bit; with the
+    one-voxel halo it stays zero (covered above)."""
+    W, H = 96, 64
+    prm = pkg.default_params()
+    full = pkg.make_grid(dims)
+    f0, f1 = pkg.alloc_textures(full)
+    pkg.fill_grid(prm, full, f0, f1)
+    rp = pkg.default_render_params(full)
+    cam = pkg.camera_look_at(eye=eye, aspect=W / H)
+    want_rgba, want_aux = pkg.raymarch(rp, f0, f1, cam, W, H, want_aux=True)
+    slabs, grids = [], []
+    for r in range(world):
+        slab = par.alloc_slab(dims, r, world, "cuda", fill_value=float("nan"), halo_hi=2)
+        g = pkg.make_grid(dims, z_begin=slab.z_begin, z_end=slab.z_end)
+        pkg.fill_grid(prm, g, slab.owned0, slab.owned1)
+        lo, hi = slab.z_begin - slab.ghost_lo, slab.z_end + slab.ghost_hi
+        for t, f in ((slab.tex0, f0), (slab.tex1, f1)):   # ghosts as the (two-slice) halo exchange leaves them
+            t[:slab.ghost_lo].copy_(f[lo:slab.z_begin])
+            t[t.shape[0] - slab.ghost_hi:].copy_(f[slab.z_end:hi])
+        assert slab.ghost_hi == (2 if r < world - 1 else 0)
+        slabs.append(slab)
+        grids.append(g)
+    got_rgba, got_aux, _ = run_lockstep(pkg, par, rp, slabs, grids, cam, W, H)
+    np.testing.assert_array_equal(got_rgba.cpu().numpy().view(np.uint32), want_rgba[0].cpu().numpy().view(np.uint32))
+    ga, wa = got_aux.cpu().numpy(), want_aux[0].cpu().numpy()
+    np.testing.assert_array_equal(ga, wa)                    # every word, normals included
+    assert (wa[..., 14:17] != 0).any()
