@@ -163,6 +163,15 @@ int sdfvh_viewer_render(void* v, uint32_t width, uint32_t height, const float ey
     return hipMemcpy(rgba_host, out.get(), out.bytes(), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
+// Same frame, left in a caller-owned DEVICE image (width x height x 4 floats); enqueue only, no synchronisation.
+int sdfvh_viewer_render_device(void* v, uint32_t width, uint32_t height, const float eye[3], float* rgba_device) {
+    Camera cam;
+    if (eye) cam.position = Vec3{eye[0], eye[1], eye[2]};
+    cam.set_viewport(width, height);
+    return V(v).material.render(cam, rgba_device, nullptr, V(v).stream);
+}
+int sdfvh_viewer_sync(void* v) { return hipStreamSynchronize((hipStream_t)V(v).stream) == hipSuccess ? 0 : -1; }
+
 // ---- SDFViewerAppScene (a manual clock, in milliseconds, makes the 500 ms commit spacing testable) ----
 struct SceneHandle {
     long long now_ms = 0;

@@ -40,6 +40,8 @@ for name, res, args in [
     ("sdfvh_viewer_download", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("sdfvh_viewer_tex0", C.c_void_p, [C.c_void_p]), ("sdfvh_viewer_tex1", C.c_void_p, [C.c_void_p]),
     ("sdfvh_viewer_render", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("sdfvh_viewer_render_device", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("sdfvh_viewer_sync", C.c_int, [C.c_void_p]),
     ("sdfvh_format_f32", SZ, [C.c_float, C.c_char_p, SZ]), ("sdfvh_ply_color_u8", C.c_uint32, [C.c_float]),
     ("sdfvh_mesh_sdf", C.c_void_p, [C.c_void_p, C.c_char_p, SZ, C.c_int, C.c_char_p, SZ]),
     ("sdfvh_mesh_from_arrays", C.c_void_p, [C.c_void_p, SZ, C.c_void_p, SZ]), ("sdfvh_mesh_free", None, [C.c_void_p]),
@@ -63,7 +65,8 @@ class LoadingManager:
         self.h = H.sdfvh_lm_new(*limits, passes)
 
     def __del__(self):
-        H.sdfvh_lm_free(self.h)
+        if H is not None:
+            H.sdfvh_lm_free(self.h)
 
     def next(self):
         out = (SZ * 3)()
@@ -91,7 +94,8 @@ class SDF:
         self.h = handle
 
     def __del__(self):
-        H.sdfvh_sdf_free(self.h)
+        if H is not None:  # interpreter shutdown clears module globals first
+            H.sdfvh_sdf_free(self.h)
 
     @staticmethod
     def demo(*args):
@@ -164,7 +168,8 @@ class Viewer:
         self.h = handle
 
     def __del__(self):
-        H.sdfvh_viewer_free(self.h)
+        if H is not None:
+            H.sdfvh_viewer_free(self.h)
 
     @staticmethod
     def from_bb(bb, max_voxels_side, passes):
@@ -203,6 +208,14 @@ class Viewer:
         assert H.sdfvh_viewer_download(self.h, t0.ctypes.data, t1.ctypes.data) == 0
         return t0, t1
 
+    def render_device(self, width, height, rgba_ptr, eye=None):
+        """Enqueue the frame into a device image (address of width x height x 4 floats); sync() waits for it."""
+        e = None if eye is None else np.asarray(eye, np.float32)
+        assert H.sdfvh_viewer_render_device(self.h, width, height, None if e is None else e.ctypes.data, rgba_ptr) == 0
+
+    def sync(self):
+        assert H.sdfvh_viewer_sync(self.h) == 0
+
     def render(self, width, height, eye=None):
         out = np.empty((height, width, 4), np.float32)
         e = None if eye is None else np.asarray(eye, np.float32)
@@ -218,7 +231,8 @@ class Scene:
         assert self.h, "SDFViewerAppScene creation failed (no GPU?)"
 
     def __del__(self):
-        H.sdfvh_scene_free(self.h)
+        if H is not None:
+            H.sdfvh_scene_free(self.h)
 
     def advance_clock(self, ms):
         H.sdfvh_scene_advance_clock(self.h, ms)
@@ -259,7 +273,8 @@ class Mesh:
         self.h = handle
 
     def __del__(self):
-        H.sdfvh_mesh_free(self.h)
+        if H is not None:
+            H.sdfvh_mesh_free(self.h)
 
     @staticmethod
     def from_sdf(sdf, mesher="marching-cubes", max_voxels_per_axis=64, postproc=True):
