@@ -166,8 +166,29 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
     // one asynchronous launch): the state all passes converge to is the dense fill, which moves 32 B/voxel once
     // instead of re-reading and partially rewriting the grid once per pass.  No intermediate state is observable
     // inside one update() call; the LoadingManager is advanced exactly as the passes would have advanced it.
-    if (fresh_ && !changed_box && loading_mgr.total_iterations() == 0 && loading_mgr.step_size() != 0 &&
-        max_delta_time >= std::chrono::milliseconds(1)) {
+    // The same holds for a re-sampling whose changed box contains every voxel of the grid (the demo SDF reports its
+    // whole bounding box on any parameter edit, demo/mod.rs:135-144): inside the box update_required is true for
+    // every visited voxel, so the passes' common final state is again the dense fill.  "Contains every voxel" is
+    // decided on the voxels' own coordinates (first and last index per axis, same arithmetic as the kernels).
+    auto box_covers_grid = [&]() {
+        if (!changed_box) return false;
+        const float lo[3] = {(*changed_box)[0].x, (*changed_box)[0].y, (*changed_box)[0].z};
+        const float hi[3] = {(*changed_box)[1].x, (*changed_box)[1].y, (*changed_box)[1].z};
+        for (int i = 0; i < 3; ++i) {
+            const float dm1 = (float)g.dims[i] - 1.0f, size = g.bb_max[i] - g.bb_min[i];
+            float first = 0.0f / dm1;  // scene/sdf/mod.rs:179-182, three separately rounded steps
+            first = first * size;
+            first = first + g.bb_min[i];
+            float last = ((float)g.dims[i] - 1.0f) / dm1;
+            last = last * size;
+            last = last + g.bb_min[i];
+            if (!(first >= lo[i] && first <= hi[i] && last >= lo[i] && last <= hi[i])) return false;  // NaN: no
+        }
+        return true;
+    };
+    const bool all_passes_fit = loading_mgr.total_iterations() == 0 && loading_mgr.step_size() != 0 &&
+                                max_delta_time >= std::chrono::milliseconds(1);
+    if (all_passes_fit && ((fresh_ && !changed_box) || box_covers_grid())) {
         // The fill writes the distance volume in the same pass (+4 B/voxel instead of a second pass over tex0).
         float* dist_out = dist_synced_ ? material.dist->f32() : nullptr;
         if (sdfv_fill_grid_commit(&dev->params, dev->sdf_id, &g, tex0_device(), tex1_device(), dist_out, stream) != 0) {

@@ -41,6 +41,6 @@ for side in (256, 512):
         lat.append((time.perf_counter() - t0) * 1e3)
         assert err is None and updates > 0, (err, updates)
     lat.sort()
-    print(f"{side}^3 + {W}x{H}: parameter edit -> refill of the changed box (the demo reports its whole box; 3 passes) "
+    print(f"{side}^3 + {W}x{H}: parameter edit -> refill of the changed box (the demo reports its whole box: dense refill) "
           f"-> commit -> frame: "
           f"median {lat[len(lat) // 2]:.3f} ms, best {lat[0]:.3f} ms (host wall clock, {len(lat)} edits)")
