@@ -447,6 +447,14 @@ def main():
             "warmup": args.warmup,
             "prewarm_ms": args.prewarm_ms,
             "texture_placement": placement_note(args, slab),
+            "ms_per_step": round((fill_dt + march_dt) / args.steps * 1e3, 4),
+            "ms_per_step_fill": round(fill_dt / args.steps * 1e3, 4),
+            "ms_per_step_raymarch": round(march_dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (demo SDF defaults on the integer lattice, fixed cameras; no RNG)",
             "sharded_fill_verified": verified,
             "sharded_march": sharded_march,
             "backend": None if world == 1 else ("rccl" if backend == "nccl" else backend + " (test only)"),

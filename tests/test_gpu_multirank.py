@@ -35,3 +35,22 @@ def test_bench_weak_scaling_path_two_ranks_one_gpu(world, geometry):
     assert d["sharded_fill_verified"] is True  # gathered slabs == dense fill, ghost slices == neighbour's slices
     # the grid raymarched where it lies (rays handed between the ranks over gloo) == the march over the whole grid
     assert d["sharded_march"]["verified"] is True, d["sharded_march"]
+
+
+def test_bench_line_carries_the_whole_contract():
+    """Every key the driver's contract names is in bench.py's JSON line (N = 1, tiny workload)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--workload", "64",
+           "--cpu-baseline-seconds", "1", "--prewarm-ms", "5"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and "workload" in d["config"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in d["cpu_baseline"], key
+    assert d["roofline"]["bound"] == "hbm" and d["cpu_baseline"]["kind"] == "port"
