@@ -8,7 +8,9 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python bench.py --steps 10 --warmup 2 --workload $WL --no-cpu-baseline --no-batch"
+# --no-tuned-placement: the placement probe launches the same kernel over the first slices only, which would mix
+# shorter launches into the per-kernel averages (at 256^3 probe and step have the same shape, at 512^3 they do not)
+CMD="python bench.py --steps 10 --warmup 2 --workload $WL --no-cpu-baseline --no-batch --no-tuned-placement"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $CMD > $OUT/trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS -d $OUT/pmc_sq -o pmc --output-format csv -- $CMD > $OUT/pmc_sq.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE GRBM_GUI_ACTIVE -d $OUT/pmc_wr -o pmc --output-format csv -- $CMD > $OUT/pmc_wr.log 2>&1
