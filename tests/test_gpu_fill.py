@@ -323,10 +323,15 @@ def test_tuned_texture_placement(pkg, oracle):
     import ctypes as C
     dims = (64, 48, 40)
     g = pkg.make_grid(dims)
-    t0, t1 = pkg.alloc_textures(g, tuned=True)
     n_bytes = dims[0] * dims[1] * dims[2] * 16
+    # attempts=1: only the block candidates of sdfv_tune_texture_placement
+    t0, t1 = pkg.alloc_textures(g, tuned=True, attempts=1)
     gap = t1.data_ptr() - t0.data_ptr() - n_bytes
     assert 0 <= gap <= pkg._capi.PLACEMENT_SLACK and gap % 16 == 0 and t1.data_ptr() % 16 == 0
+    # default: the probe may also keep a pair of separate allocations; either way two disjoint, aligned textures
+    t0, t1 = pkg.alloc_textures(g, tuned=True)
+    assert t0.shape == t1.shape == (dims[2], dims[1], dims[0], 4) and t0.data_ptr() % 16 == 0 and t1.data_ptr() % 16 == 0
+    assert abs(t1.data_ptr() - t0.data_ptr()) >= n_bytes
     prm = pkg.default_params(cube_material=1)
     pkg.fill_grid(prm, g, t0, t1)
     torch.cuda.synchronize()
