@@ -637,7 +637,11 @@ int sdfv_raymarch_accel(const sdfv_render_params* rp, const float* tex0, const f
     a.height = height;
     a.y0 = y0;
     a.y1 = y1;
-    a.compute_normal = getenv("SDFV_RAYMARCH_SKIP_NORMAL") ? 0u : 1u;
+    // sdfNormal's result only feeds calculate_lighting (material.frag:155,163), and the one AmbientLight the scene
+    // configures (scene/mod.rs:106-112) does not read it: dead code a GLSL compiler removes.  It is evaluated when the
+    // aux record asks for it; SDFV_RAYMARCH_KEEP_NORMAL=1 evaluates it per hit regardless (what it would cost once a
+    // directional light uses it).
+    a.compute_normal = getenv("SDFV_RAYMARCH_KEEP_NORMAL") ? 1u : 0u;
     if (const char* s = getenv("SDFV_RAYMARCH_WAVE_TIMING"))  // tuning: address of a device buffer, 32 B per wave
         a.wave_timing = reinterpret_cast<unsigned long long*>(strtoull(s, nullptr, 0));
     const uint64_t pixels_per_cam = (uint64_t)(y1 - y0) * width;
