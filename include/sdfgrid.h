@@ -216,7 +216,9 @@ typedef struct sdfv_mesh {
  * its HermiteSource normal, material fields zero (Vertex::default) until sdfv_mesh_postproc.  The extraction
  * algorithm itself is the build's own (the reference delegates to the un-vendored `isosurface` crate); algorithms
  * other than marching cubes are rejected like the reference's "Unsupported algorithm" (isosurface.rs:49).
- * Synchronises `stream` (the output size is data dependent). */
+ * Synchronises `stream` (the output size is data dependent).  Vertex and triangle counts are 32-bit: a surface has
+ * O(N^2) of them, far below 2^32 for max_voxels_per_axis <= 1024; a field crossing zero on nearly every lattice edge
+ * (not a distance field) at the largest sizes would overflow them. */
 int sdfv_mesh_extract(const sdfv_demo_params *params, uint32_t sdf_id, const float bb_min[3], const float bb_max[3],
                       uint32_t max_voxels_per_axis, uint32_t algorithm, sdfv_mesh *out, void *stream);
 int sdfv_mesh_free(sdfv_mesh *mesh);
