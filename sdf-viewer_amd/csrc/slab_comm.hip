@@ -121,17 +121,23 @@ int enqueue_exchange(const Rccl* lib, const sdfv_slab_comm* c, const sdfv_grid* 
     const size_t lo = c->has_lo() ? 1 : 0;
     if (!c->has_lo() && !c->has_hi()) return SDFV_OK;
     SDFV_RCCL(lib, GroupStart());
+    int first_error = kNcclSuccess;  // a group that was opened is always closed, whatever happens inside it
+    auto post = [&](int r) {
+        if (first_error == kNcclSuccess) first_error = r;
+    };
     for (float* t : {tex0, tex1}) {
         float* first_owned = t + lo * slice;
         float* last_owned = t + (lo + owned - 1) * slice;
         // Sends go down then up, receives come from above then from below: messages between one pair of ranks
         // match in posting order, and with a periodic world of 1 or 2 both neighbours are the same rank.
-        if (c->has_lo()) SDFV_RCCL(lib, Send(first_owned, slice, kNcclFloat, c->lo_peer(), c->comm, stream));
-        if (c->has_hi()) SDFV_RCCL(lib, Send(last_owned, slice, kNcclFloat, c->hi_peer(), c->comm, stream));
-        if (c->has_hi()) SDFV_RCCL(lib, Recv(t + (lo + owned) * slice, slice, kNcclFloat, c->hi_peer(), c->comm, stream));
-        if (c->has_lo()) SDFV_RCCL(lib, Recv(t, slice, kNcclFloat, c->lo_peer(), c->comm, stream));
+        if (c->has_lo()) post(lib->Send(first_owned, slice, kNcclFloat, c->lo_peer(), c->comm, stream));
+        if (c->has_hi()) post(lib->Send(last_owned, slice, kNcclFloat, c->hi_peer(), c->comm, stream));
+        if (c->has_hi()) post(lib->Recv(t + (lo + owned) * slice, slice, kNcclFloat, c->hi_peer(), c->comm, stream));
+        if (c->has_lo()) post(lib->Recv(t, slice, kNcclFloat, c->lo_peer(), c->comm, stream));
     }
-    SDFV_RCCL(lib, GroupEnd());
+    post(lib->GroupEnd());
+    if (first_error != kNcclSuccess)
+        return sdfv::set_error(SDFV_ERR_COMM, "RCCL halo exchange: %s", lib->GetErrorString(first_error));
     return SDFV_OK;
 }
 
