@@ -1,0 +1,64 @@
+/* gpu_roundtrip.c -- the hot path driven from plain C with nothing but the HIP runtime API for memory: what a host in
+ * any language with a C FFI does.  hipMalloc -> sdfv_fill_grid_commit -> sdfv_raymarch_accel -> hipMemcpy back; the raw
+ * results go to <prefix>.tex0.f32 / .tex1.f32 / .rgba.f32 for tests/test_gpu_host.py to compare with the oracle. */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "sdfgrid.h"
+
+#define DIE(msg)                                                        \
+    do {                                                                \
+        fprintf(stderr, "%s: %s\n", msg, sdfv_last_error());            \
+        return 1;                                                       \
+    } while (0)
+
+static int dump(const char *prefix, const char *suffix, const void *dev, size_t bytes) {
+    char path[1024];
+    void *host = malloc(bytes);
+    FILE *f;
+    if (!host || hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    snprintf(path, sizeof path, "%s.%s", prefix, suffix);
+    f = fopen(path, "wb");
+    if (!f || fwrite(host, 1, bytes, f) != bytes) return 1;
+    fclose(f);
+    free(host);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    const char *prefix = argc > 1 ? argv[1] : "roundtrip";
+    const uint32_t W = 64, H = 48;
+    const float lo[3] = {-1.0f, -1.0f, -1.0f}, hi[3] = {1.0f, 1.0f, 1.0f};
+    const float eye[3] = {2.5f, 3.0f, 5.0f}, target[3] = {0.0f, 0.0f, 0.0f}, up[3] = {0.0f, 1.0f, 0.0f};
+    sdfv_demo_params prm;
+    sdfv_grid grid;
+    sdfv_render_params rp;
+    sdfv_camera cam;
+    float *tex0 = NULL, *tex1 = NULL, *dist = NULL, *rgba = NULL;
+    size_t voxels, tex_bytes;
+
+    if (sdfv_device_count() < 1) DIE("no device");
+    sdfv_demo_params_default(&prm);
+    if (sdfv_grid_from_bb(lo, hi, 32, &grid) != SDFV_OK) DIE("grid_from_bb");
+    voxels = (size_t)grid.dims[0] * grid.dims[1] * grid.dims[2];
+    tex_bytes = voxels * 16;
+    if (hipMalloc((void **)&tex0, tex_bytes) != hipSuccess || hipMalloc((void **)&tex1, tex_bytes) != hipSuccess ||
+        hipMalloc((void **)&dist, voxels * 4) != hipSuccess || hipMalloc((void **)&rgba, (size_t)W * H * 16) != hipSuccess)
+        return 1;
+    if (sdfv_fill_grid_commit(&prm, SDFV_SDF_DEMO, &grid, tex0, tex1, dist, NULL) != SDFV_OK) DIE("fill_grid_commit");
+    sdfv_render_params_default(&rp, &grid);
+    if (sdfv_camera_look_at(&cam, eye, target, up, 45.0f, (float)W / (float)H, 0.1f, 1000.0f) != SDFV_OK) DIE("camera");
+    if (sdfv_raymarch_accel(&rp, tex0, tex1, dist, &cam, 1, W, H, 0, H, rgba, NULL, NULL) != SDFV_OK) DIE("raymarch");
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (dump(prefix, "tex0.f32", tex0, tex_bytes) || dump(prefix, "tex1.f32", tex1, tex_bytes) ||
+        dump(prefix, "rgba.f32", rgba, (size_t)W * H * 16))
+        return 1;
+    hipFree(tex0);
+    hipFree(tex1);
+    hipFree(dist);
+    hipFree(rgba);
+    printf("ok %ux%ux%u\n", grid.dims[0], grid.dims[1], grid.dims[2]);
+    return 0;
+}

@@ -301,3 +301,33 @@ def test_cli_mesh_writes_the_ply_the_library_mesh_describes(pkg, oracle, tmp_pat
     assert r2.returncode != 0 and "Output file already exists" in r2.stderr
     r3 = subprocess.run([exe, "mesh", "-o", "-", "-v", "20", "demo", "-c", "0.8"], capture_output=True, text=True, timeout=300)
     assert r3.returncode == 0 and r3.stdout == open(out).read()
+
+
+def test_plain_c_host_drives_the_hot_path(oracle, tmp_path):
+    """tests/c/gpu_roundtrip.c: gcc, the HIP runtime API for memory, and include/sdfgrid.h -- no C++, no Python in the
+    data path.  Its textures equal the oracle's bit for bit, its frame within the RGBA tolerance."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "gpu_roundtrip"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include",
+           os.path.join(root, "tests", "c", "gpu_roundtrip.c"), "-o", str(exe),
+           "-L", os.path.join(root, "sdf-viewer_amd"), "-lsdfgrid", "-L", "/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + os.path.join(root, "sdf-viewer_amd"), "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    prefix = str(tmp_path / "rt")
+    r = subprocess.run([str(exe), prefix], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok 32x32x32"), r.stdout + r.stderr
+    dims = (32, 32, 32)
+    prm = oracle.default_params()
+    r0, r1 = oracle.fill_dense(prm, dims)
+    t0 = np.fromfile(prefix + ".tex0.f32", np.float32).reshape(r0.shape)
+    t1 = np.fromfile(prefix + ".tex1.f32", np.float32).reshape(r1.shape)
+    np.testing.assert_array_equal(t0.view(np.uint32), r0.view(np.uint32))
+    np.testing.assert_array_equal(t1.view(np.uint32), r1.view(np.uint32))
+    W, H = 64, 48
+    want, _ = oracle.raymarch(oracle.default_render_params(dims), r0, r1, oracle.camera_look_at(aspect=W / H), W, H,
+                              want_aux=False)
+    got = np.fromfile(prefix + ".rgba.f32", np.float32).reshape(H, W, 4)
+    assert np.abs(got - want).max() <= 1e-4 and (got[..., 3] > 0).any()
