@@ -62,3 +62,33 @@ def test_config5_batch_of_64_cameras(pkg, oracle):
             for f in ("status", "steps", "hit_pos", "t", "raw0", "raw1", "normal", "depth"):
                 assert (got[f].view(np.uint32) == want_aux[f].view(np.uint32)).all(), (k, f)
     assert worst <= RGBA_TOL
+
+
+def test_config4_sharded_march_equals_single_gpu_march(pkg):
+    """Config 4's 1024^3 grid held as 8 z-slabs (+ ghosts) next to the whole grid on ONE GPU (138 GB): the sharded
+    march, ranks run in lockstep, against sdfv_raymarch over the whole grid -- every pixel and aux word (normals apart)."""
+    import importlib
+    import numpy as np
+    import torch
+    if torch.cuda.mem_get_info()[0] < 170 << 30:
+        pytest.skip("needs 170 GB of free HBM")
+    par = importlib.import_module("sdf-viewer_amd.parallel")
+    spec = importlib.util.spec_from_file_location("sharded", os.path.join(ROOT, "tests", "test_gpu_sharded_march.py"))
+    sharded = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharded)
+    dims, world, W, H = (1024, 1024, 1024), 8, 1920, 1080
+    bb = ((-1, -1, -1), (1, 1, 1))
+    prm = pkg.default_params()
+    full = pkg.make_grid(dims)
+    f0, f1 = pkg.alloc_textures(full)
+    pkg.fill_grid(prm, full, f0, f1)
+    rp = pkg.default_render_params(full)
+    cam = pkg.camera_look_at(aspect=W / H)
+    want_rgba, want_aux = pkg.raymarch(rp, f0, f1, cam, W, H, want_aux=True)
+    slabs, grids = sharded.build_slabs(pkg, par, prm, dims, world, bb)
+    got_rgba, got_aux, handed = sharded.run_lockstep(pkg, par, rp, slabs, grids, cam, W, H)
+    assert torch.equal(got_rgba.view(torch.int32), want_rgba[0].view(torch.int32))
+    ga, wa = got_aux.cpu().numpy(), want_aux[0].cpu().numpy()
+    np.testing.assert_array_equal(ga[..., :14], wa[..., :14])
+    np.testing.assert_array_equal(ga[..., 17], wa[..., 17])
+    assert handed > 10000 and (wa[..., 0] == 1).sum() > 100000
