@@ -117,3 +117,21 @@ def test_errors_are_status_codes(pkg, par, loop_comm):
     assert lib.sdfv_slab_fill_step(loop_comm.handle, C.byref(pkg.default_params()), 0, C.byref(empty),
                                    C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), None) == -1
     assert lib.sdfv_slab_comm_destroy(None) == 0
+
+
+def test_config4_sized_slices_through_the_loopback_exchange(pkg, par, loop_comm):
+    """Config 4's halo: 1024 x 1024 slices (16.8 MB per texture and direction) through the RCCL group, overlapped with
+    the interior fill of a 64-slice slab; ghosts must equal the wrapped owned slices, the owned slices a plain fill."""
+    dims = (1024, 1024, 64)
+    prm = pkg.default_params()
+    slab = par.alloc_slab(dims, 0, 1, "cuda", fill_value=-7.0, periodic=True)
+    grid = pkg.make_grid(dims)
+    for _ in range(3):
+        loop_comm.fill_step(prm, grid, slab)
+    torch.cuda.synchronize()
+    c0, c1 = pkg.alloc_textures(grid)
+    pkg.fill_grid(prm, grid, c0, c1)
+    torch.cuda.synchronize()
+    assert torch.equal(slab.owned0, c0) and torch.equal(slab.owned1, c1)
+    for tex, ref in ((slab.tex0, c0), (slab.tex1, c1)):
+        assert torch.equal(tex[0], ref[-1]) and torch.equal(tex[-1], ref[0])
