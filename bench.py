@@ -247,7 +247,39 @@ def raymarch_traffic_report(workload_key, launch_ms):
             "note": "HBM bytes per frame from the committed PMC pass of this same configuration"}
 
 
+class NativeStdoutToStderr:
+    """RCCL prints a version banner to the C-level stdout when its first communicator comes up (buffered, so it lands
+    after anything Python has printed).  The contract is ONE JSON line on stdout: while the benchmark runs, file
+    descriptor 1 points at stderr; it is restored (after flushing the C streams) just before the JSON line is printed."""
+
+    def __enter__(self):
+        import ctypes
+        self.libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self.libc.fflush(None)
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def restore(self):
+        if self.saved is not None:
+            sys.stdout.flush()
+            self.libc.fflush(None)
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+            self.saved = None
+
+    def __exit__(self, *exc):
+        self.restore()
+        return False
+
+
 def main():
+    with NativeStdoutToStderr() as redirect:
+        run(redirect)
+
+
+def run(redirect):
     global PREWARM_S
     args = parse_args()
     PREWARM_S = args.prewarm_ms / 1e3
@@ -272,7 +304,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
+            # device_id = eager communicator creation, and one collective on an uninitialised buffer to be sure: the
+            # process's first RCCL communicator has to exist BEFORE the fill stream launches its first kernel (a
+            # stream whose hardware queue predates it runs sdfv_slab_fill_step 2.5x slower).
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.all_reduce(torch.empty(1, device=device))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
@@ -361,6 +397,22 @@ def main():
     march_dt, march_ev_ms = timed_region(march_step, args.steps, torch, dist, world, device)
     total_rays = W * H * world
     march_mrays = total_rays * args.steps / march_dt / 1e6
+
+    # ---------------- N = 1 extra: the multi-GPU fill step in loopback (not `value`) ----------------
+    # What one rank's step costs with the halo exchange in it, measured on this GPU by tools/slab_step_probe.py in a
+    # process of its own (so that this process never brings up an RCCL communicator at N = 1).
+    halo_loopback = None
+    if world == 1 and not args.no_batch:
+        try:
+            import subprocess
+            torch.cuda.synchronize()
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "slab_step_probe.py"), str(side), str(args.steps)],
+                               capture_output=True, text=True, timeout=300)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            halo_loopback = json.loads(lines[-1]) if (r.returncode == 0 and lines) else \
+                {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:  # noqa: BLE001 -- an extra, never fatal
+            halo_loopback = {"error": f"{type(e).__name__}: {e}"}
 
     # ---------------- config 5 shape: a batch of 64 cameras, split over the ranks (extra, not `value`) ----------------
     n_batch = 64
@@ -482,9 +534,11 @@ def main():
                                       "stored), what SDFViewer::update uses for a fresh grid; not part of ms_per_step",
             "roofline_raymarch": raymarch_traffic_report(args.workload if world == 1 else None, march_ev_ms / args.steps),
             "batch_raymarch": batch_report,
+            "halo_loopback": halo_loopback,
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0, N = 1 only
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_seconds)
+        redirect.restore()
         print(json.dumps(out), flush=True)
     if world > 1:
         if getattr(filler, "comm", None) is not None:

@@ -303,7 +303,12 @@ typedef struct sdfv_slab_comm sdfv_slab_comm;
 
 /* Rank 0 makes the id; the HOST hands the 128 bytes to every rank by whatever channel it has. */
 int sdfv_slab_comm_unique_id(unsigned char id_out[SDFV_COMM_ID_BYTES]);
-/* Collective over all ranks (ncclCommInitRank on the current HIP device).  Owns a second HIP stream + events. */
+/* Collective over all ranks (ncclCommInitRank on the current HIP device).  Owns a second HIP stream + events.
+ * Ordering matters for speed (measured on MI355X / ROCm 7, not understood): a stream whose hardware queue was already
+ * in use when the process brought up its FIRST RCCL communicator runs sdfv_slab_fill_step's fill / record / wait
+ * pattern 2.5x slower than a stream created afterwards.  So create the communicator (or any RCCL communicator, e.g.
+ * a torch.distributed process group) before the stream you will pass to sdfv_slab_fill_step launches its first
+ * kernel, or pass a stream created after it. */
 int sdfv_slab_comm_create(const unsigned char id[SDFV_COMM_ID_BYTES], int rank, int world, uint32_t flags,
                           sdfv_slab_comm **out);
 int sdfv_slab_comm_destroy(sdfv_slab_comm *comm);
