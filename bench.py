@@ -29,6 +29,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The multi-GPU fill step uses
+# the caller's stream, the communicator's high-priority stream and RCCL's own; with 4 queues two of them can end up on
+# one queue and the step runs 2.5x slower (265 us instead of 106 at 256^3, depending on creation order); with 8 every
+# order measured is fast.  Read by the HIP runtime at start-up, hence set before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 FILL_BYTES_PER_VOXEL = 32  # tex0 16 B + tex1 16 B, store-only
 

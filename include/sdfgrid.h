@@ -304,11 +304,11 @@ typedef struct sdfv_slab_comm sdfv_slab_comm;
 /* Rank 0 makes the id; the HOST hands the 128 bytes to every rank by whatever channel it has. */
 int sdfv_slab_comm_unique_id(unsigned char id_out[SDFV_COMM_ID_BYTES]);
 /* Collective over all ranks (ncclCommInitRank on the current HIP device).  Owns a second HIP stream + events.
- * Ordering matters for speed (measured on MI355X / ROCm 7, not understood): a stream whose hardware queue was already
- * in use when the process brought up its FIRST RCCL communicator runs sdfv_slab_fill_step's fill / record / wait
- * pattern 2.5x slower than a stream created afterwards.  So create the communicator (or any RCCL communicator, e.g.
- * a torch.distributed process group) before the stream you will pass to sdfv_slab_fill_step launches its first
- * kernel, or pass a stream created after it. */
+ * Hardware queues: HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The fill
+ * step involves the caller's stream, the communicator's high-priority stream and RCCL's internal ones; when two of
+ * them land on one queue the step serialises (measured 265 us instead of 106 at 256^3; which streams collide depends on
+ * creation order -- e.g. a stream used before the process's first RCCL communicator came up).  Start the process with
+ * GPU_MAX_HW_QUEUES=8 (read by the HIP runtime at start-up): every creation order measured is then fast. */
 int sdfv_slab_comm_create(const unsigned char id[SDFV_COMM_ID_BYTES], int rank, int world, uint32_t flags,
                           sdfv_slab_comm **out);
 int sdfv_slab_comm_destroy(sdfv_slab_comm *comm);
