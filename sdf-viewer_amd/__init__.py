@@ -9,8 +9,13 @@ The package directory name contains a hyphen; import it with
     importlib.import_module("sdf-viewer_amd")
 """
 import ctypes as C
+import os
 
-import torch
+# The multi-GPU fill step needs its streams on separate HIP hardware queues (DESIGN.md 6); the runtime reads this when
+# it initialises, which is at the first HIP call, not at import.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
 
 from . import _capi
 from ._capi import (Camera, DemoParams, Grid, MarchAux, RenderParams, Sample, SdfvError, check, f3, lib,  # noqa: F401
