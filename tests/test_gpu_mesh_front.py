@@ -102,3 +102,19 @@ def test_golden_mesh_front_fixture(pkg):
             np.testing.assert_array_equal(got.view(np.uint32), g[f"normal_{k}_{sdf_id}"].view(np.uint32))
             got = pkg.mesh_postproc(prm, torch.from_numpy(g["vertices"]).cuda(), sdf_id=sdf_id).cpu().numpy()
             np.testing.assert_array_equal(got.view(np.uint32), g[f"postproc_{k}_{sdf_id}"].view(np.uint32))
+
+
+def test_empty_inputs_are_no_ops(pkg):
+    """n = 0 everywhere in the mesher front end: success, nothing touched, no launch."""
+    import ctypes as C
+    prm = pkg.default_params()
+    empty3 = torch.empty((0, 3), device="cuda")
+    assert pkg.source_sample_scalar(prm, empty3).shape == (0,)
+    assert pkg.source_sample_normal(prm, empty3).shape == (0, 3)
+    assert pkg.mesh_postproc(prm, torch.empty((0, 12), device="cuda")).shape == (0, 12)
+    assert pkg.lib.sdfv_mesh_postproc(C.byref(prm), 0, None, 0, None) == 0
+    assert pkg.lib.sdfv_mesh_postproc_host(C.byref(prm), 0, None, 0) == 0
+    lo, hi = pkg.f3((-1, -1, -1)), pkg.f3((1, 1, 1))
+    assert pkg.lib.sdfv_source_sample_scalar(C.byref(prm), 0, lo, hi, None, 0, None, None) == 0
+    assert pkg.lib.sdfv_source_sample_scalar(C.byref(prm), 0, None, hi, None, 0, None, None) == -1  # no bounding box
+    assert pkg.lib.sdfv_source_sample_scalar(C.byref(prm), 0, lo, hi, None, 5, None, None) == -1    # n without buffers
