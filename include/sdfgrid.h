@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SDFV_ABI_VERSION 1
+#define SDFV_ABI_VERSION 2
 
 typedef enum sdfv_status {
     SDFV_OK = 0,
@@ -87,6 +87,20 @@ typedef struct sdfv_camera {
     float bvp[16];    /* column-major bias * projection * view, material.rs:89-97 */
 } sdfv_camera;
 
+/* An entry of the scene's light list (`lights: Vec<Box<dyn Light>>`, scene/mod.rs:106-112).  The reference
+ * configures ONE AmbientLight (intensity 1.0, white); its two DirectionalLights are commented out (scene/mod.rs:107-112).
+ * Only SDFV_LIGHT_AMBIENT is implemented: what a directional light adds to calculate_lighting (material.frag:163) is
+ * three-d 0.18.2's PBR shader text, which is not under the reference tree -- a call whose light list holds a
+ * directional entry fails with SDFV_ERR_INVALID_ARGUMENT instead of rendering a guessed BRDF. */
+enum { SDFV_LIGHT_AMBIENT = 0, SDFV_LIGHT_DIRECTIONAL = 1 };
+#define SDFV_MAX_LIGHTS 4
+typedef struct sdfv_light {
+    uint32_t kind;         /* SDFV_LIGHT_* */
+    float    color[3];     /* linear rgb */
+    float    intensity;
+    float    direction[3]; /* directional lights only */
+} sdfv_light;
+
 /* The shader's uniforms (material.rs:50-73) + three-d's tone/colour mapping selectors. */
 typedef struct sdfv_render_params {
     float    bounds_min[3];            /* sdfBoundsMin */
@@ -98,6 +112,8 @@ typedef struct sdfv_render_params {
     float    gamma;                    /* GAMMA_CORRECTION define (env "gamma", material.rs:39); <= 0 = undefined */
     uint32_t tone_mapping;             /* 0 none, 1 Reinhard, 2 ACES (three-d default), 3 filmic */
     uint32_t color_mapping;            /* 0 none, 1 compute-to-sRGB (three-d default) */
+    uint32_t n_lights;                 /* FURTHER lights, after the scene's ambient light above; default 0 */
+    sdfv_light lights[SDFV_MAX_LIGHTS]; /* each ambient entry adds occlusion * (intensity * color) * mix(albedo, 0, metallic) */
 } sdfv_render_params;
 
 /* Optional per-pixel march record (parity/debug): everything main() knows before shading. */
@@ -117,6 +133,28 @@ uint32_t    sdfv_abi_version(void);
 const char *sdfv_last_error(void);  /* thread-local, never NULL */
 int         sdfv_device_count(void); /* number of HIP devices visible, 0 if none */
 float       sdfv_air_dist(void);     /* AIR_DIST, scene/sdf/mod.rs:42 */
+
+/* ---- per-thread options ----
+ * Everything here defaults to what the product uses; the options exist for A/B measurements and so that the parity
+ * tests can force every kernel specialisation.  Thread-local (like the error string and the reference's registry,
+ * ffi.rs:15-17), read once per call; the library reads no environment variables. */
+typedef enum sdfv_option {
+    SDFV_OPT_FILL_NONTEMPORAL = 1,     /* 0 (default) | 1: the dense fill stores with the nt hint */
+    SDFV_OPT_FILL_FORM = 2,            /* 0 auto (default) | 1 row-chunk form | 2 flat form of the dense fill */
+    SDFV_OPT_RAYMARCH_DISABLE = 3,     /* mask of SDFV_RM_NO_*: exact-arithmetic specialisations left out (default 0) */
+    SDFV_OPT_RAYMARCH_KEEP_NORMAL = 4, /* 0 (default) | 1: evaluate sdfNormal per hit although nothing consumes it */
+    SDFV_OPT_SLAB_STEP_FORM = 5,       /* sdfv_slab_fill_step: 0 auto (default) | SDFV_STEP_* below */
+    SDFV_OPT_TUNING_WAVE_TIMING = 100  /* tuning build only (-DSDFV_TUNING): DEVICE address of 32 B per raymarch wave */
+} sdfv_option;
+#define SDFV_RM_NO_FAST_INDEX  1u /* general kernel: full MirroredRepeat, the shader's nested loop */
+#define SDFV_RM_NO_POW2_EXTENT 2u /* (p - min) / size by IEEE divide instead of the exact reciprocal */
+#define SDFV_RM_NO_POW2_SIZE   4u /* no fused (1/size)*N scale */
+#define SDFV_RM_NO_SYMMETRIC   8u /* max(min - p, p - max) instead of |p| - max */
+#define SDFV_STEP_TWO_LAUNCH   1u /* boundary slices in a launch of their own, then the interior */
+#define SDFV_STEP_ONE_LAUNCH   2u /* one dense launch whose first workgroups fill the boundary slices and signal */
+#define SDFV_STEP_UNPACKED     4u /* flag: 2 messages per texture and neighbour straight into the ghosts (no staging) */
+int sdfv_set_option(uint32_t option, uint64_t value); /* unknown option / value out of range: SDFV_ERR_INVALID_ARGUMENT */
+int sdfv_get_option(uint32_t option, uint64_t *value);
 
 void sdfv_demo_params_default(sdfv_demo_params *p);
 /* SDFViewer::from_bb voxel sizing, scene/sdf/mod.rs:46-72 */
@@ -245,6 +283,16 @@ int sdfv_raymarch_accel(const sdfv_render_params *rp, const float *tex0, const f
                         const sdfv_camera *cameras, uint32_t n_cameras,
                         uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                         float *rgba, sdfv_march_aux *aux, void *stream);
+
+/* sdfv_raymarch_accel with a depth plane: `depth` (DEVICE, n_cameras x (y1-y0) x W floats, or NULL) receives
+ * gl_FragDepth per pixel (material.frag:180-181: (BVP * vec4(hit, 1)).z / .w at a hit; 1.0 for a fragment that
+ * hits nothing, material.frag:147; 1.0 where the ray misses the box and no fragment exists) -- 4 B/pixel, equal bit
+ * for bit to sdfv_march_aux.depth without paying for the 72-byte record.  Fails with SDFV_ERR_INVALID_ARGUMENT when
+ * rp->lights holds an entry that is not SDFV_LIGHT_AMBIENT (three-d 0.18.2's shader source is not available). */
+int sdfv_raymarch_depth(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
+                        const sdfv_camera *cameras, uint32_t n_cameras,
+                        uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                        float *rgba, float *depth, sdfv_march_aux *aux, void *stream);
 
 /* ---- raymarch over a z-sharded grid (multi-GPU; the consumer of the slab halo) ----
  * The grid stays sharded: rank r holds [ghost_lo][owned z_begin..z_end)[ghost_hi] as laid out for sdfv_slab_*.

@@ -209,6 +209,8 @@ void or_shade(const OrRenderParams *rp, const float raw0[4], const float raw1[4]
     for (int c = 0; c < 3; ++c) {
         float albedo = raw0[1 + c] * rp->tint[c];                              /* :158-159 */
         float lit = occlusion * rp->ambient[c] * mixf(albedo, 0.0f, metallic); /* :163, ambient light */
+        for (uint32_t l = 0; l < rp->n_lights && l < OR_MAX_LIGHTS; ++l)       /* further ambient lights, summed */
+            lit += occlusion * (rp->lights[l].intensity * rp->lights[l].color[c]) * mixf(albedo, 0.0f, metallic);
         lit = tone_map(rp->tone_mapping, lit);                                 /* :167 */
         lit = color_map(rp->color_mapping, lit);                               /* :168 */
         if (rp->gamma > 0.0f) lit = powf(lit, rp->gamma);                      /* :171-173 */

@@ -132,6 +132,15 @@ typedef struct {
     float bvp[16]; /* column-major bias*projection*view, material.rs:89-97 */
 } OrCamera;
 
+/* one further entry of the scene's light list (scene/mod.rs:106-112); only ambient lights are restated */
+typedef struct {
+    uint32_t kind;       /* 0 ambient, 1 directional (not restated: three-d 0.18.2 shader text is not in the tree) */
+    float color[3];
+    float intensity;
+    float direction[3];
+} OrLight;
+#define OR_MAX_LIGHTS 4
+
 typedef struct {
     float bounds_min[3];
     float bounds_max[3];
@@ -142,6 +151,8 @@ typedef struct {
     float gamma;                    /* GAMMA_CORRECTION define; <=0 = not defined */
     uint32_t tone_mapping;          /* 0 none, 1 reinhard, 2 aces(default), 3 filmic */
     uint32_t color_mapping;         /* 0 none, 1 compute-to-srgb(default) */
+    uint32_t n_lights;              /* further AMBIENT lights; calculate_lighting sums the lights' contributions [EXT] */
+    OrLight lights[OR_MAX_LIGHTS];
 } OrRenderParams;
 
 /* Per-pixel march record for parity on quantities fully determined by in-tree source. */

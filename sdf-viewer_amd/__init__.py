@@ -18,7 +18,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 
 from . import _capi
-from ._capi import (Camera, DemoParams, Grid, MarchAux, RenderParams, Sample, SdfvError, check, f3, lib,  # noqa: F401
+from ._capi import (Camera, DemoParams, Grid, Light, MarchAux, RenderParams, Sample, SdfvError, check, f3, lib,  # noqa: F401
                     MATERIAL_BRICK, MATERIAL_NORMAL, SDF_CUBE, SDF_DEMO, SDF_SPHERE)
 
 AIR_DIST = lib.sdfv_air_dist()  # scene/sdf/mod.rs:42
@@ -301,9 +301,40 @@ def commit_distance(grid, tex0, dist=None, stream=None):
     return dist
 
 
-def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=False, stream=None, out=None, dist=None):
+def set_option(option, value):
+    """sdfv_set_option: per-thread option of the library (A/B measurements, forcing kernel specialisations in tests)."""
+    check(lib.sdfv_set_option(int(option), int(value)))
+
+
+def get_option(option):
+    v = C.c_uint64(0)
+    check(lib.sdfv_get_option(int(option), C.byref(v)))
+    return int(v.value)
+
+
+class options:
+    """with pkg.options({pkg._capi.OPT_FILL_FORM: 2}): ...  -- sets the options, restores the previous values on exit."""
+
+    def __init__(self, values):
+        self.values = dict(values)
+
+    def __enter__(self):
+        self.saved = {k: get_option(k) for k in self.values}
+        for k, v in self.values.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            set_option(k, v)
+        return False
+
+
+def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=False, stream=None, out=None, dist=None,
+             want_depth=False, depth_out=None):
     """material.frag main() over rows [y0,y1).  Returns rgba [n_cam, rows, W, 4] (+ aux [n_cam, rows, W, 18] words).
-    `dist` = optional compact distance volume from commit_distance()."""
+    `dist` = optional compact distance volume from commit_distance().  want_depth / depth_out: also return the
+    gl_FragDepth plane [n_cam, rows, W] (sdfv_raymarch_depth); return order: rgba[, depth][, aux]."""
     if isinstance(cameras, Camera):
         cameras = [cameras]
     y1 = height if y1 is None else y1
@@ -311,8 +342,13 @@ def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=Fal
     cam_arr = (Camera * n)(*cameras)
     rgba = out if out is not None else torch.empty((n, y1 - y0, width, 4), dtype=torch.float32, device=tex0.device)
     aux = torch.empty((n, y1 - y0, width, AUX_FLOATS), dtype=torch.int32, device=tex0.device) if want_aux else None
-    check(lib.sdfv_raymarch_accel(C.byref(rp), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"),
+    depth = depth_out
+    if depth is None and want_depth:
+        depth = torch.empty((n, y1 - y0, width), dtype=torch.float32, device=tex0.device)
+    check(lib.sdfv_raymarch_depth(C.byref(rp), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"),
                                   None if dist is None else _dev_ptr(dist, "dist"), cam_arr, n, width, height,
                                   y0, y1, C.c_void_p(rgba.data_ptr()),
+                                  None if depth is None else _dev_ptr(depth, "depth"),
                                   C.c_void_p(aux.data_ptr()) if want_aux else None, _stream_ptr(stream)))
-    return (rgba, aux) if want_aux else rgba
+    ret = (rgba,) + ((depth,) if (want_depth or depth_out is not None) else ()) + ((aux,) if want_aux else ())
+    return ret if len(ret) > 1 else rgba

@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdfgrid.so")
+# SDFGRID_LIBRARY (read by this HARNESS, not by the library): load another build of the same ABI, e.g. the tuning
+# build libsdfgrid_tuning.so that tools/wave_timing.py needs.
+LIB_PATH = os.environ.get("SDFGRID_LIBRARY") or os.path.join(_HERE, "libsdfgrid.so")
 
 
 class SdfvError(RuntimeError):
@@ -39,10 +41,15 @@ class Camera(C.Structure):
                 ("bvp", C.c_float * 16)]
 
 
+class Light(C.Structure):  # sdfv_light
+    _fields_ = [("kind", C.c_uint32), ("color", C.c_float * 3), ("intensity", C.c_float), ("direction", C.c_float * 3)]
+
+
 class RenderParams(C.Structure):
     _fields_ = [("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3), ("tex_size", C.c_uint32 * 3),
                 ("lod_dist_between_samples", C.c_float), ("tint", C.c_float * 4), ("ambient", C.c_float * 3),
-                ("gamma", C.c_float), ("tone_mapping", C.c_uint32), ("color_mapping", C.c_uint32)]
+                ("gamma", C.c_float), ("tone_mapping", C.c_uint32), ("color_mapping", C.c_uint32),
+                ("n_lights", C.c_uint32), ("lights", Light * 4)]
 
 
 class MarchAux(C.Structure):
@@ -69,6 +76,8 @@ PROTOTYPES = {
     "sdfv_last_error": (C.c_char_p, []),
     "sdfv_device_count": (C.c_int, []),
     "sdfv_air_dist": (C.c_float, []),
+    "sdfv_set_option": (C.c_int, [C.c_uint32, C.c_uint64]),
+    "sdfv_get_option": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint64)]),
     "sdfv_demo_params_default": (None, [C.POINTER(DemoParams)]),
     "sdfv_grid_from_bb": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(Grid)]),
     "sdfv_render_params_default": (None, [C.POINTER(RenderParams), C.POINTER(Grid)]),
@@ -96,6 +105,9 @@ PROTOTYPES = {
     "sdfv_raymarch_accel": (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Camera),
                                       C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
+    "sdfv_raymarch_depth": (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Camera),
+                                      C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_fill_grid_host": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p, C.c_void_p]),
     "sdfv_sample_points_host": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_int,
                                           C.c_void_p]),
@@ -123,6 +135,13 @@ PROTOTYPES = {
     "sdfv_slab_fill_step": (C.c_int, [C.c_void_p, C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
 }
+LIGHT_AMBIENT, LIGHT_DIRECTIONAL, MAX_LIGHTS = 0, 1, 4
+# sdfv_option / values (include/sdfgrid.h)
+OPT_FILL_NONTEMPORAL, OPT_FILL_FORM, OPT_RAYMARCH_DISABLE, OPT_RAYMARCH_KEEP_NORMAL, OPT_SLAB_STEP_FORM = 1, 2, 3, 4, 5
+OPT_TUNING_WAVE_TIMING = 100
+RM_NO_FAST_INDEX, RM_NO_POW2_EXTENT, RM_NO_POW2_SIZE, RM_NO_SYMMETRIC = 1, 2, 4, 8
+STEP_TWO_LAUNCH, STEP_ONE_LAUNCH, STEP_UNPACKED = 1, 2, 4
+FILL_FORM = {"auto": 0, "rows": 1, "flat": 2}
 PLACEMENT_SLACK = 64 << 10
 COMM_ID_BYTES = 128
 COMM_PERIODIC = 1

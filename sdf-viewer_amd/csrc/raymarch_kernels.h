@@ -28,7 +28,10 @@ struct RaymarchArgs {
     uint32_t compute_normal;     // evaluate sdfNormal per hit even when no aux is stored
     float4* rgba;                // n_cameras x (y1-y0) x width
     sdfv_march_aux* aux;         // same layout or nullptr
-    unsigned long long* wave_timing;  // tuning only: per wave {start, end, iterations, xcc|cu} or nullptr
+    float* depth;                // gl_FragDepth plane, same pixel layout, or nullptr
+#ifdef SDFV_TUNING
+    unsigned long long* wave_timing;  // tuning build only: per wave {start, end, iterations, covered mask} or nullptr
+#endif
     sdfv_camera cameras[16];
 };
 

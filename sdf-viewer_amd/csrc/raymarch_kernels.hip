@@ -296,6 +296,9 @@ __device__ __forceinline__ float4 shade(const RaymarchArgs& a, float4 raw0, floa
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float lit = occlusion * a.rp.ambient[c] * mixf(albedo[c], 0.0f, metallic);
+        // further ambient lights of the light list: calculate_lighting sums the lights' contributions
+        for (uint32_t l = 0; l < a.rp.n_lights; ++l)
+            lit += occlusion * (a.rp.lights[l].intensity * a.rp.lights[l].color[c]) * mixf(albedo[c], 0.0f, metallic);
         lit = tone_map(a.rp.tone_mapping, lit);
         lit = color_map(a.rp.color_mapping, lit);
         if (a.rp.gamma > 0.0f) lit = powf(lit, a.rp.gamma);
@@ -322,6 +325,7 @@ __device__ __forceinline__ void aux_clear(sdfv_march_aux& aux) {
     aux.depth = 1.0f;
 }
 
+#ifdef SDFV_TUNING
 __device__ __forceinline__ void stamp_wave(const RaymarchArgs& a, uint32_t wave, unsigned long long t_start,
                                            int iterations, unsigned long long covered_mask) {
     const uint64_t wave_id = ((uint64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
@@ -330,6 +334,7 @@ __device__ __forceinline__ void stamp_wave(const RaymarchArgs& a, uint32_t wave,
     a.wave_timing[wave_id * 4 + 2] = (unsigned long long)iterations;
     a.wave_timing[wave_id * 4 + 3] = covered_mask;
 }
+#endif
 
 // Primary ray through the centre of pixel (px, py) (image row 0 = top), not yet normalised.
 __device__ __forceinline__ V3 pixel_ray_raw(const RaymarchArgs& a, const sdfv_camera& cam, uint32_t px, uint32_t py) {
@@ -380,7 +385,9 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
     const bool in_image = px < a.width && py < a.y1;
     const sdfv_camera& cam = a.cameras[cam_idx];
     const uint64_t out_index = ((uint64_t)cam_idx * (a.y1 - a.y0) + row) * a.width + px;
+#ifdef SDFV_TUNING
     const unsigned long long t_start = a.wave_timing ? __builtin_readcyclecounter() : 0ull;
+#endif
 
     const V3 eye = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
     const V3 d_raw = pixel_ray_raw(a, cam, px, py);
@@ -404,7 +411,10 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
                     a.aux[out_index] = aux;
                 }
             }
+            if (in_image && a.depth) a.depth[out_index] = 1.0f;
+#ifdef SDFV_TUNING
             if (a.wave_timing && lane == 0) stamp_wave(a, wave, t_start, 0, 0ull);
+#endif
             return;
         }
     }
@@ -451,6 +461,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
     }
 
     float4 rgba = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float frag_depth = 1.0f;  // material.frag:147 (no hit); also where no fragment exists
     sdfv_march_aux aux;
     if (AUX) {
         aux_clear(aux);
@@ -467,6 +478,12 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
         const float4 raw0 = sample_rgba<LINEAR, XF, FAST>(a, tex0, ray_pos);  // == the march's last sample
         const float4 raw1 = sample_rgba<LINEAR, XF, FAST>(a, tex1, ray_pos);  // material.frag:154
         rgba = shade(a, raw0, raw1);
+        if (a.depth) {  // gl_FragDepth, material.frag:180-181
+            const float* m = cam.bvp;
+            const float hz = m[2] * ray_pos.x + m[6] * ray_pos.y + m[10] * ray_pos.z + m[14];
+            const float hw = m[3] * ray_pos.x + m[7] * ray_pos.y + m[11] * ray_pos.z + m[15];
+            frag_depth = hz / hw;
+        }
         if (AUX || a.compute_normal) {
             // sdfNormal, material.frag:73-80
             const float sxn = (float)tex0.w / a.rp.lod_dist_between_samples;
@@ -511,9 +528,12 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
         }
     }
 
+#ifdef SDFV_TUNING
     if (a.wave_timing && lane == 0) stamp_wave(a, wave, t_start, iterations, __ballot(covered));
+#endif
     if (in_image) {
         store_rgba(a.rgba + out_index, rgba);
+        if (a.depth) a.depth[out_index] = frag_depth;
         if (AUX) a.aux[out_index] = aux;
     }
 }

@@ -18,6 +18,7 @@
 namespace {
 
 thread_local char g_err[512] = "";
+thread_local sdfv::Options g_options;
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -56,6 +57,14 @@ int check_grid(const sdfv_grid* g) {
     if (!g) return fail(SDFV_ERR_INVALID_ARGUMENT, "grid is NULL");
     if (g->z_begin > g->z_end || g->z_end > g->dims[2])
         return fail(SDFV_ERR_INVALID_ARGUMENT, "slab [%u,%u) outside depth %u", g->z_begin, g->z_end, g->dims[2]);
+    return SDFV_OK;
+}
+
+// Every entry point that reinterprets a float* as float4* (dwordx4 loads and stores) checks this first: a misaligned
+// caller buffer is an argument error, not a GPU fault.
+int check_texel_alignment(const void* a, const void* b = nullptr, const void* c = nullptr) {
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "texel buffers (tex0, tex1, rgba) must be 16-byte aligned");
     return SDFV_OK;
 }
 
@@ -100,21 +109,31 @@ sdfv::FillArgs make_fill_args(const sdfv_demo_params& p, uint32_t sdf_id, const 
     return a;
 }
 
-// Store policy of the dense fill.  SDFV_FILL_NT overrides for tuning runs.
+// Store policy and index form of the dense fill (SDFV_OPT_FILL_*; plain stores and automatic choice by default).
 sdfv::FillLaunch fill_launch_config() {
     sdfv::FillLaunch c;
-    c.nontemporal = false;
-    if (const char* s = getenv("SDFV_FILL_NT")) c.nontemporal = atoi(s) != 0;
-    if (const char* s = getenv("SDFV_FILL_FORM")) {
-        c.force_flat = strcmp(s, "flat") == 0;
-        c.force_rows = strcmp(s, "rows") == 0;
-    }
+    c.nontemporal = g_options.fill_nontemporal;
+    c.force_rows = g_options.fill_form == 1;
+    c.force_flat = g_options.fill_form == 2;
     return c;
+}
+
+// The per-thread device caches below belong to the HIP device that was current when they were allocated.  A thread
+// that later calls in with another device current (one process driving several GPUs) must not launch kernels on
+// device B over pointers of device A: each cache records its owner and is released and re-made on a mismatch.
+int current_device() {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return d;
 }
 
 struct MeshScratch {
     void* p = nullptr;
     size_t bytes = 0;
+    int device = -1;
 };
 thread_local MeshScratch g_mesh_scratch;  // freed by sdfv_mesh_trim(); a thread that exits without it leaks the block
 
@@ -125,7 +144,14 @@ struct SmallStage {
     static constexpr size_t kBytes = 64 << 10;  // in + out of up to 1024 points
     char* dev = nullptr;
     char* host = nullptr;
+    int device = -1;
     bool ensure() {
+        const int now = current_device();
+        if (dev && device != now) {  // the staging block lives on another GPU than the one this call runs on
+            (void)hipFree(dev);
+            dev = nullptr;
+        }
+        device = now;
         if (dev && host) return true;
         if (!dev && hipMalloc((void**)&dev, kBytes) != hipSuccess) dev = nullptr;
         if (!host && hipHostMalloc((void**)&host, kBytes, hipHostMallocDefault) != hipSuccess) host = nullptr;
@@ -168,8 +194,9 @@ int run_over_host_buffers(const void* in_host, size_t in_bytes, void* out_host, 
 void derive_raymarch_args(const sdfv_render_params* rp, sdfv::RaymarchArgs& a) {
     memset(&a, 0, sizeof(a));
     a.rp = *rp;
-    a.pow2_extent = getenv("SDFV_RAYMARCH_NO_POW2") ? 0u : 1u;
-    a.fast_index = getenv("SDFV_RAYMARCH_GENERAL") ? 0u : 1u;
+    const uint32_t off = g_options.raymarch_disable;
+    a.pow2_extent = (off & SDFV_RM_NO_POW2_EXTENT) ? 0u : 1u;
+    a.fast_index = (off & SDFV_RM_NO_FAST_INDEX) ? 0u : 1u;
     a.pow2_size = 1;
     a.symmetric_box = 1;
     a.fast_normal = 1;
@@ -197,13 +224,29 @@ void derive_raymarch_args(const sdfv_render_params* rp, sdfv::RaymarchArgs& a) {
     }
     a.cull_radius2 = radius2 * 1.0201f + 1e-12f;  // (1.01 r)^2
     if (!(a.cull_radius2 > 0.0f) || !std::isfinite(a.cull_radius2)) a.cull_radius2 = INFINITY;  // never cull
-    if (getenv("SDFV_RAYMARCH_NO_SYMM")) a.symmetric_box = 0;
-    if (getenv("SDFV_RAYMARCH_NO_POW2N")) a.pow2_size = 0;
+    if (off & SDFV_RM_NO_SYMMETRIC) a.symmetric_box = 0;
+    if (off & SDFV_RM_NO_POW2_SIZE) a.pow2_size = 0;
+}
+
+// The light list: the scene's ambient light (rp->ambient) plus rp->lights.  Only ambient entries can be rendered.
+int check_lights(const sdfv_render_params* rp) {
+    if (rp->n_lights > SDFV_MAX_LIGHTS)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "n_lights %u exceeds SDFV_MAX_LIGHTS", rp->n_lights);
+    for (uint32_t i = 0; i < rp->n_lights; ++i) {
+        if (rp->lights[i].kind == SDFV_LIGHT_DIRECTIONAL)
+            return fail(SDFV_ERR_INVALID_ARGUMENT,
+                        "lights[%u] is directional: three-d 0.18.2 shader source not available (scene/mod.rs:107-112 keeps "
+                        "its directional lights commented out; their BRDF is not restated from memory)", i);
+        if (rp->lights[i].kind != SDFV_LIGHT_AMBIENT)
+            return fail(SDFV_ERR_INVALID_ARGUMENT, "lights[%u] has unknown kind %u", i, rp->lights[i].kind);
+    }
+    return SDFV_OK;
 }
 
 }  // namespace
 
 namespace sdfv {
+const Options& options() { return g_options; }
 int set_error(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -216,6 +259,7 @@ int fill_boundary_slices(const sdfv_demo_params* params, uint32_t sdf_id, const 
     if (int rc = check_params(params, sdf_id)) return rc;
     if (int rc = check_grid(slab)) return rc;
     if (slab->z_end - slab->z_begin < 2) return fail(SDFV_ERR_INVALID_ARGUMENT, "a slab of one slice has one boundary");
+    if (int rc = check_texel_alignment(o0, o1)) return rc;
     if (int rc = need_device()) return rc;
     FillArgs a = make_fill_args(*params, sdf_id, *slab, o0, o1);
     a.z_step = a.slab_d - 1;
@@ -242,6 +286,56 @@ int sdfv_device_count(void) {
 }
 
 float sdfv_air_dist(void) { return air_dist(); }
+
+int sdfv_set_option(uint32_t option, uint64_t value) {
+    switch (option) {
+        case SDFV_OPT_FILL_NONTEMPORAL:
+            if (value > 1) break;
+            g_options.fill_nontemporal = value != 0;
+            return SDFV_OK;
+        case SDFV_OPT_FILL_FORM:
+            if (value > 2) break;
+            g_options.fill_form = (uint32_t)value;
+            return SDFV_OK;
+        case SDFV_OPT_RAYMARCH_DISABLE:
+            if (value & ~(uint64_t)(SDFV_RM_NO_FAST_INDEX | SDFV_RM_NO_POW2_EXTENT | SDFV_RM_NO_POW2_SIZE | SDFV_RM_NO_SYMMETRIC)) break;
+            g_options.raymarch_disable = (uint32_t)value;
+            return SDFV_OK;
+        case SDFV_OPT_RAYMARCH_KEEP_NORMAL:
+            if (value > 1) break;
+            g_options.raymarch_keep_normal = value != 0;
+            return SDFV_OK;
+        case SDFV_OPT_SLAB_STEP_FORM: {
+            const uint64_t form = value & ~(uint64_t)SDFV_STEP_UNPACKED;
+            if (form != 0 && form != SDFV_STEP_TWO_LAUNCH && form != SDFV_STEP_ONE_LAUNCH) break;
+            g_options.slab_step_form = (uint32_t)value;
+            return SDFV_OK;
+        }
+        case SDFV_OPT_TUNING_WAVE_TIMING:
+#ifdef SDFV_TUNING
+            g_options.wave_timing = value;
+            return SDFV_OK;
+#else
+            return fail(SDFV_ERR_INVALID_ARGUMENT, "SDFV_OPT_TUNING_WAVE_TIMING needs the tuning build (make tuning)");
+#endif
+        default:
+            return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown option %u", option);
+    }
+    return fail(SDFV_ERR_INVALID_ARGUMENT, "value %llu is out of range for option %u", (unsigned long long)value, option);
+}
+
+int sdfv_get_option(uint32_t option, uint64_t* value) {
+    if (!value) return fail(SDFV_ERR_INVALID_ARGUMENT, "value is NULL");
+    switch (option) {
+        case SDFV_OPT_FILL_NONTEMPORAL: *value = g_options.fill_nontemporal; return SDFV_OK;
+        case SDFV_OPT_FILL_FORM: *value = g_options.fill_form; return SDFV_OK;
+        case SDFV_OPT_RAYMARCH_DISABLE: *value = g_options.raymarch_disable; return SDFV_OK;
+        case SDFV_OPT_RAYMARCH_KEEP_NORMAL: *value = g_options.raymarch_keep_normal; return SDFV_OK;
+        case SDFV_OPT_SLAB_STEP_FORM: *value = g_options.slab_step_form; return SDFV_OK;
+        case SDFV_OPT_TUNING_WAVE_TIMING: *value = g_options.wave_timing; return SDFV_OK;
+        default: return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown option %u", option);
+    }
+}
 
 void sdfv_demo_params_default(sdfv_demo_params* p) {
     if (!p) return;
@@ -341,6 +435,7 @@ int sdfv_camera_look_at(sdfv_camera* cam, const float eye[3], const float target
 int sdfv_grid_init(const sdfv_grid* grid, float* tex0, float* tex1, void* stream) {
     if (int rc = check_grid(grid)) return rc;
     if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
+    if (int rc = check_texel_alignment(tex0, tex1)) return rc;
     if (int rc = need_device()) return rc;
     const uint64_t n = (uint64_t)grid->dims[0] * grid->dims[1] * (grid->z_end - grid->z_begin);
     SDFV_HIP(sdfv::launch_grid_init(tex0, tex1, n, air_dist(), (hipStream_t)stream));
@@ -352,7 +447,7 @@ int sdfv_fill_grid_commit(const sdfv_demo_params* params, uint32_t sdf_id, const
     if (int rc = check_params(params, sdf_id)) return rc;
     if (int rc = check_grid(grid)) return rc;
     if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
-    if (((uintptr_t)tex0 | (uintptr_t)tex1) & 15) return fail(SDFV_ERR_INVALID_ARGUMENT, "textures must be 16-byte aligned");
+    if (int rc = check_texel_alignment(tex0, tex1)) return rc;
     if ((uintptr_t)dist & 3) return fail(SDFV_ERR_INVALID_ARGUMENT, "dist must be 4-byte aligned");
     if (int rc = need_device()) return rc;
     sdfv::FillArgs a = make_fill_args(*params, sdf_id, *grid, tex0, tex1);
@@ -449,6 +544,8 @@ int sdfv_fill_grid_pass_dist(const sdfv_demo_params* params, uint32_t sdf_id, co
     if (int rc = check_grid(grid)) return rc;
     if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
     if (step == 0 || (step & (step - 1))) return fail(SDFV_ERR_INVALID_ARGUMENT, "step %u is not a power of two", step);
+    if (int rc = check_texel_alignment(tex0, tex1)) return rc;
+    if ((uintptr_t)dist & 3) return fail(SDFV_ERR_INVALID_ARGUMENT, "dist must be 4-byte aligned");
     if (int rc = need_device()) return rc;
     sdfv::FillArgs a = make_fill_args(*params, sdf_id, *grid, tex0, tex1);
     sdfv::PassArgs p;
@@ -548,11 +645,13 @@ int sdfv_mesh_extract(const sdfv_demo_params* params, uint32_t sdf_id, const flo
     const size_t o_dist = 0, o_first = o_dist + up(n_points * 4), o_cfirst = o_first + up(n_points * 4),
                  o_mask = o_cfirst + up(n_cells * 4), o_tmp = o_mask + up(n_points), o_totals = o_tmp + up(w.scan_tmp_bytes),
                  need = o_totals + 256;
-    if (g_mesh_scratch.bytes < need) {
+    const int device_now = current_device();
+    if (g_mesh_scratch.bytes < need || g_mesh_scratch.device != device_now) {
         if (g_mesh_scratch.p) (void)hipFree(g_mesh_scratch.p);
         g_mesh_scratch = MeshScratch{};
         SDFV_HIP(hipMalloc(&g_mesh_scratch.p, need));
         g_mesh_scratch.bytes = need;
+        g_mesh_scratch.device = device_now;
     }
     char* base = static_cast<char*>(g_mesh_scratch.p);
     w.dist = (float*)(base + o_dist);
@@ -604,6 +703,8 @@ int sdfv_mesh_free(sdfv_mesh* mesh) {
 int sdfv_commit_distance(const sdfv_grid* grid, const float* tex0, float* dist, void* stream) {
     if (int rc = check_grid(grid)) return rc;
     if (!tex0 || !dist) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (int rc = check_texel_alignment(tex0)) return rc;
+    if ((uintptr_t)dist & 3) return fail(SDFV_ERR_INVALID_ARGUMENT, "dist must be 4-byte aligned");
     if (int rc = need_device()) return rc;
     const uint64_t n = (uint64_t)grid->dims[0] * grid->dims[1] * (grid->z_end - grid->z_begin);
     SDFV_HIP(sdfv::launch_commit_distance(tex0, dist, n, (hipStream_t)stream));
@@ -619,7 +720,17 @@ int sdfv_raymarch(const sdfv_render_params* rp, const float* tex0, const float* 
 int sdfv_raymarch_accel(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
                         const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width, uint32_t height, uint32_t y0,
                         uint32_t y1, float* rgba, sdfv_march_aux* aux, void* stream) {
+    return sdfv_raymarch_depth(rp, tex0, tex1, dist, cameras, n_cameras, width, height, y0, y1, rgba, nullptr, aux, stream);
+}
+
+int sdfv_raymarch_depth(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
+                        const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width, uint32_t height, uint32_t y0,
+                        uint32_t y1, float* rgba, float* depth, sdfv_march_aux* aux, void* stream) {
     if (!rp || !tex0 || !tex1 || !rgba) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (int rc = check_lights(rp)) return rc;
+    if (int rc = check_texel_alignment(tex0, tex1, rgba)) return rc;
+    if ((uintptr_t)dist & 3 || (uintptr_t)depth & 3 || (uintptr_t)aux & 3)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "dist, depth and aux must be 4-byte aligned");
     if (n_cameras && !cameras) return fail(SDFV_ERR_INVALID_ARGUMENT, "cameras is NULL");
     if (y0 > y1 || y1 > height) return fail(SDFV_ERR_INVALID_ARGUMENT, "rows [%u,%u) outside height %u", y0, y1, height);
     if (rp->tex_size[0] == 0 || rp->tex_size[1] == 0 || rp->tex_size[2] == 0)
@@ -639,11 +750,12 @@ int sdfv_raymarch_accel(const sdfv_render_params* rp, const float* tex0, const f
     a.y1 = y1;
     // sdfNormal's result only feeds calculate_lighting (material.frag:155,163), and the one AmbientLight the scene
     // configures (scene/mod.rs:106-112) does not read it: dead code a GLSL compiler removes.  It is evaluated when the
-    // aux record asks for it; SDFV_RAYMARCH_KEEP_NORMAL=1 evaluates it per hit regardless (what it would cost once a
+    // aux record asks for it; SDFV_OPT_RAYMARCH_KEEP_NORMAL evaluates it per hit regardless (what it would cost once a
     // directional light uses it).
-    a.compute_normal = getenv("SDFV_RAYMARCH_KEEP_NORMAL") ? 1u : 0u;
-    if (const char* s = getenv("SDFV_RAYMARCH_WAVE_TIMING"))  // tuning: address of a device buffer, 32 B per wave
-        a.wave_timing = reinterpret_cast<unsigned long long*>(strtoull(s, nullptr, 0));
+    a.compute_normal = g_options.raymarch_keep_normal ? 1u : 0u;
+#ifdef SDFV_TUNING
+    a.wave_timing = reinterpret_cast<unsigned long long*>(g_options.wave_timing);  // 32 B per wave, or 0
+#endif
     const uint64_t pixels_per_cam = (uint64_t)(y1 - y0) * width;
     for (uint32_t c0 = 0; c0 < n_cameras; c0 += sdfv::kMaxCamerasPerLaunch) {
         const uint32_t nc = n_cameras - c0 < sdfv::kMaxCamerasPerLaunch ? n_cameras - c0 : sdfv::kMaxCamerasPerLaunch;
@@ -651,6 +763,7 @@ int sdfv_raymarch_accel(const sdfv_render_params* rp, const float* tex0, const f
         memcpy(a.cameras, cameras + c0, nc * sizeof(sdfv_camera));
         a.rgba = reinterpret_cast<float4*>(rgba) + c0 * pixels_per_cam;
         a.aux = aux ? aux + c0 * pixels_per_cam : nullptr;
+        a.depth = depth ? depth + c0 * pixels_per_cam : nullptr;
         SDFV_HIP(sdfv::launch_raymarch(a, (hipStream_t)stream));
     }
     return SDFV_OK;
@@ -664,6 +777,8 @@ int sdfv_raymarch_slab(const sdfv_render_params* rp, const sdfv_grid* slab, uint
     if (!rp || !slab || !tex0 || !tex1 || !camera || !rgba || !out_down || !out_up || !counters)
         return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
     if (int rc = check_grid(slab)) return rc;
+    if (int rc = check_lights(rp)) return rc;
+    if (int rc = check_texel_alignment(tex0, tex1, rgba)) return rc;
     for (int i = 0; i < 3; ++i)
         if (rp->tex_size[i] != slab->dims[i])
             return fail(SDFV_ERR_INVALID_ARGUMENT, "render parameters describe a %ux%ux%u grid, the slab a %ux%ux%u one",

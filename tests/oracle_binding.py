@@ -31,10 +31,15 @@ class Camera(C.Structure):
                 ("bvp", C.c_float * 16)]
 
 
+class Light(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("color", C.c_float * 3), ("intensity", C.c_float), ("direction", C.c_float * 3)]
+
+
 class RenderParams(C.Structure):
     _fields_ = [("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3), ("tex_size", C.c_uint32 * 3),
                 ("lod_dist_between_samples", C.c_float), ("tint", C.c_float * 4), ("ambient", C.c_float * 3),
-                ("gamma", C.c_float), ("tone_mapping", C.c_uint32), ("color_mapping", C.c_uint32)]
+                ("gamma", C.c_float), ("tone_mapping", C.c_uint32), ("color_mapping", C.c_uint32),
+                ("n_lights", C.c_uint32), ("lights", Light * 4)]
 
 
 AUX_DTYPE = np.dtype([("status", "<i4"), ("steps", "<i4"), ("hit_pos", "<f4", 3), ("t", "<f4"),

@@ -27,9 +27,62 @@ def test_struct_layouts(pkg):
     assert C.sizeof(pkg.DemoParams) == 24
     assert C.sizeof(pkg.Grid) == 44
     assert C.sizeof(pkg.Camera) == 120
-    assert C.sizeof(pkg.RenderParams) == 80
+    assert C.sizeof(pkg.Light) == 32
+    assert C.sizeof(pkg.RenderParams) == 80 + 4 + 4 * 32
     assert C.sizeof(pkg.MarchAux) == 72
-    assert pkg.lib.sdfv_abi_version() == 1
+    assert pkg.lib.sdfv_abi_version() == 2
+
+
+def test_options_are_explicit_and_the_library_reads_no_environment(pkg):
+    """Kernel-variant knobs travel through sdfv_set_option (thread-local), never through getenv."""
+    K = pkg._capi
+    for opt in (K.OPT_FILL_NONTEMPORAL, K.OPT_FILL_FORM, K.OPT_RAYMARCH_DISABLE, K.OPT_RAYMARCH_KEEP_NORMAL,
+                K.OPT_SLAB_STEP_FORM):
+        assert pkg.get_option(opt) == 0                     # product defaults
+    with pkg.options({K.OPT_FILL_FORM: 2, K.OPT_RAYMARCH_DISABLE: K.RM_NO_SYMMETRIC | K.RM_NO_POW2_SIZE}):
+        assert pkg.get_option(K.OPT_FILL_FORM) == 2 and pkg.get_option(K.OPT_RAYMARCH_DISABLE) == 12
+        import threading
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(pkg.get_option(K.OPT_FILL_FORM)))
+        t.start()
+        t.join()
+        assert seen == [0]                                  # another thread keeps the defaults
+    assert pkg.get_option(K.OPT_FILL_FORM) == 0
+    assert pkg.lib.sdfv_set_option(K.OPT_FILL_FORM, 3) == -1
+    assert pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_DISABLE, 16) == -1
+    assert pkg.lib.sdfv_set_option(77, 0) == -1 and b"unknown option" in pkg.lib.sdfv_last_error()
+    # the wave-timing stamps exist only in the tuning build
+    assert pkg.lib.sdfv_set_option(K.OPT_TUNING_WAVE_TIMING, 4096) == -1
+    assert b"tuning build" in pkg.lib.sdfv_last_error()
+    for src in os.listdir(os.path.join(ROOT, "sdf-viewer_amd", "csrc")):
+        if src.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(ROOT, "sdf-viewer_amd", "csrc", src)).read(), src
+
+
+def test_light_list_rejects_what_the_reference_does_not_pin(pkg):
+    """Only ambient lights are rendered; a directional entry is an argument error (three-d 0.18.2's shader text is not
+    in the reference tree), reported before any device work -- so this runs without a GPU."""
+    g = pkg.make_grid((4, 4, 4))
+    rp = pkg.default_render_params(g)
+    assert rp.n_lights == 0
+    cam = pkg.camera_look_at()
+    args = (C.c_void_p(16), C.c_void_p(16), None, C.byref(cam), 1, 8, 8, 0, 8, C.c_void_p(16), None, None, None)
+    rp.n_lights = 1
+    rp.lights[0].kind = pkg._capi.LIGHT_DIRECTIONAL
+    assert pkg.lib.sdfv_raymarch_depth(C.byref(rp), *args) == -1
+    assert b"three-d 0.18.2 shader source not available" in pkg.lib.sdfv_last_error()
+    rp.lights[0].kind = 9
+    assert pkg.lib.sdfv_raymarch_depth(C.byref(rp), *args) == -1 and b"unknown kind" in pkg.lib.sdfv_last_error()
+    rp.n_lights = 5
+    assert pkg.lib.sdfv_raymarch_depth(C.byref(rp), *args) == -1
+    # misaligned texel buffers are argument errors too (they are read and written as 16-byte texels)
+    rp.n_lights = 0
+    bad = (C.c_void_p(20),) + args[1:]
+    assert pkg.lib.sdfv_raymarch_depth(C.byref(rp), *bad) == -1 and b"16-byte aligned" in pkg.lib.sdfv_last_error()
+    p = pkg.default_params()
+    assert pkg.lib.sdfv_grid_init(C.byref(g), C.c_void_p(24), C.c_void_p(16), None) == -1
+    assert pkg.lib.sdfv_fill_grid_pass(C.byref(p), 0, C.byref(g), 1, None, C.c_void_p(16), C.c_void_p(8), None) == -1
+    assert pkg.lib.sdfv_commit_distance(C.byref(g), C.c_void_p(8), C.c_void_p(16), None) == -1
 
 
 def test_defaults_match_reference_flags(pkg):

@@ -54,13 +54,13 @@ def test_dense_fill_matches_oracle(pkg, oracle, dims):
 
 @pytest.mark.parametrize("form", ["flat", "rows"])
 @pytest.mark.parametrize("dims", [(64, 16, 8), (7, 13, 300), (257, 3, 5), (1, 9, 4), (1000, 6, 2)])
-def test_both_index_forms_of_the_dense_fill(pkg, oracle, monkeypatch, form, dims):
+def test_both_index_forms_of_the_dense_fill(pkg, oracle, form, dims):
     """The row-chunk and the flat form of the dense kernel produce the same texels on every width, whichever the
-    launcher would have picked (SDFV_FILL_FORM overrides the choice; slab offsets included)."""
-    monkeypatch.setenv("SDFV_FILL_FORM", form)
+    launcher would have picked (SDFV_OPT_FILL_FORM overrides the choice; slab offsets included)."""
     for prm in (pkg.default_params(), pkg.default_params(cube_material=1, disable_sphere=1)):
         z0 = dims[2] // 3
-        t0, t1 = gpu_fill(pkg, prm, dims, z0=z0, z1=dims[2])
+        with pkg.options({pkg._capi.OPT_FILL_FORM: pkg._capi.FILL_FORM[form]}):
+            t0, t1 = gpu_fill(pkg, prm, dims, z0=z0, z1=dims[2])
         r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, z0=z0, z1=dims[2])
         assert_bits_equal(t0, r0)
         assert_bits_equal(t1, r1)

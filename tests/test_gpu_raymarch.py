@@ -40,18 +40,20 @@ def compare(pkg, oracle, g, t0, t1, h0, h1, cam_kw, width, height, rp_edit=None,
     # every march kernel family must reproduce the oracle: the fast march (symmetric-box / fused-scale /
     # reciprocal / divide variants) over tex0.r, the same over the compact distance volume, and the general
     # kernel (full MirroredRepeat, the shader's nested loop)
-    env_of = {"fast": {}, "dist": {}, "general": {"SDFV_RAYMARCH_GENERAL": "1"},
-              "fast_plain": {"SDFV_RAYMARCH_NO_SYMM": "1", "SDFV_RAYMARCH_NO_POW2N": "1"},
-              "fast_div": {"SDFV_RAYMARCH_NO_SYMM": "1", "SDFV_RAYMARCH_NO_POW2": "1"}}
-    for variant, env in env_of.items():
-        os.environ.update(env)
-        try:
-            rgba, aux = pkg.raymarch(rp, t0, t1, cam, width, height, y0=y0, y1=y1, want_aux=True,
-                                     dist=dist if variant == "dist" else None)
+    K = pkg._capi
+    disabled = {"fast": 0, "dist": 0, "general": K.RM_NO_FAST_INDEX,
+                "fast_plain": K.RM_NO_SYMMETRIC | K.RM_NO_POW2_SIZE,
+                "fast_div": K.RM_NO_SYMMETRIC | K.RM_NO_POW2_EXTENT}
+    for variant, mask in disabled.items():
+        with pkg.options({K.OPT_RAYMARCH_DISABLE: mask}):
+            rgba, depth, aux = pkg.raymarch(rp, t0, t1, cam, width, height, y0=y0, y1=y1, want_aux=True,
+                                            want_depth=True, dist=dist if variant == "dist" else None)
+            # the depth plane without the 72-byte record must be the same plane
+            _, depth_only = pkg.raymarch(rp, t0, t1, cam, width, height, y0=y0, y1=y1, want_depth=True,
+                                         dist=dist if variant == "dist" else None)
             torch.cuda.synchronize()
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
+        assert torch.equal(depth.view(torch.int32), depth_only.view(torch.int32)), variant
+        assert torch.equal(depth.view(torch.int32), aux[..., -1]), f"{variant}: depth plane != aux.depth"
         got_rgba = rgba[0].cpu().numpy()
         got_aux = aux_to_np(oracle, aux)[0]
         for field in ("status", "steps"):
@@ -105,6 +107,18 @@ def test_other_sdf_params_and_shading_options(pkg, oracle):
         rp.color_mapping = 0
 
     compare(pkg, oracle, *env, cam_kw={}, width=80, height=60, rp_edit=edit2)
+
+    def two_more_ambient_lights(rp):  # the light list beyond the scene's one AmbientLight (scene/mod.rs:106-112)
+        rp.ambient[0], rp.ambient[1], rp.ambient[2] = 0.25, 0.25, 0.25
+        rp.n_lights = 2
+        rp.lights[0].kind, rp.lights[0].intensity = pkg._capi.LIGHT_AMBIENT, 0.5
+        rp.lights[0].color[0], rp.lights[0].color[1], rp.lights[0].color[2] = 1.0, 0.5, 0.25
+        rp.lights[1].kind, rp.lights[1].intensity = pkg._capi.LIGHT_AMBIENT, 0.125
+        rp.lights[1].color[0], rp.lights[1].color[1], rp.lights[1].color[2] = 0.0, 1.0, 1.0
+
+    rgba, _ = compare(pkg, oracle, *env, cam_kw={}, width=80, height=60, rp_edit=two_more_ambient_lights)
+    base, _ = compare(pkg, oracle, *env, cam_kw={}, width=80, height=60)
+    assert np.abs(rgba[..., :3] - base[..., :3]).max() > 0.05  # the lights really change the picture
 
 
 def test_tiny_bbox_disables_fast_index(pkg, oracle):

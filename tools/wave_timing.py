@@ -1,29 +1,66 @@
 #!/usr/bin/env python3
-"""Tuning: per-wave start/end cycle stamps of the raymarch kernel (SDFV_RAYMARCH_WAVE_TIMING)."""
-import importlib, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+"""Tuning: per-wave start/end cycle stamps of the raymarch kernel (option SDFV_OPT_TUNING_WAVE_TIMING of the TUNING
+build, `make -C sdf-viewer_amd/csrc tuning`; the product library has no such code).  Prints a summary and, with
+--json PATH, writes the histogram of wave durations / iterations of the default 1080p frame over the 256^3 grid.
+Usage: python tools/wave_timing.py [--dist] [--json profiles/r02_wave_timing_1080p.json]"""
+import importlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["SDFGRID_LIBRARY"] = os.path.join(ROOT, "sdf-viewer_amd", "libsdfgrid_tuning.so")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
 pkg = importlib.import_module("sdf-viewer_amd")
+K = pkg._capi
 side, W, H = 256, 1920, 1080
-prm = pkg.default_params(); g = pkg.make_grid((side,) * 3)
-t0, t1 = pkg.alloc_textures(g); pkg.fill_grid(prm, g, t0, t1)
-rp = pkg.default_render_params(g); cam = pkg.camera_look_at(aspect=W / H)
+prm = pkg.default_params()
+g = pkg.make_grid((side,) * 3)
+t0, t1 = pkg.alloc_textures(g)
+pkg.fill_grid(prm, g, t0, t1)
+rp = pkg.default_render_params(g)
+cam = pkg.camera_look_at(aspect=W / H)
 n_waves = ((W + 15) // 16) * ((H + 15) // 16) * 4
 buf = torch.zeros((n_waves, 4), dtype=torch.int64, device="cuda")
 dist = pkg.commit_distance(g, t0) if "--dist" in sys.argv else None
-for _ in range(3): pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist)
-os.environ["SDFV_RAYMARCH_WAVE_TIMING"] = hex(buf.data_ptr())
+for _ in range(200):  # clock ramp
+    pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist)
+pkg.set_option(K.OPT_TUNING_WAVE_TIMING, buf.data_ptr())
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-a.record(); pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist); b.record(); torch.cuda.synchronize()
+a.record()
+pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist)
+b.record()
+torch.cuda.synchronize()
+pkg.set_option(K.OPT_TUNING_WAVE_TIMING, 0)
 d = buf.cpu().numpy()
 start, end, it = d[:, 0], d[:, 1], d[:, 2]
-t00 = start.min(); dur = end - start
-print("kernel ms", a.elapsed_time(b), "span cycles", end.max() - t00, "waves", n_waves)
-print("iterations: max", it.max(), "mean(active)", it[it > 0].mean(), "active waves", (it > 0).sum())
-print("wave duration cycles: idle-waves median", np.median(dur[it == 0]), "active median", np.median(dur[it > 0]), "max", dur.max())
+t00 = start.min()
+dur = end - start
 act = it > 0
 cpi = dur[act] / it[act]
-print("cycles per iteration (active waves): median", np.median(cpi), "p10", np.percentile(cpi, 10), "p90", np.percentile(cpi, 90))
 order = np.argsort(-dur)[:10]
-for i in order: print("wave", i, "iters", it[i], "dur", dur[i], "cyc/iter", dur[i] / max(it[i], 1), "start", start[i] - t00, "end", end[i] - t00)
-print("last start", (start - t00).max(), "pct of waves started by 25/50/75% of span", [np.mean((start - t00) < f * (end.max() - t00)) for f in (.25, .5, .75)])
+summary = {
+    "kernel_ms": a.elapsed_time(b), "span_cycles": int(end.max() - t00), "waves": int(n_waves),
+    "active_waves": int(act.sum()), "iterations_max": int(it.max()), "iterations_mean_active": float(it[act].mean()),
+    "wave_cycles_idle_median": float(np.median(dur[~act])), "wave_cycles_active_median": float(np.median(dur[act])),
+    "wave_cycles_max": int(dur.max()),
+    "cycles_per_iteration_active": {"p10": float(np.percentile(cpi, 10)), "median": float(np.median(cpi)),
+                                    "p90": float(np.percentile(cpi, 90))},
+    "longest_waves": [{"wave": int(i), "iterations": int(it[i]), "cycles": int(dur[i]),
+                       "cycles_per_iteration": float(dur[i] / max(it[i], 1)), "start": int(start[i] - t00),
+                       "end": int(end[i] - t00)} for i in order],
+    "hist_iterations": {"edges": [0, 1, 8, 16, 32, 64, 128, 192, 255, 256],
+                        "counts": np.histogram(it, bins=[0, 1, 8, 16, 32, 64, 128, 192, 255, 256])[0].tolist()},
+    "hist_wave_kcycles": {"edges": [0, 2, 5, 10, 20, 50, 100, 150, 200, 300, 1000],
+                          "counts": np.histogram(dur / 1e3, bins=[0, 2, 5, 10, 20, 50, 100, 150, 200, 300, 1000])[0].tolist()},
+    "waves_started_by_fraction_of_span": {str(f): float(np.mean((start - t00) < f * (end.max() - t00)))
+                                          for f in (0.25, 0.5, 0.75)},
+    "config": {"grid": side, "image": [W, H], "dist_volume": dist is not None},
+}
+print(json.dumps(summary, indent=1))
+if "--json" in sys.argv:
+    with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
+        json.dump(summary, f, indent=1)
