@@ -347,6 +347,9 @@ int sdfv_raymarch_host(const sdfv_render_params *rp, const float *tex0_host, con
  * RCCL is loaded at run time (librccl.so.1), so hosts that never create a communicator do not need it. */
 #define SDFV_COMM_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
 #define SDFV_COMM_PERIODIC 1u
+#define SDFV_COMM_HALO2    2u /* TWO ghost slices on the upper side: [ghost_lo (0/1)] [owned] [ghost_hi (0/2)], every rank
+                               * sends its first two owned slices down.  What sdfNormal's taps need in sdfv_raymarch_slab
+                               * (material.frag:73-80 reaches one slice beyond the march's own fetch). */
 typedef struct sdfv_slab_comm sdfv_slab_comm;
 
 /* Rank 0 makes the id; the HOST hands the 128 bytes to every rank by whatever channel it has. */
@@ -360,12 +363,22 @@ int sdfv_slab_comm_unique_id(unsigned char id_out[SDFV_COMM_ID_BYTES]);
 int sdfv_slab_comm_create(const unsigned char id[SDFV_COMM_ID_BYTES], int rank, int world, uint32_t flags,
                           sdfv_slab_comm **out);
 int sdfv_slab_comm_destroy(sdfv_slab_comm *comm);
-/* The halo exchange alone, enqueued on `stream` (one ncclGroup of up to 4 sends + 4 receives). DEVICE pointers. */
+/* Ghost slices this rank's textures carry below / above the owned slices, and whether the one-launch step is available
+ * on this device (hipStreamWaitValue32).  Any output pointer may be NULL. */
+int sdfv_slab_comm_info(const sdfv_slab_comm *comm, uint32_t *ghost_lo, uint32_t *ghost_hi, uint32_t *one_launch_capable);
+/* The halo exchange alone, enqueued on `stream` (one ncclGroup of up to 4 sends + 4 receives straight on the textures:
+ * the first 1 (2 with SDFV_COMM_HALO2) owned slices down, the last owned slice up). DEVICE pointers. */
 int sdfv_slab_halo_exchange(sdfv_slab_comm *comm, const sdfv_grid *slab, float *tex0, float *tex1, void *stream);
 /* One fill step of this rank = sdfv_fill_grid over the owned slab + the halo exchange, with the exchange hidden
- * behind the fill: the two boundary slices are filled first, the exchange runs on the communicator's own stream
- * while `stream` fills the interior, and `stream` then waits for the exchange.  On return everything is enqueued;
- * work later put on `stream` sees owned and ghost slices complete. */
+ * behind the fill.  The dense fill runs in BOUNDARY-FIRST workgroup order: the slices the neighbours wait for are filled
+ * by the first workgroups of the launch, which also copy them into the communicator's packed send buffers (ONE message
+ * per neighbour and direction carrying both textures' slices), publish them device-wide and signal; the communicator's
+ * high-priority stream waits on that signal (hipStreamWaitValue32) -- not on the kernel -- so the RCCL exchange and the
+ * copy of the received slices into the ghosts run under the rest of the SAME launch; `stream` then waits for them.
+ * SDFV_OPT_SLAB_STEP_FORM selects the two-launch form (boundary workgroups as a launch of their own + event; the
+ * default where hipStreamWaitValue32 is unavailable) or unpacked messages.  Slabs too thin to have an interior, or
+ * whose rows do not fill whole workgroups, are filled and then exchanged.  On return everything is enqueued; work later
+ * put on `stream` sees owned and ghost slices complete. */
 int sdfv_slab_fill_step(sdfv_slab_comm *comm, const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *slab,
                         float *tex0, float *tex1, void *stream);
 

@@ -106,8 +106,17 @@ static float vec_len(const float v[3]) {
     return sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
 }
 
+uint32_t or_ext_variant_flags = 0; /* [EXT] sensitivity switches, see sdf_oracle.h */
+void or_set_ext_variant(uint32_t flags) { or_ext_variant_flags = flags; }
+uint32_t or_get_ext_variant(void) { return or_ext_variant_flags; }
+
 /* SDFDemoSphere::normal, sphere.rs:122-124; cgmath normalize = v * (1 / |v|) [EXT] */
 static void sphere_normal(const float p[3], float n[3]) {
+    if (or_ext_variant_flags & OR_EXT_CGMATH_NORMALIZE_DIV) {
+        float l = vec_len(p);
+        n[0] = p[0] / l; n[1] = p[1] / l; n[2] = p[2] / l;
+        return;
+    }
     float inv = 1.0f / vec_len(p);
     n[0] = p[0] * inv;
     n[1] = p[1] * inv;

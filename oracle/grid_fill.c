@@ -47,8 +47,10 @@ float or_voxel_coord(uint32_t idx, uint32_t dim, float bb_min, float bb_max) {
 
 /* three-d-asset 0.9.2 [EXT]: impl From<Vec3> for Srgba -> (c * 255.0) as u8 (truncating, saturating,
  * NaN -> 0) */
+extern uint32_t or_ext_variant_flags;
 uint8_t or_srgb_quantize(float c) {
     float v = c * 255.0f;
+    if (or_ext_variant_flags & OR_EXT_SRGB_QUANT_ROUND) v = v + 0.5f;
     if (!(v > 0.0f)) return 0; /* negatives, -0, NaN */
     if (v >= 255.0f) return 255;
     return (uint8_t)v;
@@ -58,7 +60,11 @@ uint8_t or_srgb_quantize(float c) {
 float or_srgb_u8_to_linear(uint8_t c8) {
     float c = (float)c8 / 255.0f;
     if (c < 0.04045f) return c / 12.92f;
-    return powf((c + 0.055f) / 1.055f, 2.4f);
+    if (or_ext_variant_flags & OR_EXT_SRGB_DOUBLE_POW) return (float)pow(((double)c + 0.055) / 1.055, 2.4);
+    float r = powf((c + 0.055f) / 1.055f, 2.4f);
+    if (or_ext_variant_flags & OR_EXT_SRGB_POW_ULP_UP) r = nextafterf(r, 2.0f);
+    if (or_ext_variant_flags & OR_EXT_SRGB_POW_ULP_DOWN) r = nextafterf(r, -1.0f);
+    return r;
 }
 
 /* scene/sdf/mod.rs:196-208 */

@@ -27,11 +27,23 @@ static v3 v3_from(const float *p) { return v3_make(p[0], p[1], p[2]); }
 static v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
 static v3 v3_madd(v3 a, v3 d, float t) { return v3_make(a.x + d.x * t, a.y + d.y * t, a.z + d.z * t); }
 static float v3_len(v3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+extern uint32_t or_ext_variant_flags; /* [EXT] sensitivity switches (sdf_oracle.h); 0 in every parity test */
 static v3 v3_normalize(v3 a) {
     float l = v3_len(a);
+    if (or_ext_variant_flags & OR_EXT_GLSL_NORMALIZE_RSQ) {
+        float r = 1.0f / l;
+        return v3_make(a.x * r, a.y * r, a.z * r);
+    }
     return v3_make(a.x / l, a.y / l, a.z / l);
 }
-static float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+static float mixf(float a, float b, float t) {
+    if (or_ext_variant_flags & OR_EXT_GLSL_MIX_LERP) return a + t * (b - a);
+    return a * (1.0f - t) + b * t;
+}
+
+/* Texel-touch recording for or_raymarch_touch: the map the current phase of the current thread marks, or NULL. */
+static _Thread_local uint8_t *tl_touch_map = NULL;
+static _Thread_local const float *tl_touch_tex = NULL;
 
 void or_default_render_params(OrRenderParams *rp, const uint32_t dims[3], const float bb_min[3], const float bb_max[3]) {
     memset(rp, 0, sizeof(*rp));
@@ -102,7 +114,9 @@ static const float *texel(const float *tex, const uint32_t size[3], int64_t i, i
     i = mirror_index(i, size[0]);
     j = mirror_index(j, size[1]);
     k = mirror_index(k, size[2]);
-    return tex + (((size_t)k * size[1] + (size_t)j) * size[0] + (size_t)i) * 4;
+    const size_t at = ((size_t)k * size[1] + (size_t)j) * size[0] + (size_t)i;
+    if (tl_touch_map && tex == tl_touch_tex) tl_touch_map[at] = 1;
+    return tex + at * 4;
 }
 
 /* texture(sampler3D, p01) with min/mag LINEAR (scene/sdf/mod.rs:241-250), wrap MirroredRepeat (:113-115) */
@@ -117,6 +131,13 @@ static void tex_linear(const float *tex, const uint32_t size[3], const float p01
     const float *t010 = texel(tex, size, i0, j0 + 1, k0), *t110 = texel(tex, size, i0 + 1, j0 + 1, k0);
     const float *t001 = texel(tex, size, i0, j0, k0 + 1), *t101 = texel(tex, size, i0 + 1, j0, k0 + 1);
     const float *t011 = texel(tex, size, i0, j0 + 1, k0 + 1), *t111 = texel(tex, size, i0 + 1, j0 + 1, k0 + 1);
+    if (or_ext_variant_flags & OR_EXT_TRILINEAR_WEIGHTED) { /* GL 4.6 spec 8.14.2, eq. for TEXTURE_3D LINEAR */
+        float bx = 1.0f - ax, by = 1.0f - ay, bz = 1.0f - az;
+        for (int c = 0; c < 4; ++c)
+            out[c] = bx * by * bz * t000[c] + ax * by * bz * t100[c] + bx * ay * bz * t010[c] + ax * ay * bz * t110[c] +
+                     bx * by * az * t001[c] + ax * by * az * t101[c] + bx * ay * az * t011[c] + ax * ay * az * t111[c];
+        return;
+    }
     for (int c = 0; c < 4; ++c) {
         float c00 = mixf(t000[c], t100[c], ax);
         float c10 = mixf(t010[c], t110[c], ax);
@@ -219,6 +240,11 @@ void or_shade(const OrRenderParams *rp, const float raw0[4], const float raw1[4]
     rgba[3] = rp->tint[3]; /* :169 */
 }
 
+/* maps of the recording run (NULL outside or_raymarch_touch) */
+typedef struct { uint8_t *march0, *hit0, *hit1, *normal0; } TouchMaps;
+static const TouchMaps *g_touch = NULL;
+static void touch_phase(const float *tex, uint8_t *map) { tl_touch_tex = tex; tl_touch_map = map; }
+
 static void march_pixel(const OrRenderParams *rp, const float *tex0, const float *tex1, const OrCamera *cam,
                         uint32_t W, uint32_t H, uint32_t px, uint32_t py, float rgba[4], OrMarchAux *aux) {
     OrMarchAux a;
@@ -264,6 +290,7 @@ static void march_pixel(const OrRenderParams *rp, const float *tex0, const float
     float hit_w = 0.0f; /* vec4(0.0) if the loop ends without a break: cannot happen for maxSteps=256 */
     float raw0[4] = {0, 0, 0, 0};
     int steps = 0, hit = 0;
+    if (g_touch) touch_phase(tex0, g_touch->march0);
     for (int i = 0; i < max_steps; ++i) {
         if (i >= max_steps - 1) { hit_w = -1.0f; break; }
         if (oob_dist(rp, ray_pos) > 1e-4f) { hit_w = -2.0f; break; }
@@ -280,6 +307,7 @@ static void march_pixel(const OrRenderParams *rp, const float *tex0, const float
         dist_from_origin += sample_dist;
         ray_pos = v3_madd(ray_pos, ray_dir, sample_dist);
     }
+    if (g_touch) touch_phase(NULL, NULL);
     a.steps = steps;
     a.hit_pos[0] = ray_pos.x; a.hit_pos[1] = ray_pos.y; a.hit_pos[2] = ray_pos.z;
     a.t = dist_from_origin;
@@ -290,8 +318,16 @@ static void march_pixel(const OrRenderParams *rp, const float *tex0, const float
     }
     a.status = 1;
     memcpy(a.raw0, raw0, sizeof(raw0));
+    if (g_touch) { /* the texels under the hit: tex0's are those of the march's last fetch */
+        float again[4];
+        touch_phase(tex0, g_touch->hit0);
+        sdf_sample_raw_interp(tex0, rp, ray_pos, again);
+        touch_phase(tex1, g_touch->hit1);
+    }
     sdf_sample_raw_interp(tex1, rp, ray_pos, a.raw1); /* :154 */
+    if (g_touch) touch_phase(tex0, g_touch->normal0);
     v3 n = sdf_normal(tex0, rp, ray_pos);              /* :155 */
+    if (g_touch) touch_phase(NULL, NULL);
     a.normal[0] = n.x; a.normal[1] = n.y; a.normal[2] = n.z;
     or_shade(rp, a.raw0, a.raw1, rgba);
     /* :180-181 */
@@ -314,5 +350,38 @@ void or_raymarch(const OrRenderParams *rp, const float *tex0, const float *tex1,
             size_t o = ((size_t)(y - y0)) * width + x;
             march_pixel(rp, tex0, tex1, cam, width, height, x, (uint32_t)y, rgba + o * 4, aux ? aux + o : NULL);
         }
+    }
+}
+
+void or_raymarch_touch(const OrRenderParams *rp, const float *tex0, const float *tex1, const OrCamera *cam,
+                       uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                       uint8_t *march0, uint8_t *hit0, uint8_t *hit1, uint8_t *normal0,
+                       OrMarchCounts *counts, int n_threads) {
+    (void)n_threads;
+    const TouchMaps maps = {march0, hit0, hit1, normal0};
+    g_touch = &maps; /* marks are idempotent byte stores of 1: threads may race on them */
+    uint64_t covered = 0, hits = 0, sum_steps = 0, max_steps = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads > 0 ? n_threads : 1) \
+    reduction(+ : covered, hits, sum_steps) reduction(max : max_steps)
+#endif
+    for (int64_t y = y0; y < (int64_t)y1; ++y) {
+        for (uint32_t x = 0; x < width; ++x) {
+            float rgba[4];
+            OrMarchAux a;
+            march_pixel(rp, tex0, tex1, cam, width, height, x, (uint32_t)y, rgba, &a);
+            covered += a.status != 0;
+            hits += a.status == 1;
+            sum_steps += (uint64_t)a.steps;
+            if ((uint64_t)a.steps > max_steps) max_steps = (uint64_t)a.steps;
+        }
+    }
+    g_touch = NULL;
+    if (counts) {
+        counts->pixels = (uint64_t)(y1 - y0) * width;
+        counts->covered = covered;
+        counts->hits = hits;
+        counts->sum_steps = sum_steps;
+        counts->max_steps = max_steps;
     }
 }

@@ -30,6 +30,22 @@
 extern "C" {
 #endif
 
+/* ---- [EXT] sensitivity: the arithmetic restated from crates / GL that are not under the reference tree can be
+ * switched, one piece at a time, to its plausible alternative (tools/ext_sensitivity.py measures how far the outputs
+ * move).  0 = the restatement the parity tests use.  Process-wide; not for concurrent use with other oracle calls. */
+enum {
+    OR_EXT_SRGB_POW_ULP_UP      = 1u << 0, /* to_linear_srgb's powf result one ulp up (a libm that is not correctly rounded) */
+    OR_EXT_SRGB_POW_ULP_DOWN    = 1u << 1, /* ... one ulp down */
+    OR_EXT_SRGB_QUANT_ROUND     = 1u << 2, /* Srgba::from(Vec3): round(c * 255) instead of the truncating `as u8` */
+    OR_EXT_CGMATH_NORMALIZE_DIV = 1u << 3, /* cgmath normalize as v / |v| instead of v * (1 / |v|) */
+    OR_EXT_GLSL_MIX_LERP        = 1u << 4, /* mix(a, b, t) as a + t * (b - a) instead of a * (1 - t) + b * t */
+    OR_EXT_GLSL_NORMALIZE_RSQ   = 1u << 5, /* GLSL normalize as v * (1 / sqrt(dot)) instead of v / length(v) */
+    OR_EXT_TRILINEAR_WEIGHTED   = 1u << 6, /* GL spec form: sum of 8 weighted texels instead of nested mix x, y, z */
+    OR_EXT_SRGB_DOUBLE_POW      = 1u << 7  /* to_linear_srgb evaluated in f64 and rounded once */
+};
+void     or_set_ext_variant(uint32_t flags);
+uint32_t or_get_ext_variant(void);
+
 /* src/sdf/mod.rs:104-118  #[repr(C)] SDFSample, 28 bytes */
 typedef struct {
     float distance;
@@ -177,6 +193,21 @@ void or_tex_sample(const float *tex, const OrRenderParams *rp, const float p[3],
 void or_raymarch(const OrRenderParams *rp, const float *tex0, const float *tex1, const OrCamera *cam,
                  uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                  float *rgba, OrMarchAux *aux /* may be NULL */, int n_threads);
+/* The same march, recording WHICH texels it reads (SURVEY.md 8d's raymarch byte model): one byte per texel of the grid
+ * in each map, set to 1 when touched (maps may be NULL).  march0: tex0 texels read by sdfRaycast's trilinear fetches;
+ * hit0 / hit1: the 8 texels of tex0 / tex1 under each hit (material.frag:118,154); normal0: tex0 texels under
+ * sdfNormal's four taps (material.frag:155).  Counts are deterministic. */
+typedef struct {
+    uint64_t pixels;     /* rows * width */
+    uint64_t covered;    /* pixels whose ray meets the box */
+    uint64_t hits;       /* status == 1 */
+    uint64_t sum_steps;  /* tex0 fetches of sdfRaycast over all pixels */
+    uint64_t max_steps;
+} OrMarchCounts;
+void or_raymarch_touch(const OrRenderParams *rp, const float *tex0, const float *tex1, const OrCamera *cam,
+                       uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                       uint8_t *march0, uint8_t *hit0, uint8_t *hit1, uint8_t *normal0,
+                       OrMarchCounts *counts, int n_threads);
 /* shading tail only (material.frag:158-173) for unit tests of the [EXT] restatement */
 void or_shade(const OrRenderParams *rp, const float raw0[4], const float raw1[4], float rgba[4]);
 

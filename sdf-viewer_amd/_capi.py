@@ -131,6 +131,7 @@ PROTOTYPES = {
     "sdfv_slab_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "sdfv_slab_comm_create": (C.c_int, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
     "sdfv_slab_comm_destroy": (C.c_int, [C.c_void_p]),
+    "sdfv_slab_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "sdfv_slab_halo_exchange": (C.c_int, [C.c_void_p, C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_slab_fill_step": (C.c_int, [C.c_void_p, C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
@@ -145,6 +146,7 @@ FILL_FORM = {"auto": 0, "rows": 1, "flat": 2}
 PLACEMENT_SLACK = 64 << 10
 COMM_ID_BYTES = 128
 COMM_PERIODIC = 1
+COMM_HALO2 = 2
 
 
 def load(path=LIB_PATH):

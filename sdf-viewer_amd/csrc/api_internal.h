@@ -20,6 +20,24 @@ const Options& options();
 int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 // The first and the last slice of `slab` (the ones the z-neighbours need) in one launch; o0/o1 address the first
 // owned slice.  Same texels as sdfv_fill_grid over those two slices.  Requires at least two owned slices.
+// Dense fill of `slab` in boundary-first workgroup order (fill_kernels.h): the `lead` first slices and the last one come
+// first, optionally copied into the packed staging buffers and followed by the arrival/signal protocol.
+struct OrderedFill {
+    uint32_t lead = 1;
+    float* stage_lo = nullptr;
+    float* stage_hi = nullptr;
+    uint32_t* arrive = nullptr;
+    uint32_t arrive_target = 0;
+    uint32_t* signal = nullptr;
+    uint32_t signal_value = 0;
+};
+// Workgroups per slice and in total of that order for this slab; per_slice = 0: the shape does not allow it.
+int ordered_fill_blocks(const sdfv_grid* slab, uint32_t* per_slice, uint32_t* total);
+// Logical workgroups [block_begin, block_end) of the ordered fill; o0/o1 address the first owned slice.
+int fill_slab_ordered(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* slab, float* o0, float* o1,
+                      const OrderedFill& of, uint32_t block_begin, uint32_t block_end, void* stream);
+// dst[i] = src[i] over up to four segments of `n` 16-byte texels (ghost slices out of the packed receive buffers).
+int copy_texel_segments(const float* const src[4], float* const dst[4], const size_t n[4], void* stream);
 int fill_boundary_slices(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* slab, float* o0, float* o1,
                          void* stream);
 }  // namespace sdfv

@@ -25,6 +25,18 @@ struct FillArgs {
     float4* tex0;
     float4* tex1;
     float* dist;             // optional compact copy of tex0.r written in the same pass (fused SDFViewer::commit)
+    // ---- boundary-first order (multi-GPU fill step, launch_fill_dense_ordered) ----
+    // The slab's `order_lead` first slices and its last slice are the ones the z-neighbours wait for: the workgroups
+    // that fill them come FIRST in dispatch order, the interior follows in memory order.
+    uint32_t order_bps;      // workgroups per slice (0 = plain memory order)
+    uint32_t order_lead;     // leading boundary slices: 1 (one-voxel halo) or 2 (two ghost slices on the upper side)
+    uint32_t block_base;     // first logical workgroup of this launch (two-launch form: boundary, then the rest)
+    float4* stage_lo;        // packed copy of the lead slices for the lower neighbour: [tex0 lead slices | tex1 lead slices]
+    float4* stage_hi;        // packed copy of the last slice for the upper neighbour:  [tex0 slice | tex1 slice]
+    uint32_t* arrive;        // arrival counter of the boundary workgroups (monotonic, wraps) or nullptr = no signal
+    uint32_t arrive_target;  // counter value that means "all boundary workgroups of this step have published"
+    uint32_t* signal;        // word the communicator's stream waits on (hipStreamWaitValue32)
+    uint32_t signal_value;
 };
 
 struct PassArgs {
@@ -45,6 +57,21 @@ struct FillLaunch {
 };
 
 hipError_t launch_fill_dense(const FillArgs& a, const FillLaunch& cfg, hipStream_t stream);
+// Boundary-first order.  ordered_blocks() = {workgroups per slice, total} or {0, 0} when the slab's shape does not
+// allow it (rows that do not fill whole workgroups); launch_fill_dense_ordered runs logical workgroups
+// [block_begin, block_end) of that order -- [0, total) is one launch, [0, (lead + 1) * bps) are the boundary slices.
+struct OrderedBlocks {
+    uint32_t per_slice, total;
+};
+OrderedBlocks ordered_blocks(const FillArgs& a);
+hipError_t launch_fill_dense_ordered(const FillArgs& a, uint32_t block_begin, uint32_t block_end, hipStream_t stream);
+// Ghost slices out of the packed receive buffers: up to four contiguous copies of float4 texels in one launch.
+struct CopySegments {
+    const float4* src[4];
+    float4* dst[4];
+    uint32_t n[4];  // texels
+};
+hipError_t launch_copy_segments(const CopySegments& c, hipStream_t stream);
 // slab_d slices z_begin + k * z_step in ONE launch (the two boundary slices of a slab: slab_d = 2).
 hipError_t launch_fill_slices(const FillArgs& a, hipStream_t stream);
 hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& p, hipStream_t stream);

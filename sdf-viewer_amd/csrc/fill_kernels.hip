@@ -46,7 +46,53 @@ __device__ __forceinline__ void store_texel(float4* dst, const float4& v) {
 // voxels and does ONE voxel per thread, so the grid walks memory front to back in dispatch order exactly
 // like a memset.  Measured on MI355X (profiles/r01_v1_fill_sweep.json, r01_v2_fill_sweep.json): persistent
 // strided workgroups lose 25-40 % of the store rate and 2/4/8 rows per thread lose 7/11/14 %.
-template <int TX, bool NT, typename Cfg>
+// Boundary-first order: logical workgroup `b` of a launch -> the workgroup of the memory-order grid whose voxels it
+// fills.  The first order_lead * bps workgroups are the slab's leading slices, the next bps its LAST slice, then the
+// interior in memory order.  All operands are wave-uniform (SGPRs).
+struct OrderedBlock {
+    uint32_t block;     // memory-order workgroup index
+    bool boundary;      // one of the slices a z-neighbour waits for
+    bool last_slice;    // ... the slab's last one (goes to the upper neighbour)
+};
+__device__ __forceinline__ OrderedBlock ordered_block(const FillArgs& a, uint32_t b) {
+    OrderedBlock r;
+    const uint32_t lead = a.order_lead * a.order_bps;
+    r.boundary = b < lead + a.order_bps;
+    r.last_slice = r.boundary && b >= lead;
+    r.block = r.last_slice ? (a.slab_d - 1) * a.order_bps + (b - lead) : (r.boundary ? b : b - a.order_bps);
+    return r;
+}
+
+// The boundary workgroups' packed copies (one message per neighbour and direction instead of one per texture).
+__device__ __forceinline__ void store_staged(const FillArgs& a, const OrderedBlock& ob, uint64_t o, const float4& v0,
+                                             const float4& v1) {
+    const uint64_t slice = (uint64_t)a.W * a.H;
+    if (ob.last_slice) {
+        if (a.stage_hi) {
+            const uint64_t w = o - (uint64_t)(a.slab_d - 1) * slice;
+            a.stage_hi[w] = v0;
+            a.stage_hi[slice + w] = v1;
+        }
+    } else if (a.stage_lo) {
+        a.stage_lo[o] = v0;  // o < order_lead * slice
+        a.stage_lo[a.order_lead * slice + o] = v1;
+    }
+}
+
+// A boundary workgroup publishes its texels to the whole device (the exchange that follows reads them from other
+// XCDs, whose L2s are not coherent with this one) and arrives; the last arrival releases the communicator's stream.
+__device__ __forceinline__ void publish_boundary(const FillArgs& a) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t old = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == a.arrive_target)
+            __hip_atomic_store(a.signal, a.signal_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <int TX, bool NT, typename Cfg, bool ORDERED = false>
 __global__ __launch_bounds__(kBlock) void fill_dense_kernel(FillArgs a) {
     constexpr int TY = kBlock / TX;
     __shared__ float s_lut[256];
@@ -54,9 +100,11 @@ __global__ __launch_bounds__(kBlock) void fill_dense_kernel(FillArgs a) {
 
     const uint32_t tid = threadIdx.x;
     const uint32_t n_rows = a.H * a.slab_d;  // rows of the slab: row = z_local * H + y
+    OrderedBlock ob{blockIdx.x, false, false};
+    if (ORDERED) ob = ordered_block(a, blockIdx.x + a.block_base);
     // 1-D grid, x-chunk fastest: workgroup id -> (row group, x chunk); both uniform (SGPRs)
-    const uint32_t row_group = a.x_chunks == 1 ? blockIdx.x : blockIdx.x / a.x_chunks;
-    const uint32_t chunk = blockIdx.x - row_group * a.x_chunks;
+    const uint32_t row_group = a.x_chunks == 1 ? ob.block : ob.block / a.x_chunks;
+    const uint32_t chunk = ob.block - row_group * a.x_chunks;
     const uint32_t row0 = row_group * TY;
     s_lut[tid] = c_srgb_lut[tid];
     if (tid < TY && row0 + tid < n_rows) {
@@ -71,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void fill_dense_kernel(FillArgs a) {
     const uint32_t tx = tid % TX, ty = tid / TX;
     const uint32_t x = chunk * TX + tx;
     const uint32_t row = row0 + ty;
-    if (x >= a.W || row >= n_rows) return;
+    if (!ORDERED && (x >= a.W || row >= n_rows)) return;  // ordered launches cover whole workgroups only
     const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
     const float2 yz = s_yz[ty];
     float4 v0, v1;
@@ -80,6 +128,10 @@ __global__ __launch_bounds__(kBlock) void fill_dense_kernel(FillArgs a) {
     store_texel<NT>(a.tex0 + o, v0);
     store_texel<NT>(a.tex1 + o, v1);
     if (a.dist) a.dist[o] = v0.x;  // wave-uniform: +4 B/voxel instead of a second pass over tex0
+    if (ORDERED && ob.boundary) {  // wave-uniform
+        store_staged(a, ob, o, v0, v1);
+        if (a.arrive) publish_boundary(a);
+    }
 }
 
 // Flat form of the dense kernel for widths that do not fill the row-chunk form's lanes (W not a multiple of the
@@ -87,13 +139,15 @@ __global__ __launch_bounds__(kBlock) void fill_dense_kernel(FillArgs a) {
 // is 1 KiB whatever W is.  x and row come from an exact division by W done as a 64-bit multiply-high with
 // M = floor(2^64 / W) + 1 (exact for dividends below 2^32); the (y, z) coordinates of the few rows a workgroup
 // touches are staged in LDS by its first lanes.
-template <bool NT, typename Cfg, bool STRIDED = false>
+template <bool NT, typename Cfg, bool STRIDED = false, bool ORDERED = false>
 __global__ __launch_bounds__(kBlock) void fill_dense_flat_kernel(FillArgs a) {
     __shared__ float s_lut[256];
     __shared__ float2 s_yz[kBlock + 1];
     const uint32_t tid = threadIdx.x;
     const uint32_t n_vox = a.W * a.H * a.slab_d;  // < 2^32, checked by the launcher
-    const uint32_t v0 = blockIdx.x * kBlock;
+    OrderedBlock ob{blockIdx.x, false, false};
+    if (ORDERED) ob = ordered_block(a, blockIdx.x + a.block_base);  // slices are whole numbers of workgroups here
+    const uint32_t v0 = ob.block * kBlock;
     auto div_w = [&](uint32_t v) -> uint32_t {
         if (a.W == 1) return v;
         const unsigned long long t = ((unsigned long long)v * (uint32_t)a.w_magic) >> 32;
@@ -112,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void fill_dense_flat_kernel(FillArgs a) {
     }
     __syncthreads();
     const uint32_t v = v0 + tid;
-    if (v >= n_vox) return;
+    if (!ORDERED && v >= n_vox) return;  // ordered launches cover whole workgroups only
     const uint32_t row = div_w(v);
     const uint32_t x = v - row * a.W;
     const LdsLut lut{s_lut};
@@ -125,6 +179,19 @@ __global__ __launch_bounds__(kBlock) void fill_dense_flat_kernel(FillArgs a) {
     store_texel<NT>(a.tex0 + at, v0t);
     store_texel<NT>(a.tex1 + at, v1t);
     if (a.dist) a.dist[at] = v0t.x;
+    if (ORDERED && ob.boundary) {  // wave-uniform
+        store_staged(a, ob, at, v0t, v1t);
+        if (a.arrive) publish_boundary(a);
+    }
+}
+
+// Ghost slices out of the packed receive buffers (one launch for up to four contiguous copies).
+__global__ __launch_bounds__(kBlock) void copy_segments_kernel(CopySegments c) {
+    const uint32_t seg = blockIdx.y;
+    const uint32_t n = c.n[seg];
+    const float4* __restrict__ src = c.src[seg];
+    float4* __restrict__ dst = c.dst[seg];
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) dst[i] = src[i];
 }
 
 // One visited voxel of a LoadingManager pass: update_required (scene/sdf/mod.rs:184-190) and, when it holds, the
@@ -283,6 +350,85 @@ hipError_t launch_dense_flat(const FillArgs& args, hipStream_t stream) {
         hipLaunchKernelGGL((fill_dense_flat_kernel<NT, DefaultCfg>), dim3(blocks), dim3(kBlock), 0, stream, a);
     else
         hipLaunchKernelGGL((fill_dense_flat_kernel<NT, RuntimeCfg>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+namespace {
+// Which index form an ordered launch uses, and its workgroup counts: the row-chunk form when rows fill whole
+// workgroups in both directions, else the flat form when a slice is a whole number of workgroups, else none.
+struct OrderedPlan {
+    int tx;  // 64 / 128 / 256 = row-chunk form, 0 = flat form, -1 = not possible
+    uint32_t per_slice, total;
+};
+OrderedPlan plan_ordered(const FillArgs& a) {
+    OrderedPlan p{-1, 0, 0};
+    if (a.W == 0 || a.H == 0 || a.slab_d == 0) return p;
+    const uint64_t slice = (uint64_t)a.W * a.H, n_vox = slice * a.slab_d;
+    if (n_vox >= (1ull << 32)) return p;
+    const uint32_t chunk = a.W <= 64 ? 64 : (a.W <= 128 ? 128 : 256);
+    const uint32_t ty = kBlock / chunk;
+    if (a.W % chunk == 0 && a.H % ty == 0) {
+        p.tx = (int)chunk;
+        p.per_slice = (a.W / chunk) * (a.H / ty);
+    } else if (slice % kBlock == 0) {
+        p.tx = 0;
+        p.per_slice = (uint32_t)(slice / kBlock);
+    } else {
+        return p;
+    }
+    p.total = p.per_slice * a.slab_d;
+    return p;
+}
+
+template <int TX>
+void launch_ordered_rows(const FillArgs& args, uint32_t blocks, hipStream_t stream) {
+    FillArgs a = args;
+    a.x_chunks = (a.W + TX - 1) / TX;
+    if (is_default_config(a))
+        hipLaunchKernelGGL((fill_dense_kernel<TX, false, DefaultCfg, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    else
+        hipLaunchKernelGGL((fill_dense_kernel<TX, false, RuntimeCfg, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
+}
+}  // namespace
+
+OrderedBlocks ordered_blocks(const FillArgs& a) {
+    const OrderedPlan p = plan_ordered(a);
+    return p.tx < 0 ? OrderedBlocks{0, 0} : OrderedBlocks{p.per_slice, p.total};
+}
+
+hipError_t launch_fill_dense_ordered(const FillArgs& args, uint32_t block_begin, uint32_t block_end, hipStream_t stream) {
+    const OrderedPlan p = plan_ordered(args);
+    if (p.tx < 0 || block_begin > block_end || block_end > p.total || args.order_lead == 0 ||
+        args.order_lead + 1 >= args.slab_d)
+        return hipErrorInvalidValue;
+    if (block_begin == block_end) return hipSuccess;
+    FillArgs a = args;
+    a.order_bps = p.per_slice;
+    a.block_base = block_begin;
+    const uint32_t blocks = block_end - block_begin;
+    if (p.tx == 64) launch_ordered_rows<64>(a, blocks, stream);
+    else if (p.tx == 128) launch_ordered_rows<128>(a, blocks, stream);
+    else if (p.tx == 256) launch_ordered_rows<256>(a, blocks, stream);
+    else {
+        a.w_magic = a.W > 1 ? (~0ull / a.W) + 1ull : 0ull;
+        if (is_default_config(a))
+            hipLaunchKernelGGL((fill_dense_flat_kernel<false, DefaultCfg, false, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        else
+            hipLaunchKernelGGL((fill_dense_flat_kernel<false, RuntimeCfg, false, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_segments(const CopySegments& c, hipStream_t stream) {
+    uint32_t n_max = 0, segs = 0;
+    for (int i = 0; i < 4; ++i)
+        if (c.n[i]) {
+            segs = i + 1;
+            if (c.n[i] > n_max) n_max = c.n[i];
+        }
+    if (segs == 0) return hipSuccess;
+    const uint32_t bx = (n_max + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(copy_segments_kernel, dim3(bx < 4096 ? bx : 4096, segs), dim3(kBlock), 0, stream, c);
     return hipGetLastError();
 }
 

@@ -254,6 +254,49 @@ int set_error(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+int ordered_fill_blocks(const sdfv_grid* slab, uint32_t* per_slice, uint32_t* total) {
+    if (int rc = check_grid(slab)) return rc;
+    sdfv_demo_params prm;
+    sdfv_demo_params_default(&prm);
+    const FillArgs a = make_fill_args(prm, SDFV_SDF_DEMO, *slab, nullptr, nullptr);
+    const OrderedBlocks b = ordered_blocks(a);
+    *per_slice = b.per_slice;
+    *total = b.total;
+    return SDFV_OK;
+}
+
+int fill_slab_ordered(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* slab, float* o0, float* o1,
+                      const OrderedFill& of, uint32_t block_begin, uint32_t block_end, void* stream) {
+    if (int rc = check_params(params, sdf_id)) return rc;
+    if (int rc = check_grid(slab)) return rc;
+    if (int rc = check_texel_alignment(o0, o1)) return rc;
+    if (int rc = check_texel_alignment(of.stage_lo, of.stage_hi)) return rc;
+    if (int rc = need_device()) return rc;
+    FillArgs a = make_fill_args(*params, sdf_id, *slab, o0, o1);
+    a.order_lead = of.lead;
+    a.stage_lo = reinterpret_cast<float4*>(of.stage_lo);
+    a.stage_hi = reinterpret_cast<float4*>(of.stage_hi);
+    a.arrive = of.arrive;
+    a.arrive_target = of.arrive_target;
+    a.signal = of.signal;
+    a.signal_value = of.signal_value;
+    SDFV_HIP(launch_fill_dense_ordered(a, block_begin, block_end, (hipStream_t)stream));
+    return SDFV_OK;
+}
+
+int copy_texel_segments(const float* const src[4], float* const dst[4], const size_t n[4], void* stream) {
+    CopySegments c;
+    memset(&c, 0, sizeof(c));
+    for (int i = 0; i < 4; ++i) {
+        if (n[i] >= (1ull << 32)) return fail(SDFV_ERR_INVALID_ARGUMENT, "segment too large");
+        c.src[i] = reinterpret_cast<const float4*>(src[i]);
+        c.dst[i] = reinterpret_cast<float4*>(dst[i]);
+        c.n[i] = (uint32_t)n[i];
+    }
+    SDFV_HIP(launch_copy_segments(c, (hipStream_t)stream));
+    return SDFV_OK;
+}
+
 int fill_boundary_slices(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* slab, float* o0, float* o1,
                          void* stream) {
     if (int rc = check_params(params, sdf_id)) return rc;

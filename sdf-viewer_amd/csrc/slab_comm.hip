@@ -93,13 +93,31 @@ struct sdfv_slab_comm {
     NcclComm comm = nullptr;
     int rank = 0, world = 1;
     bool periodic = false;
+    uint32_t halo_hi = 1;  // upper halo depth: every rank sends this many leading slices down
     hipStream_t comm_stream = nullptr;
     hipEvent_t boundary_done = nullptr, halo_done = nullptr;
+    // packed messages: one block holding [send_lo | send_hi | recv_hi | recv_lo], sized for stage_slice texels per slice
+    float* stage = nullptr;
+    size_t stage_slice = 0;
+    // one-launch form: arrival counter of the boundary workgroups and the word the communicator's stream waits on
+    uint32_t* arrive = nullptr;
+    uint32_t* signal = nullptr;
+    uint32_t arrive_total = 0, step = 0;
+    bool can_wait_value = false;
 
     bool has_lo() const { return periodic || rank > 0; }
     bool has_hi() const { return periodic || rank < world - 1; }
     int lo_peer() const { return (rank + world - 1) % world; }
     int hi_peer() const { return (rank + 1) % world; }
+    uint32_t ghost_lo() const { return has_lo() ? 1u : 0u; }
+    uint32_t ghost_hi() const { return has_hi() ? halo_hi : 0u; }
+    // staging layout, in floats (a slice of one texture = 4 * stage_slice floats)
+    size_t slice_f() const { return stage_slice * 4; }
+    float* send_lo() const { return stage; }                                                  // 2 * halo_hi slices
+    float* send_hi() const { return stage + 2 * halo_hi * slice_f(); }                        // 2 slices
+    float* recv_hi() const { return stage + (2 * halo_hi + 2) * slice_f(); }                  // 2 * halo_hi slices
+    float* recv_lo() const { return stage + (4 * halo_hi + 2) * slice_f(); }                  // 2 slices
+    size_t stage_floats() const { return (4 * halo_hi + 4) * slice_f(); }
 };
 
 namespace {
@@ -107,18 +125,36 @@ namespace {
 int check_slab(const sdfv_slab_comm* c, const sdfv_grid* g, const float* tex0, const float* tex1) {
     if (!c) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "communicator is NULL");
     if (!g || !tex0 || !tex1) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "grid or texture pointer is NULL");
+    if (((uintptr_t)tex0 | (uintptr_t)tex1) & 15)
+        return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "texel buffers (tex0, tex1) must be 16-byte aligned");
     if (g->z_begin >= g->z_end || g->z_end > g->dims[2] || g->dims[0] == 0 || g->dims[1] == 0)
         return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "slab [%u, %u) is empty or outside the %u slices of the grid",
                                g->z_begin, g->z_end, g->dims[2]);
+    if ((c->has_lo() || c->has_hi()) && g->z_end - g->z_begin < c->halo_hi)
+        return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "a halo of %u slices needs slabs of at least %u slices",
+                               c->halo_hi, c->halo_hi);
     return SDFV_OK;
 }
 
-// One ncclGroup: first owned slice down, last owned slice up, the neighbours' into the ghosts; both textures.
-int enqueue_exchange(const Rccl* lib, const sdfv_slab_comm* c, const sdfv_grid* g, float* tex0, float* tex1,
-                     hipStream_t stream) {
+int ensure_staging(sdfv_slab_comm* c, size_t slice_texels) {
+    if (c->stage && c->stage_slice == slice_texels) return SDFV_OK;
+    if (c->stage) {
+        SDFV_HIPC(hipStreamSynchronize(c->comm_stream));
+        (void)hipFree(c->stage);
+        c->stage = nullptr;
+    }
+    c->stage_slice = slice_texels;
+    SDFV_HIPC(hipMalloc((void**)&c->stage, c->stage_floats() * sizeof(float)));
+    return SDFV_OK;
+}
+
+// One ncclGroup straight on the textures: the first halo_hi owned slices down, the last owned slice up, the neighbours'
+// into the ghosts; one message per texture, neighbour and direction.
+int enqueue_exchange_direct(const Rccl* lib, const sdfv_slab_comm* c, const sdfv_grid* g, float* tex0, float* tex1,
+                            hipStream_t stream) {
     const size_t slice = (size_t)g->dims[0] * g->dims[1] * 4;  // floats per z-slice of one texture
     const size_t owned = g->z_end - g->z_begin;
-    const size_t lo = c->has_lo() ? 1 : 0;
+    const size_t lo = c->ghost_lo();
     if (!c->has_lo() && !c->has_hi()) return SDFV_OK;
     SDFV_RCCL(lib, GroupStart());
     int first_error = kNcclSuccess;  // a group that was opened is always closed, whatever happens inside it
@@ -130,15 +166,49 @@ int enqueue_exchange(const Rccl* lib, const sdfv_slab_comm* c, const sdfv_grid* 
         float* last_owned = t + (lo + owned - 1) * slice;
         // Sends go down then up, receives come from above then from below: messages between one pair of ranks
         // match in posting order, and with a periodic world of 1 or 2 both neighbours are the same rank.
-        if (c->has_lo()) post(lib->Send(first_owned, slice, kNcclFloat, c->lo_peer(), c->comm, stream));
+        if (c->has_lo()) post(lib->Send(first_owned, c->halo_hi * slice, kNcclFloat, c->lo_peer(), c->comm, stream));
         if (c->has_hi()) post(lib->Send(last_owned, slice, kNcclFloat, c->hi_peer(), c->comm, stream));
-        if (c->has_hi()) post(lib->Recv(t + (lo + owned) * slice, slice, kNcclFloat, c->hi_peer(), c->comm, stream));
+        if (c->has_hi()) post(lib->Recv(t + (lo + owned) * slice, c->halo_hi * slice, kNcclFloat, c->hi_peer(), c->comm, stream));
         if (c->has_lo()) post(lib->Recv(t, slice, kNcclFloat, c->lo_peer(), c->comm, stream));
     }
     post(lib->GroupEnd());
     if (first_error != kNcclSuccess)
         return sdfv::set_error(SDFV_ERR_COMM, "RCCL halo exchange: %s", lib->GetErrorString(first_error));
     return SDFV_OK;
+}
+
+// One ncclGroup over the packed staging buffers (filled by the boundary workgroups of the ordered fill): ONE message per
+// neighbour and direction carrying both textures' slices, then one launch that copies the received slices into the ghosts.
+int enqueue_exchange_packed(const Rccl* lib, const sdfv_slab_comm* c, const sdfv_grid* g, float* tex0, float* tex1,
+                            hipStream_t stream) {
+    const size_t slice = c->slice_f();
+    const size_t owned = g->z_end - g->z_begin;
+    const size_t lo = c->ghost_lo();
+    if (!c->has_lo() && !c->has_hi()) return SDFV_OK;
+    SDFV_RCCL(lib, GroupStart());
+    int first_error = kNcclSuccess;
+    auto post = [&](int r) {
+        if (first_error == kNcclSuccess) first_error = r;
+    };
+    if (c->has_lo()) post(lib->Send(c->send_lo(), 2 * c->halo_hi * slice, kNcclFloat, c->lo_peer(), c->comm, stream));
+    if (c->has_hi()) post(lib->Send(c->send_hi(), 2 * slice, kNcclFloat, c->hi_peer(), c->comm, stream));
+    if (c->has_hi()) post(lib->Recv(c->recv_hi(), 2 * c->halo_hi * slice, kNcclFloat, c->hi_peer(), c->comm, stream));
+    if (c->has_lo()) post(lib->Recv(c->recv_lo(), 2 * slice, kNcclFloat, c->lo_peer(), c->comm, stream));
+    post(lib->GroupEnd());
+    if (first_error != kNcclSuccess)
+        return sdfv::set_error(SDFV_ERR_COMM, "RCCL halo exchange: %s", lib->GetErrorString(first_error));
+    const float* src[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* dst[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t n[4] = {0, 0, 0, 0};
+    if (c->has_hi()) {  // [tex0 halo_hi slices | tex1 halo_hi slices] from above -> the upper ghosts
+        src[0] = c->recv_hi();                          dst[0] = tex0 + (lo + owned) * slice; n[0] = c->halo_hi * c->stage_slice;
+        src[1] = c->recv_hi() + c->halo_hi * slice;     dst[1] = tex1 + (lo + owned) * slice; n[1] = c->halo_hi * c->stage_slice;
+    }
+    if (c->has_lo()) {  // [tex0 slice | tex1 slice] from below -> the lower ghost
+        src[2] = c->recv_lo();                          dst[2] = tex0; n[2] = c->stage_slice;
+        src[3] = c->recv_lo() + slice;                  dst[3] = tex1; n[3] = c->stage_slice;
+    }
+    return sdfv::copy_texel_segments(src, dst, n, stream);
 }
 
 }  // namespace
@@ -162,7 +232,8 @@ int sdfv_slab_comm_create(const unsigned char id[SDFV_COMM_ID_BYTES], int rank, 
     *out = nullptr;
     if (world < 1 || rank < 0 || rank >= world)
         return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "rank %d is not in a world of %d", rank, world);
-    if (flags & ~SDFV_COMM_PERIODIC) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", flags);
+    if (flags & ~(SDFV_COMM_PERIODIC | SDFV_COMM_HALO2))
+        return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", flags);
     const Rccl* lib;
     if (int rc = need_rccl(lib)) return rc;
     int n_dev = 0;
@@ -173,6 +244,7 @@ int sdfv_slab_comm_create(const unsigned char id[SDFV_COMM_ID_BYTES], int rank, 
     c->rank = rank;
     c->world = world;
     c->periodic = (flags & SDFV_COMM_PERIODIC) != 0;
+    c->halo_hi = (flags & SDFV_COMM_HALO2) ? 2u : 1u;
     NcclUniqueId uid;
     memcpy(uid.internal, id, SDFV_COMM_ID_BYTES);
     int r = lib->CommInitRank(&c->comm, world, uid, rank);
@@ -188,9 +260,23 @@ int sdfv_slab_comm_create(const unsigned char id[SDFV_COMM_ID_BYTES], int rank, 
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, prio_high);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->boundary_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->halo_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->arrive, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(c->arrive, 0, sizeof(uint32_t));
     if (e != hipSuccess) {
         sdfv_slab_comm_destroy(c);
         return sdfv::set_error(SDFV_ERR_HIP, "communicator stream/events: %s", hipGetErrorString(e));
+    }
+    // The one-launch step needs hipStreamWaitValue32 on a word of signal memory; without either, the two-launch form.
+    int dev = 0, can = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can &&
+        hipExtMallocWithFlags((void**)&c->signal, 8, hipMallocSignalMemory) == hipSuccess &&
+        hipMemset(c->signal, 0, 8) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
+        c->can_wait_value = true;
+    } else {
+        (void)hipGetLastError();
+        if (c->signal) (void)hipFree(c->signal);
+        c->signal = nullptr;
     }
     *out = c;
     return SDFV_OK;
@@ -204,7 +290,18 @@ int sdfv_slab_comm_destroy(sdfv_slab_comm* c) {
     if (c->boundary_done) (void)hipEventDestroy(c->boundary_done);
     if (c->halo_done) (void)hipEventDestroy(c->halo_done);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    if (c->stage) (void)hipFree(c->stage);
+    if (c->arrive) (void)hipFree(c->arrive);
+    if (c->signal) (void)hipFree(c->signal);
     delete c;
+    return SDFV_OK;
+}
+
+int sdfv_slab_comm_info(const sdfv_slab_comm* c, uint32_t* ghost_lo, uint32_t* ghost_hi, uint32_t* one_launch_capable) {
+    if (!c) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "communicator is NULL");
+    if (ghost_lo) *ghost_lo = c->ghost_lo();
+    if (ghost_hi) *ghost_hi = c->ghost_hi();
+    if (one_launch_capable) *one_launch_capable = c->can_wait_value ? 1u : 0u;
     return SDFV_OK;
 }
 
@@ -212,7 +309,7 @@ int sdfv_slab_halo_exchange(sdfv_slab_comm* c, const sdfv_grid* slab, float* tex
     if (int rc = check_slab(c, slab, tex0, tex1)) return rc;
     const Rccl* lib;
     if (int rc = need_rccl(lib)) return rc;
-    return enqueue_exchange(lib, c, slab, tex0, tex1, (hipStream_t)stream);
+    return enqueue_exchange_direct(lib, c, slab, tex0, tex1, (hipStream_t)stream);
 }
 
 int sdfv_slab_fill_step(sdfv_slab_comm* c, const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* slab,
@@ -221,30 +318,65 @@ int sdfv_slab_fill_step(sdfv_slab_comm* c, const sdfv_demo_params* params, uint3
     const Rccl* lib;
     if (int rc = need_rccl(lib)) return rc;
     hipStream_t main = (hipStream_t)stream;
-    const size_t slice = (size_t)slab->dims[0] * slab->dims[1] * 4;
+    const size_t slice_texels = (size_t)slab->dims[0] * slab->dims[1];
+    const size_t slice = slice_texels * 4;
     const uint32_t z0 = slab->z_begin, z1 = slab->z_end, owned = z1 - z0;
-    float* o0 = tex0 + (c->has_lo() ? slice : 0);  // first owned slice
-    float* o1 = tex1 + (c->has_lo() ? slice : 0);
+    float* o0 = tex0 + c->ghost_lo() * slice;  // first owned slice
+    float* o1 = tex1 + c->ghost_lo() * slice;
     const bool exchange = c->has_lo() || c->has_hi();
+    const uint32_t lead = c->halo_hi;
 
-    auto fill = [&](uint32_t za, uint32_t zb) {
+    // Which form: the ordered fill needs whole workgroups per slice and an interior to hide the exchange behind.
+    uint32_t form = sdfv::options().slab_step_form;
+    const bool packed = !(form & SDFV_STEP_UNPACKED);
+    form &= ~SDFV_STEP_UNPACKED;
+    uint32_t bps = 0, total = 0;
+    if (int rc = sdfv::ordered_fill_blocks(slab, &bps, &total)) return rc;
+    if (!exchange || owned < lead + 2 || bps == 0) {  // nothing to hide the exchange behind / shape not supported
         sdfv_grid part = *slab;
-        part.z_begin = za;
-        part.z_end = zb;
-        return sdfv_fill_grid(params, sdf_id, &part, o0 + (size_t)(za - z0) * slice, o1 + (size_t)(za - z0) * slice, main);
+        if (int rc = sdfv_fill_grid(params, sdf_id, &part, o0, o1, main)) return rc;
+        return exchange ? enqueue_exchange_direct(lib, c, slab, tex0, tex1, main) : SDFV_OK;
+    }
+    if (form == 0) form = c->can_wait_value ? SDFV_STEP_ONE_LAUNCH : SDFV_STEP_TWO_LAUNCH;
+    if (form == SDFV_STEP_ONE_LAUNCH && !c->can_wait_value)
+        return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "the one-launch step needs hipStreamWaitValue32 on this device");
+    if (packed)
+        if (int rc = ensure_staging(c, slice_texels)) return rc;
+
+    sdfv::OrderedFill of;
+    of.lead = lead;
+    if (packed) {
+        of.stage_lo = c->has_lo() ? c->send_lo() : nullptr;
+        of.stage_hi = c->has_hi() ? c->send_hi() : nullptr;
+    }
+    const uint32_t nb = (lead + 1) * bps;  // the boundary workgroups: what the neighbours wait for
+    auto exchange_on = [&](hipStream_t st) {
+        return packed ? enqueue_exchange_packed(lib, c, slab, tex0, tex1, st) : enqueue_exchange_direct(lib, c, slab, tex0, tex1, st);
     };
 
-    if (!exchange || owned < 3) {  // nothing to hide the exchange behind
-        if (int rc = fill(z0, z1)) return rc;
-        return exchange ? enqueue_exchange(lib, c, slab, tex0, tex1, main) : SDFV_OK;
+    if (form == SDFV_STEP_ONE_LAUNCH) {
+        // ONE dense launch: its first workgroups fill the boundary slices, publish them and signal; the communicator's
+        // stream waits on that word, not on the kernel, so the exchange runs under the rest of the same launch.
+        c->arrive_total += nb;  // wraps; the kernel compares for equality
+        c->step += 1;
+        of.arrive = c->arrive;
+        of.arrive_target = c->arrive_total;
+        of.signal = c->signal;
+        of.signal_value = c->step;
+        if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, 0, total, main)) return rc;
+        SDFV_HIPC(hipStreamWaitValue32(c->comm_stream, c->signal, c->step, hipStreamWaitValueEq, 0xffffffffu));
+        if (int rc = exchange_on(c->comm_stream)) return rc;
+        SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));
+        SDFV_HIPC(hipStreamWaitEvent(main, c->halo_done, 0));
+        return SDFV_OK;
     }
-    // boundary slices first: they are what the neighbours wait for
-    if (int rc = sdfv::fill_boundary_slices(params, sdf_id, slab, o0, o1, main)) return rc;
+    // Two launches of the same ordered grid: the boundary workgroups, then (overlapping the exchange) the rest.
+    if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, 0, nb, main)) return rc;
     SDFV_HIPC(hipEventRecord(c->boundary_done, main));
     SDFV_HIPC(hipStreamWaitEvent(c->comm_stream, c->boundary_done, 0));
-    if (int rc = enqueue_exchange(lib, c, slab, tex0, tex1, c->comm_stream)) return rc;
+    if (int rc = exchange_on(c->comm_stream)) return rc;
     SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));
-    if (int rc = fill(z0 + 1, z1 - 1)) return rc;  // overlaps the exchange
+    if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, nb, total, main)) return rc;
     SDFV_HIPC(hipStreamWaitEvent(main, c->halo_done, 0));
     return SDFV_OK;
 }

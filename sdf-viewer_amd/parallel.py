@@ -141,21 +141,45 @@ class SlabComm:
     torch.distributed only carries its 128 bytes to the other ranks; after that no torch call is on the step path.
     `periodic` wraps the end ranks around -- with world 1 a rank exchanges with itself (single-GPU tests)."""
 
-    def __init__(self, pkg, rank, world, group=None, periodic=False):
+    def __init__(self, pkg, rank, world, group=None, periodic=False, halo_hi=1):
+        """Collective over the ranks.  Every stage that can fail on one rank only (drawing the id, creating the RCCL
+        communicator) is followed by an agreement (all-reduce of a flag) so that a failure raises on EVERY rank instead of
+        leaving the others inside a collective nobody else joins."""
         capi = pkg._capi
-        self.pkg, self.rank, self.world, self.periodic = pkg, rank, world, periodic
+        self.pkg, self.rank, self.world, self.periodic, self.halo_hi = pkg, rank, world, periodic, halo_hi
+        self.handle = None
+        assert halo_hi in (1, 2)
+        on_gpu = world > 1 and dist.get_backend(group) == "nccl"
+        dev = "cuda" if on_gpu else "cpu"
+
+        def agree(ok, what):
+            if world > 1:
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+                everyone = bool(t.item())
+            else:
+                everyone = ok
+            if not everyone:
+                raise pkg.SdfvError(-5, f"{what} failed on {'this rank' if not ok else 'another rank'}: "
+                                        f"{pkg.lib.sdfv_last_error().decode('utf-8', 'replace') if not ok else ''}")
+
         ident = (C.c_ubyte * capi.COMM_ID_BYTES)()
-        if rank == 0:
-            pkg.check(pkg.lib.sdfv_slab_comm_unique_id(ident))
+        rc = pkg.lib.sdfv_slab_comm_unique_id(ident) if rank == 0 else 0
+        agree(rc == 0, "sdfv_slab_comm_unique_id")
         if world > 1:
-            on_gpu = dist.get_backend(group) == "nccl"
-            t = torch.tensor(list(ident), dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+            t = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
             dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             ident = (C.c_ubyte * capi.COMM_ID_BYTES)(*t.cpu().tolist())
         handle = C.c_void_p()
-        pkg.check(pkg.lib.sdfv_slab_comm_create(ident, rank, world, capi.COMM_PERIODIC if periodic else 0,
-                                                C.byref(handle)))
-        self.handle = handle
+        flags = (capi.COMM_PERIODIC if periodic else 0) | (capi.COMM_HALO2 if halo_hi == 2 else 0)
+        rc = pkg.lib.sdfv_slab_comm_create(ident, rank, world, flags, C.byref(handle))
+        if rc == 0:
+            self.handle = handle
+        try:
+            agree(rc == 0, "sdfv_slab_comm_create")
+        except Exception:
+            self.close()
+            raise
 
     @property
     def ghost_lo(self):
@@ -163,7 +187,13 @@ class SlabComm:
 
     @property
     def ghost_hi(self):
-        return 1 if (self.periodic or self.rank < self.world - 1) else 0
+        return self.halo_hi if (self.periodic or self.rank < self.world - 1) else 0
+
+    @property
+    def one_launch_capable(self):
+        v = C.c_uint32(0)
+        self.pkg.check(self.pkg.lib.sdfv_slab_comm_info(self.handle, None, None, C.byref(v)))
+        return bool(v.value)
 
     def _args(self, grid, slab, stream):
         n_owned = int(grid.z_end) - int(grid.z_begin)
@@ -202,7 +232,7 @@ class SlabFiller:
     dozen slices the two are of the same order and overlapping them is what keeps weak scaling near linear.
     """
 
-    def __init__(self, pkg, params, dims, slab, rank, world, sdf_id=0, group=None, transport="auto"):
+    def __init__(self, pkg, params, dims, slab, rank, world, sdf_id=0, group=None, transport="auto", periodic=False):
         """transport: "rccl" = the library's communicator (one C call per step), "torch" = torch.distributed P2P
         ops on a second stream, "auto" = rccl on GPUs under the nccl backend, torch otherwise."""
         self.pkg, self.params, self.dims, self.slab = pkg, params, dims, slab
@@ -210,7 +240,7 @@ class SlabFiller:
         if transport == "auto":
             transport = "rccl" if (world > 1 and slab.tex0.is_cuda and dist.get_backend(group) == "nccl") else "torch"
         self.transport = transport
-        self.comm = SlabComm(pkg, rank, world, group) if transport == "rccl" else None
+        self.comm = SlabComm(pkg, rank, world, group, periodic=periodic, halo_hi=slab.halo_hi) if transport == "rccl" else None
         self.overlap = (transport == "torch" and world > 1 and slab.tex0.is_cuda
                         and (slab.z_end - slab.z_begin) >= 3)
         # highest priority: HIP keeps streams of different priorities on different hardware queues; with equal

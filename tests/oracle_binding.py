@@ -200,6 +200,34 @@ def raymarch(rp, t0, t1, cam, width, height, y0=0, y1=None, threads=8, want_aux=
     return rgba, aux
 
 
+class MarchCounts(C.Structure):
+    _fields_ = [("pixels", C.c_uint64), ("covered", C.c_uint64), ("hits", C.c_uint64), ("sum_steps", C.c_uint64),
+                ("max_steps", C.c_uint64)]
+
+
+L.or_raymarch_touch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+L.or_set_ext_variant.argtypes = [C.c_uint32]
+L.or_get_ext_variant.restype = C.c_uint32
+EXT_VARIANTS = {"srgb_pow_ulp_up": 1, "srgb_pow_ulp_down": 2, "srgb_quant_round": 4, "cgmath_normalize_div": 8,
+                "glsl_mix_lerp": 16, "glsl_normalize_rsq": 32, "trilinear_weighted_sum": 64, "srgb_double_pow": 128}
+
+
+def raymarch_touch(rp, t0, t1, cam, width, height, y0=0, y1=None, threads=8, maps=None):
+    """The march with texel-touch recording (SURVEY 8d byte model).  maps: dict of uint8 arrays [D, H, W] keyed
+    march0 / hit0 / hit1 / normal0 (created when None; pass the same dict again to accumulate over cameras).
+    Returns (maps, counts dict)."""
+    y1 = height if y1 is None else y1
+    shape = t0.shape[:3]
+    if maps is None:
+        maps = {k: np.zeros(shape, np.uint8) for k in ("march0", "hit0", "hit1", "normal0")}
+    c = MarchCounts()
+    L.or_raymarch_touch(C.byref(rp), t0.ctypes.data, t1.ctypes.data, C.byref(cam), width, height, y0, y1,
+                        maps["march0"].ctypes.data, maps["hit0"].ctypes.data, maps["hit1"].ctypes.data,
+                        maps["normal0"].ctypes.data, C.byref(c), threads)
+    return maps, {k: int(getattr(c, k)) for k, _ in MarchCounts._fields_}
+
+
 # ---- mesher front end (oracle/mesh_front.c) ----
 VERTEX_FLOATS = 12
 L.or_source_scalar.restype = C.c_float

@@ -32,21 +32,67 @@ def check_slab(oracle, pkg, prm, dims, z0, z1, slab, sdf_id=0):
     r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, z0=z0, z1=z1, sdf_id=sdf_id)
     np.testing.assert_array_equal(bits(slab.owned0), r0.view(np.uint32))
     np.testing.assert_array_equal(bits(slab.owned1), r1.view(np.uint32))
+    h = slab.halo_hi
     for tex, ref in ((slab.tex0, r0), (slab.tex1, r1)):
-        np.testing.assert_array_equal(bits(tex[0]), ref[-1].view(np.uint32))   # ghost_lo <- last owned (wrap)
-        np.testing.assert_array_equal(bits(tex[-1]), ref[0].view(np.uint32))   # ghost_hi <- first owned (wrap)
+        np.testing.assert_array_equal(bits(tex[0]), ref[-1].view(np.uint32))    # ghost_lo <- last owned (wrap)
+        np.testing.assert_array_equal(bits(tex[-h:]), ref[:h].view(np.uint32))  # ghost_hi <- first owned slice(s) (wrap)
 
 
+def step_forms(pkg):
+    K = pkg._capi
+    return {"auto": 0, "one_launch": K.STEP_ONE_LAUNCH, "one_launch_unpacked": K.STEP_ONE_LAUNCH | K.STEP_UNPACKED,
+            "two_launch": K.STEP_TWO_LAUNCH, "two_launch_unpacked": K.STEP_TWO_LAUNCH | K.STEP_UNPACKED}
+
+
+# (40, 24, *) and (33, 7, *), (130, 5, 3): rows that do not fill whole workgroups -> fill, then exchange;
+# (64, 64, 64), (128, 8, 10), (256, 4, 7): the row-chunk form of the boundary-first order; (48, 16, 12): its flat form
+@pytest.mark.parametrize("form", ["auto", "one_launch", "one_launch_unpacked", "two_launch", "two_launch_unpacked"])
 @pytest.mark.parametrize("dims,z0,z1", [((40, 24, 16), 0, 16), ((40, 24, 16), 5, 12), ((33, 7, 9), 0, 2),
-                                        ((33, 7, 9), 4, 5), ((64, 64, 64), 0, 64), ((130, 5, 3), 0, 3)])
-def test_fill_step_fills_slab_and_ghosts(pkg, par, oracle, loop_comm, dims, z0, z1):
+                                        ((33, 7, 9), 4, 5), ((64, 64, 64), 0, 64), ((130, 5, 3), 0, 3),
+                                        ((128, 8, 10), 2, 9), ((256, 4, 7), 0, 7), ((48, 16, 12), 3, 12),
+                                        ((64, 64, 64), 10, 13)])
+def test_fill_step_fills_slab_and_ghosts(pkg, par, oracle, loop_comm, dims, z0, z1, form):
+    """Every form of the step (boundary-first single launch with the in-kernel signal / two launches with an event;
+    packed messages / one message per texture) leaves the same texels: owned slices = the oracle's, ghosts = the wrap."""
+    if "one_launch" in form and not loop_comm.one_launch_capable:
+        pytest.skip("hipStreamWaitValue32 not available on this device")
     prm = pkg.default_params()
     slab = par.alloc_slab((dims[0], dims[1], z1 - z0), 0, 1, "cuda", fill_value=-7.0, periodic=True)
     slab.z_begin, slab.z_end = z0, z1
     grid = pkg.make_grid(dims, z_begin=z0, z_end=z1)
-    loop_comm.fill_step(prm, grid, slab)
+    with pkg.options({pkg._capi.OPT_SLAB_STEP_FORM: step_forms(pkg)[form]}):
+        for _ in range(3):  # counters and signal values advance from step to step
+            loop_comm.fill_step(prm, grid, slab)
     torch.cuda.synchronize()
     check_slab(oracle, pkg, prm, dims, z0, z1, slab)
+
+
+@pytest.mark.parametrize("form", ["auto", "one_launch_unpacked", "two_launch", "two_launch_unpacked"])
+@pytest.mark.parametrize("dims,z0,z1", [((64, 32, 12), 0, 12), ((64, 32, 12), 4, 8), ((40, 24, 16), 2, 9), ((64, 8, 9), 3, 5)])
+def test_two_slice_upper_halo(pkg, par, oracle, dims, z0, z1, form):
+    """SDFV_COMM_HALO2: two ghost slices above the owned ones (what sdfNormal's taps need in the sharded march); every rank
+    sends its first TWO owned slices down.  Fill step and the exchange alone."""
+    comm = par.SlabComm(pkg, 0, 1, periodic=True, halo_hi=2)
+    try:
+        if "one_launch" in form and not comm.one_launch_capable:
+            pytest.skip("hipStreamWaitValue32 not available on this device")
+        prm = pkg.default_params(cube_half_side=0.8)
+        slab = par.alloc_slab((dims[0], dims[1], z1 - z0), 0, 1, "cuda", fill_value=-7.0, periodic=True, halo_hi=2)
+        assert slab.ghost_hi == 2 and slab.tex0.shape[0] == (z1 - z0) + 3
+        slab.z_begin, slab.z_end = z0, z1
+        grid = pkg.make_grid(dims, z_begin=z0, z_end=z1)
+        with pkg.options({pkg._capi.OPT_SLAB_STEP_FORM: step_forms(pkg)[form]}):
+            for _ in range(2):
+                comm.fill_step(prm, grid, slab)
+        torch.cuda.synchronize()
+        check_slab(oracle, pkg, prm, dims, z0, z1, slab)
+        slab.tex0[0].fill_(-7.0)
+        slab.tex1[-2:].fill_(-7.0)
+        comm.halo_exchange(grid, slab)
+        torch.cuda.synchronize()
+        check_slab(oracle, pkg, prm, dims, z0, z1, slab)
+    finally:
+        comm.close()
 
 
 def test_repeated_steps_on_a_side_stream(pkg, par, oracle, loop_comm):
@@ -110,6 +156,9 @@ def test_errors_are_status_codes(pkg, par, loop_comm):
     assert lib.sdfv_slab_comm_create(ident, 3, 2, 0, C.byref(out)) == -1
     assert b"rank 3" in lib.sdfv_last_error()
     assert lib.sdfv_slab_comm_create(ident, 0, 1, 0x80, C.byref(out)) == -1
+    gl, gh = C.c_uint32(9), C.c_uint32(9)
+    assert lib.sdfv_slab_comm_info(loop_comm.handle, C.byref(gl), C.byref(gh), None) == 0 and (gl.value, gh.value) == (1, 1)
+    assert lib.sdfv_slab_comm_info(None, None, None, None) == -1
     g = pkg.make_grid((4, 4, 4))
     assert lib.sdfv_slab_halo_exchange(None, C.byref(g), None, None, None) == -1
     empty = pkg.make_grid((4, 4, 4), z_begin=2, z_end=2)

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """One rank's multi-GPU fill step, measured on ONE GPU in a process of its own (bench.py runs this at N = 1 and
 attaches the result as "halo_loopback"): a periodic communicator of world size 1 makes the rank its own z-neighbour, so
-boundary fills, the RCCL group (4 sends + 4 receives of one slice) on its own stream, the interior fill and both stream
+the boundary-first fill, the signal / event hand-off, the RCCL group on its own stream, the ghost copy and both stream
 dependencies all run; only the xGMI transfer is missing.  The communicator is created before the first kernel, as the
 process group is at N > 1 (a stream whose hardware queue predates the process's first RCCL communicator runs the
 step's fill / record / wait pattern 2.5x slower -- DESIGN.md 6).  Prints one JSON line.
-Usage: python tools/slab_step_probe.py <side> <steps>"""
+Usage: python tools/slab_step_probe.py <side> <steps> [--forms]     (--forms: every form of the step, interleaved)"""
 import importlib
 import json
 import os
@@ -21,10 +21,12 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    side = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    side = int(args[0]) if len(args) > 0 else 256
+    steps = int(args[1]) if len(args) > 1 else 30
     pkg = importlib.import_module("sdf-viewer_amd")
     par = importlib.import_module("sdf-viewer_amd.parallel")
+    K = pkg._capi
     torch.cuda.set_device(0)
     comm = par.SlabComm(pkg, 0, 1, periodic=True)  # first: see the docstring
     prm = pkg.default_params()
@@ -32,8 +34,8 @@ def main():
     grid = pkg.make_grid(dims)
     slab = par.alloc_slab(dims, 0, 1, "cuda", periodic=True, pkg=pkg)
 
-    def run(fn, n):
-        t_end = time.perf_counter() + 0.25  # device clock ramp, like bench.py's pre-warm
+    def run(fn, n, warm_s=0.25):
+        t_end = time.perf_counter() + warm_s  # device clock ramp, like bench.py's pre-warm
         while time.perf_counter() < t_end:
             fn()
             torch.cuda.synchronize()
@@ -44,15 +46,49 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
 
-    step_ms = run(lambda: comm.fill_step(prm, grid, slab), steps)
-    same = torch.equal(slab.tex0[0], slab.owned0[-1]) and torch.equal(slab.tex1[-1], slab.owned1[0])
-    fill_ms = run(lambda: pkg.fill_grid(prm, grid, slab.owned0, slab.owned1), steps)
+    def ghosts_ok():
+        return bool(torch.equal(slab.tex0[0], slab.owned0[-1]) and torch.equal(slab.tex1[-1], slab.owned1[0]) and
+                    torch.equal(slab.tex1[0], slab.owned1[-1]) and torch.equal(slab.tex0[-1], slab.owned0[0]))
+
+    def step():
+        comm.fill_step(prm, grid, slab)
+
+    def plain():
+        pkg.fill_grid(prm, grid, slab.owned0, slab.owned1)
+
+    out = {"steps": steps, "one_launch_capable": comm.one_launch_capable}
+    if "--forms" in sys.argv:
+        forms = {"two_launch_unpacked": K.STEP_TWO_LAUNCH | K.STEP_UNPACKED, "two_launch": K.STEP_TWO_LAUNCH}
+        if comm.one_launch_capable:
+            forms.update({"one_launch_unpacked": K.STEP_ONE_LAUNCH | K.STEP_UNPACKED, "one_launch": K.STEP_ONE_LAUNCH})
+        res = {k: [] for k in forms}
+        res["plain_fill"] = []
+        for rnd in range(3):
+            for name, form in forms.items():
+                slab.tex0[0].fill_(-1.0)
+                slab.tex1[-1].fill_(-1.0)
+                with pkg.options({K.OPT_SLAB_STEP_FORM: form}):
+                    ms = run(step, steps, warm_s=0.1)
+                res[name].append(round(ms, 4))
+                if not ghosts_ok():
+                    res[name].append("GHOSTS WRONG")
+            res["plain_fill"].append(round(run(plain, steps, warm_s=0.1), 4))
+        out["forms_ms"] = res
+        best_plain = min(res["plain_fill"])
+        out["fraction_of_plain_fill_rate"] = {k: round(best_plain / min(x for x in v if not isinstance(x, str)), 3)
+                                              for k, v in res.items() if k != "plain_fill"}
+    else:
+        step_ms = run(step, steps)
+        same = ghosts_ok()
+        fill_ms = run(plain, steps)
+        out.update({"ms_per_step": round(step_ms, 4), "plain_fill_ms": round(fill_ms, 4),
+                    "fraction_of_plain_fill_rate": round(fill_ms / step_ms, 3), "ghosts_verified": same,
+                    "form": "one launch (boundary-first order, in-kernel signal), packed messages"
+                            if comm.one_launch_capable else "two launches, packed messages",
+                    "note": "sdfv_slab_fill_step with the rank as its own neighbour (periodic world of 1), in its own "
+                            "process: the step bench.py --gpus N times per rank, minus the xGMI transfer"})
     comm.close()
-    print(json.dumps({"ms_per_step": round(step_ms, 4), "plain_fill_ms": round(fill_ms, 4),
-                      "fraction_of_plain_fill_rate": round(fill_ms / step_ms, 3), "ghosts_verified": bool(same),
-                      "steps": steps,
-                      "note": "sdfv_slab_fill_step with the rank as its own neighbour (periodic world of 1), in its own "
-                              "process: the step bench.py --gpus N times per rank, minus the xGMI transfer"}), flush=True)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
