@@ -152,6 +152,8 @@ typedef enum sdfv_option {
 #define SDFV_RM_NO_SYMMETRIC   8u /* max(min - p, p - max) instead of |p| - max */
 #define SDFV_STEP_TWO_LAUNCH   1u /* boundary slices in a launch of their own, then the interior */
 #define SDFV_STEP_ONE_LAUNCH   2u /* one dense launch whose first workgroups fill the boundary slices and signal */
+#define SDFV_STEP_SIDE_BOUNDARY 3u /* the caller's stream runs the plain dense fill of the whole slab; the communicator's
+                                    * stream computes the boundary slices once more, into the packed send buffers only */
 #define SDFV_STEP_UNPACKED     4u /* flag: 2 messages per texture and neighbour straight into the ghosts (no staging) */
 int sdfv_set_option(uint32_t option, uint64_t value); /* unknown option / value out of range: SDFV_ERR_INVALID_ARGUMENT */
 int sdfv_get_option(uint32_t option, uint64_t *value);
@@ -370,15 +372,17 @@ int sdfv_slab_comm_info(const sdfv_slab_comm *comm, uint32_t *ghost_lo, uint32_t
  * the first 1 (2 with SDFV_COMM_HALO2) owned slices down, the last owned slice up). DEVICE pointers. */
 int sdfv_slab_halo_exchange(sdfv_slab_comm *comm, const sdfv_grid *slab, float *tex0, float *tex1, void *stream);
 /* One fill step of this rank = sdfv_fill_grid over the owned slab + the halo exchange, with the exchange hidden
- * behind the fill.  The dense fill runs in BOUNDARY-FIRST workgroup order: the slices the neighbours wait for are filled
- * by the first workgroups of the launch, which also copy them into the communicator's packed send buffers (ONE message
- * per neighbour and direction carrying both textures' slices), publish them device-wide and signal; the communicator's
- * high-priority stream waits on that signal (hipStreamWaitValue32) -- not on the kernel -- so the RCCL exchange and the
- * copy of the received slices into the ghosts run under the rest of the SAME launch; `stream` then waits for them.
- * SDFV_OPT_SLAB_STEP_FORM selects the two-launch form (boundary workgroups as a launch of their own + event; the
- * default where hipStreamWaitValue32 is unavailable) or unpacked messages.  Slabs too thin to have an interior, or
- * whose rows do not fill whole workgroups, are filled and then exchanged.  On return everything is enqueued; work later
- * put on `stream` sees owned and ghost slices complete. */
+ * behind the fill.  Default form (SDFV_STEP_SIDE_BOUNDARY): `stream` runs the plain dense fill of the whole slab -- the
+ * same single launch as sdfv_fill_grid, nothing before it -- while the communicator's high-priority stream, released by
+ * an event recorded on `stream` at the start of the step, (1) computes the boundary slices (the first 1 or 2 and the
+ * last owned one: under 1 % of the slab, computed twice) straight into packed send buffers, (2) exchanges ONE RCCL
+ * message per neighbour and direction carrying both textures' slices, (3) copies the received slices into the ghosts;
+ * `stream` then waits for that chain, which is shorter than the fill it runs under.  SDFV_OPT_SLAB_STEP_FORM selects
+ * the other forms that were measured: boundary workgroups as a launch of their own on `stream` + event
+ * (two-launch), or ONE launch in boundary-first workgroup order whose first workgroups publish and signal the
+ * communicator's stream through hipStreamWaitValue32 (one-launch); both with packed or per-texture messages.  Slabs
+ * too thin to have an interior, or whose rows do not fill whole workgroups, are filled and then exchanged.  On return
+ * everything is enqueued; work later put on `stream` sees owned and ghost slices complete. */
 int sdfv_slab_fill_step(sdfv_slab_comm *comm, const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *slab,
                         float *tex0, float *tex1, void *stream);
 

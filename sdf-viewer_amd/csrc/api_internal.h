@@ -24,6 +24,7 @@ int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3
 // first, optionally copied into the packed staging buffers and followed by the arrival/signal protocol.
 struct OrderedFill {
     uint32_t lead = 1;
+    bool stage_only = false;  // write the packed copies only (the textures are another launch's)
     float* stage_lo = nullptr;
     float* stage_hi = nullptr;
     uint32_t* arrive = nullptr;

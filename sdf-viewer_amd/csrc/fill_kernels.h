@@ -31,6 +31,7 @@ struct FillArgs {
     uint32_t order_bps;      // workgroups per slice (0 = plain memory order)
     uint32_t order_lead;     // leading boundary slices: 1 (one-voxel halo) or 2 (two ghost slices on the upper side)
     uint32_t block_base;     // first logical workgroup of this launch (two-launch form: boundary, then the rest)
+    uint32_t stage_only;     // boundary workgroups write the packed copies only, not the textures (another launch does)
     float4* stage_lo;        // packed copy of the lead slices for the lower neighbour: [tex0 lead slices | tex1 lead slices]
     float4* stage_hi;        // packed copy of the last slice for the upper neighbour:  [tex0 slice | tex1 slice]
     uint32_t* arrive;        // arrival counter of the boundary workgroups (monotonic, wraps) or nullptr = no signal

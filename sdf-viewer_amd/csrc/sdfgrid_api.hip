@@ -274,6 +274,7 @@ int fill_slab_ordered(const sdfv_demo_params* params, uint32_t sdf_id, const sdf
     if (int rc = need_device()) return rc;
     FillArgs a = make_fill_args(*params, sdf_id, *slab, o0, o1);
     a.order_lead = of.lead;
+    a.stage_only = of.stage_only ? 1u : 0u;
     a.stage_lo = reinterpret_cast<float4*>(of.stage_lo);
     a.stage_hi = reinterpret_cast<float4*>(of.stage_hi);
     a.arrive = of.arrive;
@@ -350,7 +351,7 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             return SDFV_OK;
         case SDFV_OPT_SLAB_STEP_FORM: {
             const uint64_t form = value & ~(uint64_t)SDFV_STEP_UNPACKED;
-            if (form != 0 && form != SDFV_STEP_TWO_LAUNCH && form != SDFV_STEP_ONE_LAUNCH) break;
+            if (form != 0 && form != SDFV_STEP_TWO_LAUNCH && form != SDFV_STEP_ONE_LAUNCH && form != SDFV_STEP_SIDE_BOUNDARY) break;
             g_options.slab_step_form = (uint32_t)value;
             return SDFV_OK;
         }

@@ -328,7 +328,7 @@ int sdfv_slab_fill_step(sdfv_slab_comm* c, const sdfv_demo_params* params, uint3
 
     // Which form: the ordered fill needs whole workgroups per slice and an interior to hide the exchange behind.
     uint32_t form = sdfv::options().slab_step_form;
-    const bool packed = !(form & SDFV_STEP_UNPACKED);
+    bool packed = !(form & SDFV_STEP_UNPACKED);
     form &= ~SDFV_STEP_UNPACKED;
     uint32_t bps = 0, total = 0;
     if (int rc = sdfv::ordered_fill_blocks(slab, &bps, &total)) return rc;
@@ -337,7 +337,15 @@ int sdfv_slab_fill_step(sdfv_slab_comm* c, const sdfv_demo_params* params, uint3
         if (int rc = sdfv_fill_grid(params, sdf_id, &part, o0, o1, main)) return rc;
         return exchange ? enqueue_exchange_direct(lib, c, slab, tex0, tex1, main) : SDFV_OK;
     }
-    if (form == 0) form = c->can_wait_value ? SDFV_STEP_ONE_LAUNCH : SDFV_STEP_TWO_LAUNCH;
+    bool unpacked_auto = false;
+    if (form == 0) {
+        // Measured in loopback (tools/slab_step_probe.py): packed messages halve the exchange kernel's time, which is what
+        // a short fill (256^3: 80 us) needs to hide it; a long fill (512^3: 580 us) hides either and is disturbed
+        // less by per-texture messages straight into the ghosts (no staging stores, no ghost copy: 16 MB less traffic).
+        form = SDFV_STEP_SIDE_BOUNDARY;
+        unpacked_auto = (uint64_t)slice_texels * owned >= (1ull << 26);
+    }
+    if (unpacked_auto) packed = false;
     if (form == SDFV_STEP_ONE_LAUNCH && !c->can_wait_value)
         return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "the one-launch step needs hipStreamWaitValue32 on this device");
     if (packed)
@@ -354,6 +362,36 @@ int sdfv_slab_fill_step(sdfv_slab_comm* c, const sdfv_demo_params* params, uint3
         return packed ? enqueue_exchange_packed(lib, c, slab, tex0, tex1, st) : enqueue_exchange_direct(lib, c, slab, tex0, tex1, st);
     };
 
+    if (form == SDFV_STEP_SIDE_BOUNDARY) {
+        // `main` runs the plain dense fill, nothing before it.  The communicator's stream starts when `main` reaches
+        // this step (work enqueued earlier on `main` may still be reading what the exchange overwrites), computes the
+        // boundary slices into the packed send buffers only, exchanges, and copies the received slices into the ghosts.
+#ifdef SDFV_TUNING  // diagnostics of the tuning build: drop one of the two stream dependencies to price it (results undefined)
+        const bool no_start = (sdfv::options().wave_timing & 1) != 0, no_wait = (sdfv::options().wave_timing & 2) != 0;
+#else
+        const bool no_start = false, no_wait = false;
+#endif
+        if (!no_start) {
+            SDFV_HIPC(hipEventRecord(c->boundary_done, main));
+            SDFV_HIPC(hipStreamWaitEvent(c->comm_stream, c->boundary_done, 0));
+        }
+        if (packed) {
+            of.stage_only = true;
+            if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, 0, nb, c->comm_stream)) return rc;
+            if (int rc = enqueue_exchange_packed(lib, c, slab, tex0, tex1, c->comm_stream)) return rc;
+            SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));
+            if (int rc = sdfv_fill_grid(params, sdf_id, slab, o0, o1, main)) return rc;
+        } else {
+            // per-texture messages straight out of / into the textures: the communicator's stream fills the boundary
+            // slices in place, `main` everything else (the same ordered grid, split between the two streams)
+            if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, 0, nb, c->comm_stream)) return rc;
+            if (int rc = enqueue_exchange_direct(lib, c, slab, tex0, tex1, c->comm_stream)) return rc;
+            SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));
+            if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, nb, total, main)) return rc;
+        }
+        if (!no_wait) SDFV_HIPC(hipStreamWaitEvent(main, c->halo_done, 0));
+        return SDFV_OK;
+    }
     if (form == SDFV_STEP_ONE_LAUNCH) {
         // ONE dense launch: its first workgroups fill the boundary slices, publish them and signal; the communicator's
         // stream waits on that word, not on the kernel, so the exchange runs under the rest of the same launch.

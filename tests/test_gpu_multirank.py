@@ -54,3 +54,21 @@ def test_bench_line_carries_the_whole_contract():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in d["cpu_baseline"], key
     assert d["roofline"]["bound"] == "hbm" and d["cpu_baseline"]["kind"] == "port"
+
+
+def test_two_processes_on_one_gpu_over_the_library_rccl_communicator():
+    """two ranks, one device, RCCL (no loopback wrap, no gloo).  RCCL either accepts two ranks on the
+    same GPU -- then the fill step's ghosts must equal the neighbour's slices -- or refuses; the refusal is then a
+    clean status code with RCCL's message on both ranks (and is what DESIGN.md 6 records)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_two_ranks_one_gpu.py")], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["backend"] == "rccl" and d["ranks"] == 2
+    if d["same_device_accepted"]:
+        for r in d["ranks_out"]:
+            assert r["result"]["rc"] == 0 and r["result"]["ghosts_and_owned_equal_dense_fill"] is True, d
+    else:
+        for r in d["ranks_out"]:
+            assert r["result"] is not None and r["result"]["stage"] in ("comm_create", "unique_id"), d
+            assert r["result"]["rc"] == -5 and "RCCL" in r["result"]["error"], d

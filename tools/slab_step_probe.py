@@ -58,7 +58,8 @@ def main():
 
     out = {"steps": steps, "one_launch_capable": comm.one_launch_capable}
     if "--forms" in sys.argv:
-        forms = {"two_launch_unpacked": K.STEP_TWO_LAUNCH | K.STEP_UNPACKED, "two_launch": K.STEP_TWO_LAUNCH}
+        forms = {"two_launch_unpacked": K.STEP_TWO_LAUNCH | K.STEP_UNPACKED, "two_launch": K.STEP_TWO_LAUNCH,
+                 "side_boundary": K.STEP_SIDE_BOUNDARY, "side_boundary_unpacked": K.STEP_SIDE_BOUNDARY | K.STEP_UNPACKED}
         if comm.one_launch_capable:
             forms.update({"one_launch_unpacked": K.STEP_ONE_LAUNCH | K.STEP_UNPACKED, "one_launch": K.STEP_ONE_LAUNCH})
         res = {k: [] for k in forms}
@@ -83,8 +84,8 @@ def main():
         fill_ms = run(plain, steps)
         out.update({"ms_per_step": round(step_ms, 4), "plain_fill_ms": round(fill_ms, 4),
                     "fraction_of_plain_fill_rate": round(fill_ms / step_ms, 3), "ghosts_verified": same,
-                    "form": "one launch (boundary-first order, in-kernel signal), packed messages"
-                            if comm.one_launch_capable else "two launches, packed messages",
+                    "form": "plain dense fill on the caller's stream; boundary slices -> packed buffers, RCCL, ghost copy "
+                            "on the communicator's stream",
                     "note": "sdfv_slab_fill_step with the rank as its own neighbour (periodic world of 1), in its own "
                             "process: the step bench.py --gpus N times per rank, minus the xGMI transfer"})
     comm.close()
