@@ -7,6 +7,12 @@ halves are timed in two separately bracketed regions of exactly K steps each:
     value       = Mvoxels/s of the fill  (the half BASELINE.json's target is stated on)
     value_rays  = Mrays/s of the raymarch (all W*H pixels counted, misses included)
     ms_per_step = fill ms + raymarch ms.
+Both halves belong to ONE pipeline over the same buffers: at N = 1 two are timed -- `pipeline_plain` (sdfv_fill_grid,
+32 B/voxel -> sdfv_raymarch over tex0.r) and `pipeline_fused` (sdfv_fill_grid_commit, 36 B/voxel -> sdfv_raymarch_accel
+over the compact distance volume that fill wrote) -- and value / value_rays / ms_per_step / roofline come from the one
+that is faster end to end (`pipeline`).  The N = 1 line also carries `target_512` (the 512^3 fill the north-star target
+is stated on), `roofline_raymarch` with SURVEY 8(d)'s modelled bytes, and `halo_loopback`; N > 1 lines carry `config4`
+(cube geometry at 512^3 voxels per rank: 8 ranks = BASELINE config 4's 1024^3) next to the default slab geometry.
 Inputs are deterministic (integer lattice + fixed cameras) and already resident in HBM; outputs stay in HBM.
 
 N = 1 workload: BASELINE.json configs[1] (256^3 grid + 1920x1080).  --workload 512 selects configs[2]
@@ -68,6 +74,10 @@ def parse_args():
                     help="N>1, 64-camera batch: deal whole cameras to the ranks (default) or give every rank a band of "
                          "rows of every camera (BASELINE.json config 5's image-tile split)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--no-target-512", action="store_true", help="N=1: skip the 512^3 fill block (north-star target config)")
+    ap.add_argument("--no-config4", action="store_true", help="N>1: skip the cube-geometry block (BASELINE config 4)")
+    ap.add_argument("--config4-side", type=int, default=512,
+                    help="N>1: voxels per rank of the cube-geometry block are side^3 (8 x 512^3 = config 4's 1024^3)")
     return ap.parse_args()
 
 
@@ -242,15 +252,44 @@ def load_traffic(workload_key, name="fill_pmc_traffic.json"):
         return None
 
 
-def raymarch_traffic_report(workload_key, launch_ms):
-    """Informational: HBM traffic of one raymarch launch (committed PMC pass) over the live launch time.  The
-    kernel is bound by dependent-gather latency / instruction issue, not by HBM."""
+def raymarch_traffic_report(workload_key, launch_ms, path_key="product_path"):
+    """SURVEY.md 8(d)'s raymarch byte model next to the measured figures.  compulsory / nominal bytes come from the
+    oracle's deterministic counts (tools/raymarch_bytes.py -> profiles/raymarch_model_bytes.json, committed); `traffic`
+    is the HBM bytes of one launch from the committed PMC pass.  The kernel is bound by dependent-gather latency /
+    instruction issue, not by HBM: `frac` says how far from the HBM roofline the COMPULSORY bytes are."""
+    rep = {"kernel": "raymarch_kernel", "bound": "latency (<=255 dependent gathers per ray), not hbm",
+           "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": round(launch_ms, 5)}
     traffic = load_traffic(workload_key, "raymarch_pmc_traffic.json") if workload_key else None
-    gbs = None if traffic is None else traffic / (launch_ms * 1e-3) / 1e9
-    return {"kernel": "raymarch_kernel", "bound": "latency (<=255 dependent gathers per ray), not hbm",
-            "traffic": traffic, "achieved": None if gbs is None else round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": None if gbs is None else round(gbs / HBM_PEAK_GBS, 4),
-            "note": "HBM bytes per frame from the committed PMC pass of this same configuration"}
+    model = None
+    try:
+        model = json.load(open(os.path.join(ROOT, "profiles", "raymarch_model_bytes.json"))).get(workload_key)
+    except Exception:
+        pass
+    sec = launch_ms * 1e-3
+    rep["traffic"] = traffic
+    rep["traffic_GBs"] = None if traffic is None else round(traffic / sec / 1e9, 1)
+    if model:
+        comp, nominal = model["compulsory_bytes"], model["nominal_gather_bytes"]
+        pp = model[path_key]
+        rep.update({
+            "compulsory_bytes": comp, "nominal_gather_bytes": nominal,
+            "achieved": round(comp / sec / 1e9, 1), "frac": round(comp / sec / 1e9 / HBM_PEAK_GBS, 4),
+            "nominal_gather_GBs": round(nominal / sec / 1e9, 1),
+            "traffic_over_compulsory": None if traffic is None else round(traffic / comp, 3),
+            "path_run": {"which": path_key, "compulsory_bytes": pp["compulsory_bytes"],
+                         "compulsory_line_bytes": pp["compulsory_line_bytes"],
+                         "nominal_gather_bytes": pp["nominal_gather_bytes"],
+                         "nominal_gather_GBs": round(pp["nominal_gather_bytes"] / sec / 1e9, 1),
+                         "traffic_over_compulsory_lines": None if traffic is None else round(traffic / pp["compulsory_line_bytes"], 3)},
+            "counts": model["counts"], "unique_texels": model["unique_texels"],
+            "note": "SURVEY 8(d): compulsory = 16 B x (unique tex0 + tex1 texels touched) + 16 B x W*H (achieved/frac "
+                    "are computed from it); nominal = 128 B x (sum steps + 5 x hits) + 16 B x W*H (cache-level gather "
+                    "rate); path_run = the same two figures for the kernel variant timed here; traffic = PMC HBM bytes "
+                    "per launch of this configuration (committed pass)"})
+    else:
+        rep.update({"achieved": rep["traffic_GBs"], "frac": None if traffic is None else round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "no byte model committed for this configuration (tools/raymarch_bytes.py)"})
+    return rep
 
 
 class NativeStdoutToStderr:
@@ -292,6 +331,25 @@ def main():
     faulthandler.cancel_dump_traceback_later()
 
 
+def region(fn, steps, warmup, torch, dist, world, device):
+    """prewarm + `warmup` untimed calls + EXACTLY `steps` timed calls of fn -> (wall ms per call, HIP-event ms per call)."""
+    prewarm(fn, torch, dist, world, device)
+    for _ in range(warmup):
+        fn()
+    dt, ev_ms = timed_region(fn, steps, torch, dist, world, device)
+    return dt / steps * 1e3, ev_ms / steps
+
+
+def fill_roofline(kern_ms, voxels, bytes_per_voxel, traffic):
+    gbs = bytes_per_voxel * voxels / (kern_ms * 1e-3) / 1e9
+    return {"kernel": "fill_dense_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_voxel": bytes_per_voxel,
+            "algorithmic_bytes_per_launch": bytes_per_voxel * voxels, "avg_launch_ms": round(kern_ms, 5),
+            "avg_launch_note": "HIP events around K back-to-back launches / K: includes the ~6 us gap between "
+                               "launches, which rocprofv3's kernel-only average leaves out (8 % at 256^3, under 1 % at 512^3)"}
+
+
 def run(redirect):
     global PREWARM_S
     args = parse_args()
@@ -324,106 +382,192 @@ def run(redirect):
             dist.all_reduce(torch.empty(1, device=device))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    cdev = device if (world > 1 and backend == "nccl") else "cpu"  # where small agreement tensors live
 
     wl = WORKLOADS[args.workload]
     side, W, H = wl["side"], wl["width"], wl["height"]
     prm = pkg.default_params()
+    K, Wm = args.steps, args.warmup
+    aux_steps = max(2, min(K, 10))
 
-    # ---------------- fill: side^3 voxels per rank, z-slab of the weak-scaled global grid ----------------
+    def make_filler(gdims, slab):
+        """N>1: halo exchange overlapped with the fill.  Under nccl the library's own RCCL communicator carries it (one C
+        call per step); should any rank fail to create or use one, EVERY rank falls back to torch.distributed P2P."""
+        transport = args.halo_transport
+        if transport == "auto":
+            transport = "rccl" if (world > 1 and backend == "nccl") else "torch"
+        filler = None
+        if transport == "rccl":
+            try:
+                filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="rccl")
+                filler.step()  # a first step, so that a communicator that cannot exchange shows up here, not mid-run
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001 -- reported, then decided collectively below
+                filler = None
+                print(f"[bench rank {rank}] library communicator unavailable: {e}", file=sys.stderr, flush=True)
+            if world > 1:
+                ok = torch.tensor([1 if filler is not None else 0], device=cdev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    if filler is not None and filler.comm is not None:
+                        filler.comm.close()
+                    filler = None
+        if filler is None:
+            transport = "torch"
+            filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="torch")
+        return filler, transport
+
+    # ---------------- the grid: side^3 voxels per rank, z-slab of the weak-scaled global grid ----------------
     gdims = par.weak_scaling_dims(side, world, args.weak_geometry)
     slab = par.alloc_slab(gdims, rank, world, device, pkg=None if args.no_tuned_placement else pkg)
     grid = pkg.make_grid(gdims, z_begin=slab.z_begin, z_end=slab.z_end)
     owned0, owned1 = slab.owned0, slab.owned1
     voxels_per_rank = pkg.slab_voxels(grid)
-
-    # N>1: halo exchange overlapped with the interior fill.  Under nccl the library's own RCCL communicator carries
-    # it (one C call per step); should any rank fail to create one, every rank falls back to torch.distributed P2P.
-    transport = args.halo_transport
-    if transport == "auto":
-        transport = "rccl" if (world > 1 and backend == "nccl") else "torch"
-    filler = None
-    if transport == "rccl":
-        try:
-            filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="rccl")
-            filler.step()  # a first step, so that a communicator that cannot exchange shows up here, not mid-run
-            torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001 -- reported, then decided collectively below
-            filler = None
-            print(f"[bench rank {rank}] library communicator unavailable: {e}", file=sys.stderr, flush=True)
-        if world > 1:
-            ok = torch.tensor([1 if filler is not None else 0], device=device if backend == "nccl" else "cpu")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                filler, transport = None, "torch"
-    if filler is None:
-        transport = "torch"
-        filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="torch")
-
-    def fill_step():
-        filler.step()
-
-    def fill_only():
-        pkg.fill_grid(prm, grid, owned0, owned1)
-
-    prewarm(fill_step, torch, dist, world, device)
-    for _ in range(args.warmup):
-        fill_step()
-    fill_dt, fill_ev_ms = timed_region(fill_step, args.steps, torch, dist, world, device)
-    # dominant kernel alone, HIP events on the launch stream.  At N = 1 a step IS one launch of that kernel, so the
-    # events of the timed region itself are used; at N > 1 (boundary/interior launches + halo) it gets its own region.
-    if world == 1:
-        kern_ms = fill_ev_ms / args.steps
-    else:
-        _, kern_ms_total = timed_region(fill_only, args.steps, torch, dist, world, device)
-        kern_ms = kern_ms_total / args.steps
     total_voxels = voxels_per_rank * world  # identical per rank by construction
-    fill_mvox = total_voxels * args.steps / fill_dt / 1e6
-    achieved_gbs = FILL_BYTES_PER_VOXEL * voxels_per_rank / (kern_ms * 1e-3) / 1e9
 
-    # ---------------- raymarch: one camera per rank over a replica of the N=1 grid ----------------
-    rdims = (side, side, side)
-    rgrid = pkg.make_grid(rdims)
-    r0, r1 = pkg.alloc_textures(rgrid, device=device)
-    pkg.fill_grid(prm, rgrid, r0, r1)
-    rp = pkg.default_render_params(rgrid)
-    cams = pkg.orbit_cameras(world, aspect=W / H)  # camera 0 = the reference default (scene/mod.rs:82-95)
-    my_cams = [cams[i] for i in par.split_cameras(world, rank, world)]
-    rgba = torch.empty((len(my_cams), H, W, 4), dtype=torch.float32, device=device)
+    out = {}
+    if world == 1:
+        # ---------------- N = 1: two CONSISTENT pipelines over the SAME buffers ----------------
+        #   plain: sdfv_fill_grid (32 B/voxel)         -> sdfv_raymarch over tex0.r in place
+        #   fused: sdfv_fill_grid_commit (36 B/voxel)  -> sdfv_raymarch_accel over the compact distance volume it wrote
+        # Each half is timed in its own region of exactly K steps (voxels and rays are different units); the textures
+        # the march reads are the ones the timed fill wrote.  value / value_rays / ms_per_step all come from ONE
+        # pipeline: the one that is faster end to end.
+        rp = pkg.default_render_params(grid)
+        cam0 = pkg.camera_look_at(aspect=W / H)  # the reference default camera (scene/mod.rs:82-95)
+        rgba = torch.empty((1, H, W, 4), dtype=torch.float32, device=device)
+        dist_vol = torch.empty((side, side, side), dtype=torch.float32, device=device)
 
-    # SDFViewer::commit on the device (scene/sdf/mod.rs:220-239 uploads both textures there): derive the compact
-    # distance volume the march reads.  Once per load, so outside the per-frame raymarch region; timed on its own.
-    dist_vol = pkg.commit_distance(rgrid, r0)
-    commit_dt, _ = timed_region(lambda: pkg.commit_distance(rgrid, r0, dist=dist_vol), max(2, min(args.steps, 10)),
-                                torch, dist, world, device)
-    commit_ms = commit_dt / max(2, min(args.steps, 10)) * 1e3
-    # the same load as ONE pass: the dense fill also stores the distance volume (sdfv_fill_grid_commit)
-    fused_dt, _ = timed_region(lambda: pkg.fill_grid(prm, rgrid, r0, r1, dist=dist_vol), max(2, min(args.steps, 10)),
-                               torch, dist, world, device)
-    fused_ms = fused_dt / max(2, min(args.steps, 10)) * 1e3
+        fill_plain_ms, fill_plain_ev = region(lambda: pkg.fill_grid(prm, grid, owned0, owned1), K, Wm, torch, dist, 1, device)
+        march_tex0_ms, march_tex0_ev = region(lambda: pkg.raymarch(rp, owned0, owned1, cam0, W, H, out=rgba), K, Wm,
+                                              torch, dist, 1, device)
+        fill_fused_ms, fill_fused_ev = region(lambda: pkg.fill_grid(prm, grid, owned0, owned1, dist=dist_vol), K, Wm,
+                                              torch, dist, 1, device)
+        march_dist_ms, march_dist_ev = region(lambda: pkg.raymarch(rp, owned0, owned1, cam0, W, H, out=rgba, dist=dist_vol),
+                                              K, Wm, torch, dist, 1, device)
 
-    def march_step():
-        pkg.raymarch(rp, r0, r1, my_cams, W, H, out=rgba, dist=dist_vol)
+        def both(fill_kw, march_kw):
+            def step():
+                pkg.fill_grid(prm, grid, owned0, owned1, **fill_kw)
+                pkg.raymarch(rp, owned0, owned1, cam0, W, H, out=rgba, **march_kw)
+            return region(step, K, Wm, torch, dist, 1, device)[0]
 
-    prewarm(march_step, torch, dist, world, device)
-    for _ in range(args.warmup):
-        march_step()
-    march_dt, march_ev_ms = timed_region(march_step, args.steps, torch, dist, world, device)
-    total_rays = W * H * world
-    march_mrays = total_rays * args.steps / march_dt / 1e6
+        inter_plain_ms = both({}, {})
+        inter_fused_ms = both({"dist": dist_vol}, {"dist": dist_vol})
+        # the separate device-side commit (what a caller pays who filled without the volume and wants it afterwards)
+        commit_ms = region(lambda: pkg.commit_distance(grid, owned0, dist=dist_vol), aux_steps, 1, torch, dist, 1, device)[0]
+        pipes = {
+            "plain": {"fill": "sdfv_fill_grid (32 B/voxel)", "march": "sdfv_raymarch over tex0.r",
+                      "ms_fill": round(fill_plain_ms, 4), "ms_raymarch": round(march_tex0_ms, 4),
+                      "ms_per_step": round(fill_plain_ms + march_tex0_ms, 4),
+                      "ms_per_step_interleaved": round(inter_plain_ms, 4),
+                      "Mvoxels_s": round(voxels_per_rank / fill_plain_ms / 1e3, 1), "Mrays_s": round(W * H / march_tex0_ms / 1e3, 1),
+                      "fill_frac_of_hbm_peak": round(32 * voxels_per_rank / (fill_plain_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "fused": {"fill": "sdfv_fill_grid_commit (36 B/voxel: textures + compact distance volume)",
+                      "march": "sdfv_raymarch_accel over the distance volume",
+                      "ms_fill": round(fill_fused_ms, 4), "ms_raymarch": round(march_dist_ms, 4),
+                      "ms_per_step": round(fill_fused_ms + march_dist_ms, 4),
+                      "ms_per_step_interleaved": round(inter_fused_ms, 4),
+                      "Mvoxels_s": round(voxels_per_rank / fill_fused_ms / 1e3, 1), "Mrays_s": round(W * H / march_dist_ms / 1e3, 1),
+                      "fill_frac_of_hbm_peak": round(36 * voxels_per_rank / (fill_fused_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        }
+        chosen = "fused" if fill_fused_ms + march_dist_ms < fill_plain_ms + march_tex0_ms else "plain"
+        if chosen == "fused":
+            fill_ms, march_ms, kern_ms, march_ev, bpv = fill_fused_ms, march_dist_ms, fill_fused_ev, march_dist_ev, 36
+        else:
+            fill_ms, march_ms, kern_ms, march_ev, bpv = fill_plain_ms, march_tex0_ms, fill_plain_ev, march_tex0_ev, 32
+        fill_mvox = voxels_per_rank / fill_ms / 1e3
+        march_mrays = W * H / march_ms / 1e3
+        out["pipeline"] = chosen
+        out["pipeline_plain"], out["pipeline_fused"] = pipes["plain"], pipes["fused"]
+        out["pipeline_note"] = ("two consistent pipelines over the same buffers; value, value_rays, ms_per_step and "
+                                "roofline all come from `pipeline` (the faster one end to end); *_interleaved = K steps "
+                                "of fill immediately followed by its march in one timed region")
+        out["commit_ms"] = round(commit_ms, 4)
+        out["commit_note"] = ("sdfv_commit_distance as a pass of its own (device-side SDFViewer::commit for a grid filled "
+                              "without the volume); not part of either pipeline")
+        traffic = load_traffic(args.workload) if bpv == 32 else None
+        out["roofline"] = fill_roofline(kern_ms, voxels_per_rank, bpv, traffic)
+        out["roofline_raymarch"] = raymarch_traffic_report(args.workload, march_ev,
+                                                           "product_path" if chosen == "fused" else "tex0_path")
+        if chosen == "plain":  # the committed PMC pass was taken over the distance volume
+            out["roofline_raymarch"]["traffic_note"] = "PMC pass committed for the distance-volume march"
+        transport, filler = None, None
+        my_cams, r0, r1 = [cam0], owned0, owned1
+    else:
+        # ---------------- N > 1: z-slab fill step with the halo exchange; raymarch over a replica ----------------
+        filler, transport = make_filler(gdims, slab)
+        fill_ms, _ = region(filler.step, K, Wm, torch, dist, world, device)
+        # dominant kernel alone (a step = boundary work + exchange + fill), HIP events on the launch stream
+        _, kern_ms = region(lambda: pkg.fill_grid(prm, grid, owned0, owned1), K, 1, torch, dist, world, device)
+        fill_mvox = total_voxels / fill_ms / 1e3
+        out["roofline"] = fill_roofline(kern_ms, voxels_per_rank, 32, load_traffic(args.workload))
+        out["fill_step_fraction_of_plain_fill"] = round(kern_ms / fill_ms, 3)
+        # raymarch: one camera per rank over a replica of the N = 1 grid (plain pipeline: tex0.r in place)
+        rgrid = pkg.make_grid((side, side, side))
+        r0, r1 = pkg.alloc_textures(rgrid, device=device)
+        pkg.fill_grid(prm, rgrid, r0, r1)
+        rp = pkg.default_render_params(rgrid)
+        cams = pkg.orbit_cameras(world, aspect=W / H)  # camera 0 = the reference default (scene/mod.rs:82-95)
+        my_cams = [cams[i] for i in par.split_cameras(world, rank, world)]
+        rgba = torch.empty((len(my_cams), H, W, 4), dtype=torch.float32, device=device)
+        march_ms, march_ev = region(lambda: pkg.raymarch(rp, r0, r1, my_cams, W, H, out=rgba), K, Wm, torch, dist, world, device)
+        march_mrays = W * H * world / march_ms / 1e3
+        out["pipeline"] = "plain"
+        out["pipeline_note"] = ("N > 1: value = z-slab fill step incl. the RCCL halo exchange (32 B/voxel), value_rays = one "
+                                "camera per rank over a replica, marched over tex0.r in place")
+        out["roofline_raymarch"] = raymarch_traffic_report(None, march_ev)
+        dist_vol = pkg.commit_distance(rgrid, r0)
 
-    # ---------------- N = 1 extra: the multi-GPU fill step in loopback (not `value`) ----------------
-    # What one rank's step costs with the halo exchange in it, measured on this GPU by tools/slab_step_probe.py in a
-    # process of its own (so that this process never brings up an RCCL communicator at N = 1).
+    # ---------------- N = 1 extras ----------------
+    target_512 = None
     halo_loopback = None
     if world == 1 and not args.no_batch:
+        # the north-star target configuration (>= 70 % of the HBM roofline on the 512^3 fill), whatever --workload is
+        if not args.no_target_512:
+            try:
+                if side == 512:
+                    t_slab, t_grid = slab, grid
+                else:
+                    t_slab = par.alloc_slab((512, 512, 512), 0, 1, device, pkg=None if args.no_tuned_placement else pkg)
+                    t_grid = pkg.make_grid((512, 512, 512))
+                t_dist = torch.empty((512, 512, 512), dtype=torch.float32, device=device)
+                ts = max(5, min(K, 20))
+                t_ms, t_ev = region(lambda: pkg.fill_grid(prm, t_grid, t_slab.owned0, t_slab.owned1), ts, 2, torch, dist, 1, device)
+                f_ms, f_ev = region(lambda: pkg.fill_grid(prm, t_grid, t_slab.owned0, t_slab.owned1, dist=t_dist), ts, 2,
+                                    torch, dist, 1, device)
+                n512 = 512 ** 3
+                target_512 = {"grid": [512, 512, 512], "steps": ts, "ms_fill": round(t_ms, 4),
+                              "Mvoxels_s": round(n512 / t_ms / 1e3, 1), "avg_launch_ms": round(t_ev, 5),
+                              "achieved_GBs": round(32 * n512 / (t_ev * 1e-3) / 1e9, 1),
+                              "frac": round(32 * n512 / (t_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "fused_commit": {"ms_fill": round(f_ms, 4),
+                                               "achieved_GBs": round(36 * n512 / (f_ev * 1e-3) / 1e9, 1),
+                                               "frac": round(36 * n512 / (f_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                              "texture_placement": placement_note(args, t_slab), "target_frac": 0.70,
+                              "note": "north_star: >= 70 % HBM-roofline Mvoxels/s on the demo SDF 512^3 grid fill at 1 GPU; "
+                                      "32 B/voxel algorithmic, HIP events over the timed launches"}
+                del t_dist
+                if side != 512:
+                    del t_slab
+            except Exception as e:  # noqa: BLE001 -- an extra, never fatal
+                target_512 = {"error": f"{type(e).__name__}: {e}"}
+        # the multi-GPU fill step in loopback, measured by tools/slab_step_probe.py in a process of its own (so that
+        # this process never brings up an RCCL communicator at N = 1)
         try:
             import subprocess
             torch.cuda.synchronize()
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "slab_step_probe.py"), str(side), str(args.steps)],
-                               capture_output=True, text=True, timeout=300)
-            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            halo_loopback = json.loads(lines[-1]) if (r.returncode == 0 and lines) else \
-                {"error": (r.stderr or r.stdout)[-300:]}
+            loop = {}
+            for s_side in sorted({side, 512}):
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "slab_step_probe.py"), str(s_side), str(K)],
+                                   capture_output=True, text=True, timeout=300)
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                loop[str(s_side)] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else \
+                    {"error": (r.stderr or r.stdout)[-300:]}
+            halo_loopback = loop[str(side)]
+            halo_loopback["by_side"] = {k: {kk: v.get(kk) for kk in ("ms_per_step", "plain_fill_ms", "fraction_of_plain_fill_rate",
+                                                                     "ghosts_verified", "error") if kk in v}
+                                        for k, v in loop.items()}
         except Exception as e:  # noqa: BLE001 -- an extra, never fatal
             halo_loopback = {"error": f"{type(e).__name__}: {e}"}
 
@@ -431,6 +575,8 @@ def run(redirect):
     n_batch = 64
     batch_report = None
     if not args.no_batch:
+        if world == 1:
+            pkg.fill_grid(prm, grid, owned0, owned1, dist=dist_vol)  # the volume of the grid being marched
         batch_cams = pkg.orbit_cameras(n_batch, aspect=W / H)
         if args.batch_split == "rows":
             mine = batch_cams
@@ -444,22 +590,50 @@ def run(redirect):
             pkg.raymarch(rp, r0, r1, mine, W, H, y0=by0, y1=by1, out=batch_out, dist=dist_vol)
 
         batch_step()
-        batch_steps = max(2, min(args.steps, 5))
+        batch_steps = max(2, min(K, 5))
         batch_dt, _ = timed_region(batch_step, batch_steps, torch, dist, world, device)
         batch_report = {"cameras": n_batch, "image": [W, H], "cameras_per_gpu": len(mine),
                         "rows_per_gpu": by1 - by0, "split": args.batch_split if world > 1 else None,
                         "value": round(n_batch * W * H * batch_steps / batch_dt / 1e6, 1), "unit": "Mrays/s",
                         "ms_per_batch": round(batch_dt / batch_steps * 1e3, 4),
-                        "note": "BASELINE.json configs[4] shape (64-camera orbit) over the same grid"}
+                        "note": "BASELINE.json configs[4] shape (64-camera orbit) over the same grid, distance-volume march"}
         del batch_out
 
+    # ---------------- N > 1 extras: BASELINE config 4's geometry, and the self-checks ----------------
+    config4 = None
     verified = None
     sharded_march = None
     if world > 1:
+        if not args.no_config4:
+            # cube geometry at --config4-side^3 voxels per rank: 8 ranks x 512^3 = config 4's 1024^3 (1024 x 1024 slices,
+            # 33.5 MB per halo message pair and direction against a 128-slice slab)
+            try:
+                cside = args.config4_side
+                cdims = par.weak_scaling_dims(cside, world, "cube")
+                cslab = par.alloc_slab(cdims, rank, world, device, pkg=None if args.no_tuned_placement else pkg)
+                cgrid = pkg.make_grid(cdims, z_begin=cslab.z_begin, z_end=cslab.z_end)
+                cfiller = par.SlabFiller(pkg, prm, cdims, cslab, rank, world, transport=transport,
+                                         comm=filler.comm)  # the same communicator serves this slab too
+                cs = max(3, min(K, 10))
+                c_ms, _ = region(cfiller.step, cs, 2, torch, dist, world, device)
+                _, c_kern = region(lambda: pkg.fill_grid(prm, cgrid, cslab.owned0, cslab.owned1), cs, 1, torch, dist, world, device)
+                cvox = pkg.slab_voxels(cgrid)
+                config4 = {"grid_global": list(cdims), "voxels_per_gpu": cvox, "steps": cs,
+                           "value": round(cvox * world / c_ms / 1e3, 1), "unit": "Mvoxels/s",
+                           "ms_per_step_fill": round(c_ms, 4), "plain_fill_ms": round(c_kern, 4),
+                           "fill_step_fraction_of_plain_fill": round(c_kern / c_ms, 3),
+                           "frac_of_hbm_peak_per_gpu": round(32 * cvox / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "halo_bytes_per_direction": int(cdims[0]) * int(cdims[1]) * 32,
+                           "note": "BASELINE.json configs[3] geometry (cube; 8 x 512^3 = 1024^3), weak scaling like `value`"}
+                del cslab
+            except Exception as e:  # noqa: BLE001 -- an extra, never fatal
+                config4 = {"error": f"{type(e).__name__}: {e}"}
         # outside the timed regions: the gathered slabs must equal a dense local fill of the global grid, and the
         # ghost slices must equal what the neighbour computed (= a local recompute: the SDF is analytic)
         if gdims[0] * gdims[1] * gdims[2] * 32 <= 8 << 30:
             try:
+                filler.step()
+                torch.cuda.synchronize()
                 full0, full1 = par.gather_replica(slab, gdims, world)
                 chk0, chk1 = pkg.alloc_textures(pkg.make_grid(gdims), device=device)
                 pkg.fill_grid(prm, pkg.make_grid(gdims), chk0, chk1)
@@ -467,7 +641,7 @@ def run(redirect):
                 ok = torch.equal(full0, chk0) and torch.equal(full1, chk1)
                 lo, hi = slab.z_begin - slab.ghost_lo, slab.z_end + slab.ghost_hi
                 ok = ok and torch.equal(slab.tex0, chk0[lo:hi]) and torch.equal(slab.tex1, chk1[lo:hi])
-                flag = torch.tensor([1.0 if ok else 0.0], device=device if backend == "nccl" else "cpu")
+                flag = torch.tensor([1.0 if ok else 0.0], device=cdev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 verified = bool(flag.item() == 1.0)
                 del full0, full1
@@ -485,7 +659,7 @@ def run(redirect):
                     sharded_march_ms = (time.perf_counter() - t0) * 1e3
                     want = pkg.raymarch(grp, chk0, chk1, scam, sw, sh)[0]
                     same = torch.equal(got.view(torch.int32), want.view(torch.int32)) and bool((want[..., 3] > 0).any())
-                    flag = torch.tensor([1.0 if same else 0.0], device=device if backend == "nccl" else "cpu")
+                    flag = torch.tensor([1.0 if same else 0.0], device=cdev)
                     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                     sharded_march = {"verified": bool(flag.item() == 1.0), "image": [sw, sh], "rounds": world,
                                      "ms": round(sharded_march_ms, 3),
@@ -500,7 +674,7 @@ def run(redirect):
             verified = "skipped (global grid > 8 GiB)"
 
     if rank == 0:
-        out = {
+        line = {
             "metric": "Mvoxels/s grid fill + Mrays/s sphere-trace @1080p, demo SDF",
             "metric_note": "the metric is a pair: value = Mvoxels/s of the grid fill, value_rays = Mrays/s of the sphere-trace",
             "value": round(fill_mvox, 1),
@@ -508,13 +682,13 @@ def run(redirect):
             "value_rays": round(march_mrays, 1),
             "unit_rays": "Mrays/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
+            "steps": K,
+            "warmup": Wm,
             "prewarm_ms": args.prewarm_ms,
             "texture_placement": placement_note(args, slab),
-            "ms_per_step": round((fill_dt + march_dt) / args.steps * 1e3, 4),
-            "ms_per_step_fill": round(fill_dt / args.steps * 1e3, 4),
-            "ms_per_step_raymarch": round(march_dt / args.steps * 1e3, 4),
+            "ms_per_step": round(fill_ms + march_ms, 4),
+            "ms_per_step_fill": round(fill_ms, 4),
+            "ms_per_step_raymarch": round(march_ms, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -529,30 +703,17 @@ def run(redirect):
                        "image": [W, H], "cameras_per_gpu": len(my_cams),
                        "weak_geometry": None if world == 1 else args.weak_geometry,
                        "parallelism": "single GPU" if world == 1 else f"z-slab x{world} + 1-voxel RCCL halo; 1 camera/GPU"},
-            "roofline": {"kernel": "fill_dense_kernel", "bound": "hbm",
-                         "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
-                         "traffic": load_traffic(args.workload),
-                         "algorithmic_bytes_per_launch": FILL_BYTES_PER_VOXEL * voxels_per_rank,
-                         "avg_launch_ms": round(kern_ms, 5),
-                         "avg_launch_note": "HIP events around K back-to-back launches / K: includes the ~6 us gap "
-                                            "between launches, which rocprofv3's kernel-only average leaves out "
-                                            "(8 % at 256^3, under 1 % at 512^3)"},
-            "raymarch_kernel_ms": round(march_ev_ms / args.steps, 4),
-            "commit_ms": round(commit_ms, 4),
-            "commit_note": "device-side SDFViewer::commit (compact distance volume for the march), once per load; "
-                           "not part of ms_per_step",
-            "fill_commit_fused_ms": round(fused_ms, 4),
-            "fill_commit_fused_note": "fill + commit of the N=1 grid as one pass (sdfv_fill_grid_commit, 36 B/voxel "
-                                      "stored), what SDFViewer::update uses for a fresh grid; not part of ms_per_step",
-            "roofline_raymarch": raymarch_traffic_report(args.workload if world == 1 else None, march_ev_ms / args.steps),
-            "batch_raymarch": batch_report,
-            "halo_loopback": halo_loopback,
         }
+        line.update(out)
+        line["raymarch_kernel_ms"] = round(march_ev, 4)
+        line["batch_raymarch"] = batch_report
+        line["target_512"] = target_512
+        line["halo_loopback"] = halo_loopback
+        line["config4"] = config4
         if not args.no_cpu_baseline and world == 1:  # rank 0, N = 1 only
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_seconds)
+            line["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_seconds)
         redirect.restore()
-        print(json.dumps(out), flush=True)
+        print(json.dumps(line), flush=True)
     if world > 1:
         if getattr(filler, "comm", None) is not None:
             torch.cuda.synchronize()

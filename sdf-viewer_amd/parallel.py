@@ -232,7 +232,8 @@ class SlabFiller:
     dozen slices the two are of the same order and overlapping them is what keeps weak scaling near linear.
     """
 
-    def __init__(self, pkg, params, dims, slab, rank, world, sdf_id=0, group=None, transport="auto", periodic=False):
+    def __init__(self, pkg, params, dims, slab, rank, world, sdf_id=0, group=None, transport="auto", periodic=False,
+                 comm=None):
         """transport: "rccl" = the library's communicator (one C call per step), "torch" = torch.distributed P2P
         ops on a second stream, "auto" = rccl on GPUs under the nccl backend, torch otherwise."""
         self.pkg, self.params, self.dims, self.slab = pkg, params, dims, slab
@@ -240,7 +241,9 @@ class SlabFiller:
         if transport == "auto":
             transport = "rccl" if (world > 1 and slab.tex0.is_cuda and dist.get_backend(group) == "nccl") else "torch"
         self.transport = transport
-        self.comm = SlabComm(pkg, rank, world, group, periodic=periodic, halo_hi=slab.halo_hi) if transport == "rccl" else None
+        # comm: an existing SlabComm to reuse (one communicator serves any number of slabs; the caller closes it)
+        self.comm = (comm or SlabComm(pkg, rank, world, group, periodic=periodic, halo_hi=slab.halo_hi)) \
+            if transport == "rccl" else None
         self.overlap = (transport == "torch" and world > 1 and slab.tex0.is_cuda
                         and (slab.z_end - slab.z_begin) >= 3)
         # highest priority: HIP keeps streams of different priorities on different hardware queues; with equal

@@ -19,6 +19,7 @@ def test_bench_weak_scaling_path_two_ranks_one_gpu(world, geometry):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "64", "--no-cpu-baseline",
+           "--config4-side", "32", "--prewarm-ms", "5",
            "--weak-geometry", geometry, "--batch-split", "rows" if geometry == "cube" else "cameras"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -33,6 +34,8 @@ def test_bench_weak_scaling_path_two_ranks_one_gpu(world, geometry):
     b = d["batch_raymarch"]
     assert b["value"] > 0 and (b["rows_per_gpu"] == 512 // world if geometry == "cube" else b["cameras_per_gpu"] == 64 // world)
     assert d["sharded_fill_verified"] is True  # gathered slabs == dense fill, ghost slices == neighbour's slices
+    c4 = d["config4"]  # the cube geometry next to the default one, in the same line
+    assert c4["value"] > 0 and c4["voxels_per_gpu"] == 32 ** 3 and len(c4["grid_global"]) == 3, c4
     # the grid raymarched where it lies (rays handed between the ranks over gloo) == the march over the whole grid
     assert d["sharded_march"]["verified"] is True, d["sharded_march"]
 
@@ -54,6 +57,15 @@ def test_bench_line_carries_the_whole_contract():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in d["cpu_baseline"], key
     assert d["roofline"]["bound"] == "hbm" and d["cpu_baseline"]["kind"] == "port"
+    # one consistent pipeline: value / value_rays / ms_per_step / roofline all come from `pipeline`
+    pipe = d["pipeline_" + d["pipeline"]]
+    assert d["pipeline"] in ("plain", "fused") and abs(pipe["ms_per_step"] - d["ms_per_step"]) < 1e-3
+    assert d["roofline"]["algorithmic_bytes_per_voxel"] == (36 if d["pipeline"] == "fused" else 32)
+    other = d["pipeline_fused" if d["pipeline"] == "plain" else "pipeline_plain"]
+    assert pipe["ms_per_step"] <= other["ms_per_step"]
+    assert d["target_512"]["frac"] > 0 and d["target_512"]["grid"] == [512, 512, 512]
+    rr = d["roofline_raymarch"]
+    assert "note" in rr and rr["avg_launch_ms"] > 0
 
 
 def test_two_processes_on_one_gpu_over_the_library_rccl_communicator():

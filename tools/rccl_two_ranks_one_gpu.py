@@ -6,6 +6,7 @@ Parent: python tools/rccl_two_ranks_one_gpu.py           -> one JSON line
 Child:  python tools/rccl_two_ranks_one_gpu.py <rank> <id file>"""
 import ctypes as C
 import importlib
+import re
 import json
 import os
 import subprocess
@@ -73,9 +74,9 @@ def parent():
                 p.kill()
                 o, e = p.communicate()
                 o += json.dumps({"stage": "timeout"})
-            lines = [ln for ln in o.splitlines() if ln.startswith("{")]
-            warn = [ln for ln in (o + e).splitlines() if "WARN" in ln or "Duplicate" in ln or "error" in ln.lower()]
-            outs.append({"result": json.loads(lines[-1]) if lines else None, "rccl_messages": warn[-4:]})
+            found = re.findall(r'\{"rank": \d.*?\}', o)  # RCCL's own WARN lines share stdout and may interleave
+            warn = sorted({m for m in re.findall(r"NCCL WARN ([^\[\n{]*)", o + e) if "Could not read node" not in m})
+            outs.append({"result": json.loads(found[-1]) if found else None, "rccl_messages": warn[-3:]})
     accepted = all(o["result"] and o["result"].get("stage") == "fill_step" for o in outs)
     print(json.dumps({"backend": "rccl", "n_gpus": 1, "ranks": 2, "same_device_accepted": accepted, "ranks_out": outs}))
 
