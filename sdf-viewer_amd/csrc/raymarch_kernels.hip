@@ -268,6 +268,294 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     if (covered) status = marching ? -1 : (oob_dist<SYMM>(a, ray_pos) > 1e-4f ? -2 : 1);
 }
 
+// ---- the march loop in gfx950 assembly -------------------------------------------------------------------------------
+// A frame is as long as its longest wave: ONE grazing ray doing up to 255 dependent iterations alone on its SIMD, where
+// a lone wave issues one instruction every ~6-11 cycles whatever the instruction is.  So the loop is priced per
+// INSTRUCTION, and hipcc's lowering of either C++ form (predicated march_fast: ~74 per iteration; divergent-loop
+// march_simt: ~83, the structurizer's mask bookkeeping) leaves a third of the cost on the table.  This is the same loop
+// written by hand (profiles/r02_raymarch_loop_isa.md lists all three):
+//   * the set of marching lanes IS the EXEC mask: v_cmpx removes the lanes that stop (out-of-bounds test, hit test), so
+//     nothing is predicated and no mask register is maintained; s_cbranch_execz is the wave-level early exit;
+//   * the one-cell cache is tested on the interpolation weights themselves: a = u - floor_cached(u) is the weight if the
+//     cell is unchanged, and it is in [0, 1) -- as an unsigned integer: below 0x3f800000 -- exactly when it is unchanged;
+//     three subtractions the filter needs anyway + v_max3_u32 + one compare replace 3 floors + 3 compares + 2 s_or;
+//   * (y, z) components ride in packed-f32 instructions (v_pk_add/mul_f32), the corner values are kept as z-pairs so
+//     that the x and y levels of the trilinear filter are packed as well;
+//   * no per-iteration status or step counters (derived after the loop as in march_fast; the aux variant counts).
+// 42 instructions per iteration on the common path.  Every arithmetic instruction is the one the C++ form performs, in
+// the same order on the same operands (no fma, no reassociation): results are bit-identical, which the parity tests
+// check against the oracle for every pixel.  Covers: LINEAR filter, power-of-two extents and texture sizes (XF == 2),
+// symmetric box, clamp-for-mirror (fast_index); STRIDE 1 = compact distance volume (one 8-byte load per corner row),
+// STRIDE 4 = tex0.r in place.  Byte offsets are 32-bit: the launcher checks the volume's size.
+// Registers: v80-v127 and s64-s85 are this block's (declared as clobbers); operands stay where hipcc put them.
+#define SDFV_MARCH_ASM_HEAD                                                                                         \
+    "s_mov_b64 s[76:77], exec\n"                                                                                    \
+    "s_and_b64 exec, exec, %[cov]\n"                                                                                \
+    "s_cbranch_execz .Ldone_%=\n"                                                                                   \
+    "v_mov_b32 v96, %[px]\n v_mov_b32 v98, %[py]\n v_mov_b32 v99, %[pz]\n"                                           \
+    "v_mov_b32 v100, %[dx]\n v_mov_b32 v102, %[dy]\n v_mov_b32 v103, %[dz]\n"                                        \
+    "s_mov_b32 s66, %[miny]\n s_mov_b32 s67, %[minz]\n"      /* (miny, minz) */                                      \
+    "s_mov_b32 s70, %[ky]\n s_mov_b32 s71, %[kz]\n"          /* (ky, kz) */                                          \
+    "s_mov_b32 s72, 0xbf000000\n s_mov_b32 s73, 0xbf000000\n" /* (-0.5, -0.5) */                                     \
+    "s_add_i32 s75, %[wm1], -1\n"                            /* W - 2 */                                             \
+    "s_movk_i32 s74, 254\n"                                  /* 255 iterations */                                    \
+    "v_mov_b32 v124, 0x7f800000\n v_mov_b32 v126, 0x7f800000\n v_mov_b32 v127, 0x7f800000\n" /* no cell cached */    \
+    ".Lloop_%=:\n"                                                                                                  \
+    /* out of bounds?  max(|p| - max) > 1e-4  (material.frag:106-109) */                                            \
+    "v_sub_f32_e64 v88, |v96|, %[mx]\n"                                                                             \
+    "v_sub_f32_e64 v89, |v98|, %[my]\n"                                                                             \
+    "v_sub_f32_e64 v90, |v99|, %[mz]\n"                                                                             \
+    "v_max3_f32 v88, v88, v89, v90\n"                                                                               \
+    "v_cmpx_nlt_f32_e32 vcc, 0x38d1b717, v88\n"              /* exec &= !(1e-4 < oob) */                             \
+    "s_cbranch_execz .Ldone_%=\n"
+#define SDFV_MARCH_ASM_COORDS                                                                                       \
+    /* u = (p - min) * (N / size) - 0.5 */                                                                          \
+    "v_subrev_f32_e32 v104, %[minx], v96\n"                                                                         \
+    "v_pk_add_f32 v[106:107], v[98:99], s[66:67] neg_lo:[0,1] neg_hi:[0,1]\n"                                       \
+    "v_mul_f32_e32 v104, %[kx], v104\n"                                                                             \
+    "v_pk_mul_f32 v[106:107], v[106:107], s[70:71]\n"                                                               \
+    "v_add_f32_e32 v104, -0.5, v104\n"                                                                              \
+    "v_pk_add_f32 v[106:107], v[106:107], s[72:73]\n"                                                               \
+    /* weights relative to the cached cell; all three in [0, 1) <=> the cell is unchanged */                        \
+    "v_sub_f32_e32 v108, v104, v124\n"                                                                              \
+    "v_sub_f32_e32 v110, v106, v126\n"                                                                              \
+    "v_sub_f32_e32 v112, v107, v127\n"                                                                              \
+    "v_max3_u32 v88, v108, v110, v112\n"                                                                            \
+    "v_cmp_gt_u32_e32 vcc, 0x3f800000, v88\n"                                                                       \
+    "s_andn1_saveexec_b64 s[78:79], vcc\n"                   /* exec = lanes whose cell changed */                   \
+    "s_cbranch_execz .Lcached_%=\n"                                                                                 \
+    "v_floor_f32_e32 v124, v104\n v_floor_f32_e32 v126, v106\n v_floor_f32_e32 v127, v107\n"                         \
+    "v_sub_f32_e32 v108, v104, v124\n v_sub_f32_e32 v110, v106, v126\n v_sub_f32_e32 v112, v107, v127\n"             \
+    "v_cvt_i32_f32_e32 v88, v124\n v_cvt_i32_f32_e32 v89, v126\n v_cvt_i32_f32_e32 v90, v127\n"                      \
+    "v_max_i32_e32 v91, 0, v88\n"                            /* i0c = max(i0, 0) */                                  \
+    "v_add_u32_e32 v88, 1, v88\n v_min_i32_e32 v88, %[wm1], v88\n" /* i1c = min(i0 + 1, W - 1) */                     \
+    "v_max_i32_e32 v93, 0, v89\n"                                                                                   \
+    "v_add_u32_e32 v89, 1, v89\n v_min_i32_e32 v89, %[hm1], v89\n"                                                   \
+    "v_max_i32_e32 v94, 0, v90\n"                                                                                   \
+    "v_add_u32_e32 v90, 1, v90\n v_min_i32_e32 v90, %[dm1], v90\n"                                                   \
+    "v_mul_lo_u32 v93, v93, %[sy]\n v_mul_lo_u32 v89, v89, %[sy]\n"   /* j0c, j1c rows */                            \
+    "v_mul_lo_u32 v94, v94, %[sz]\n v_mul_lo_u32 v90, v90, %[sz]\n"   /* k0c, k1c slices */
+// STRIDE 1: x-neighbours are adjacent floats: one 8-byte load per (y, z) row at b = clamp(i0, 0, W - 2); where the clamp
+// folds the two x-corners together both come from the same half (lo_is_x / hi_is_y).
+#define SDFV_MARCH_ASM_FETCH_DIST                                                                                   \
+    "v_min_i32_e32 v92, s75, v91\n"                          /* b = min(i0c, W - 2) */                               \
+    "v_add3_u32 v95, v94, v93, v92\n v_lshlrev_b32_e32 v95, 2, v95\n"                                                \
+    "global_load_dwordx2 v[80:81], v95, %[base]\n"           /* (z0, y0) */                                          \
+    "v_add3_u32 v95, v94, v89, v92\n v_lshlrev_b32_e32 v95, 2, v95\n"                                                \
+    "global_load_dwordx2 v[82:83], v95, %[base]\n"           /* (z0, y1) */                                          \
+    "v_add3_u32 v95, v90, v93, v92\n v_lshlrev_b32_e32 v95, 2, v95\n"                                                \
+    "global_load_dwordx2 v[84:85], v95, %[base]\n"           /* (z1, y0) */                                          \
+    "v_add3_u32 v95, v90, v89, v92\n v_lshlrev_b32_e32 v95, 2, v95\n"                                                \
+    "global_load_dwordx2 v[86:87], v95, %[base]\n"           /* (z1, y1) */                                          \
+    "v_cmp_eq_u32_e32 vcc, v91, v92\n"                       /* lo_is_x */                                           \
+    "v_add_u32_e32 v92, 1, v92\n"                                                                                   \
+    "v_cmp_eq_u32_e64 s[80:81], v88, v92\n"                  /* hi_is_y */                                           \
+    "s_waitcnt vmcnt(0)\n"                                                                                          \
+    "s_nop 1\n"                                                                                                     \
+    "v_cndmask_b32_e32 v116, v81, v80, vcc\n v_cndmask_b32_e64 v118, v80, v81, s[80:81]\n" /* t000, t100 */          \
+    "v_cndmask_b32_e32 v120, v83, v82, vcc\n v_cndmask_b32_e64 v122, v82, v83, s[80:81]\n" /* t010, t110 */          \
+    "v_cndmask_b32_e32 v117, v85, v84, vcc\n v_cndmask_b32_e64 v119, v84, v85, s[80:81]\n" /* t001, t101 */          \
+    "v_cndmask_b32_e32 v121, v87, v86, vcc\n v_cndmask_b32_e64 v123, v86, v87, s[80:81]\n" /* t011, t111 */
+// STRIDE 4: tex0.r out of 16-byte texels, one dword load per corner.
+#define SDFV_MARCH_ASM_FETCH_TEX0                                                                                   \
+    "v_add_u32_e32 v92, v94, v93\n v_add_u32_e32 v95, v94, v89\n"     /* z0: rows y0, y1 */                          \
+    "v_add_lshl_u32 v80, v92, v91, 4\n v_add_lshl_u32 v81, v92, v88, 4\n"                                            \
+    "global_load_dword v116, v80, %[base]\n global_load_dword v118, v81, %[base]\n"                                  \
+    "v_add_lshl_u32 v82, v95, v91, 4\n v_add_lshl_u32 v83, v95, v88, 4\n"                                            \
+    "global_load_dword v120, v82, %[base]\n global_load_dword v122, v83, %[base]\n"                                  \
+    "v_add_u32_e32 v92, v90, v93\n v_add_u32_e32 v95, v90, v89\n"     /* z1 */                                       \
+    "v_add_lshl_u32 v84, v92, v91, 4\n v_add_lshl_u32 v85, v92, v88, 4\n"                                            \
+    "global_load_dword v117, v84, %[base]\n global_load_dword v119, v85, %[base]\n"                                  \
+    "v_add_lshl_u32 v86, v95, v91, 4\n v_add_lshl_u32 v87, v95, v88, 4\n"                                            \
+    "global_load_dword v121, v86, %[base]\n global_load_dword v123, v87, %[base]\n"                                  \
+    "s_waitcnt vmcnt(0)\n"
+// Corner registers as z-pairs: A0 = v[116:117] = (t000, t001), A1 = v[118:119] = (t100, t101), B0 = v[120:121] =
+// (t010, t011), B1 = v[122:123] = (t110, t111); weights (a, 1 - a) as pairs v[108:109], v[110:111], v[112:113].
+#define SDFV_MARCH_ASM_FILTER                                                                                       \
+    ".Lcached_%=:\n"                                                                                                \
+    "s_mov_b64 exec, s[78:79]\n"                                                                                    \
+    "v_sub_f32_e32 v109, 1.0, v108\n v_sub_f32_e32 v111, 1.0, v110\n v_sub_f32_e32 v113, 1.0, v112\n"                \
+    /* mix along x: c = t(x0) * (1 - ax) + t(x1) * ax */                                                            \
+    "v_pk_mul_f32 v[88:89], v[116:117], v[108:109] op_sel:[0,1] op_sel_hi:[1,1]\n"                                   \
+    "v_pk_mul_f32 v[90:91], v[118:119], v[108:109] op_sel_hi:[1,0]\n"                                                \
+    "v_pk_mul_f32 v[92:93], v[120:121], v[108:109] op_sel:[0,1] op_sel_hi:[1,1]\n"                                   \
+    "v_pk_mul_f32 v[94:95], v[122:123], v[108:109] op_sel_hi:[1,0]\n"                                                \
+    "v_pk_add_f32 v[88:89], v[88:89], v[90:91]\n"            /* (c00, c01) */                                        \
+    "v_pk_add_f32 v[92:93], v[92:93], v[94:95]\n"            /* (c10, c11) */                                        \
+    /* mix along y */                                                                                               \
+    "v_pk_mul_f32 v[88:89], v[88:89], v[110:111] op_sel:[0,1] op_sel_hi:[1,1]\n"                                     \
+    "v_pk_mul_f32 v[92:93], v[92:93], v[110:111] op_sel_hi:[1,0]\n"                                                  \
+    "v_pk_add_f32 v[88:89], v[88:89], v[92:93]\n"            /* (c0, c1) */                                          \
+    /* mix along z, then sample_dist = r - 0.1 */                                                                   \
+    "v_pk_mul_f32 v[88:89], v[88:89], v[112:113] op_sel:[0,1] op_sel_hi:[1,0]\n" /* (c0 * (1 - az), c1 * az) */      \
+    "v_add_f32_e32 v92, v88, v89\n"                                                                                 \
+    "v_add_f32_e32 v92, 0xbdcccccd, v92\n"                                                                          \
+    /* hit?  (material.frag:117-121) */                                                                             \
+    "v_cmpx_ngt_f32_e32 vcc, 0x3727c5ac, v92\n"              /* exec &= !(1e-5 > sample_dist) */
+#define SDFV_MARCH_ASM_ADVANCE                                                                                      \
+    /* advance the rays that go on (material.frag:124-125) */                                                       \
+    "v_mul_f32_e32 v88, v100, v92\n"                                                                                \
+    "v_pk_mul_f32 v[90:91], v[102:103], v[92:93] op_sel_hi:[1,0]\n"                                                  \
+    "v_add_f32_e32 v96, v96, v88\n"                                                                                 \
+    "v_pk_add_f32 v[98:99], v[98:99], v[90:91]\n"                                                                   \
+    "s_add_u32 s74, s74, -1\n"                               /* carry out <=> iterations left */                     \
+    "s_cbranch_scc1 .Lloop_%=\n"                                                                                    \
+    ".Ldone_%=:\n"                                                                                                  \
+    "s_mov_b64 %[ran], exec\n"                               /* lanes still marching after 255 iterations */         \
+    "s_and_b64 exec, s[76:77], %[cov]\n"                                                                            \
+    "v_mov_b32 %[px], v96\n v_mov_b32 %[py], v98\n v_mov_b32 %[pz], v99\n"
+#define SDFV_MARCH_ASM_END "s_mov_b64 exec, s[76:77]\n"
+#define SDFV_MARCH_ASM_OPERANDS                                                                                     \
+    [dx] "v"(ray_dir.x), [dy] "v"(ray_dir.y), [dz] "v"(ray_dir.z), [cov] "s"(cov), [mx] "s"(a.rp.bounds_max[0]),    \
+        [my] "s"(a.rp.bounds_max[1]), [mz] "s"(a.rp.bounds_max[2]), [minx] "s"(a.rp.bounds_min[0]),                 \
+        [miny] "s"(a.rp.bounds_min[1]), [minz] "s"(a.rp.bounds_min[2]), [kx] "s"(kx), [ky] "s"(ky), [kz] "s"(kz),   \
+        [wm1] "s"(wm1), [hm1] "s"(hm1), [dm1] "s"(dm1), [sy] "s"(sy), [sz] "s"(sz), [base] "s"(vol)
+#define SDFV_MARCH_ASM_CLOBBERS                                                                                     \
+    "vcc", "scc", "memory", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",    \
+        "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "v80", "v81", "v82", "v83", "v84",  \
+        "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99",    \
+        "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",   \
+        "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125",   \
+        "v126", "v127"
+
+template <bool SYMM_UNUSED, int STRIDE, bool T>
+__device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __restrict__ vol, const Tex& t,
+                                          V3 ray_dir, bool covered, V3& ray_pos, float& dist_from_origin,
+                                          int& status, int& steps) {
+    // float multiplies are VALU work on gfx950: the (uniform) products are moved to scalar registers explicitly
+    auto uniform = [](float f) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f))); };
+    const float kx = uniform(a.inv_bsize[0] * (float)t.w), ky = uniform(a.inv_bsize[1] * (float)t.h),
+                kz = uniform(a.inv_bsize[2] * (float)t.d);  // exact: powers of two times powers of two
+    const int wm1 = t.w - 1, hm1 = t.h - 1, dm1 = t.d - 1;
+    const uint32_t sy = (uint32_t)t.w, sz = (uint32_t)t.w * (uint32_t)t.h;
+    const unsigned long long cov = __ballot(covered);
+    unsigned long long ran_out;
+    float px = ray_pos.x, py = ray_pos.y, pz = ray_pos.z;
+    if (T) {
+        // aux variant: distanceFromOrigin (v114) and the per-ray fetch count (v115) ride along
+        float tt = dist_from_origin;
+        int n = 0;
+        if (STRIDE == 1) {
+            asm volatile("v_mov_b32 v114, %[tt]\n v_mov_b32 v115, 0\n" SDFV_MARCH_ASM_HEAD
+                         "v_add_u32_e32 v115, 1, v115\n" SDFV_MARCH_ASM_COORDS SDFV_MARCH_ASM_FETCH_DIST SDFV_MARCH_ASM_FILTER
+                         "v_add_f32_e32 v114, v114, v92\n" SDFV_MARCH_ASM_ADVANCE
+                         "v_mov_b32 %[tt], v114\n v_mov_b32 %[n], v115\n" SDFV_MARCH_ASM_END
+                         : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tt] "+v"(tt), [n] "+v"(n), [ran] "=&s"(ran_out)
+                         : SDFV_MARCH_ASM_OPERANDS
+                         : SDFV_MARCH_ASM_CLOBBERS);
+        } else {
+            asm volatile("v_mov_b32 v114, %[tt]\n v_mov_b32 v115, 0\n" SDFV_MARCH_ASM_HEAD
+                         "v_add_u32_e32 v115, 1, v115\n" SDFV_MARCH_ASM_COORDS SDFV_MARCH_ASM_FETCH_TEX0 SDFV_MARCH_ASM_FILTER
+                         "v_add_f32_e32 v114, v114, v92\n" SDFV_MARCH_ASM_ADVANCE
+                         "v_mov_b32 %[tt], v114\n v_mov_b32 %[n], v115\n" SDFV_MARCH_ASM_END
+                         : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tt] "+v"(tt), [n] "+v"(n), [ran] "=&s"(ran_out)
+                         : SDFV_MARCH_ASM_OPERANDS
+                         : SDFV_MARCH_ASM_CLOBBERS);
+        }
+        dist_from_origin = tt;
+        steps = n;
+    } else if (STRIDE == 1) {
+        asm volatile(SDFV_MARCH_ASM_HEAD SDFV_MARCH_ASM_COORDS SDFV_MARCH_ASM_FETCH_DIST SDFV_MARCH_ASM_FILTER
+                         SDFV_MARCH_ASM_ADVANCE SDFV_MARCH_ASM_END
+                     : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [ran] "=&s"(ran_out)
+                     : SDFV_MARCH_ASM_OPERANDS
+                     : SDFV_MARCH_ASM_CLOBBERS);
+    } else {
+        asm volatile(SDFV_MARCH_ASM_HEAD SDFV_MARCH_ASM_COORDS SDFV_MARCH_ASM_FETCH_TEX0 SDFV_MARCH_ASM_FILTER
+                         SDFV_MARCH_ASM_ADVANCE SDFV_MARCH_ASM_END
+                     : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [ran] "=&s"(ran_out)
+                     : SDFV_MARCH_ASM_OPERANDS
+                     : SDFV_MARCH_ASM_CLOBBERS);
+    }
+    if (covered) {
+        ray_pos = mk(px, py, pz);
+        const bool ran = ((ran_out >> (threadIdx.x & 63)) & 1ull) != 0;
+        // a stopped ray's position no longer moves: "out of bounds" is re-derived from it, as in march_fast
+        status = ran ? -1 : (oob_dist<true>(a, ray_pos) > 1e-4f ? -2 : 1);
+    }
+}
+
+// The same loop as march_fast, written as a plain divergent (SIMT) loop: a lane that stops BREAKS, so the set of marching
+// lanes IS the EXEC mask -- stopped lanes cost no v_cndmask to hold their state, the out-of-bounds and hit tests each
+// shrink EXEC with one compare, and the wave leaves when EXEC is empty (the back edge's s_cbranch_execnz is the ballot).
+// Per iteration of the no-refetch path: ~50 instructions against march_fast's ~74 (profiles/r02_raymarch_loop_isa.md).
+// Values and operation order are those of sample_r() / the oracle, as in march_fast.
+template <int XF, bool SYMM, int STRIDE, bool T>
+__device__ __forceinline__ void march_simt(const RaymarchArgs& a, const float* __restrict__ vol, const Tex& t,
+                                           V3 ray_dir, bool covered, V3& ray_pos, float& dist_from_origin,
+                                           int& status, int& steps, int& iterations) {
+    const float fw_ = (float)t.w, fh_ = (float)t.h, fd_ = (float)t.d;
+    const float kx = a.inv_bsize[0] * fw_, ky = a.inv_bsize[1] * fh_, kz = a.inv_bsize[2] * fd_;  // exact if XF == 2
+    const int wm1 = t.w - 1, hm1 = t.h - 1, dm1 = t.d - 1;
+    const uint32_t sy = (uint32_t)t.w, sz = (uint32_t)t.w * (uint32_t)t.h;
+    if (!covered) return;
+    V3 p = ray_pos;
+    float tt = dist_from_origin;
+    bool hit = false, out_of_bounds = false;
+    float cfu = -4.0f, cfv = -4.0f, cfw = -4.0f;  // never a valid floor(u) of a marching lane
+    float t000 = 0.0f, t100 = 0.0f, t010 = 0.0f, t110 = 0.0f, t001 = 0.0f, t101 = 0.0f, t011 = 0.0f, t111 = 0.0f;
+    int i = 0;
+    for (; i < 255; ++i) {
+        // Stop condition: out of bounds (material.frag:106-109)
+        if (oob_dist<SYMM>(a, p) > 1e-4f) {
+            out_of_bounds = true;
+            break;
+        }
+#ifdef SDFV_TUNING
+        ++iterations;
+#endif
+        float u, v, w;
+        if (XF == 2) {
+            u = (p.x - a.rp.bounds_min[0]) * kx - 0.5f;
+            v = (p.y - a.rp.bounds_min[1]) * ky - 0.5f;
+            w = (p.z - a.rp.bounds_min[2]) * kz - 0.5f;
+        } else {
+            const V3 q = to_p01<XF>(a, p);
+            u = q.x * fw_ - 0.5f; v = q.y * fh_ - 0.5f; w = q.z * fd_ - 0.5f;
+        }
+        const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
+        if (fu != cfu || fv != cfv || fw != cfw) {  // one-cell register cache, as in march_fast
+            cfu = fu; cfv = fv; cfw = fw;
+            const int i0 = (int)fu, j0 = (int)fv, k0 = (int)fw;
+            const uint32_t i0c = (uint32_t)max(i0, 0), i1c = (uint32_t)min(i0 + 1, wm1);
+            const uint32_t j0c = (uint32_t)max(j0, 0) * sy, j1c = (uint32_t)min(j0 + 1, hm1) * sy;
+            const uint32_t k0c = (uint32_t)max(k0, 0) * sz, k1c = (uint32_t)min(k0 + 1, dm1) * sz;
+            const uint32_t r00 = k0c + j0c, r10 = k0c + j1c, r01 = k1c + j0c, r11 = k1c + j1c;
+            if (STRIDE == 1 && wm1 >= 1) {
+                const uint32_t b = (uint32_t)min(max(i0, 0), wm1 - 1);
+                const bool lo_is_x = i0c == b, hi_is_y = i1c == b + 1;
+                typedef float f2 __attribute__((ext_vector_type(2), aligned(4)));
+                const f2 q00 = *reinterpret_cast<const f2*>(vol + (uint64_t)(r00 + b));
+                const f2 q10 = *reinterpret_cast<const f2*>(vol + (uint64_t)(r10 + b));
+                const f2 q01 = *reinterpret_cast<const f2*>(vol + (uint64_t)(r01 + b));
+                const f2 q11 = *reinterpret_cast<const f2*>(vol + (uint64_t)(r11 + b));
+                t000 = lo_is_x ? q00.x : q00.y; t100 = hi_is_y ? q00.y : q00.x;
+                t010 = lo_is_x ? q10.x : q10.y; t110 = hi_is_y ? q10.y : q10.x;
+                t001 = lo_is_x ? q01.x : q01.y; t101 = hi_is_y ? q01.y : q01.x;
+                t011 = lo_is_x ? q11.x : q11.y; t111 = hi_is_y ? q11.y : q11.x;
+            } else {
+                t000 = vol[(uint64_t)(r00 + i0c) * STRIDE]; t100 = vol[(uint64_t)(r00 + i1c) * STRIDE];
+                t010 = vol[(uint64_t)(r10 + i0c) * STRIDE]; t110 = vol[(uint64_t)(r10 + i1c) * STRIDE];
+                t001 = vol[(uint64_t)(r01 + i0c) * STRIDE]; t101 = vol[(uint64_t)(r01 + i1c) * STRIDE];
+                t011 = vol[(uint64_t)(r11 + i0c) * STRIDE]; t111 = vol[(uint64_t)(r11 + i1c) * STRIDE];
+            }
+        }
+        const float sample_dist = trilerp(t000, t100, t010, t110, t001, t101, t011, t111, u - fu, v - fv, w - fw) - 1e-1f;
+        // Stop condition: actually hit the surface (material.frag:117-121)
+        if (sample_dist < 1e-5f) {
+            hit = true;
+            break;
+        }
+        // Move the ray forward by the minimum distance to the surface (material.frag:124-125)
+        p = madd(p, ray_dir, sample_dist);
+        if (T) tt += sample_dist;
+    }
+    ray_pos = p;
+    dist_from_origin = tt;
+    steps = hit ? i + 1 : i;  // tex0 fetches done: the hit's iteration sampled, the out-of-bounds one did not
+    status = hit ? 1 : (out_of_bounds ? -2 : -1);
+}
+
 // three-d 0.18.2 tone_mapping / color_mapping (material.frag:167-168) [not vendored in the reference]
 __device__ __forceinline__ float tone_map(uint32_t type, float c) {
     if (type == 1) c = c / (c + 1.0f);
@@ -373,7 +661,7 @@ __device__ __forceinline__ bool box_fragment_ray(const RaymarchArgs& a, V3 eye, 
 #ifndef SDFV_RM_MIN_WAVES
 #define SDFV_RM_MIN_WAVES 1
 #endif
-template <int MODE, bool LINEAR, int XF, bool SYMM, bool AUX>
+template <int MODE, bool LINEAR, int XF, bool SYMM, bool AUX, bool ASM = false>
 __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(RaymarchArgs a) {
     constexpr bool FAST = MODE != 0;
     // 8x8 pixel tile per wave, 2x2 waves per workgroup
@@ -430,11 +718,21 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
     int status = covered ? -1 : 0;  // -1 = out of steps unless something else ends the ray
     int steps = 0;
     int iterations = 0;
-    if (MODE == 1) {
-        march_fast<XF, SYMM, 4, AUX>(a, reinterpret_cast<const float*>(a.tex0), tex0, ray_dir, covered, ray_pos,
+#ifdef SDFV_MARCH_SIMT  // the divergent-loop C++ form (hipcc's structurizer makes it longer than the predicated one)
+#define SDFV_MARCH march_simt
+#else
+#define SDFV_MARCH march_fast
+#endif
+    if (ASM && MODE == 1) {
+        march_asm<SYMM, 4, AUX>(a, reinterpret_cast<const float*>(a.tex0), tex0, ray_dir, covered, ray_pos, dist_from_origin,
+                                status, steps);
+    } else if (ASM && MODE == 2) {
+        march_asm<SYMM, 1, AUX>(a, a.dist, tex0, ray_dir, covered, ray_pos, dist_from_origin, status, steps);
+    } else if (MODE == 1) {
+        SDFV_MARCH<XF, SYMM, 4, AUX>(a, reinterpret_cast<const float*>(a.tex0), tex0, ray_dir, covered, ray_pos,
                                      dist_from_origin, status, steps, iterations);
     } else if (MODE == 2) {
-        march_fast<XF, SYMM, 1, AUX>(a, a.dist, tex0, ray_dir, covered, ray_pos, dist_from_origin, status, steps,
+        SDFV_MARCH<XF, SYMM, 1, AUX>(a, a.dist, tex0, ray_dir, covered, ray_pos, dist_from_origin, status, steps,
                                      iterations);
     } else {
         bool marching = covered;
@@ -752,6 +1050,13 @@ template <int MODE>
 void launch_fast(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
     const int xf = a.pow2_extent ? (a.pow2_size ? 2 : 1) : 0;
     const bool symm = a.symmetric_box != 0;
+    // the hand-written loop: its specialisation (power-of-two extents and sizes, symmetric box) and 32-bit byte offsets
+    const uint64_t texels = (uint64_t)a.rp.tex_size[0] * a.rp.tex_size[1] * a.rp.tex_size[2];
+    if (xf == 2 && symm && a.asm_loop && texels <= (MODE == 2 ? (1ull << 30) : (1ull << 28))) {
+        if (a.aux) hipLaunchKernelGGL((raymarch_kernel<MODE, true, 2, true, true, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((raymarch_kernel<MODE, true, 2, true, false, true>), grid, dim3(256), 0, stream, a);
+        return;
+    }
     if (xf == 2 && symm) launch_aux<MODE, true, 2, true>(a, grid, stream);
     else if (xf == 2) launch_aux<MODE, true, 2, false>(a, grid, stream);
     else if (xf == 1 && symm) launch_aux<MODE, true, 1, true>(a, grid, stream);

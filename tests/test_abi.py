@@ -49,7 +49,7 @@ def test_options_are_explicit_and_the_library_reads_no_environment(pkg):
         assert seen == [0]                                  # another thread keeps the defaults
     assert pkg.get_option(K.OPT_FILL_FORM) == 0
     assert pkg.lib.sdfv_set_option(K.OPT_FILL_FORM, 3) == -1
-    assert pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_DISABLE, 16) == -1
+    assert pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_DISABLE, 32) == -1
     assert pkg.lib.sdfv_set_option(77, 0) == -1 and b"unknown option" in pkg.lib.sdfv_last_error()
     # the wave-timing stamps exist only in the tuning build
     assert pkg.lib.sdfv_set_option(K.OPT_TUNING_WAVE_TIMING, 4096) == -1

@@ -41,16 +41,18 @@ def compare(pkg, oracle, g, t0, t1, h0, h1, cam_kw, width, height, rp_edit=None,
     # reciprocal / divide variants) over tex0.r, the same over the compact distance volume, and the general
     # kernel (full MirroredRepeat, the shader's nested loop)
     K = pkg._capi
-    disabled = {"fast": 0, "dist": 0, "general": K.RM_NO_FAST_INDEX,
+    # "fast" / "dist" take the hand-written gfx950 march loop where its specialisation applies (power-of-two grid,
+    # symmetric box); "*_c" force the compiler's loop on the same kernels
+    disabled = {"fast": 0, "dist": 0, "fast_c": K.RM_NO_ASM_LOOP, "dist_c": K.RM_NO_ASM_LOOP, "general": K.RM_NO_FAST_INDEX,
                 "fast_plain": K.RM_NO_SYMMETRIC | K.RM_NO_POW2_SIZE,
                 "fast_div": K.RM_NO_SYMMETRIC | K.RM_NO_POW2_EXTENT}
     for variant, mask in disabled.items():
         with pkg.options({K.OPT_RAYMARCH_DISABLE: mask}):
             rgba, depth, aux = pkg.raymarch(rp, t0, t1, cam, width, height, y0=y0, y1=y1, want_aux=True,
-                                            want_depth=True, dist=dist if variant == "dist" else None)
+                                            want_depth=True, dist=dist if variant.startswith("dist") else None)
             # the depth plane without the 72-byte record must be the same plane
             _, depth_only = pkg.raymarch(rp, t0, t1, cam, width, height, y0=y0, y1=y1, want_depth=True,
-                                         dist=dist if variant == "dist" else None)
+                                         dist=dist if variant.startswith("dist") else None)
             torch.cuda.synchronize()
         assert torch.equal(depth.view(torch.int32), depth_only.view(torch.int32)), variant
         assert torch.equal(depth.view(torch.int32), aux[..., -1]), f"{variant}: depth plane != aux.depth"
