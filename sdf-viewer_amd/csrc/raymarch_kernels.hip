@@ -298,76 +298,78 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "s_mov_b32 s70, %[ky]\n s_mov_b32 s71, %[kz]\n"          /* (ky, kz) */                                          \
     "s_mov_b32 s72, 0xbf000000\n s_mov_b32 s73, 0xbf000000\n" /* (-0.5, -0.5) */                                     \
     "s_add_i32 s75, %[wm1], -1\n"                            /* W - 2 */                                             \
+    "s_add_i32 s82, %[lgw], 2\n s_add_i32 s83, %[lgw], 4\n"  /* log2(W) + 2 / + 4: row -> byte offset shifts */      \
     "s_movk_i32 s74, 254\n"                                  /* 255 iterations */                                    \
     "v_mov_b32 v124, 0x7f800000\n v_mov_b32 v126, 0x7f800000\n v_mov_b32 v127, 0x7f800000\n" /* no cell cached */    \
-    ".Lloop_%=:\n"                                                                                                  \
-    /* out of bounds?  max(|p| - max) > 1e-4  (material.frag:106-109) */                                            \
+    ".Lloop_%=:\n"
+// One iteration, top half.  Two independent chains are interleaved so that a lone wave rarely issues an instruction
+// that waits for the one before it: (A) out of bounds? max(|p| - max) > 1e-4 (material.frag:106-109) -> v_cmpx removes
+// the lanes that left the box; (B) u = (p - min) * (N / size) - 0.5, x alone and (y, z) packed.  Then the weights
+// relative to the cached cell: all three in [0, 1) <=> the cell is unchanged.
+#define SDFV_MARCH_ASM_TOP(T_STEP)                                                                                  \
     "v_sub_f32_e64 v88, |v96|, %[mx]\n"                                                                             \
-    "v_sub_f32_e64 v89, |v98|, %[my]\n"                                                                             \
-    "v_sub_f32_e64 v90, |v99|, %[mz]\n"                                                                             \
-    "v_max3_f32 v88, v88, v89, v90\n"                                                                               \
-    "v_cmpx_nlt_f32_e32 vcc, 0x38d1b717, v88\n"              /* exec &= !(1e-4 < oob) */                             \
-    "s_cbranch_execz .Ldone_%=\n"
-#define SDFV_MARCH_ASM_COORDS                                                                                       \
-    /* u = (p - min) * (N / size) - 0.5 */                                                                          \
     "v_subrev_f32_e32 v104, %[minx], v96\n"                                                                         \
+    "v_sub_f32_e64 v89, |v98|, %[my]\n"                                                                             \
     "v_pk_add_f32 v[106:107], v[98:99], s[66:67] neg_lo:[0,1] neg_hi:[0,1]\n"                                       \
+    "v_sub_f32_e64 v90, |v99|, %[mz]\n"                                                                             \
     "v_mul_f32_e32 v104, %[kx], v104\n"                                                                             \
     "v_pk_mul_f32 v[106:107], v[106:107], s[70:71]\n"                                                               \
+    "v_max3_f32 v88, v88, v89, v90\n"                                                                               \
     "v_add_f32_e32 v104, -0.5, v104\n"                                                                              \
     "v_pk_add_f32 v[106:107], v[106:107], s[72:73]\n"                                                               \
-    /* weights relative to the cached cell; all three in [0, 1) <=> the cell is unchanged */                        \
+    "v_cmpx_nlt_f32_e32 vcc, 0x38d1b717, v88\n"              /* exec &= !(1e-4 < oob) */                             \
+    "s_cbranch_execz .Ldone_%=\n"                                                                                   \
     "v_sub_f32_e32 v108, v104, v124\n"                                                                              \
     "v_sub_f32_e32 v110, v106, v126\n"                                                                              \
-    "v_sub_f32_e32 v112, v107, v127\n"                                                                              \
+    "v_sub_f32_e32 v112, v107, v127\n" T_STEP                                                                       \
     "v_max3_u32 v88, v108, v110, v112\n"                                                                            \
     "v_cmp_gt_u32_e32 vcc, 0x3f800000, v88\n"                                                                       \
     "s_andn1_saveexec_b64 s[78:79], vcc\n"                   /* exec = lanes whose cell changed */                   \
     "s_cbranch_execz .Lcached_%=\n"                                                                                 \
+    /* new cell: floor, weights, clamped corner indices (MirroredRepeat == clamp here), row numbers by shifts */    \
     "v_floor_f32_e32 v124, v104\n v_floor_f32_e32 v126, v106\n v_floor_f32_e32 v127, v107\n"                         \
-    "v_sub_f32_e32 v108, v104, v124\n v_sub_f32_e32 v110, v106, v126\n v_sub_f32_e32 v112, v107, v127\n"             \
     "v_cvt_i32_f32_e32 v88, v124\n v_cvt_i32_f32_e32 v89, v126\n v_cvt_i32_f32_e32 v90, v127\n"                      \
-    "v_max_i32_e32 v91, 0, v88\n"                            /* i0c = max(i0, 0) */                                  \
-    "v_add_u32_e32 v88, 1, v88\n v_min_i32_e32 v88, %[wm1], v88\n" /* i1c = min(i0 + 1, W - 1) */                     \
-    "v_max_i32_e32 v93, 0, v89\n"                                                                                   \
-    "v_add_u32_e32 v89, 1, v89\n v_min_i32_e32 v89, %[hm1], v89\n"                                                   \
-    "v_max_i32_e32 v94, 0, v90\n"                                                                                   \
-    "v_add_u32_e32 v90, 1, v90\n v_min_i32_e32 v90, %[dm1], v90\n"                                                   \
-    "v_mul_lo_u32 v93, v93, %[sy]\n v_mul_lo_u32 v89, v89, %[sy]\n"   /* j0c, j1c rows */                            \
-    "v_mul_lo_u32 v94, v94, %[sz]\n v_mul_lo_u32 v90, v90, %[sz]\n"   /* k0c, k1c slices */
+    "v_sub_f32_e32 v108, v104, v124\n v_sub_f32_e32 v110, v106, v126\n v_sub_f32_e32 v112, v107, v127\n"             \
+    "v_max_i32_e32 v91, 0, v88\n v_max_i32_e32 v93, 0, v89\n v_max_i32_e32 v94, 0, v90\n"  /* i0c, j0c, k0c */       \
+    "v_add_u32_e32 v88, 1, v88\n v_add_u32_e32 v89, 1, v89\n v_add_u32_e32 v90, 1, v90\n"                            \
+    "v_min_i32_e32 v88, %[wm1], v88\n v_min_i32_e32 v89, %[hm1], v89\n v_min_i32_e32 v90, %[dm1], v90\n" /* i1c.. */  \
+    "v_lshl_add_u32 v84, v94, %[lgh], v93\n"                 /* rows: (k0c, j0c) */                                  \
+    "v_lshl_add_u32 v85, v94, %[lgh], v89\n"                 /*       (k0c, j1c) */                                  \
+    "v_lshl_add_u32 v86, v90, %[lgh], v93\n"                 /*       (k1c, j0c) */                                  \
+    "v_lshl_add_u32 v87, v90, %[lgh], v89\n"                 /*       (k1c, j1c) */
 // STRIDE 1: x-neighbours are adjacent floats: one 8-byte load per (y, z) row at b = clamp(i0, 0, W - 2); where the clamp
 // folds the two x-corners together both come from the same half (lo_is_x / hi_is_y).
 #define SDFV_MARCH_ASM_FETCH_DIST                                                                                   \
     "v_min_i32_e32 v92, s75, v91\n"                          /* b = min(i0c, W - 2) */                               \
-    "v_add3_u32 v95, v94, v93, v92\n v_lshlrev_b32_e32 v95, 2, v95\n"                                                \
-    "global_load_dwordx2 v[80:81], v95, %[base]\n"           /* (z0, y0) */                                          \
-    "v_add3_u32 v95, v94, v89, v92\n v_lshlrev_b32_e32 v95, 2, v95\n"                                                \
-    "global_load_dwordx2 v[82:83], v95, %[base]\n"           /* (z0, y1) */                                          \
-    "v_add3_u32 v95, v90, v93, v92\n v_lshlrev_b32_e32 v95, 2, v95\n"                                                \
-    "global_load_dwordx2 v[84:85], v95, %[base]\n"           /* (z1, y0) */                                          \
-    "v_add3_u32 v95, v90, v89, v92\n v_lshlrev_b32_e32 v95, 2, v95\n"                                                \
-    "global_load_dwordx2 v[86:87], v95, %[base]\n"           /* (z1, y1) */                                          \
-    "v_cmp_eq_u32_e32 vcc, v91, v92\n"                       /* lo_is_x */                                           \
+    "v_lshlrev_b32_e32 v95, 2, v92\n"                                                                               \
+    "v_lshl_add_u32 v84, v84, s82, v95\n v_lshl_add_u32 v85, v85, s82, v95\n"                                        \
+    "v_lshl_add_u32 v86, v86, s82, v95\n v_lshl_add_u32 v87, v87, s82, v95\n"                                        \
+    "global_load_dwordx2 v[80:81], v84, %[base]\n"           /* (z0, y0) */                                          \
+    "global_load_dwordx2 v[82:83], v85, %[base]\n"           /* (z0, y1) */                                          \
+    "global_load_dwordx2 v[84:85], v86, %[base]\n"           /* (z1, y0) */                                          \
+    "global_load_dwordx2 v[86:87], v87, %[base]\n"           /* (z1, y1) */                                          \
+    "v_cmp_eq_u32_e64 s[80:81], v91, v92\n"                  /* lo_is_x */                                           \
     "v_add_u32_e32 v92, 1, v92\n"                                                                                   \
-    "v_cmp_eq_u32_e64 s[80:81], v88, v92\n"                  /* hi_is_y */                                           \
+    "v_cmp_eq_u32_e32 vcc, v88, v92\n"                       /* hi_is_y */                                           \
+    "s_waitcnt vmcnt(3)\n"                                                                                          \
+    "v_cndmask_b32_e64 v116, v81, v80, s[80:81]\n v_cndmask_b32_e32 v118, v80, v81, vcc\n" /* t000, t100 */          \
+    "s_waitcnt vmcnt(2)\n"                                                                                          \
+    "v_cndmask_b32_e64 v120, v83, v82, s[80:81]\n v_cndmask_b32_e32 v122, v82, v83, vcc\n" /* t010, t110 */          \
+    "s_waitcnt vmcnt(1)\n"                                                                                          \
+    "v_cndmask_b32_e64 v117, v85, v84, s[80:81]\n v_cndmask_b32_e32 v119, v84, v85, vcc\n" /* t001, t101 */          \
     "s_waitcnt vmcnt(0)\n"                                                                                          \
-    "s_nop 1\n"                                                                                                     \
-    "v_cndmask_b32_e32 v116, v81, v80, vcc\n v_cndmask_b32_e64 v118, v80, v81, s[80:81]\n" /* t000, t100 */          \
-    "v_cndmask_b32_e32 v120, v83, v82, vcc\n v_cndmask_b32_e64 v122, v82, v83, s[80:81]\n" /* t010, t110 */          \
-    "v_cndmask_b32_e32 v117, v85, v84, vcc\n v_cndmask_b32_e64 v119, v84, v85, s[80:81]\n" /* t001, t101 */          \
-    "v_cndmask_b32_e32 v121, v87, v86, vcc\n v_cndmask_b32_e64 v123, v86, v87, s[80:81]\n" /* t011, t111 */
+    "v_cndmask_b32_e64 v121, v87, v86, s[80:81]\n v_cndmask_b32_e32 v123, v86, v87, vcc\n" /* t011, t111 */
 // STRIDE 4: tex0.r out of 16-byte texels, one dword load per corner.
 #define SDFV_MARCH_ASM_FETCH_TEX0                                                                                   \
-    "v_add_u32_e32 v92, v94, v93\n v_add_u32_e32 v95, v94, v89\n"     /* z0: rows y0, y1 */                          \
-    "v_add_lshl_u32 v80, v92, v91, 4\n v_add_lshl_u32 v81, v92, v88, 4\n"                                            \
+    "v_lshlrev_b32_e32 v91, 4, v91\n v_lshlrev_b32_e32 v88, 4, v88\n"   /* i0c, i1c as byte offsets */               \
+    "v_lshl_add_u32 v80, v84, s83, v91\n v_lshl_add_u32 v81, v84, s83, v88\n"                                        \
     "global_load_dword v116, v80, %[base]\n global_load_dword v118, v81, %[base]\n"                                  \
-    "v_add_lshl_u32 v82, v95, v91, 4\n v_add_lshl_u32 v83, v95, v88, 4\n"                                            \
+    "v_lshl_add_u32 v82, v85, s83, v91\n v_lshl_add_u32 v83, v85, s83, v88\n"                                        \
     "global_load_dword v120, v82, %[base]\n global_load_dword v122, v83, %[base]\n"                                  \
-    "v_add_u32_e32 v92, v90, v93\n v_add_u32_e32 v95, v90, v89\n"     /* z1 */                                       \
-    "v_add_lshl_u32 v84, v92, v91, 4\n v_add_lshl_u32 v85, v92, v88, 4\n"                                            \
-    "global_load_dword v117, v84, %[base]\n global_load_dword v119, v85, %[base]\n"                                  \
-    "v_add_lshl_u32 v86, v95, v91, 4\n v_add_lshl_u32 v87, v95, v88, 4\n"                                            \
-    "global_load_dword v121, v86, %[base]\n global_load_dword v123, v87, %[base]\n"                                  \
+    "v_lshl_add_u32 v80, v86, s83, v91\n v_lshl_add_u32 v81, v86, s83, v88\n"                                        \
+    "global_load_dword v117, v80, %[base]\n global_load_dword v119, v81, %[base]\n"                                  \
+    "v_lshl_add_u32 v82, v87, s83, v91\n v_lshl_add_u32 v83, v87, s83, v88\n"                                        \
+    "global_load_dword v121, v82, %[base]\n global_load_dword v123, v83, %[base]\n"                                  \
     "s_waitcnt vmcnt(0)\n"
 // Corner registers as z-pairs: A0 = v[116:117] = (t000, t001), A1 = v[118:119] = (t100, t101), B0 = v[120:121] =
 // (t010, t011), B1 = v[122:123] = (t110, t111); weights (a, 1 - a) as pairs v[108:109], v[110:111], v[112:113].
@@ -376,10 +378,10 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "s_mov_b64 exec, s[78:79]\n"                                                                                    \
     "v_sub_f32_e32 v109, 1.0, v108\n v_sub_f32_e32 v111, 1.0, v110\n v_sub_f32_e32 v113, 1.0, v112\n"                \
     /* mix along x: c = t(x0) * (1 - ax) + t(x1) * ax */                                                            \
-    "v_pk_mul_f32 v[88:89], v[116:117], v[108:109] op_sel:[0,1] op_sel_hi:[1,1]\n"                                   \
     "v_pk_mul_f32 v[90:91], v[118:119], v[108:109] op_sel_hi:[1,0]\n"                                                \
-    "v_pk_mul_f32 v[92:93], v[120:121], v[108:109] op_sel:[0,1] op_sel_hi:[1,1]\n"                                   \
     "v_pk_mul_f32 v[94:95], v[122:123], v[108:109] op_sel_hi:[1,0]\n"                                                \
+    "v_pk_mul_f32 v[88:89], v[116:117], v[108:109] op_sel:[0,1] op_sel_hi:[1,1]\n"                                   \
+    "v_pk_mul_f32 v[92:93], v[120:121], v[108:109] op_sel:[0,1] op_sel_hi:[1,1]\n"                                   \
     "v_pk_add_f32 v[88:89], v[88:89], v[90:91]\n"            /* (c00, c01) */                                        \
     "v_pk_add_f32 v[92:93], v[92:93], v[94:95]\n"            /* (c10, c11) */                                        \
     /* mix along y */                                                                                               \
@@ -402,6 +404,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "s_cbranch_scc1 .Lloop_%=\n"                                                                                    \
     ".Ldone_%=:\n"                                                                                                  \
     "s_mov_b64 %[ran], exec\n"                               /* lanes still marching after 255 iterations */         \
+    "s_mov_b32 %[left], s74\n"                                                                                      \
     "s_and_b64 exec, s[76:77], %[cov]\n"                                                                            \
     "v_mov_b32 %[px], v96\n v_mov_b32 %[py], v98\n v_mov_b32 %[pz], v99\n"
 #define SDFV_MARCH_ASM_END "s_mov_b64 exec, s[76:77]\n"
@@ -409,7 +412,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     [dx] "v"(ray_dir.x), [dy] "v"(ray_dir.y), [dz] "v"(ray_dir.z), [cov] "s"(cov), [mx] "s"(a.rp.bounds_max[0]),    \
         [my] "s"(a.rp.bounds_max[1]), [mz] "s"(a.rp.bounds_max[2]), [minx] "s"(a.rp.bounds_min[0]),                 \
         [miny] "s"(a.rp.bounds_min[1]), [minz] "s"(a.rp.bounds_min[2]), [kx] "s"(kx), [ky] "s"(ky), [kz] "s"(kz),   \
-        [wm1] "s"(wm1), [hm1] "s"(hm1), [dm1] "s"(dm1), [sy] "s"(sy), [sz] "s"(sz), [base] "s"(vol)
+        [wm1] "s"(wm1), [hm1] "s"(hm1), [dm1] "s"(dm1), [lgw] "s"(lgw), [lgh] "s"(lgh), [base] "s"(vol)
 #define SDFV_MARCH_ASM_CLOBBERS                                                                                     \
     "vcc", "scc", "memory", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",    \
         "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "v80", "v81", "v82", "v83", "v84",  \
@@ -421,15 +424,16 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 template <bool SYMM_UNUSED, int STRIDE, bool T>
 __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __restrict__ vol, const Tex& t,
                                           V3 ray_dir, bool covered, V3& ray_pos, float& dist_from_origin,
-                                          int& status, int& steps) {
+                                          int& status, int& steps, int& iterations) {
     // float multiplies are VALU work on gfx950: the (uniform) products are moved to scalar registers explicitly
     auto uniform = [](float f) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f))); };
     const float kx = uniform(a.inv_bsize[0] * (float)t.w), ky = uniform(a.inv_bsize[1] * (float)t.h),
                 kz = uniform(a.inv_bsize[2] * (float)t.d);  // exact: powers of two times powers of two
     const int wm1 = t.w - 1, hm1 = t.h - 1, dm1 = t.d - 1;
-    const uint32_t sy = (uint32_t)t.w, sz = (uint32_t)t.w * (uint32_t)t.h;
+    const int lgw = 31 - __builtin_clz((uint32_t)t.w), lgh = 31 - __builtin_clz((uint32_t)t.h);  // sizes are powers of two
     const unsigned long long cov = __ballot(covered);
     unsigned long long ran_out;
+    int left = 254;  // the loop's down-counter at exit (tuning build: iterations the wave ran)
     float px = ray_pos.x, py = ray_pos.y, pz = ray_pos.z;
     if (T) {
         // aux variant: distanceFromOrigin (v114) and the per-ray fetch count (v115) ride along
@@ -437,36 +441,42 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
         int n = 0;
         if (STRIDE == 1) {
             asm volatile("v_mov_b32 v114, %[tt]\n v_mov_b32 v115, 0\n" SDFV_MARCH_ASM_HEAD
-                         "v_add_u32_e32 v115, 1, v115\n" SDFV_MARCH_ASM_COORDS SDFV_MARCH_ASM_FETCH_DIST SDFV_MARCH_ASM_FILTER
+                         SDFV_MARCH_ASM_TOP("v_add_u32_e32 v115, 1, v115\n") SDFV_MARCH_ASM_FETCH_DIST SDFV_MARCH_ASM_FILTER
                          "v_add_f32_e32 v114, v114, v92\n" SDFV_MARCH_ASM_ADVANCE
                          "v_mov_b32 %[tt], v114\n v_mov_b32 %[n], v115\n" SDFV_MARCH_ASM_END
-                         : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tt] "+v"(tt), [n] "+v"(n), [ran] "=&s"(ran_out)
+                         : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tt] "+v"(tt), [n] "+v"(n), [ran] "=&s"(ran_out), [left] "=&s"(left)
                          : SDFV_MARCH_ASM_OPERANDS
                          : SDFV_MARCH_ASM_CLOBBERS);
         } else {
             asm volatile("v_mov_b32 v114, %[tt]\n v_mov_b32 v115, 0\n" SDFV_MARCH_ASM_HEAD
-                         "v_add_u32_e32 v115, 1, v115\n" SDFV_MARCH_ASM_COORDS SDFV_MARCH_ASM_FETCH_TEX0 SDFV_MARCH_ASM_FILTER
+                         SDFV_MARCH_ASM_TOP("v_add_u32_e32 v115, 1, v115\n") SDFV_MARCH_ASM_FETCH_TEX0 SDFV_MARCH_ASM_FILTER
                          "v_add_f32_e32 v114, v114, v92\n" SDFV_MARCH_ASM_ADVANCE
                          "v_mov_b32 %[tt], v114\n v_mov_b32 %[n], v115\n" SDFV_MARCH_ASM_END
-                         : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tt] "+v"(tt), [n] "+v"(n), [ran] "=&s"(ran_out)
+                         : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tt] "+v"(tt), [n] "+v"(n), [ran] "=&s"(ran_out), [left] "=&s"(left)
                          : SDFV_MARCH_ASM_OPERANDS
                          : SDFV_MARCH_ASM_CLOBBERS);
         }
         dist_from_origin = tt;
         steps = n;
     } else if (STRIDE == 1) {
-        asm volatile(SDFV_MARCH_ASM_HEAD SDFV_MARCH_ASM_COORDS SDFV_MARCH_ASM_FETCH_DIST SDFV_MARCH_ASM_FILTER
+        asm volatile(SDFV_MARCH_ASM_HEAD SDFV_MARCH_ASM_TOP("") SDFV_MARCH_ASM_FETCH_DIST SDFV_MARCH_ASM_FILTER
                          SDFV_MARCH_ASM_ADVANCE SDFV_MARCH_ASM_END
-                     : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [ran] "=&s"(ran_out)
+                     : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [ran] "=&s"(ran_out), [left] "=&s"(left)
                      : SDFV_MARCH_ASM_OPERANDS
                      : SDFV_MARCH_ASM_CLOBBERS);
     } else {
-        asm volatile(SDFV_MARCH_ASM_HEAD SDFV_MARCH_ASM_COORDS SDFV_MARCH_ASM_FETCH_TEX0 SDFV_MARCH_ASM_FILTER
+        asm volatile(SDFV_MARCH_ASM_HEAD SDFV_MARCH_ASM_TOP("") SDFV_MARCH_ASM_FETCH_TEX0 SDFV_MARCH_ASM_FILTER
                          SDFV_MARCH_ASM_ADVANCE SDFV_MARCH_ASM_END
-                     : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [ran] "=&s"(ran_out)
+                     : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [ran] "=&s"(ran_out), [left] "=&s"(left)
                      : SDFV_MARCH_ASM_OPERANDS
                      : SDFV_MARCH_ASM_CLOBBERS);
     }
+#ifdef SDFV_TUNING
+    iterations = cov ? min(255, 255 - left) : 0;
+#else
+    (void)iterations;
+    (void)left;
+#endif
     if (covered) {
         ray_pos = mk(px, py, pz);
         const bool ran = ((ran_out >> (threadIdx.x & 63)) & 1ull) != 0;
@@ -725,9 +735,9 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
 #endif
     if (ASM && MODE == 1) {
         march_asm<SYMM, 4, AUX>(a, reinterpret_cast<const float*>(a.tex0), tex0, ray_dir, covered, ray_pos, dist_from_origin,
-                                status, steps);
+                                status, steps, iterations);
     } else if (ASM && MODE == 2) {
-        march_asm<SYMM, 1, AUX>(a, a.dist, tex0, ray_dir, covered, ray_pos, dist_from_origin, status, steps);
+        march_asm<SYMM, 1, AUX>(a, a.dist, tex0, ray_dir, covered, ray_pos, dist_from_origin, status, steps, iterations);
     } else if (MODE == 1) {
         SDFV_MARCH<XF, SYMM, 4, AUX>(a, reinterpret_cast<const float*>(a.tex0), tex0, ray_dir, covered, ray_pos,
                                      dist_from_origin, status, steps, iterations);
