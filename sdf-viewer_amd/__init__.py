@@ -11,9 +11,21 @@ The package directory name contains a hyphen; import it with
 import ctypes as C
 import os
 
-# The multi-GPU fill step needs its streams on separate HIP hardware queues; the runtime reads this when
-# it initialises, which is at the first HIP call, not at import.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# The multi-GPU fill step needs its streams on separate HIP hardware queues.  The HIP runtime reads
+# GPU_MAX_HW_QUEUES once, when it initialises (the first HIP call of the process): this harness sets a default before
+# importing torch and says so when that is already too late.  A C / Rust host sets it in its own environment
+# (include/sdfgrid.h); the library itself never touches the environment.
+import sys
+import warnings
+
+_hip_already_up = "torch" in sys.modules and getattr(sys.modules["torch"], "cuda", None) is not None \
+    and sys.modules["torch"].cuda.is_initialized()
+if "GPU_MAX_HW_QUEUES" not in os.environ:
+    if _hip_already_up:
+        warnings.warn("sdf-viewer_amd imported after the HIP runtime initialised: GPU_MAX_HW_QUEUES keeps its default "
+                      "(4); the multi-GPU fill step may serialise its streams (DESIGN.md 6)", RuntimeWarning)
+    else:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 import torch  # noqa: E402
 

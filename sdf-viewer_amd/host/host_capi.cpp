@@ -160,6 +160,8 @@ int sdfvh_viewer_render(void* v, uint32_t width, uint32_t height, const float ey
     if (!out.ok()) return -1;
     int rc = V(v).material.render(cam, out.f32(), nullptr, V(v).stream);
     if (rc != 0) return rc;
+    // the frame was enqueued on the viewer's stream, which may be a non-blocking one: wait for it before the copy
+    if (hipStreamSynchronize((hipStream_t)V(v).stream) != hipSuccess) return -1;
     return hipMemcpy(rgba_host, out.get(), out.bytes(), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
@@ -205,6 +207,7 @@ int sdfvh_scene_render(void* h, uint32_t width, uint32_t height, float* rgba_hos
     if (!img.ok()) return -1;
     RenderReport r = sc.render(width, height, rgba_host ? img.f32() : nullptr);
     out[0] = r.cpu_updates; out[1] = r.committed; out[2] = r.last_chunk; out[3] = r.request_repaint;
+    if (rgba_host && hipStreamSynchronize((hipStream_t)sc.sdf_viewer->stream) != hipSuccess) return -1;
     if (rgba_host && hipMemcpy(rgba_host, img.get(), img.bytes(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return 0;
 }

@@ -98,7 +98,10 @@ SDFParamValueC value_from_api(const SDFParamValue& v) {  // ffi.rs:212-221
     return c;
 }
 
-SDFParamValue value_to_api(const SDFParamValueC& c) {  // ffi.rs:223-231 (takes ownership of a String payload)
+// ffi.rs:223-231.  Deliberate difference, documented in sdf_provider.h: a String payload is COPIED and stays the caller's
+// (the reference re-owns it as a Rust Vec, which is only sound when caller and callee share an allocator); nothing is freed
+// here and nothing leaks on this side.
+SDFParamValue value_to_api(const SDFParamValueC& c) {
     switch (c.tag) {
     case 0: return SDFParamValue{(bool)c.v.boolean};
     case 1: return SDFParamValue{(int32_t)c.v.int_};

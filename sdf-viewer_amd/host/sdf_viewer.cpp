@@ -197,6 +197,7 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
         }
         fresh_ = false;
         while (loading_mgr.step_size() != 0) loading_mgr.finish_pass();
+        publish_lod();
         return loading_mgr.total_iterations() - start_iter;
     }
     bool first = true;
@@ -219,13 +220,23 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
         }
         fresh_ = false;
         loading_mgr.finish_pass();
+        publish_lod();
     }
     return loading_mgr.total_iterations() - start_iter;
 }
 
+// The reference's textures change only in commit(), together with the LOD uniform (scene/sdf/mod.rs:220-239).  Here a
+// pass rewrites the device textures the moment it runs, so the uniform that tells the shader how to read them (NEAREST
+// snap to the coarse lattice while loading, LINEAR + distance volume when loaded) must move with the data, not with the
+// scene's 500 ms commit throttle: a frame rendered between two commits would otherwise sample a half-rewritten grid
+// with the filter of the previous state.
+void SDFViewer::publish_lod() {
+    material.lod_dist_between_samples = std::pow(2.0f, (float)(uint8_t)loading_mgr.passes_left());  // :226
+}
+
 void SDFViewer::commit() {
     // tex0.fill / tex1.fill re-upload nothing here: the textures already live on the device.  (:222-234)
-    material.lod_dist_between_samples = std::pow(2.0f, (float)(uint8_t)loading_mgr.passes_left());  // :226
+    publish_lod();  // idempotent: update() has already published it with the data
     // lod == 1 switches the GL filter to LINEAR (:227-230): the kernel selects the filter from the same uniform.
     // Where the reference uploads both textures there is nothing to move, and nothing to derive either: the compact
     // distance volume the LINEAR march reads has been kept in sync by every fill.  Without one (allocation failed at

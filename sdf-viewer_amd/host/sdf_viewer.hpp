@@ -5,9 +5,10 @@
 // with the two textures living in HBM instead of a CPU Vec + GL texture pair:
 //   - update() launches LoadingManager passes as kernels (sdfv_fill_grid_pass) -- or the dense kernel when a
 //     fresh grid can be finished within the call -- instead of calling sample() once per voxel;
-//   - commit() has nothing to upload (the reference re-uploads both whole textures, :220-239): it publishes
-//     lod_dist_between_samples = 2^passes_left to the material and, once the grid is fully loaded, derives the
-//     raymarch's compact distance volume from tex0 (sdfv_commit_distance);
+//   - every pass that update() enqueues rewrites the device textures at once, so update() also publishes
+//     lod_dist_between_samples = 2^passes_left (the uniform that tells the shader how to read them) with the data;
+//     commit() has nothing to upload (the reference re-uploads both whole textures and sets the uniform there,
+//     :220-239) and nothing to derive: the compact distance volume is kept in sync by every fill and pass;
 //   - SDFViewerMaterial::render() is the fragment shader over every pixel (sdfv_raymarch).
 #pragma once
 
@@ -88,6 +89,8 @@ class SDFViewer {
     size_t update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_time);
     // scene/sdf/mod.rs:220-239
     void commit();
+    // lod_dist_between_samples = 2^passes_left (scene/sdf/mod.rs:226), published with the data it describes
+    void publish_lod();
 
     sdfv_grid grid() const;
     float* tex0_device() const { return material.tex0->f32(); }
