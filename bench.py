@@ -74,6 +74,9 @@ def parse_args():
                     help="N>1, 64-camera batch: deal whole cameras to the ranks (default) or give every rank a band of "
                          "rows of every camera (BASELINE.json config 5's image-tile split)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--pipeline", choices=["both", "plain", "fused"], default="both",
+                    help="N=1: time both pipelines and report the faster one (default), or only one (profiling runs: "
+                         "per-kernel rocprof averages then belong to one kernel variant)")
     ap.add_argument("--no-target-512", action="store_true", help="N=1: skip the 512^3 fill block (north-star target config)")
     ap.add_argument("--no-config4", action="store_true", help="N>1: skip the cube-geometry block (BASELINE config 4)")
     ap.add_argument("--config4-side", type=int, default=512,
@@ -252,14 +255,14 @@ def load_traffic(workload_key, name="fill_pmc_traffic.json"):
         return None
 
 
-def raymarch_traffic_report(workload_key, launch_ms, path_key="product_path"):
+def raymarch_traffic_report(workload_key, launch_ms, path_key="product_path", traffic_key=None):
     """SURVEY.md 8(d)'s raymarch byte model next to the measured figures.  compulsory / nominal bytes come from the
     oracle's deterministic counts (tools/raymarch_bytes.py -> profiles/raymarch_model_bytes.json, committed); `traffic`
     is the HBM bytes of one launch from the committed PMC pass.  The kernel is bound by dependent-gather latency /
     instruction issue, not by HBM: `frac` says how far from the HBM roofline the COMPULSORY bytes are."""
     rep = {"kernel": "raymarch_kernel", "bound": "latency (<=255 dependent gathers per ray), not hbm",
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": round(launch_ms, 5)}
-    traffic = load_traffic(workload_key, "raymarch_pmc_traffic.json") if workload_key else None
+    traffic = load_traffic(traffic_key or workload_key, "raymarch_pmc_traffic.json") if workload_key else None
     model = None
     try:
         model = json.load(open(os.path.join(ROOT, "profiles", "raymarch_model_bytes.json"))).get(workload_key)
@@ -438,24 +441,30 @@ def run(redirect):
         rgba = torch.empty((1, H, W, 4), dtype=torch.float32, device=device)
         dist_vol = torch.empty((side, side, side), dtype=torch.float32, device=device)
 
-        fill_plain_ms, fill_plain_ev = region(lambda: pkg.fill_grid(prm, grid, owned0, owned1), K, Wm, torch, dist, 1, device)
-        march_tex0_ms, march_tex0_ev = region(lambda: pkg.raymarch(rp, owned0, owned1, cam0, W, H, out=rgba), K, Wm,
-                                              torch, dist, 1, device)
-        fill_fused_ms, fill_fused_ev = region(lambda: pkg.fill_grid(prm, grid, owned0, owned1, dist=dist_vol), K, Wm,
-                                              torch, dist, 1, device)
-        march_dist_ms, march_dist_ev = region(lambda: pkg.raymarch(rp, owned0, owned1, cam0, W, H, out=rgba, dist=dist_vol),
-                                              K, Wm, torch, dist, 1, device)
-
         def both(fill_kw, march_kw):
             def step():
                 pkg.fill_grid(prm, grid, owned0, owned1, **fill_kw)
                 pkg.raymarch(rp, owned0, owned1, cam0, W, H, out=rgba, **march_kw)
             return region(step, K, Wm, torch, dist, 1, device)[0]
 
-        inter_plain_ms = both({}, {})
-        inter_fused_ms = both({"dist": dist_vol}, {"dist": dist_vol})
+        INF = float("inf")
+        fill_plain_ms = fill_plain_ev = march_tex0_ms = march_tex0_ev = inter_plain_ms = INF
+        fill_fused_ms = fill_fused_ev = march_dist_ms = march_dist_ev = inter_fused_ms = INF
+        if args.pipeline in ("both", "plain"):
+            fill_plain_ms, fill_plain_ev = region(lambda: pkg.fill_grid(prm, grid, owned0, owned1), K, Wm, torch, dist, 1, device)
+            march_tex0_ms, march_tex0_ev = region(lambda: pkg.raymarch(rp, owned0, owned1, cam0, W, H, out=rgba), K, Wm,
+                                                  torch, dist, 1, device)
+            inter_plain_ms = both({}, {})
+        if args.pipeline in ("both", "fused"):
+            fill_fused_ms, fill_fused_ev = region(lambda: pkg.fill_grid(prm, grid, owned0, owned1, dist=dist_vol), K, Wm,
+                                                  torch, dist, 1, device)
+            march_dist_ms, march_dist_ev = region(lambda: pkg.raymarch(rp, owned0, owned1, cam0, W, H, out=rgba, dist=dist_vol),
+                                                  K, Wm, torch, dist, 1, device)
+            inter_fused_ms = both({"dist": dist_vol}, {"dist": dist_vol})
         # the separate device-side commit (what a caller pays who filled without the volume and wants it afterwards)
-        commit_ms = region(lambda: pkg.commit_distance(grid, owned0, dist=dist_vol), aux_steps, 1, torch, dist, 1, device)[0]
+        commit_ms = INF
+        if args.pipeline == "both":
+            commit_ms = region(lambda: pkg.commit_distance(grid, owned0, dist=dist_vol), aux_steps, 1, torch, dist, 1, device)[0]
         pipes = {
             "plain": {"fill": "sdfv_fill_grid (32 B/voxel)", "march": "sdfv_raymarch over tex0.r",
                       "ms_fill": round(fill_plain_ms, 4), "ms_raymarch": round(march_tex0_ms, 4),
@@ -479,19 +488,19 @@ def run(redirect):
         fill_mvox = voxels_per_rank / fill_ms / 1e3
         march_mrays = W * H / march_ms / 1e3
         out["pipeline"] = chosen
-        out["pipeline_plain"], out["pipeline_fused"] = pipes["plain"], pipes["fused"]
+        out["pipeline_plain"] = pipes["plain"] if args.pipeline in ("both", "plain") else None
+        out["pipeline_fused"] = pipes["fused"] if args.pipeline in ("both", "fused") else None
         out["pipeline_note"] = ("two consistent pipelines over the same buffers; value, value_rays, ms_per_step and "
                                 "roofline all come from `pipeline` (the faster one end to end); *_interleaved = K steps "
                                 "of fill immediately followed by its march in one timed region")
-        out["commit_ms"] = round(commit_ms, 4)
+        out["commit_ms"] = round(commit_ms, 4) if commit_ms != INF else None
         out["commit_note"] = ("sdfv_commit_distance as a pass of its own (device-side SDFViewer::commit for a grid filled "
                               "without the volume); not part of either pipeline")
-        traffic = load_traffic(args.workload) if bpv == 32 else None
+        traffic = load_traffic(args.workload + ("_fused" if bpv == 36 else ""))
         out["roofline"] = fill_roofline(kern_ms, voxels_per_rank, bpv, traffic)
         out["roofline_raymarch"] = raymarch_traffic_report(args.workload, march_ev,
-                                                           "product_path" if chosen == "fused" else "tex0_path")
-        if chosen == "plain":  # the committed PMC pass was taken over the distance volume
-            out["roofline_raymarch"]["traffic_note"] = "PMC pass committed for the distance-volume march"
+                                                           "product_path" if chosen == "fused" else "tex0_path",
+                                                           args.workload + ("" if chosen == "fused" else "_tex0"))
         transport, filler = None, None
         my_cams, r0, r1 = [cam0], owned0, owned1
     else:
