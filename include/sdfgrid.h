@@ -139,7 +139,8 @@ float       sdfv_air_dist(void);     /* AIR_DIST, scene/sdf/mod.rs:42 */
  * tests can force every kernel specialisation.  Thread-local (like the error string and the reference's registry,
  * ffi.rs:15-17), read once per call; the library reads no environment variables. */
 typedef enum sdfv_option {
-    SDFV_OPT_FILL_NONTEMPORAL = 1,     /* 0 (default) | 1: the dense fill stores with the nt hint */
+    SDFV_OPT_FILL_NONTEMPORAL = 1,     /* texture stores of the dense fill: 0 auto (default: nt when the same launch also
+                                        * writes the distance volume, plain otherwise) | 1 always nt | 2 never */
     SDFV_OPT_FILL_FORM = 2,            /* 0 auto (default) | 1 row-chunk form | 2 flat form of the dense fill */
     SDFV_OPT_RAYMARCH_DISABLE = 3,     /* mask of SDFV_RM_NO_*: exact-arithmetic specialisations left out (default 0) */
     SDFV_OPT_RAYMARCH_KEEP_NORMAL = 4, /* 0 (default) | 1: evaluate sdfNormal per hit although nothing consumes it */

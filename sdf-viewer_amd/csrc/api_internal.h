@@ -8,7 +8,7 @@
 namespace sdfv {
 // The calling thread's options (sdfv_set_option); every entry point copies what it needs once per call.
 struct Options {
-    bool fill_nontemporal = false;
+    uint32_t fill_nontemporal = 0;   // 0 auto (nt when the launch also writes the distance volume), 1 always, 2 never
     uint32_t fill_form = 0;          // 0 auto, 1 rows, 2 flat
     uint32_t raymarch_disable = 0;   // SDFV_RM_NO_*
     bool raymarch_keep_normal = false;

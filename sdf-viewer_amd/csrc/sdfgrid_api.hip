@@ -109,10 +109,14 @@ sdfv::FillArgs make_fill_args(const sdfv_demo_params& p, uint32_t sdf_id, const 
     return a;
 }
 
-// Store policy and index form of the dense fill (SDFV_OPT_FILL_*; plain stores and automatic choice by default).
-sdfv::FillLaunch fill_launch_config() {
+// Store policy and index form of the dense fill (SDFV_OPT_FILL_*).  Store policy "auto": a launch that also writes the
+// compact distance volume streams the two textures past L2 (nt) -- nothing re-reads them before the march's few texels
+// under the hits, while the distance volume, which the march gathers from, keeps its place in the caches: the fused
+// fill itself runs 6 % faster (0.097 -> 0.091 ms at 256^3) and fill + march 0.188 -> 0.177 ms (tools/pipeline_nt.py).
+// The plain fill keeps plain stores (nt: within noise alone, +3 % on the 256^3 pipeline, -3 % on the 512^3 one).
+sdfv::FillLaunch fill_launch_config(bool writes_distance_volume) {
     sdfv::FillLaunch c;
-    c.nontemporal = g_options.fill_nontemporal;
+    c.nontemporal = g_options.fill_nontemporal == 1 || (g_options.fill_nontemporal == 0 && writes_distance_volume);
     c.force_rows = g_options.fill_form == 1;
     c.force_flat = g_options.fill_form == 2;
     return c;
@@ -335,8 +339,8 @@ float sdfv_air_dist(void) { return air_dist(); }
 int sdfv_set_option(uint32_t option, uint64_t value) {
     switch (option) {
         case SDFV_OPT_FILL_NONTEMPORAL:
-            if (value > 1) break;
-            g_options.fill_nontemporal = value != 0;
+            if (value > 2) break;
+            g_options.fill_nontemporal = (uint32_t)value;
             return SDFV_OK;
         case SDFV_OPT_FILL_FORM:
             if (value > 2) break;
@@ -500,7 +504,7 @@ int sdfv_fill_grid_commit(const sdfv_demo_params* params, uint32_t sdf_id, const
     a.dist = dist;
     if ((uint64_t)a.H * a.slab_d > 0x7fffffffull || a.W > 0x7fffffffu)
         return fail(SDFV_ERR_INVALID_ARGUMENT, "slab of %u x %u rows is too large for one launch", a.H, a.slab_d);
-    SDFV_HIP(sdfv::launch_fill_dense(a, fill_launch_config(), (hipStream_t)stream));
+    SDFV_HIP(sdfv::launch_fill_dense(a, fill_launch_config(dist != nullptr), (hipStream_t)stream));
     return SDFV_OK;
 }
 

@@ -59,8 +59,12 @@ def test_both_index_forms_of_the_dense_fill(pkg, oracle, form, dims):
     launcher would have picked (SDFV_OPT_FILL_FORM overrides the choice; slab offsets included)."""
     for prm in (pkg.default_params(), pkg.default_params(cube_material=1, disable_sphere=1)):
         z0 = dims[2] // 3
-        with pkg.options({pkg._capi.OPT_FILL_FORM: pkg._capi.FILL_FORM[form]}):
+        # both store policies of each form (2 = plain stores, 1 = nt; auto picks by whether a distance volume is written)
+        with pkg.options({pkg._capi.OPT_FILL_FORM: pkg._capi.FILL_FORM[form], pkg._capi.OPT_FILL_NONTEMPORAL: 1}):
+            n0, n1 = gpu_fill(pkg, prm, dims, z0=z0, z1=dims[2])
+        with pkg.options({pkg._capi.OPT_FILL_FORM: pkg._capi.FILL_FORM[form], pkg._capi.OPT_FILL_NONTEMPORAL: 2}):
             t0, t1 = gpu_fill(pkg, prm, dims, z0=z0, z1=dims[2])
+        assert torch.equal(n0, t0) and torch.equal(n1, t1)
         r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, z0=z0, z1=dims[2])
         assert_bits_equal(t0, r0)
         assert_bits_equal(t1, r1)

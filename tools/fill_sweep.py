@@ -29,7 +29,7 @@ def main():
         best = {}
         for rnd in range(3):
             for b, nt in variants:
-                pkg.set_option(pkg._capi.OPT_FILL_NONTEMPORAL, nt)
+                pkg.set_option(pkg._capi.OPT_FILL_NONTEMPORAL, 1 if nt else 2)
                 ts = time_fn(lambda: pkg.fill_grid(prm, g, t0, t1), 8)
                 best.setdefault((b, nt), []).extend(ts)
             best.setdefault("memset", []).extend(time_fn(memset, 8))

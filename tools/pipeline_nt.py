@@ -23,7 +23,7 @@ def run(fn, n=30, warm=0.2):
 res = {}
 for rnd in range(3):
     for nt in (0, 1):
-        pkg.set_option(K.OPT_FILL_NONTEMPORAL, nt)
+        pkg.set_option(K.OPT_FILL_NONTEMPORAL, 1 if nt else 2)
         def fused():
             pkg.fill_grid(prm, g, t0, t1, dist=dist); pkg.raymarch(rp, t0, t1, cam, W, H, out=rgba, dist=dist)
         def plain():
