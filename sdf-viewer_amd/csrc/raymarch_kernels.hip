@@ -1062,7 +1062,7 @@ void launch_fast(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
     const bool symm = a.symmetric_box != 0;
     // the hand-written loop: its specialisation (power-of-two extents and sizes, symmetric box) and 32-bit byte offsets
     const uint64_t texels = (uint64_t)a.rp.tex_size[0] * a.rp.tex_size[1] * a.rp.tex_size[2];
-    if (xf == 2 && symm && a.asm_loop && texels <= (MODE == 2 ? (1ull << 30) : (1ull << 28))) {
+    if (xf == 2 && symm && a.asm_loop && a.rp.tex_size[0] >= 2 && texels <= (MODE == 2 ? (1ull << 30) : (1ull << 28))) {
         if (a.aux) hipLaunchKernelGGL((raymarch_kernel<MODE, true, 2, true, true, true>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((raymarch_kernel<MODE, true, 2, true, false, true>), grid, dim3(256), 0, stream, a);
         return;

@@ -255,6 +255,47 @@ def test_randomised_cameras_grids_and_boxes(pkg, oracle):
                             fovy_degrees=float(rng.uniform(10.0, 120.0))), width=w, height=h)
 
 
+def test_randomised_sweep_of_the_hand_written_march_loop(pkg, oracle):
+    """Seeded sweep aimed at the gfx950 assembly loop's specialisation: power-of-two grids (cubic or not, down to 2 texels
+    and 1-texel-wide, which must fall back), symmetric boxes with power-of-two extents (cubic or not), cameras outside /
+    inside / on a face.  compare() runs the hand-written loop and the compiler's on the same inputs, over tex0.r and over
+    the distance volume, with the aux record (distance and step counters ride along in the loop) -- all bit for bit."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("SDFV_SOAK_SEED", 99)) + 5000)
+    sizes = [1, 2, 4, 8, 16, 32, 64, 128]
+    for trial in range(int(os.environ.get("SDFV_SOAK_TRIALS", 12))):
+        dims = tuple(int(rng.choice(sizes[1:] if trial % 6 else sizes)) for _ in range(3))
+        if dims[0] * dims[1] * dims[2] > 2 ** 19:
+            dims = (dims[0], dims[1], max(2, 2 ** 19 // (dims[0] * dims[1])))
+        half = np.array([2.0 ** int(rng.integers(-2, 3)) for _ in range(3)]) if trial % 2 else np.full(3, 2.0 ** int(rng.integers(-2, 3)))
+        bb_min, bb_max = tuple(-half), tuple(half)
+        scale = float(half.min())
+        prm = pkg.default_params(cube_half_side=0.95 * scale, sphere_radius=1.05 * scale,
+                                 max_distance_custom_material=0.05 * scale,
+                                 cube_material=int(rng.integers(0, 2)), sphere_material=int(rng.integers(0, 2)),
+                                 disable_sphere=int(trial % 7 == 3))
+        g = pkg.make_grid(dims, bb_min, bb_max)
+        t0, t1 = pkg.alloc_textures(g)
+        pkg.fill_grid(prm, g, t0, t1)
+        torch.cuda.synchronize()
+        kind = trial % 3
+        if kind == 0:
+            d = rng.normal(size=3)
+            eye = d / np.linalg.norm(d) * half.max() * rng.uniform(2.0, 6.0)
+            target = rng.uniform(-0.3, 0.3, size=3) * half
+        elif kind == 1:
+            eye = rng.uniform(-0.8, 0.8, size=3) * half
+            target = rng.uniform(-1.5, 1.5, size=3) * half
+        else:
+            eye = rng.uniform(-0.9, 0.9, size=3) * half
+            eye[trial % 3] = half[trial % 3] * (1 if trial % 2 else -1)
+            target = np.zeros(3)
+        w, h = int(rng.integers(17, 100)), int(rng.integers(17, 80))
+        compare(pkg, oracle, g, t0, t1, t0.cpu().numpy(), t1.cpu().numpy(),
+                cam_kw=dict(eye=tuple(float(x) for x in eye), target=tuple(float(x) for x in target),
+                            fovy_degrees=float(rng.uniform(10.0, 120.0)), z_near=float(0.05 * scale)), width=w, height=h)
+
+
 def test_row_bands_of_the_image_tile_split_tile_the_frame(pkg):
     """parallel.split_rows (config 5's image-tile split): the bands rendered by the "ranks" concatenate to the frame."""
     import importlib

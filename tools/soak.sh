@@ -11,6 +11,7 @@ while [ $(date +%s) -lt $END ]; do
   if ! SDFV_SOAK_SEED=$SEED SDFV_SOAK_TRIALS=40 timeout 900 python -m pytest -x -q \
         tests/test_gpu_fill.py::test_randomised_parameters_and_grids \
         tests/test_gpu_raymarch.py::test_randomised_cameras_grids_and_boxes \
+        tests/test_gpu_raymarch.py::test_randomised_sweep_of_the_hand_written_march_loop \
         tests/test_gpu_points.py::test_random_points_match_oracle \
         tests/test_gpu_mesh_extract.py::test_randomised_extractions_match_numpy_restatement \
         tests/test_gpu_sharded_march.py::test_randomised_slabs_and_cameras > gpurun_out/soak_last.log 2>&1; then
@@ -19,4 +20,4 @@ while [ $(date +%s) -lt $END ]; do
   fi
   N=$((N + 1))
 done
-echo "soak: $N rounds of 5 sweeps x 40 trials passed, seeds $(( SEED - N + 1 ))..$SEED"
+echo "soak: $N rounds of 6 sweeps x 40 trials passed, seeds $(( SEED - N + 1 ))..$SEED"
