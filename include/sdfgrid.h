@@ -157,6 +157,8 @@ typedef enum sdfv_option {
 #define SDFV_STEP_SIDE_BOUNDARY 3u /* the caller's stream runs the plain dense fill of the whole slab; the communicator's
                                     * stream computes the boundary slices once more, into the packed send buffers only */
 #define SDFV_STEP_UNPACKED     4u /* flag: 2 messages per texture and neighbour straight into the ghosts (no staging) */
+#define SDFV_STEP_START_EVENT  8u /* flag (side-boundary form): release the communicator's stream with an event recorded
+                                   * on the caller's stream instead of the fill launch's own "started" signal */
 int sdfv_set_option(uint32_t option, uint64_t value); /* unknown option / value out of range: SDFV_ERR_INVALID_ARGUMENT */
 int sdfv_get_option(uint32_t option, uint64_t *value);
 

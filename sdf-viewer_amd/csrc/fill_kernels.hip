@@ -124,6 +124,10 @@ __global__ __launch_bounds__(kBlock) void fill_dense_kernel(FillArgs a) {
 
     const uint32_t tid = threadIdx.x;
     const uint32_t n_rows = a.H * a.slab_d;  // rows of the slab: row = z_local * H + y
+    // "this launch has started" = everything enqueued before it on its stream has finished: the multi-GPU fill step lets
+    // the communicator's stream wait on this word (hipStreamWaitValue32) instead of on an event recorded before the fill
+    if (!ORDERED && a.signal && blockIdx.x == 0 && tid == 0)
+        __hip_atomic_store(a.signal, a.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     OrderedBlock ob{blockIdx.x, false, false};
     if (ORDERED) ob = ordered_block(a, blockIdx.x + a.block_base);
     // 1-D grid, x-chunk fastest: workgroup id -> (row group, x chunk); both uniform (SGPRs)
@@ -175,6 +179,8 @@ __global__ __launch_bounds__(kBlock) void fill_dense_flat_kernel(FillArgs a) {
     __shared__ float2 s_yz[kBlock + 1];
     const uint32_t tid = threadIdx.x;
     const uint32_t n_vox = a.W * a.H * a.slab_d;  // < 2^32, checked by the launcher
+    if (!ORDERED && a.signal && blockIdx.x == 0 && tid == 0)  // see fill_dense_kernel
+        __hip_atomic_store(a.signal, a.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     OrderedBlock ob{blockIdx.x, false, false};
     if (ORDERED) ob = ordered_block(a, blockIdx.x + a.block_base);  // slices are whole numbers of workgroups here
     const uint32_t v0 = ob.block * kBlock;

@@ -303,6 +303,22 @@ int copy_texel_segments(const float* const src[4], float* const dst[4], const si
     return SDFV_OK;
 }
 
+int fill_grid_signalling_start(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, float* tex0,
+                               float* tex1, uint32_t* signal, uint32_t value, void* stream) {
+    if (int rc = check_params(params, sdf_id)) return rc;
+    if (int rc = check_grid(grid)) return rc;
+    if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
+    if (int rc = check_texel_alignment(tex0, tex1)) return rc;
+    if (int rc = need_device()) return rc;
+    FillArgs a = make_fill_args(*params, sdf_id, *grid, tex0, tex1);
+    a.signal = signal;
+    a.signal_value = value;
+    if ((uint64_t)a.H * a.slab_d > 0x7fffffffull || a.W > 0x7fffffffu)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "slab of %u x %u rows is too large for one launch", a.H, a.slab_d);
+    SDFV_HIP(launch_fill_dense(a, fill_launch_config(false), (hipStream_t)stream));
+    return SDFV_OK;
+}
+
 int fill_boundary_slices(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* slab, float* o0, float* o1,
                          void* stream) {
     if (int rc = check_params(params, sdf_id)) return rc;
@@ -356,7 +372,7 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             g_options.raymarch_keep_normal = value != 0;
             return SDFV_OK;
         case SDFV_OPT_SLAB_STEP_FORM: {
-            const uint64_t form = value & ~(uint64_t)SDFV_STEP_UNPACKED;
+            const uint64_t form = value & ~(uint64_t)(SDFV_STEP_UNPACKED | SDFV_STEP_START_EVENT);
             if (form != 0 && form != SDFV_STEP_TWO_LAUNCH && form != SDFV_STEP_ONE_LAUNCH && form != SDFV_STEP_SIDE_BOUNDARY) break;
             g_options.slab_step_form = (uint32_t)value;
             return SDFV_OK;

@@ -329,7 +329,8 @@ int sdfv_slab_fill_step(sdfv_slab_comm* c, const sdfv_demo_params* params, uint3
     // Which form: the ordered fill needs whole workgroups per slice and an interior to hide the exchange behind.
     uint32_t form = sdfv::options().slab_step_form;
     bool packed = !(form & SDFV_STEP_UNPACKED);
-    form &= ~SDFV_STEP_UNPACKED;
+    const bool start_event = (form & SDFV_STEP_START_EVENT) != 0 || !c->can_wait_value;
+    form &= ~(SDFV_STEP_UNPACKED | SDFV_STEP_START_EVENT);
     uint32_t bps = 0, total = 0;
     if (int rc = sdfv::ordered_fill_blocks(slab, &bps, &total)) return rc;
     if (!exchange || owned < lead + 2 || bps == 0) {  // nothing to hide the exchange behind / shape not supported
@@ -371,7 +372,18 @@ int sdfv_slab_fill_step(sdfv_slab_comm* c, const sdfv_demo_params* params, uint3
 #else
         const bool no_start = false, no_wait = false;
 #endif
-        if (!no_start) {
+        // How the communicator's stream learns that `main` has reached this step: the packed form's fill launch says so
+        // itself (its first workgroup stores the step number to a word of signal memory the moment the launch starts,
+        // and the communicator's stream waits on that word) -- no event is recorded on `main`, which then carries
+        // nothing but the fill and the final wait; otherwise an event.
+        const bool signal_start = packed && !start_event;
+        if (signal_start) {
+            // the fill goes first in host order: should the two streams ever share a hardware queue, the launch that signals
+            // is ahead of the packet that waits for it
+            c->step += 1;
+            if (int rc = sdfv::fill_grid_signalling_start(params, sdf_id, slab, o0, o1, c->signal, c->step, main)) return rc;
+            SDFV_HIPC(hipStreamWaitValue32(c->comm_stream, c->signal, c->step, hipStreamWaitValueGte, 0xffffffffu));
+        } else if (!no_start) {
             SDFV_HIPC(hipEventRecord(c->boundary_done, main));
             SDFV_HIPC(hipStreamWaitEvent(c->comm_stream, c->boundary_done, 0));
         }
@@ -380,7 +392,8 @@ int sdfv_slab_fill_step(sdfv_slab_comm* c, const sdfv_demo_params* params, uint3
             if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, 0, nb, c->comm_stream)) return rc;
             if (int rc = enqueue_exchange_packed(lib, c, slab, tex0, tex1, c->comm_stream)) return rc;
             SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));
-            if (int rc = sdfv_fill_grid(params, sdf_id, slab, o0, o1, main)) return rc;
+            if (!signal_start)
+                if (int rc = sdfv_fill_grid(params, sdf_id, slab, o0, o1, main)) return rc;
         } else {
             // per-texture messages straight out of / into the textures: the communicator's stream fills the boundary
             // slices in place, `main` everything else (the same ordered grid, split between the two streams)
@@ -402,7 +415,7 @@ int sdfv_slab_fill_step(sdfv_slab_comm* c, const sdfv_demo_params* params, uint3
         of.signal = c->signal;
         of.signal_value = c->step;
         if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, 0, total, main)) return rc;
-        SDFV_HIPC(hipStreamWaitValue32(c->comm_stream, c->signal, c->step, hipStreamWaitValueEq, 0xffffffffu));
+        SDFV_HIPC(hipStreamWaitValue32(c->comm_stream, c->signal, c->step, hipStreamWaitValueGte, 0xffffffffu));
         if (int rc = exchange_on(c->comm_stream)) return rc;
         SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));
         SDFV_HIPC(hipStreamWaitEvent(main, c->halo_done, 0));

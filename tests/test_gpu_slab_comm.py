@@ -40,14 +40,15 @@ def check_slab(oracle, pkg, prm, dims, z0, z1, slab, sdf_id=0):
 
 def step_forms(pkg):
     K = pkg._capi
-    return {"auto": 0, "side_boundary": K.STEP_SIDE_BOUNDARY, "side_boundary_unpacked": K.STEP_SIDE_BOUNDARY | K.STEP_UNPACKED,
+    return {"auto": 0, "side_boundary": K.STEP_SIDE_BOUNDARY, "side_boundary_event": K.STEP_SIDE_BOUNDARY | K.STEP_START_EVENT,
+            "side_boundary_unpacked": K.STEP_SIDE_BOUNDARY | K.STEP_UNPACKED,
             "one_launch": K.STEP_ONE_LAUNCH, "one_launch_unpacked": K.STEP_ONE_LAUNCH | K.STEP_UNPACKED,
             "two_launch": K.STEP_TWO_LAUNCH, "two_launch_unpacked": K.STEP_TWO_LAUNCH | K.STEP_UNPACKED}
 
 
 # (40, 24, *) and (33, 7, *), (130, 5, 3): rows that do not fill whole workgroups -> fill, then exchange;
 # (64, 64, 64), (128, 8, 10), (256, 4, 7): the row-chunk form of the boundary-first order; (48, 16, 12): its flat form
-@pytest.mark.parametrize("form", ["auto", "side_boundary", "side_boundary_unpacked", "one_launch", "one_launch_unpacked", "two_launch", "two_launch_unpacked"])
+@pytest.mark.parametrize("form", ["auto", "side_boundary", "side_boundary_event", "side_boundary_unpacked", "one_launch", "one_launch_unpacked", "two_launch", "two_launch_unpacked"])
 @pytest.mark.parametrize("dims,z0,z1", [((40, 24, 16), 0, 16), ((40, 24, 16), 5, 12), ((33, 7, 9), 0, 2),
                                         ((33, 7, 9), 4, 5), ((64, 64, 64), 0, 64), ((130, 5, 3), 0, 3),
                                         ((128, 8, 10), 2, 9), ((256, 4, 7), 0, 7), ((48, 16, 12), 3, 12),

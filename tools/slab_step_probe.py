@@ -59,7 +59,8 @@ def main():
     out = {"steps": steps, "one_launch_capable": comm.one_launch_capable}
     if "--forms" in sys.argv:
         forms = {"two_launch_unpacked": K.STEP_TWO_LAUNCH | K.STEP_UNPACKED, "two_launch": K.STEP_TWO_LAUNCH,
-                 "side_boundary": K.STEP_SIDE_BOUNDARY, "side_boundary_unpacked": K.STEP_SIDE_BOUNDARY | K.STEP_UNPACKED}
+                 "side_boundary": K.STEP_SIDE_BOUNDARY, "side_boundary_event": K.STEP_SIDE_BOUNDARY | K.STEP_START_EVENT,
+                 "side_boundary_unpacked": K.STEP_SIDE_BOUNDARY | K.STEP_UNPACKED}
         if comm.one_launch_capable:
             forms.update({"one_launch_unpacked": K.STEP_ONE_LAUNCH | K.STEP_UNPACKED, "one_launch": K.STEP_ONE_LAUNCH})
         res = {k: [] for k in forms}
