@@ -287,126 +287,135 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 // check against the oracle for every pixel.  Covers: LINEAR filter, power-of-two extents and texture sizes (XF == 2),
 // symmetric box, clamp-for-mirror (fast_index); STRIDE 1 = compact distance volume (one 8-byte load per corner row),
 // STRIDE 4 = tex0.r in place.  Byte offsets are 32-bit: the launcher checks the volume's size.
-// Registers: v80-v127 and s64-s85 are this block's (declared as clobbers); operands stay where hipcc put them.
+// Registers: v40-v87 and s64-s85 are this block's (declared as clobbers; low enough that the kernel stays at 96
+// VGPRs = 5 waves per SIMD); operands stay where hipcc put them.
 #define SDFV_MARCH_ASM_HEAD                                                                                         \
     "s_mov_b64 s[76:77], exec\n"                                                                                    \
     "s_and_b64 exec, exec, %[cov]\n"                                                                                \
     "s_cbranch_execz .Ldone_%=\n"                                                                                   \
-    "v_mov_b32 v96, %[px]\n v_mov_b32 v98, %[py]\n v_mov_b32 v99, %[pz]\n"                                           \
-    "v_mov_b32 v100, %[dx]\n v_mov_b32 v102, %[dy]\n v_mov_b32 v103, %[dz]\n"                                        \
+    "v_mov_b32 v56, %[px]\n v_mov_b32 v58, %[py]\n v_mov_b32 v59, %[pz]\n"                                           \
+    "v_mov_b32 v60, %[dx]\n v_mov_b32 v62, %[dy]\n v_mov_b32 v63, %[dz]\n"                                        \
     "s_mov_b32 s66, %[miny]\n s_mov_b32 s67, %[minz]\n"      /* (miny, minz) */                                      \
     "s_mov_b32 s70, %[ky]\n s_mov_b32 s71, %[kz]\n"          /* (ky, kz) */                                          \
     "s_mov_b32 s72, 0xbf000000\n s_mov_b32 s73, 0xbf000000\n" /* (-0.5, -0.5) */                                     \
     "s_add_i32 s75, %[wm1], -1\n"                            /* W - 2 */                                             \
     "s_add_i32 s82, %[lgw], 2\n s_add_i32 s83, %[lgw], 4\n"  /* log2(W) + 2 / + 4: row -> byte offset shifts */      \
     "s_movk_i32 s74, 254\n"                                  /* 255 iterations */                                    \
-    "v_mov_b32 v124, 0x7f800000\n v_mov_b32 v126, 0x7f800000\n v_mov_b32 v127, 0x7f800000\n" /* no cell cached */    \
+    "v_mov_b32 v84, 0x7f800000\n v_mov_b32 v86, 0x7f800000\n v_mov_b32 v87, 0x7f800000\n" /* no cell cached */    \
     ".Lloop_%=:\n"
 // One iteration, top half.  Two independent chains are interleaved so that a lone wave rarely issues an instruction
 // that waits for the one before it: (A) out of bounds? max(|p| - max) > 1e-4 (material.frag:106-109) -> v_cmpx removes
 // the lanes that left the box; (B) u = (p - min) * (N / size) - 0.5, x alone and (y, z) packed.  Then the weights
 // relative to the cached cell: all three in [0, 1) <=> the cell is unchanged.
-#define SDFV_MARCH_ASM_TOP(T_STEP)                                                                                  \
-    "v_sub_f32_e64 v88, |v96|, %[mx]\n"                                                                             \
-    "v_subrev_f32_e32 v104, %[minx], v96\n"                                                                         \
-    "v_sub_f32_e64 v89, |v98|, %[my]\n"                                                                             \
-    "v_pk_add_f32 v[106:107], v[98:99], s[66:67] neg_lo:[0,1] neg_hi:[0,1]\n"                                       \
-    "v_sub_f32_e64 v90, |v99|, %[mz]\n"                                                                             \
-    "v_mul_f32_e32 v104, %[kx], v104\n"                                                                             \
-    "v_pk_mul_f32 v[106:107], v[106:107], s[70:71]\n"                                                               \
-    "v_max3_f32 v88, v88, v89, v90\n"                                                                               \
-    "v_add_f32_e32 v104, -0.5, v104\n"                                                                              \
-    "v_pk_add_f32 v[106:107], v[106:107], s[72:73]\n"                                                               \
-    "v_cmpx_nlt_f32_e32 vcc, 0x38d1b717, v88\n"              /* exec &= !(1e-4 < oob) */                             \
+// OOB4 / OOB2: the out-of-bounds distance max(|p| - max) in four instructions, or in two when the box is a cube
+// (max_x == max_y == max_z = m): max3(|p|) - m -- identical bits, rounding is monotonic so max and "- m" commute.
+#define SDFV_MARCH_ASM_OOB4_A "v_sub_f32_e64 v48, |v56|, %[mx]\n"
+#define SDFV_MARCH_ASM_OOB4_B "v_sub_f32_e64 v49, |v58|, %[my]\n"
+#define SDFV_MARCH_ASM_OOB4_C "v_sub_f32_e64 v50, |v59|, %[mz]\n"
+#define SDFV_MARCH_ASM_OOB4_D "v_max3_f32 v48, v48, v49, v50\n"
+#define SDFV_MARCH_ASM_OOB2_A "v_max3_f32 v48, |v56|, |v58|, |v59|\n"
+#define SDFV_MARCH_ASM_OOB2_D "v_subrev_f32_e32 v48, %[mx], v48\n"
+#define SDFV_MARCH_ASM_TOP(T_STEP, OOB_A, OOB_B, OOB_C, OOB_D)                                                      \
+    OOB_A                                                                                                           \
+    "v_subrev_f32_e32 v64, %[minx], v56\n"                                                                          \
+    OOB_B                                                                                                           \
+    "v_pk_add_f32 v[66:67], v[58:59], s[66:67] neg_lo:[0,1] neg_hi:[0,1]\n"                                         \
+    OOB_C                                                                                                           \
+    "v_mul_f32_e32 v64, %[kx], v64\n"                                                                               \
+    "v_pk_mul_f32 v[66:67], v[66:67], s[70:71]\n"                                                                   \
+    OOB_D                                                                                                           \
+    "v_add_f32_e32 v64, -0.5, v64\n"                                                                                \
+    "v_pk_add_f32 v[66:67], v[66:67], s[72:73]\n"                                                                   \
+    "v_cmpx_nlt_f32_e32 vcc, 0x38d1b717, v48\n"              /* exec &= !(1e-4 < oob) */                             \
     "s_cbranch_execz .Ldone_%=\n"                                                                                   \
-    "v_sub_f32_e32 v108, v104, v124\n"                                                                              \
-    "v_sub_f32_e32 v110, v106, v126\n"                                                                              \
-    "v_sub_f32_e32 v112, v107, v127\n" T_STEP                                                                       \
-    "v_max3_u32 v88, v108, v110, v112\n"                                                                            \
-    "v_cmp_gt_u32_e32 vcc, 0x3f800000, v88\n"                                                                       \
+    "v_sub_f32_e32 v68, v64, v84\n"                                                                              \
+    "v_sub_f32_e32 v70, v66, v86\n"                                                                              \
+    "v_sub_f32_e32 v72, v67, v87\n" T_STEP                                                                       \
+    "v_max3_u32 v48, v68, v70, v72\n"                                                                            \
+    "v_cmp_gt_u32_e32 vcc, 0x3f800000, v48\n"                                                                       \
     "s_andn1_saveexec_b64 s[78:79], vcc\n"                   /* exec = lanes whose cell changed */                   \
     "s_cbranch_execz .Lcached_%=\n"                                                                                 \
     /* new cell: floor, weights, clamped corner indices (MirroredRepeat == clamp here), row numbers by shifts */    \
-    "v_floor_f32_e32 v124, v104\n v_floor_f32_e32 v126, v106\n v_floor_f32_e32 v127, v107\n"                         \
-    "v_cvt_i32_f32_e32 v88, v124\n v_cvt_i32_f32_e32 v89, v126\n v_cvt_i32_f32_e32 v90, v127\n"                      \
-    "v_sub_f32_e32 v108, v104, v124\n v_sub_f32_e32 v110, v106, v126\n v_sub_f32_e32 v112, v107, v127\n"             \
-    "v_max_i32_e32 v91, 0, v88\n v_max_i32_e32 v93, 0, v89\n v_max_i32_e32 v94, 0, v90\n"  /* i0c, j0c, k0c */       \
-    "v_add_u32_e32 v88, 1, v88\n v_add_u32_e32 v89, 1, v89\n v_add_u32_e32 v90, 1, v90\n"                            \
-    "v_min_i32_e32 v88, %[wm1], v88\n v_min_i32_e32 v89, %[hm1], v89\n v_min_i32_e32 v90, %[dm1], v90\n" /* i1c.. */  \
-    "v_lshl_add_u32 v84, v94, %[lgh], v93\n"                 /* rows: (k0c, j0c) */                                  \
-    "v_lshl_add_u32 v85, v94, %[lgh], v89\n"                 /*       (k0c, j1c) */                                  \
-    "v_lshl_add_u32 v86, v90, %[lgh], v93\n"                 /*       (k1c, j0c) */                                  \
-    "v_lshl_add_u32 v87, v90, %[lgh], v89\n"                 /*       (k1c, j1c) */
+    "v_floor_f32_e32 v84, v64\n v_floor_f32_e32 v86, v66\n v_floor_f32_e32 v87, v67\n"                         \
+    "v_cvt_i32_f32_e32 v48, v84\n v_cvt_i32_f32_e32 v49, v86\n v_cvt_i32_f32_e32 v50, v87\n"                      \
+    "v_sub_f32_e32 v68, v64, v84\n v_sub_f32_e32 v70, v66, v86\n v_sub_f32_e32 v72, v67, v87\n"             \
+    "v_max_i32_e32 v51, 0, v48\n v_max_i32_e32 v53, 0, v49\n v_max_i32_e32 v54, 0, v50\n"  /* i0c, j0c, k0c */       \
+    "v_add_u32_e32 v48, 1, v48\n v_add_u32_e32 v49, 1, v49\n v_add_u32_e32 v50, 1, v50\n"                            \
+    "v_min_i32_e32 v48, %[wm1], v48\n v_min_i32_e32 v49, %[hm1], v49\n v_min_i32_e32 v50, %[dm1], v50\n" /* i1c.. */  \
+    "v_lshl_add_u32 v44, v54, %[lgh], v53\n"                 /* rows: (k0c, j0c) */                                  \
+    "v_lshl_add_u32 v45, v54, %[lgh], v49\n"                 /*       (k0c, j1c) */                                  \
+    "v_lshl_add_u32 v46, v50, %[lgh], v53\n"                 /*       (k1c, j0c) */                                  \
+    "v_lshl_add_u32 v47, v50, %[lgh], v49\n"                 /*       (k1c, j1c) */
 // STRIDE 1: x-neighbours are adjacent floats: one 8-byte load per (y, z) row at b = clamp(i0, 0, W - 2); where the clamp
 // folds the two x-corners together both come from the same half (lo_is_x / hi_is_y).
 #define SDFV_MARCH_ASM_FETCH_DIST                                                                                   \
-    "v_min_i32_e32 v92, s75, v91\n"                          /* b = min(i0c, W - 2) */                               \
-    "v_lshlrev_b32_e32 v95, 2, v92\n"                                                                               \
-    "v_lshl_add_u32 v84, v84, s82, v95\n v_lshl_add_u32 v85, v85, s82, v95\n"                                        \
-    "v_lshl_add_u32 v86, v86, s82, v95\n v_lshl_add_u32 v87, v87, s82, v95\n"                                        \
-    "global_load_dwordx2 v[80:81], v84, %[base]\n"           /* (z0, y0) */                                          \
-    "global_load_dwordx2 v[82:83], v85, %[base]\n"           /* (z0, y1) */                                          \
-    "global_load_dwordx2 v[84:85], v86, %[base]\n"           /* (z1, y0) */                                          \
-    "global_load_dwordx2 v[86:87], v87, %[base]\n"           /* (z1, y1) */                                          \
-    "v_cmp_eq_u32_e64 s[80:81], v91, v92\n"                  /* lo_is_x */                                           \
-    "v_add_u32_e32 v92, 1, v92\n"                                                                                   \
-    "v_cmp_eq_u32_e32 vcc, v88, v92\n"                       /* hi_is_y */                                           \
+    "v_min_i32_e32 v52, s75, v51\n"                          /* b = min(i0c, W - 2) */                               \
+    "v_lshlrev_b32_e32 v55, 2, v52\n"                                                                               \
+    "v_lshl_add_u32 v44, v44, s82, v55\n v_lshl_add_u32 v45, v45, s82, v55\n"                                        \
+    "v_lshl_add_u32 v46, v46, s82, v55\n v_lshl_add_u32 v47, v47, s82, v55\n"                                        \
+    "global_load_dwordx2 v[40:41], v44, %[base]\n"           /* (z0, y0) */                                          \
+    "global_load_dwordx2 v[42:43], v45, %[base]\n"           /* (z0, y1) */                                          \
+    "global_load_dwordx2 v[44:45], v46, %[base]\n"           /* (z1, y0) */                                          \
+    "global_load_dwordx2 v[46:47], v47, %[base]\n"           /* (z1, y1) */                                          \
+    "v_cmp_eq_u32_e64 s[80:81], v51, v52\n"                  /* lo_is_x */                                           \
+    "v_add_u32_e32 v52, 1, v52\n"                                                                                   \
+    "v_cmp_eq_u32_e32 vcc, v48, v52\n"                       /* hi_is_y */                                           \
     "s_waitcnt vmcnt(3)\n"                                                                                          \
-    "v_cndmask_b32_e64 v116, v81, v80, s[80:81]\n v_cndmask_b32_e32 v118, v80, v81, vcc\n" /* t000, t100 */          \
+    "v_cndmask_b32_e64 v76, v41, v40, s[80:81]\n v_cndmask_b32_e32 v78, v40, v41, vcc\n" /* t000, t100 */          \
     "s_waitcnt vmcnt(2)\n"                                                                                          \
-    "v_cndmask_b32_e64 v120, v83, v82, s[80:81]\n v_cndmask_b32_e32 v122, v82, v83, vcc\n" /* t010, t110 */          \
+    "v_cndmask_b32_e64 v80, v43, v42, s[80:81]\n v_cndmask_b32_e32 v82, v42, v43, vcc\n" /* t010, t110 */          \
     "s_waitcnt vmcnt(1)\n"                                                                                          \
-    "v_cndmask_b32_e64 v117, v85, v84, s[80:81]\n v_cndmask_b32_e32 v119, v84, v85, vcc\n" /* t001, t101 */          \
+    "v_cndmask_b32_e64 v77, v45, v44, s[80:81]\n v_cndmask_b32_e32 v79, v44, v45, vcc\n" /* t001, t101 */          \
     "s_waitcnt vmcnt(0)\n"                                                                                          \
-    "v_cndmask_b32_e64 v121, v87, v86, s[80:81]\n v_cndmask_b32_e32 v123, v86, v87, vcc\n" /* t011, t111 */
+    "v_cndmask_b32_e64 v81, v47, v46, s[80:81]\n v_cndmask_b32_e32 v83, v46, v47, vcc\n" /* t011, t111 */
 // STRIDE 4: tex0.r out of 16-byte texels, one dword load per corner.
 #define SDFV_MARCH_ASM_FETCH_TEX0                                                                                   \
-    "v_lshlrev_b32_e32 v91, 4, v91\n v_lshlrev_b32_e32 v88, 4, v88\n"   /* i0c, i1c as byte offsets */               \
-    "v_lshl_add_u32 v80, v84, s83, v91\n v_lshl_add_u32 v81, v84, s83, v88\n"                                        \
-    "global_load_dword v116, v80, %[base]\n global_load_dword v118, v81, %[base]\n"                                  \
-    "v_lshl_add_u32 v82, v85, s83, v91\n v_lshl_add_u32 v83, v85, s83, v88\n"                                        \
-    "global_load_dword v120, v82, %[base]\n global_load_dword v122, v83, %[base]\n"                                  \
-    "v_lshl_add_u32 v80, v86, s83, v91\n v_lshl_add_u32 v81, v86, s83, v88\n"                                        \
-    "global_load_dword v117, v80, %[base]\n global_load_dword v119, v81, %[base]\n"                                  \
-    "v_lshl_add_u32 v82, v87, s83, v91\n v_lshl_add_u32 v83, v87, s83, v88\n"                                        \
-    "global_load_dword v121, v82, %[base]\n global_load_dword v123, v83, %[base]\n"                                  \
+    "v_lshlrev_b32_e32 v51, 4, v51\n v_lshlrev_b32_e32 v48, 4, v48\n"   /* i0c, i1c as byte offsets */               \
+    "v_lshl_add_u32 v40, v44, s83, v51\n v_lshl_add_u32 v41, v44, s83, v48\n"                                        \
+    "global_load_dword v76, v40, %[base]\n global_load_dword v78, v41, %[base]\n"                                  \
+    "v_lshl_add_u32 v42, v45, s83, v51\n v_lshl_add_u32 v43, v45, s83, v48\n"                                        \
+    "global_load_dword v80, v42, %[base]\n global_load_dword v82, v43, %[base]\n"                                  \
+    "v_lshl_add_u32 v40, v46, s83, v51\n v_lshl_add_u32 v41, v46, s83, v48\n"                                        \
+    "global_load_dword v77, v40, %[base]\n global_load_dword v79, v41, %[base]\n"                                  \
+    "v_lshl_add_u32 v42, v47, s83, v51\n v_lshl_add_u32 v43, v47, s83, v48\n"                                        \
+    "global_load_dword v81, v42, %[base]\n global_load_dword v83, v43, %[base]\n"                                  \
     "s_waitcnt vmcnt(0)\n"
-// Corner registers as z-pairs: A0 = v[116:117] = (t000, t001), A1 = v[118:119] = (t100, t101), B0 = v[120:121] =
-// (t010, t011), B1 = v[122:123] = (t110, t111); weights (a, 1 - a) as pairs v[108:109], v[110:111], v[112:113].
+// Corner registers as z-pairs: A0 = v[76:77] = (t000, t001), A1 = v[78:79] = (t100, t101), B0 = v[80:81] =
+// (t010, t011), B1 = v[82:83] = (t110, t111); weights (a, 1 - a) as pairs v[68:69], v[70:71], v[72:73].
 #define SDFV_MARCH_ASM_FILTER                                                                                       \
     ".Lcached_%=:\n"                                                                                                \
     "s_mov_b64 exec, s[78:79]\n"                                                                                    \
-    "v_sub_f32_e32 v109, 1.0, v108\n v_sub_f32_e32 v111, 1.0, v110\n v_sub_f32_e32 v113, 1.0, v112\n"                \
+    "v_sub_f32_e32 v69, 1.0, v68\n v_sub_f32_e32 v71, 1.0, v70\n v_sub_f32_e32 v73, 1.0, v72\n"                \
     /* mix along x: c = t(x0) * (1 - ax) + t(x1) * ax */                                                            \
-    "v_pk_mul_f32 v[90:91], v[118:119], v[108:109] op_sel_hi:[1,0]\n"                                                \
-    "v_pk_mul_f32 v[94:95], v[122:123], v[108:109] op_sel_hi:[1,0]\n"                                                \
-    "v_pk_mul_f32 v[88:89], v[116:117], v[108:109] op_sel:[0,1] op_sel_hi:[1,1]\n"                                   \
-    "v_pk_mul_f32 v[92:93], v[120:121], v[108:109] op_sel:[0,1] op_sel_hi:[1,1]\n"                                   \
-    "v_pk_add_f32 v[88:89], v[88:89], v[90:91]\n"            /* (c00, c01) */                                        \
-    "v_pk_add_f32 v[92:93], v[92:93], v[94:95]\n"            /* (c10, c11) */                                        \
+    "v_pk_mul_f32 v[50:51], v[78:79], v[68:69] op_sel_hi:[1,0]\n"                                                \
+    "v_pk_mul_f32 v[54:55], v[82:83], v[68:69] op_sel_hi:[1,0]\n"                                                \
+    "v_pk_mul_f32 v[48:49], v[76:77], v[68:69] op_sel:[0,1] op_sel_hi:[1,1]\n"                                   \
+    "v_pk_mul_f32 v[52:53], v[80:81], v[68:69] op_sel:[0,1] op_sel_hi:[1,1]\n"                                   \
+    "v_pk_add_f32 v[48:49], v[48:49], v[50:51]\n"            /* (c00, c01) */                                        \
+    "v_pk_add_f32 v[52:53], v[52:53], v[54:55]\n"            /* (c10, c11) */                                        \
     /* mix along y */                                                                                               \
-    "v_pk_mul_f32 v[88:89], v[88:89], v[110:111] op_sel:[0,1] op_sel_hi:[1,1]\n"                                     \
-    "v_pk_mul_f32 v[92:93], v[92:93], v[110:111] op_sel_hi:[1,0]\n"                                                  \
-    "v_pk_add_f32 v[88:89], v[88:89], v[92:93]\n"            /* (c0, c1) */                                          \
+    "v_pk_mul_f32 v[48:49], v[48:49], v[70:71] op_sel:[0,1] op_sel_hi:[1,1]\n"                                     \
+    "v_pk_mul_f32 v[52:53], v[52:53], v[70:71] op_sel_hi:[1,0]\n"                                                  \
+    "v_pk_add_f32 v[48:49], v[48:49], v[52:53]\n"            /* (c0, c1) */                                          \
     /* mix along z, then sample_dist = r - 0.1 */                                                                   \
-    "v_pk_mul_f32 v[88:89], v[88:89], v[112:113] op_sel:[0,1] op_sel_hi:[1,0]\n" /* (c0 * (1 - az), c1 * az) */      \
-    "v_add_f32_e32 v92, v88, v89\n"                                                                                 \
-    "v_add_f32_e32 v92, 0xbdcccccd, v92\n"                                                                          \
+    "v_pk_mul_f32 v[48:49], v[48:49], v[72:73] op_sel:[0,1] op_sel_hi:[1,0]\n" /* (c0 * (1 - az), c1 * az) */      \
+    "v_add_f32_e32 v52, v48, v49\n"                                                                                 \
+    "v_add_f32_e32 v52, 0xbdcccccd, v52\n"                                                                          \
     /* hit?  (material.frag:117-121) */                                                                             \
-    "v_cmpx_ngt_f32_e32 vcc, 0x3727c5ac, v92\n"              /* exec &= !(1e-5 > sample_dist) */
+    "v_cmpx_ngt_f32_e32 vcc, 0x3727c5ac, v52\n"              /* exec &= !(1e-5 > sample_dist) */
 #define SDFV_MARCH_ASM_ADVANCE                                                                                      \
     /* advance the rays that go on (material.frag:124-125) */                                                       \
-    "v_mul_f32_e32 v88, v100, v92\n"                                                                                \
-    "v_pk_mul_f32 v[90:91], v[102:103], v[92:93] op_sel_hi:[1,0]\n"                                                  \
-    "v_add_f32_e32 v96, v96, v88\n"                                                                                 \
-    "v_pk_add_f32 v[98:99], v[98:99], v[90:91]\n"                                                                   \
+    "v_mul_f32_e32 v48, v60, v52\n"                                                                                \
+    "v_pk_mul_f32 v[50:51], v[62:63], v[52:53] op_sel_hi:[1,0]\n"                                                  \
+    "v_add_f32_e32 v56, v56, v48\n"                                                                                 \
+    "v_pk_add_f32 v[58:59], v[58:59], v[50:51]\n"                                                                   \
     "s_add_u32 s74, s74, -1\n"                               /* carry out <=> iterations left */                     \
     "s_cbranch_scc1 .Lloop_%=\n"                                                                                    \
     ".Ldone_%=:\n"                                                                                                  \
     "s_mov_b64 %[ran], exec\n"                               /* lanes still marching after 255 iterations */         \
     "s_mov_b32 %[left], s74\n"                                                                                      \
     "s_and_b64 exec, s[76:77], %[cov]\n"                                                                            \
-    "v_mov_b32 %[px], v96\n v_mov_b32 %[py], v98\n v_mov_b32 %[pz], v99\n"
+    "v_mov_b32 %[px], v56\n v_mov_b32 %[py], v58\n v_mov_b32 %[pz], v59\n"
 #define SDFV_MARCH_ASM_END "s_mov_b64 exec, s[76:77]\n"
 #define SDFV_MARCH_ASM_OPERANDS                                                                                     \
     [dx] "v"(ray_dir.x), [dy] "v"(ray_dir.y), [dz] "v"(ray_dir.z), [cov] "s"(cov), [mx] "s"(a.rp.bounds_max[0]),    \
@@ -415,11 +424,11 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
         [wm1] "s"(wm1), [hm1] "s"(hm1), [dm1] "s"(dm1), [lgw] "s"(lgw), [lgh] "s"(lgh), [base] "s"(vol)
 #define SDFV_MARCH_ASM_CLOBBERS                                                                                     \
     "vcc", "scc", "memory", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",    \
-        "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "v80", "v81", "v82", "v83", "v84",  \
-        "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99",    \
-        "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",   \
-        "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125",   \
-        "v126", "v127"
+        "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "v40", "v41", "v42", "v43", "v44",  \
+        "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",    \
+        "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72",   \
+        "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85",   \
+        "v86", "v87"
 
 template <bool SYMM_UNUSED, int STRIDE, bool T>
 __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __restrict__ vol, const Tex& t,
@@ -435,41 +444,44 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
     unsigned long long ran_out;
     int left = 254;  // the loop's down-counter at exit (tuning build: iterations the wave ran)
     float px = ray_pos.x, py = ray_pos.y, pz = ray_pos.z;
+#define SDFV_MARCH_ASM_OOB_BOX SDFV_MARCH_ASM_OOB4_A, SDFV_MARCH_ASM_OOB4_B, SDFV_MARCH_ASM_OOB4_C, SDFV_MARCH_ASM_OOB4_D
+#define SDFV_MARCH_ASM_OOB_CUBE SDFV_MARCH_ASM_OOB2_A, "", "", SDFV_MARCH_ASM_OOB2_D
+#define SDFV_MARCH_ASM_TOP_(T_STEP, ...) SDFV_MARCH_ASM_TOP(T_STEP, __VA_ARGS__)
+// aux variant: distanceFromOrigin (v74) and the per-ray fetch count (v75) ride along
+#define SDFV_MARCH_ASM_RUN_AUX(FETCH, OOB)                                                                          \
+    asm volatile("v_mov_b32 v74, %[tt]\n v_mov_b32 v75, 0\n" SDFV_MARCH_ASM_HEAD                                    \
+                 SDFV_MARCH_ASM_TOP_("v_add_u32_e32 v75, 1, v75\n", OOB) FETCH SDFV_MARCH_ASM_FILTER                 \
+                 "v_add_f32_e32 v74, v74, v52\n" SDFV_MARCH_ASM_ADVANCE                                              \
+                 "v_mov_b32 %[tt], v74\n v_mov_b32 %[n], v75\n" SDFV_MARCH_ASM_END                                   \
+                 : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tt] "+v"(tt), [n] "+v"(n), [ran] "=&s"(ran_out),   \
+                   [left] "=&s"(left)                                                                               \
+                 : SDFV_MARCH_ASM_OPERANDS                                                                          \
+                 : SDFV_MARCH_ASM_CLOBBERS)
+#define SDFV_MARCH_ASM_RUN(FETCH, OOB)                                                                              \
+    asm volatile(SDFV_MARCH_ASM_HEAD SDFV_MARCH_ASM_TOP_("", OOB) FETCH SDFV_MARCH_ASM_FILTER SDFV_MARCH_ASM_ADVANCE \
+                     SDFV_MARCH_ASM_END                                                                             \
+                 : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [ran] "=&s"(ran_out), [left] "=&s"(left)            \
+                 : SDFV_MARCH_ASM_OPERANDS                                                                          \
+                 : SDFV_MARCH_ASM_CLOBBERS)
+    const bool cube = a.cube_box != 0;  // wave-uniform: one scalar branch per kernel
     if (T) {
-        // aux variant: distanceFromOrigin (v114) and the per-ray fetch count (v115) ride along
         float tt = dist_from_origin;
         int n = 0;
         if (STRIDE == 1) {
-            asm volatile("v_mov_b32 v114, %[tt]\n v_mov_b32 v115, 0\n" SDFV_MARCH_ASM_HEAD
-                         SDFV_MARCH_ASM_TOP("v_add_u32_e32 v115, 1, v115\n") SDFV_MARCH_ASM_FETCH_DIST SDFV_MARCH_ASM_FILTER
-                         "v_add_f32_e32 v114, v114, v92\n" SDFV_MARCH_ASM_ADVANCE
-                         "v_mov_b32 %[tt], v114\n v_mov_b32 %[n], v115\n" SDFV_MARCH_ASM_END
-                         : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tt] "+v"(tt), [n] "+v"(n), [ran] "=&s"(ran_out), [left] "=&s"(left)
-                         : SDFV_MARCH_ASM_OPERANDS
-                         : SDFV_MARCH_ASM_CLOBBERS);
+            if (cube) SDFV_MARCH_ASM_RUN_AUX(SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_CUBE);
+            else SDFV_MARCH_ASM_RUN_AUX(SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_BOX);
         } else {
-            asm volatile("v_mov_b32 v114, %[tt]\n v_mov_b32 v115, 0\n" SDFV_MARCH_ASM_HEAD
-                         SDFV_MARCH_ASM_TOP("v_add_u32_e32 v115, 1, v115\n") SDFV_MARCH_ASM_FETCH_TEX0 SDFV_MARCH_ASM_FILTER
-                         "v_add_f32_e32 v114, v114, v92\n" SDFV_MARCH_ASM_ADVANCE
-                         "v_mov_b32 %[tt], v114\n v_mov_b32 %[n], v115\n" SDFV_MARCH_ASM_END
-                         : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tt] "+v"(tt), [n] "+v"(n), [ran] "=&s"(ran_out), [left] "=&s"(left)
-                         : SDFV_MARCH_ASM_OPERANDS
-                         : SDFV_MARCH_ASM_CLOBBERS);
+            if (cube) SDFV_MARCH_ASM_RUN_AUX(SDFV_MARCH_ASM_FETCH_TEX0, SDFV_MARCH_ASM_OOB_CUBE);
+            else SDFV_MARCH_ASM_RUN_AUX(SDFV_MARCH_ASM_FETCH_TEX0, SDFV_MARCH_ASM_OOB_BOX);
         }
         dist_from_origin = tt;
         steps = n;
     } else if (STRIDE == 1) {
-        asm volatile(SDFV_MARCH_ASM_HEAD SDFV_MARCH_ASM_TOP("") SDFV_MARCH_ASM_FETCH_DIST SDFV_MARCH_ASM_FILTER
-                         SDFV_MARCH_ASM_ADVANCE SDFV_MARCH_ASM_END
-                     : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [ran] "=&s"(ran_out), [left] "=&s"(left)
-                     : SDFV_MARCH_ASM_OPERANDS
-                     : SDFV_MARCH_ASM_CLOBBERS);
+        if (cube) SDFV_MARCH_ASM_RUN(SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_CUBE);
+        else SDFV_MARCH_ASM_RUN(SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_BOX);
     } else {
-        asm volatile(SDFV_MARCH_ASM_HEAD SDFV_MARCH_ASM_TOP("") SDFV_MARCH_ASM_FETCH_TEX0 SDFV_MARCH_ASM_FILTER
-                         SDFV_MARCH_ASM_ADVANCE SDFV_MARCH_ASM_END
-                     : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [ran] "=&s"(ran_out), [left] "=&s"(left)
-                     : SDFV_MARCH_ASM_OPERANDS
-                     : SDFV_MARCH_ASM_CLOBBERS);
+        if (cube) SDFV_MARCH_ASM_RUN(SDFV_MARCH_ASM_FETCH_TEX0, SDFV_MARCH_ASM_OOB_CUBE);
+        else SDFV_MARCH_ASM_RUN(SDFV_MARCH_ASM_FETCH_TEX0, SDFV_MARCH_ASM_OOB_BOX);
     }
 #ifdef SDFV_TUNING
     iterations = cov ? min(255, 255 - left) : 0;

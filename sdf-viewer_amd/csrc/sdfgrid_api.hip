@@ -229,6 +229,7 @@ void derive_raymarch_args(const sdfv_render_params* rp, sdfv::RaymarchArgs& a) {
     a.cull_radius2 = radius2 * 1.0201f + 1e-12f;  // (1.01 r)^2
     if (!(a.cull_radius2 > 0.0f) || !std::isfinite(a.cull_radius2)) a.cull_radius2 = INFINITY;  // never cull
     a.asm_loop = (off & SDFV_RM_NO_ASM_LOOP) ? 0u : 1u;
+    a.cube_box = (a.symmetric_box && rp->bounds_max[0] == rp->bounds_max[1] && rp->bounds_max[1] == rp->bounds_max[2]) ? 1u : 0u;
     if (off & SDFV_RM_NO_SYMMETRIC) a.symmetric_box = 0;
     if (off & SDFV_RM_NO_POW2_SIZE) a.pow2_size = 0;
 }
