@@ -289,6 +289,11 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 // STRIDE 4 = tex0.r in place.  Byte offsets are 32-bit: the launcher checks the volume's size.
 // Registers: v40-v87 and s64-s85 are this block's (declared as clobbers; low enough that the kernel stays at 96
 // VGPRs = 5 waves per SIMD); operands stay where hipcc put them.
+#ifdef SDFV_TUNING
+#define SDFV_MARCH_ASM_TUNE(x) x
+#else
+#define SDFV_MARCH_ASM_TUNE(x) ""
+#endif
 #define SDFV_MARCH_ASM_HEAD                                                                                         \
     "s_mov_b64 s[76:77], exec\n"                                                                                    \
     "s_and_b64 exec, exec, %[cov]\n"                                                                                \
@@ -301,6 +306,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "s_add_i32 s75, %[wm1], -1\n"                            /* W - 2 */                                             \
     "s_add_i32 s82, %[lgw], 2\n s_add_i32 s83, %[lgw], 4\n"  /* log2(W) + 2 / + 4: row -> byte offset shifts */      \
     "s_movk_i32 s74, 254\n"                                  /* 255 iterations */                                    \
+    SDFV_MARCH_ASM_TUNE("s_mov_b32 s84, 0\n")                /* tuning build: iterations that ran the fetch block */  \
     "v_mov_b32 v84, 0x7f800000\n v_mov_b32 v86, 0x7f800000\n v_mov_b32 v87, 0x7f800000\n" /* no cell cached */    \
     ".Lloop_%=:\n"
 // One iteration, top half.  Two independent chains are interleaved so that a lone wave rarely issues an instruction
@@ -335,6 +341,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "v_cmp_gt_u32_e32 vcc, 0x3f800000, v48\n"                                                                       \
     "s_andn1_saveexec_b64 s[78:79], vcc\n"                   /* exec = lanes whose cell changed */                   \
     "s_cbranch_execz .Lcached_%=\n"                                                                                 \
+    SDFV_MARCH_ASM_TUNE("s_add_u32 s84, s84, 1\n")                                                                  \
     /* new cell: floor, weights, clamped corner indices (MirroredRepeat == clamp here), row numbers by shifts */    \
     "v_floor_f32_e32 v84, v64\n v_floor_f32_e32 v86, v66\n v_floor_f32_e32 v87, v67\n"                         \
     "v_cvt_i32_f32_e32 v48, v84\n v_cvt_i32_f32_e32 v49, v86\n v_cvt_i32_f32_e32 v50, v87\n"                      \
@@ -414,6 +421,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     ".Ldone_%=:\n"                                                                                                  \
     "s_mov_b64 %[ran], exec\n"                               /* lanes still marching after 255 iterations */         \
     "s_mov_b32 %[left], s74\n"                                                                                      \
+    SDFV_MARCH_ASM_TUNE("s_lshl_b32 s84, s84, 16\n s_and_b32 %[left], %[left], 0xffff\n s_or_b32 %[left], %[left], s84\n") \
     "s_and_b64 exec, s[76:77], %[cov]\n"                                                                            \
     "v_mov_b32 %[px], v56\n v_mov_b32 %[py], v58\n v_mov_b32 %[pz], v59\n"
 #define SDFV_MARCH_ASM_END "s_mov_b64 exec, s[76:77]\n"
@@ -483,8 +491,8 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
         if (cube) SDFV_MARCH_ASM_RUN(SDFV_MARCH_ASM_FETCH_TEX0, SDFV_MARCH_ASM_OOB_CUBE);
         else SDFV_MARCH_ASM_RUN(SDFV_MARCH_ASM_FETCH_TEX0, SDFV_MARCH_ASM_OOB_BOX);
     }
-#ifdef SDFV_TUNING
-    iterations = cov ? min(255, 255 - left) : 0;
+#ifdef SDFV_TUNING  // left = (iterations that ran the fetch block) << 16 | the down-counter at exit
+    iterations = cov ? (min(255, 255 - (int)(short)(left & 0xffff)) | (left & 0xffff0000)) : 0;
 #else
     (void)iterations;
     (void)left;

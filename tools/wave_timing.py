@@ -36,7 +36,8 @@ b.record()
 torch.cuda.synchronize()
 pkg.set_option(K.OPT_TUNING_WAVE_TIMING, 0)
 d = buf.cpu().numpy()
-start, end, it = d[:, 0], d[:, 1], d[:, 2]
+start, end, it = d[:, 0], d[:, 1], d[:, 2] & 0xffff
+fetch_it = (d[:, 2] >> 16) & 0xffff  # hand-written loop, tuning build: iterations in which some lane entered a new cell
 t00 = start.min()
 dur = end - start
 act = it > 0
@@ -49,7 +50,8 @@ summary = {
     "wave_cycles_max": int(dur.max()),
     "cycles_per_iteration_active": {"p10": float(np.percentile(cpi, 10)), "median": float(np.median(cpi)),
                                     "p90": float(np.percentile(cpi, 90))},
-    "longest_waves": [{"wave": int(i), "iterations": int(it[i]), "cycles": int(dur[i]),
+    "fetch_block_iterations_fraction_active": float(fetch_it[act].sum() / max(it[act].sum(), 1)),
+    "longest_waves": [{"wave": int(i), "iterations": int(it[i]), "fetch_block_iterations": int(fetch_it[i]), "cycles": int(dur[i]),
                        "cycles_per_iteration": float(dur[i] / max(it[i], 1)), "start": int(start[i] - t00),
                        "end": int(end[i] - t00)} for i in order],
     "hist_iterations": {"edges": [0, 1, 8, 16, 32, 64, 128, 192, 255, 256],
@@ -60,6 +62,16 @@ summary = {
                                           for f in (0.25, 0.5, 0.75)},
     "config": {"grid": side, "image": [W, H], "dist_volume": dist is not None},
 }
+# least-squares model of an active wave: cycles = K + C * iterations + F * (iterations that ran the fetch block)
+if fetch_it[act].sum() > 0:
+    A = np.stack([np.ones(int(act.sum())), it[act].astype(float), fetch_it[act].astype(float)], axis=1)
+    coef, *_ = np.linalg.lstsq(A, dur[act].astype(float), rcond=None)
+    long = act & (it >= 64)
+    A2 = np.stack([np.ones(int(long.sum())), it[long].astype(float), fetch_it[long].astype(float)], axis=1)
+    coef2, *_ = np.linalg.lstsq(A2, dur[long].astype(float), rcond=None)
+    summary["wave_cycle_model"] = {"form": "cycles = K + C * iterations + F * fetch_block_iterations",
+                                   "all_active_waves": {"K": float(coef[0]), "C": float(coef[1]), "F": float(coef[2]), "n": int(act.sum())},
+                                   "waves_with_64_or_more_iterations": {"K": float(coef2[0]), "C": float(coef2[1]), "F": float(coef2[2]), "n": int(long.sum())}}
 print(json.dumps(summary, indent=1))
 if "--json" in sys.argv:
     with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
