@@ -203,3 +203,61 @@ def test_ply_colour_quantisation(oracle):
     q = oracle.L.or_ply_color_u8
     assert [q(0.0), q(1.0), q(0.5), q(2.0), q(-0.3), q(float("nan"))] == [0, 255, 127, 255, 0, 0]
     assert q(1.0 / 255.9999 * 3) in (2, 3) and q(0.999) == 255 and q(0.99) == 253
+
+
+def test_texel_touch_recording_agrees_with_the_plain_march(oracle):
+    """or_raymarch_touch (SURVEY 8d byte model) is the same march with bookkeeping: its counts equal what the aux records
+    of or_raymarch say, every texel under a hit was also read by the march's last fetch, tex1's footprint equals tex0's."""
+    dims = (24, 20, 16)
+    t0, t1 = oracle.fill_dense(oracle.default_params(), dims, threads=2)
+    rp = oracle.default_render_params(dims)
+    cam = oracle.camera_look_at(aspect=64 / 48)
+    _, aux = oracle.raymarch(rp, t0, t1, cam, 64, 48, threads=2)
+    maps, c = oracle.raymarch_touch(rp, t0, t1, cam, 64, 48, threads=2)
+    assert c["pixels"] == 64 * 48 and c["covered"] == int((aux["status"] != 0).sum())
+    assert c["hits"] == int((aux["status"] == 1).sum()) > 0
+    assert c["sum_steps"] == int(aux["steps"].sum()) and c["max_steps"] == int(aux["steps"].max())
+    assert maps["march0"].any() and (maps["hit0"] <= maps["march0"]).all()
+    np.testing.assert_array_equal(maps["hit0"], maps["hit1"])
+    assert maps["normal0"].sum() >= maps["hit0"].sum() > 0
+    # accumulating a second camera only adds texels
+    cam2 = oracle.camera_look_at(eye=(-2.5, 3.0, 5.0), aspect=64 / 48)
+    before = maps["march0"].copy()
+    maps, c2 = oracle.raymarch_touch(rp, t0, t1, cam2, 64, 48, threads=2, maps=maps)
+    assert (before <= maps["march0"]).all() and maps["march0"].sum() > before.sum()
+
+
+def test_ext_variant_switches_default_off_and_change_what_they_name(oracle):
+    """The [EXT] sensitivity switches (tools/ext_sensitivity.py) are off in every parity test and each moves only its piece."""
+    assert oracle.L.or_get_ext_variant() == 0
+    base = np.array([oracle.L.or_srgb_u8_to_linear(i) for i in range(256)], np.float32)
+    try:
+        oracle.L.or_set_ext_variant(oracle.EXT_VARIANTS["srgb_pow_ulp_up"])
+        up = np.array([oracle.L.or_srgb_u8_to_linear(i) for i in range(256)], np.float32)
+        pow_branch = np.arange(256) / 255.0 >= 0.04045
+        np.testing.assert_array_equal(up[~pow_branch], base[~pow_branch])
+        np.testing.assert_array_equal(up[pow_branch].view(np.uint32), base[pow_branch].view(np.uint32) + 1)
+        oracle.L.or_set_ext_variant(oracle.EXT_VARIANTS["srgb_quant_round"])
+        assert oracle.L.or_srgb_quantize(0.5) == 128 and oracle.L.or_srgb_quantize(0.999) == 255
+    finally:
+        oracle.L.or_set_ext_variant(0)
+    assert oracle.L.or_srgb_quantize(0.5) == 127 and oracle.L.or_srgb_quantize(0.999) == 254   # truncating `as u8`
+    np.testing.assert_array_equal(np.array([oracle.L.or_srgb_u8_to_linear(i) for i in range(256)], np.float32), base)
+
+
+def test_committed_raymarch_byte_model_matches_its_definition():
+    """profiles/raymarch_model_bytes.json (what bench.py attaches to roofline_raymarch): the two SURVEY 8(d) figures follow
+    from the recorded counts by the survey's own formulas."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "raymarch_model_bytes.json")
+    d = json.load(open(path))
+    for key in ("256", "512", "256_batch64"):
+        m = d[key]
+        out = 16 * m["image"][0] * m["image"][1] * m["cameras"]
+        assert m["output_bytes"] == out
+        assert m["nominal_gather_bytes"] == 128 * (m["counts"]["sum_steps"] + 5 * m["counts"]["hits"]) + out
+        u = m["unique_texels"]
+        assert m["compulsory_bytes"] == 16 * (u["tex0_all"] + u["tex1_hit"]) + out
+        assert u["tex0_march"] <= u["tex0_all"] <= u["of_grid"] and m["counts"]["max_steps"] <= 255
+    assert d["256"]["counts"] == {"pixels": 2073600, "covered": 283681, "hits": 245501, "sum_steps": 4367031, "max_steps": 255}
