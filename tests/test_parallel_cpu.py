@@ -131,3 +131,41 @@ def test_partition_helpers():
     assert par.split_rows(1080, 3, 8) == (400, 544)
     cams = [list(par.split_cameras(64, r, 8)) for r in range(8)]
     assert sum(cams, []) == list(range(64)) and all(len(c) == 8 for c in cams)
+
+
+def _comm_failure_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module("sdf-viewer_amd")
+        par = importlib.import_module("sdf-viewer_amd.parallel")
+        try:
+            par.SlabComm(pkg, rank, world)
+            q.put((rank, "created"))
+        except pkg.SdfvError as e:
+            q.put((rank, f"SdfvError: {e}"))
+        dist.barrier()  # every rank is still in step with the others: nobody was left inside a collective
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="exercises the failure path that a box without GPUs takes")
+def test_slab_comm_creation_fails_on_every_rank_together():
+    """SlabComm.__init__ is collective.  Without a GPU sdfv_slab_comm_create fails (no device) -- after the
+    id was drawn and broadcast -- and the agreement step must turn that into an exception on EVERY rank, with all ranks
+    still able to meet in a barrier afterwards (the old code left the healthy ranks inside a collective)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_comm_failure_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert set(results) == {0, 1}
+    assert all(v.startswith("SdfvError") and "sdfv_slab_comm_create" in v for v in results.values()), results
