@@ -393,7 +393,7 @@ def run(redirect):
     K, Wm = args.steps, args.warmup
     aux_steps = max(2, min(K, 10))
 
-    def make_filler(gdims, slab):
+    def make_filler(gdims, slab, slab_dist=None):
         """N>1: halo exchange overlapped with the fill.  Under nccl the library's own RCCL communicator carries it (one C
         call per step); should any rank fail to create or use one, EVERY rank falls back to torch.distributed P2P."""
         transport = args.halo_transport
@@ -402,7 +402,7 @@ def run(redirect):
         filler = None
         if transport == "rccl":
             try:
-                filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="rccl")
+                filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="rccl", dist=slab_dist)
                 filler.step()  # a first step, so that a communicator that cannot exchange shows up here, not mid-run
                 torch.cuda.synchronize()
             except Exception as e:  # noqa: BLE001 -- reported, then decided collectively below
@@ -417,7 +417,7 @@ def run(redirect):
                     filler = None
         if filler is None:
             transport = "torch"
-            filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="torch")
+            filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="torch", dist=slab_dist)
         return filler, transport
 
     # ---------------- the grid: side^3 voxels per rank, z-slab of the weak-scaled global grid ----------------
@@ -505,28 +505,35 @@ def run(redirect):
         my_cams, r0, r1 = [cam0], owned0, owned1
     else:
         # ---------------- N > 1: z-slab fill step with the halo exchange; raymarch over a replica ----------------
-        filler, transport = make_filler(gdims, slab)
+        # The FUSED pipeline per rank (what the N = 1 line reports): every rank's step is sdfv_slab_fill_step_commit --
+        # its slab's textures AND compact distance volume in one pass (36 B/voxel) + the halo exchange -- so that `value`
+        # at N ranks is N times the same work as `pipeline_fused` at N = 1; the march reads the volume its fill wrote.
+        slab_dist = torch.empty(tuple(slab.tex0.shape[:3]), dtype=torch.float32, device=device)
+        own_dist = slab_dist[slab.ghost_lo:slab.ghost_lo + (slab.z_end - slab.z_begin)]
+        filler, transport = make_filler(gdims, slab, slab_dist)
         fill_ms, _ = region(filler.step, K, Wm, torch, dist, world, device)
         # dominant kernel alone (a step = boundary work + exchange + fill), HIP events on the launch stream
-        _, kern_ms = region(lambda: pkg.fill_grid(prm, grid, owned0, owned1), K, 1, torch, dist, world, device)
+        _, kern_ms = region(lambda: pkg.fill_grid(prm, grid, owned0, owned1, dist=own_dist), K, 1, torch, dist, world, device)
         fill_mvox = total_voxels / fill_ms / 1e3
-        out["roofline"] = fill_roofline(kern_ms, voxels_per_rank, 32, load_traffic(args.workload))
+        out["roofline"] = fill_roofline(kern_ms, voxels_per_rank, 36, load_traffic(args.workload + "_fused"))
         out["fill_step_fraction_of_plain_fill"] = round(kern_ms / fill_ms, 3)
-        # raymarch: one camera per rank over a replica of the N = 1 grid (plain pipeline: tex0.r in place)
+        # raymarch: one camera per rank over a replica of the N = 1 grid, filled by the same fused fill
         rgrid = pkg.make_grid((side, side, side))
         r0, r1 = pkg.alloc_textures(rgrid, device=device)
-        pkg.fill_grid(prm, rgrid, r0, r1)
+        dist_vol = torch.empty((side, side, side), dtype=torch.float32, device=device)
+        pkg.fill_grid(prm, rgrid, r0, r1, dist=dist_vol)
         rp = pkg.default_render_params(rgrid)
         cams = pkg.orbit_cameras(world, aspect=W / H)  # camera 0 = the reference default (scene/mod.rs:82-95)
         my_cams = [cams[i] for i in par.split_cameras(world, rank, world)]
         rgba = torch.empty((len(my_cams), H, W, 4), dtype=torch.float32, device=device)
-        march_ms, march_ev = region(lambda: pkg.raymarch(rp, r0, r1, my_cams, W, H, out=rgba), K, Wm, torch, dist, world, device)
+        march_ms, march_ev = region(lambda: pkg.raymarch(rp, r0, r1, my_cams, W, H, out=rgba, dist=dist_vol), K, Wm,
+                                    torch, dist, world, device)
         march_mrays = W * H * world / march_ms / 1e3
-        out["pipeline"] = "plain"
-        out["pipeline_note"] = ("N > 1: value = z-slab fill step incl. the RCCL halo exchange (32 B/voxel), value_rays = one "
-                                "camera per rank over a replica, marched over tex0.r in place")
+        out["pipeline"] = "fused"
+        out["pipeline_note"] = ("N > 1: value = z-slab fill step = the fused fill per rank (textures + distance volume, "
+                                "36 B/voxel) incl. the RCCL halo exchange: N x the work of pipeline_fused at N = 1; value_rays "
+                                "= one camera per rank over a replica, marched over the distance volume that fill wrote")
         out["roofline_raymarch"] = raymarch_traffic_report(None, march_ev)
-        dist_vol = pkg.commit_distance(rgrid, r0)
 
     # ---------------- N = 1 extras ----------------
     target_512 = None
@@ -621,20 +628,23 @@ def run(redirect):
                 cdims = par.weak_scaling_dims(cside, world, "cube")
                 cslab = par.alloc_slab(cdims, rank, world, device, pkg=None if args.no_tuned_placement else pkg)
                 cgrid = pkg.make_grid(cdims, z_begin=cslab.z_begin, z_end=cslab.z_end)
+                cdist = torch.empty(tuple(cslab.tex0.shape[:3]), dtype=torch.float32, device=device)
+                c_own = cdist[cslab.ghost_lo:cslab.ghost_lo + (cslab.z_end - cslab.z_begin)]
                 cfiller = par.SlabFiller(pkg, prm, cdims, cslab, rank, world, transport=transport,
-                                         comm=filler.comm)  # the same communicator serves this slab too
+                                         comm=filler.comm, dist=cdist)  # the same communicator serves this slab too
                 cs = max(3, min(K, 10))
                 c_ms, _ = region(cfiller.step, cs, 2, torch, dist, world, device)
-                _, c_kern = region(lambda: pkg.fill_grid(prm, cgrid, cslab.owned0, cslab.owned1), cs, 1, torch, dist, world, device)
+                _, c_kern = region(lambda: pkg.fill_grid(prm, cgrid, cslab.owned0, cslab.owned1, dist=c_own), cs, 1, torch,
+                                   dist, world, device)
                 cvox = pkg.slab_voxels(cgrid)
                 config4 = {"grid_global": list(cdims), "voxels_per_gpu": cvox, "steps": cs,
                            "value": round(cvox * world / c_ms / 1e3, 1), "unit": "Mvoxels/s",
                            "ms_per_step_fill": round(c_ms, 4), "plain_fill_ms": round(c_kern, 4),
                            "fill_step_fraction_of_plain_fill": round(c_kern / c_ms, 3),
-                           "frac_of_hbm_peak_per_gpu": round(32 * cvox / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           "halo_bytes_per_direction": int(cdims[0]) * int(cdims[1]) * 32,
+                           "frac_of_hbm_peak_per_gpu": round(36 * cvox / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "bytes_per_voxel": 36, "halo_bytes_per_direction": int(cdims[0]) * int(cdims[1]) * 32,
                            "note": "BASELINE.json configs[3] geometry (cube; 8 x 512^3 = 1024^3), weak scaling like `value`"}
-                del cslab
+                del cslab, cdist
             except Exception as e:  # noqa: BLE001 -- an extra, never fatal
                 config4 = {"error": f"{type(e).__name__}: {e}"}
         # outside the timed regions: the gathered slabs must equal a dense local fill of the global grid, and the
@@ -650,6 +660,7 @@ def run(redirect):
                 ok = torch.equal(full0, chk0) and torch.equal(full1, chk1)
                 lo, hi = slab.z_begin - slab.ghost_lo, slab.z_end + slab.ghost_hi
                 ok = ok and torch.equal(slab.tex0, chk0[lo:hi]) and torch.equal(slab.tex1, chk1[lo:hi])
+                ok = ok and torch.equal(slab_dist, chk0[lo:hi, ..., 0])  # the distance volume the step wrote, ghosts included
                 flag = torch.tensor([1.0 if ok else 0.0], device=cdev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 verified = bool(flag.item() == 1.0)

@@ -389,6 +389,12 @@ int sdfv_slab_halo_exchange(sdfv_slab_comm *comm, const sdfv_grid *slab, float *
  * everything is enqueued; work later put on `stream` sees owned and ghost slices complete. */
 int sdfv_slab_fill_step(sdfv_slab_comm *comm, const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *slab,
                         float *tex0, float *tex1, void *stream);
+/* The same step with the fused commit (sdfv_fill_grid_commit per rank): `dist` (DEVICE, one float per voxel of the slab
+ * allocation INCLUDING its ghost slices, same slice layout as the textures; NULL = sdfv_slab_fill_step) receives the
+ * compact distance volume of the owned slices in the fill's own pass (36 B/voxel stored, the textures streamed past L2)
+ * and, once the halo has arrived, tex0.r of the ghost slices. */
+int sdfv_slab_fill_step_commit(sdfv_slab_comm *comm, const sdfv_demo_params *params, uint32_t sdf_id,
+                               const sdfv_grid *slab, float *tex0, float *tex1, float *dist, void *stream);
 
 #ifdef __cplusplus
 }

@@ -135,6 +135,8 @@ PROTOTYPES = {
     "sdfv_slab_halo_exchange": (C.c_int, [C.c_void_p, C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_slab_fill_step": (C.c_int, [C.c_void_p, C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
+    "sdfv_slab_fill_step_commit": (C.c_int, [C.c_void_p, C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 LIGHT_AMBIENT, LIGHT_DIRECTIONAL, MAX_LIGHTS = 0, 1, 4
 # sdfv_option / values (include/sdfgrid.h)

@@ -25,6 +25,7 @@ int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3
 struct OrderedFill {
     uint32_t lead = 1;
     bool stage_only = false;  // write the packed copies only (the textures are another launch's)
+    float* dist = nullptr;    // compact distance volume of the owned slices (fused commit), or nullptr
     float* stage_lo = nullptr;
     float* stage_hi = nullptr;
     uint32_t* arrive = nullptr;
@@ -41,7 +42,9 @@ int fill_slab_ordered(const sdfv_demo_params* params, uint32_t sdf_id, const sdf
 int copy_texel_segments(const float* const src[4], float* const dst[4], const size_t n[4], void* stream);
 // sdfv_fill_grid whose first workgroup stores `value` to `signal` (signal memory) as soon as the launch starts.
 int fill_grid_signalling_start(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, float* tex0,
-                               float* tex1, uint32_t* signal, uint32_t value, void* stream);
+                               float* tex1, float* dist, uint32_t* signal, uint32_t value, void* stream);
+// dist[i] = tex0[i].r over n texels (the ghost slices' share of the compact distance volume)
+int extract_distance(const float* tex0, float* dist, size_t n, void* stream);
 int fill_boundary_slices(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* slab, float* o0, float* o1,
                          void* stream);
 }  // namespace sdfv

@@ -281,6 +281,7 @@ int fill_slab_ordered(const sdfv_demo_params* params, uint32_t sdf_id, const sdf
     FillArgs a = make_fill_args(*params, sdf_id, *slab, o0, o1);
     a.order_lead = of.lead;
     a.stage_only = of.stage_only ? 1u : 0u;
+    a.dist = of.dist;
     a.stage_lo = reinterpret_cast<float4*>(of.stage_lo);
     a.stage_hi = reinterpret_cast<float4*>(of.stage_hi);
     a.arrive = of.arrive;
@@ -304,19 +305,26 @@ int copy_texel_segments(const float* const src[4], float* const dst[4], const si
     return SDFV_OK;
 }
 
+int extract_distance(const float* tex0, float* dist, size_t n, void* stream) {
+    SDFV_HIP(launch_commit_distance(tex0, dist, n, (hipStream_t)stream));
+    return SDFV_OK;
+}
+
 int fill_grid_signalling_start(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, float* tex0,
-                               float* tex1, uint32_t* signal, uint32_t value, void* stream) {
+                               float* tex1, float* dist, uint32_t* signal, uint32_t value, void* stream) {
     if (int rc = check_params(params, sdf_id)) return rc;
     if (int rc = check_grid(grid)) return rc;
     if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
     if (int rc = check_texel_alignment(tex0, tex1)) return rc;
     if (int rc = need_device()) return rc;
+    if ((uintptr_t)dist & 3) return fail(SDFV_ERR_INVALID_ARGUMENT, "dist must be 4-byte aligned");
     FillArgs a = make_fill_args(*params, sdf_id, *grid, tex0, tex1);
+    a.dist = dist;
     a.signal = signal;
     a.signal_value = value;
     if ((uint64_t)a.H * a.slab_d > 0x7fffffffull || a.W > 0x7fffffffu)
         return fail(SDFV_ERR_INVALID_ARGUMENT, "slab of %u x %u rows is too large for one launch", a.H, a.slab_d);
-    SDFV_HIP(launch_fill_dense(a, fill_launch_config(false), (hipStream_t)stream));
+    SDFV_HIP(launch_fill_dense(a, fill_launch_config(dist != nullptr), (hipStream_t)stream));
     return SDFV_OK;
 }
 

@@ -314,7 +314,13 @@ int sdfv_slab_halo_exchange(sdfv_slab_comm* c, const sdfv_grid* slab, float* tex
 
 int sdfv_slab_fill_step(sdfv_slab_comm* c, const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* slab,
                         float* tex0, float* tex1, void* stream) {
+    return sdfv_slab_fill_step_commit(c, params, sdf_id, slab, tex0, tex1, nullptr, stream);
+}
+
+int sdfv_slab_fill_step_commit(sdfv_slab_comm* c, const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* slab,
+                               float* tex0, float* tex1, float* dist, void* stream) {
     if (int rc = check_slab(c, slab, tex0, tex1)) return rc;
+    if ((uintptr_t)dist & 3) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "dist must be 4-byte aligned");
     const Rccl* lib;
     if (int rc = need_rccl(lib)) return rc;
     hipStream_t main = (hipStream_t)stream;
@@ -323,7 +329,19 @@ int sdfv_slab_fill_step(sdfv_slab_comm* c, const sdfv_demo_params* params, uint3
     const uint32_t z0 = slab->z_begin, z1 = slab->z_end, owned = z1 - z0;
     float* o0 = tex0 + c->ghost_lo() * slice;  // first owned slice
     float* o1 = tex1 + c->ghost_lo() * slice;
+    float* od = dist ? dist + c->ghost_lo() * slice_texels : nullptr;  // the volume follows the textures' slice layout
     const bool exchange = c->has_lo() || c->has_hi();
+    // the ghost slices' share of the distance volume = tex0.r of the slices just received, on the stream that received them
+    auto ghost_distances = [&](hipStream_t st) -> int {
+        if (!dist) return SDFV_OK;
+        if (c->has_lo())
+            if (int rc = sdfv::extract_distance(tex0, dist, slice_texels, st)) return rc;
+        if (c->has_hi())
+            if (int rc = sdfv::extract_distance(tex0 + (c->ghost_lo() + owned) * slice, dist + (c->ghost_lo() + owned) * slice_texels,
+                                                c->halo_hi * slice_texels, st))
+                return rc;
+        return SDFV_OK;
+    };
     const uint32_t lead = c->halo_hi;
 
     // Which form: the ordered fill needs whole workgroups per slice and an interior to hide the exchange behind.
@@ -335,8 +353,10 @@ int sdfv_slab_fill_step(sdfv_slab_comm* c, const sdfv_demo_params* params, uint3
     if (int rc = sdfv::ordered_fill_blocks(slab, &bps, &total)) return rc;
     if (!exchange || owned < lead + 2 || bps == 0) {  // nothing to hide the exchange behind / shape not supported
         sdfv_grid part = *slab;
-        if (int rc = sdfv_fill_grid(params, sdf_id, &part, o0, o1, main)) return rc;
-        return exchange ? enqueue_exchange_direct(lib, c, slab, tex0, tex1, main) : SDFV_OK;
+        if (int rc = sdfv_fill_grid_commit(params, sdf_id, &part, o0, o1, od, main)) return rc;
+        if (!exchange) return SDFV_OK;
+        if (int rc = enqueue_exchange_direct(lib, c, slab, tex0, tex1, main)) return rc;
+        return ghost_distances(main);
     }
     bool unpacked_auto = false;
     if (form == 0) {
@@ -354,13 +374,16 @@ int sdfv_slab_fill_step(sdfv_slab_comm* c, const sdfv_demo_params* params, uint3
 
     sdfv::OrderedFill of;
     of.lead = lead;
+    of.dist = od;
     if (packed) {
         of.stage_lo = c->has_lo() ? c->send_lo() : nullptr;
         of.stage_hi = c->has_hi() ? c->send_hi() : nullptr;
     }
     const uint32_t nb = (lead + 1) * bps;  // the boundary workgroups: what the neighbours wait for
-    auto exchange_on = [&](hipStream_t st) {
-        return packed ? enqueue_exchange_packed(lib, c, slab, tex0, tex1, st) : enqueue_exchange_direct(lib, c, slab, tex0, tex1, st);
+    auto exchange_on = [&](hipStream_t st) -> int {
+        if (int rc = packed ? enqueue_exchange_packed(lib, c, slab, tex0, tex1, st) : enqueue_exchange_direct(lib, c, slab, tex0, tex1, st))
+            return rc;
+        return ghost_distances(st);
     };
 
     if (form == SDFV_STEP_SIDE_BOUNDARY) {
@@ -381,7 +404,7 @@ int sdfv_slab_fill_step(sdfv_slab_comm* c, const sdfv_demo_params* params, uint3
             // the fill goes first in host order: should the two streams ever share a hardware queue, the launch that signals
             // is ahead of the packet that waits for it
             c->step += 1;
-            if (int rc = sdfv::fill_grid_signalling_start(params, sdf_id, slab, o0, o1, c->signal, c->step, main)) return rc;
+            if (int rc = sdfv::fill_grid_signalling_start(params, sdf_id, slab, o0, o1, od, c->signal, c->step, main)) return rc;
             SDFV_HIPC(hipStreamWaitValue32(c->comm_stream, c->signal, c->step, hipStreamWaitValueGte, 0xffffffffu));
         } else if (!no_start) {
             SDFV_HIPC(hipEventRecord(c->boundary_done, main));
@@ -390,15 +413,15 @@ int sdfv_slab_fill_step(sdfv_slab_comm* c, const sdfv_demo_params* params, uint3
         if (packed) {
             of.stage_only = true;
             if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, 0, nb, c->comm_stream)) return rc;
-            if (int rc = enqueue_exchange_packed(lib, c, slab, tex0, tex1, c->comm_stream)) return rc;
+            if (int rc = exchange_on(c->comm_stream)) return rc;
             SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));
             if (!signal_start)
-                if (int rc = sdfv_fill_grid(params, sdf_id, slab, o0, o1, main)) return rc;
+                if (int rc = sdfv_fill_grid_commit(params, sdf_id, slab, o0, o1, od, main)) return rc;
         } else {
             // per-texture messages straight out of / into the textures: the communicator's stream fills the boundary
             // slices in place, `main` everything else (the same ordered grid, split between the two streams)
             if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, 0, nb, c->comm_stream)) return rc;
-            if (int rc = enqueue_exchange_direct(lib, c, slab, tex0, tex1, c->comm_stream)) return rc;
+            if (int rc = exchange_on(c->comm_stream)) return rc;
             SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));
             if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, nb, total, main)) return rc;
         }

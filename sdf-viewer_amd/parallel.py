@@ -206,9 +206,17 @@ class SlabComm:
     def halo_exchange(self, grid, slab, stream=None):
         self.pkg.check(self.pkg.lib.sdfv_slab_halo_exchange(self.handle, *self._args(grid, slab, stream)))
 
-    def fill_step(self, params, grid, slab, sdf_id=0, stream=None):
+    def fill_step(self, params, grid, slab, sdf_id=0, stream=None, dist=None):
+        """dist: optional [slices incl. ghosts, H, W] float32 tensor = the slab's compact distance volume, written in the
+        same pass (sdfv_slab_fill_step_commit: the fused fill per rank, ghost slices' share once the halo is in)."""
         g, t0, t1, st = self._args(grid, slab, stream)
-        self.pkg.check(self.pkg.lib.sdfv_slab_fill_step(self.handle, C.byref(params), sdf_id, g, t0, t1, st))
+        if dist is None:
+            self.pkg.check(self.pkg.lib.sdfv_slab_fill_step(self.handle, C.byref(params), sdf_id, g, t0, t1, st))
+            return
+        assert dist.is_cuda and dist.dtype == torch.float32 and dist.is_contiguous() and \
+            tuple(dist.shape) == tuple(slab.tex0.shape[:3])
+        self.pkg.check(self.pkg.lib.sdfv_slab_fill_step_commit(self.handle, C.byref(params), sdf_id, g, t0, t1,
+                                                               C.c_void_p(dist.data_ptr()), st))
 
     def close(self):
         if self.handle:
@@ -233,10 +241,11 @@ class SlabFiller:
     """
 
     def __init__(self, pkg, params, dims, slab, rank, world, sdf_id=0, group=None, transport="auto", periodic=False,
-                 comm=None):
+                 comm=None, dist=None):
         """transport: "rccl" = the library's communicator (one C call per step), "torch" = torch.distributed P2P
         ops on a second stream, "auto" = rccl on GPUs under the nccl backend, torch otherwise."""
         self.pkg, self.params, self.dims, self.slab = pkg, params, dims, slab
+        self.dist = dist  # optional compact distance volume of the slab incl. ghosts: every step is the fused fill
         self.rank, self.world, self.sdf_id, self.group = rank, world, sdf_id, group
         if transport == "auto":
             transport = "rccl" if (world > 1 and slab.tex0.is_cuda and dist.get_backend(group) == "nccl") else "torch"
@@ -261,26 +270,43 @@ class SlabFiller:
     def step(self):
         pkg, slab = self.pkg, self.slab
         if self.comm is not None:
-            self.comm.fill_step(self.params, self.whole, slab, sdf_id=self.sdf_id)
+            self.comm.fill_step(self.params, self.whole, slab, sdf_id=self.sdf_id, dist=self.dist)
             return
+        n_owned = slab.z_end - slab.z_begin
+        own_dist = None if self.dist is None else self.dist[slab.ghost_lo:slab.ghost_lo + n_owned]
         if not self.overlap:
-            pkg.fill_grid(self.params, self.whole, slab.owned0, slab.owned1, sdf_id=self.sdf_id)
+            pkg.fill_grid(self.params, self.whole, slab.owned0, slab.owned1, sdf_id=self.sdf_id, dist=own_dist)
             if self.world > 1:
                 halo_exchange(slab, self.rank, self.world, self.group)
+                self._ghost_distances()
             return
         main = torch.cuda.current_stream()
-        for grid, t0, t1 in self.parts[:2]:
-            pkg.fill_grid(self.params, grid, t0, t1, sdf_id=self.sdf_id)
+        for k, (grid, t0, t1) in enumerate(self.parts[:2]):
+            pkg.fill_grid(self.params, grid, t0, t1, sdf_id=self.sdf_id,
+                          dist=None if own_dist is None else (own_dist[:1] if k == 0 else own_dist[-1:]))
         boundary_done = torch.cuda.Event()
         boundary_done.record(main)
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(boundary_done)
             halo_exchange(slab, self.rank, self.world, self.group)  # its waits block the comm stream only
+            self._ghost_distances()
             halo_done = torch.cuda.Event()
             halo_done.record(self.comm_stream)
         grid, t0, t1 = self.parts[2]
-        pkg.fill_grid(self.params, grid, t0, t1, sdf_id=self.sdf_id)  # overlaps the exchange
+        pkg.fill_grid(self.params, grid, t0, t1, sdf_id=self.sdf_id,
+                      dist=None if own_dist is None else own_dist[1:-1])  # overlaps the exchange
         main.wait_event(halo_done)
+
+    def _ghost_distances(self):
+        """torch transport: the ghost slices' share of the distance volume = tex0.r of the slices just received."""
+        if self.dist is None:
+            return
+        slab = self.slab
+        n_owned = slab.z_end - slab.z_begin
+        if slab.ghost_lo:
+            self.dist[:slab.ghost_lo].copy_(slab.tex0[:slab.ghost_lo, ..., 0])
+        if slab.ghost_hi:
+            self.dist[slab.ghost_lo + n_owned:].copy_(slab.tex0[slab.ghost_lo + n_owned:, ..., 0])
 
 
 class ShardedMarch:

@@ -97,6 +97,31 @@ def test_two_slice_upper_halo(pkg, par, oracle, dims, z0, z1, form):
         comm.close()
 
 
+@pytest.mark.parametrize("form", ["auto", "side_boundary_event", "side_boundary_unpacked", "one_launch", "two_launch", "two_launch_unpacked"])
+@pytest.mark.parametrize("dims,z0,z1,halo", [((64, 32, 12), 0, 12, 1), ((64, 32, 12), 3, 9, 2), ((40, 24, 16), 2, 9, 1),
+                                             ((128, 8, 10), 0, 10, 2)])
+def test_fill_step_with_the_fused_commit(pkg, par, oracle, dims, z0, z1, halo, form):
+    """sdfv_slab_fill_step_commit: the step's fill also writes the slab's compact distance volume (owned slices in the
+    fill's own pass, ghost slices once the halo is in): dist == tex0.r on every slice of the allocation, textures as ever."""
+    comm = par.SlabComm(pkg, 0, 1, periodic=True, halo_hi=halo)
+    try:
+        if "one_launch" in form and not comm.one_launch_capable:
+            pytest.skip("hipStreamWaitValue32 not available on this device")
+        prm = pkg.default_params(sphere_radius=0.9)
+        slab = par.alloc_slab((dims[0], dims[1], z1 - z0), 0, 1, "cuda", fill_value=-7.0, periodic=True, halo_hi=halo)
+        slab.z_begin, slab.z_end = z0, z1
+        grid = pkg.make_grid(dims, z_begin=z0, z_end=z1)
+        dist = torch.full(tuple(slab.tex0.shape[:3]), -7.0, dtype=torch.float32, device="cuda")
+        with pkg.options({pkg._capi.OPT_SLAB_STEP_FORM: step_forms(pkg)[form]}):
+            for _ in range(2):
+                comm.fill_step(prm, grid, slab, dist=dist)
+        torch.cuda.synchronize()
+        check_slab(oracle, pkg, prm, dims, z0, z1, slab)
+        assert torch.equal(dist.view(torch.int32), slab.tex0[..., 0].contiguous().view(torch.int32))
+    finally:
+        comm.close()
+
+
 def test_repeated_steps_on_a_side_stream(pkg, par, oracle, loop_comm):
     """Events and the communicator stream are reused step after step; parameters change between steps."""
     dims = (48, 40, 12)
