@@ -50,11 +50,20 @@ def main():
         return bool(torch.equal(slab.tex0[0], slab.owned0[-1]) and torch.equal(slab.tex1[-1], slab.owned1[0]) and
                     torch.equal(slab.tex1[0], slab.owned1[-1]) and torch.equal(slab.tex0[-1], slab.owned0[0]))
 
+    dist = torch.empty(tuple(slab.tex0.shape[:3]), dtype=torch.float32, device="cuda")
+    own_dist = dist[slab.ghost_lo:slab.ghost_lo + side]
+
     def step():
         comm.fill_step(prm, grid, slab)
 
     def plain():
         pkg.fill_grid(prm, grid, slab.owned0, slab.owned1)
+
+    def step_fused():  # what bench.py --gpus N runs per rank: the fused fill (textures + distance volume) + the exchange
+        comm.fill_step(prm, grid, slab, dist=dist)
+
+    def plain_fused():
+        pkg.fill_grid(prm, grid, slab.owned0, slab.owned1, dist=own_dist)
 
     out = {"steps": steps, "one_launch_capable": comm.one_launch_capable}
     if "--forms" in sys.argv:
@@ -80,11 +89,16 @@ def main():
         out["fraction_of_plain_fill_rate"] = {k: round(best_plain / min(x for x in v if not isinstance(x, str)), 3)
                                               for k, v in res.items() if k != "plain_fill"}
     else:
-        step_ms = run(step, steps)
-        same = ghosts_ok()
-        fill_ms = run(plain, steps)
+        step_ms = run(step_fused, steps)
+        same = ghosts_ok() and bool(torch.equal(dist, slab.tex0[..., 0]))
+        fill_ms = run(plain_fused, steps)
+        p_step_ms = run(step, steps)
+        p_fill_ms = run(plain, steps)
         out.update({"ms_per_step": round(step_ms, 4), "plain_fill_ms": round(fill_ms, 4),
                     "fraction_of_plain_fill_rate": round(fill_ms / step_ms, 3), "ghosts_verified": same,
+                    "what": "fused step (sdfv_slab_fill_step_commit, 36 B/voxel) against the fused fill alone",
+                    "unfused": {"ms_per_step": round(p_step_ms, 4), "plain_fill_ms": round(p_fill_ms, 4),
+                                "fraction_of_plain_fill_rate": round(p_fill_ms / p_step_ms, 3)},
                     "form": "plain dense fill on the caller's stream; boundary slices -> packed buffers, RCCL, ghost copy "
                             "on the communicator's stream",
                     "note": "sdfv_slab_fill_step with the rank as its own neighbour (periodic world of 1), in its own "
