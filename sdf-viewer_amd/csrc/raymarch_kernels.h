@@ -27,6 +27,8 @@ struct RaymarchArgs {
     uint32_t y0, y1;             // rows rendered by this launch
     uint32_t compute_normal;     // evaluate sdfNormal per hit even when no aux is stored
     uint32_t asm_loop;           // use the hand-written march loop where its specialisation applies (default 1)
+    uint32_t group_shift;        // 0 = tiles in launch order; g > 0: XCD-aware order over groups of 2^g x 2^g tiles
+    uint32_t tiles_x, tiles_y, groups_x;  // set by the launcher when group_shift > 0
     uint32_t cube_box;           // symmetric box with bounds_max[0] == [1] == [2]: two-instruction out-of-bounds test
     float4* rgba;                // n_cameras x (y1-y0) x width
     sdfv_march_aux* aux;         // same layout or nullptr

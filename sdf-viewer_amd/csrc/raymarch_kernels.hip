@@ -696,8 +696,21 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
     constexpr bool FAST = MODE != 0;
     // 8x8 pixel tile per wave, 2x2 waves per workgroup
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const uint32_t row = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);  // row within [y0, y1)
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (a.group_shift) {
+        // XCD-aware order (a.group_shift = g): the launch is 1-D over workgroups; workgroup L runs on XCD L % 8 (observed
+        // placement, used for speed only).  The image is cut into groups of 2^g x 2^g tiles; group number G goes to XCD
+        // G % 8, so that the tiles one XCD's L2 serves are compact patches spread evenly over the image.
+        const uint32_t g = a.group_shift, per = 1u << (2 * g);
+        const uint32_t L = blockIdx.x, xcd = L & 7u, k = L >> 3;
+        const uint32_t G = (k >> (2 * g)) * 8u + xcd, t = k & (per - 1u);
+        const uint32_t gx = G % a.groups_x, gy = G / a.groups_x;
+        bx = (gx << g) + (t & ((1u << g) - 1u));
+        by = (gy << g) + (t >> g);
+        if (bx >= a.tiles_x || by >= a.tiles_y) return;  // padding of the last groups
+    }
+    const uint32_t px = bx * 16 + (wave & 1) * 8 + (lane & 7);
+    const uint32_t row = by * 16 + (wave >> 1) * 8 + (lane >> 3);  // row within [y0, y1)
     const uint32_t py = a.y0 + row;
     const uint32_t cam_idx = blockIdx.z;
     const bool in_image = px < a.width && py < a.y1;
@@ -748,6 +761,9 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
     int status = covered ? -1 : 0;  // -1 = out of steps unless something else ends the ray
     int steps = 0;
     int iterations = 0;
+#ifdef SDFV_TUNING
+    const unsigned long long t_loop0 = a.wave_timing ? __builtin_readcyclecounter() : 0ull;
+#endif
 #ifdef SDFV_MARCH_SIMT  // the divergent-loop C++ form (hipcc's structurizer makes it longer than the predicated one)
 #define SDFV_MARCH march_simt
 #else
@@ -788,6 +804,9 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
         }
     }
 
+#ifdef SDFV_TUNING
+    const unsigned long long t_loop1 = a.wave_timing ? __builtin_readcyclecounter() : 0ull;
+#endif
     float4 rgba = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float frag_depth = 1.0f;  // material.frag:147 (no hit); also where no fragment exists
     sdfv_march_aux aux;
@@ -857,7 +876,10 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
     }
 
 #ifdef SDFV_TUNING
-    if (a.wave_timing && lane == 0) stamp_wave(a, wave, t_start, iterations, __ballot(covered));
+    // slot 3: cycles before the march loop (ray set-up) | cycles of the loop << 32; what is left of end - start is the hit's
+    // texel gathers and shading
+    if (a.wave_timing && lane == 0)
+        stamp_wave(a, wave, t_start, iterations, ((t_loop0 - t_start) & 0xffffffffull) | ((t_loop1 - t_loop0) << 32));
 #endif
     if (in_image) {
         store_rgba(a.rgba + out_index, rgba);
@@ -1111,10 +1133,25 @@ hipError_t launch_raymarch_slab(const RaymarchArgs& a, const SlabMarchArgs& s, h
     return hipGetLastError();
 }
 
+static hipError_t launch_raymarch_grid(const RaymarchArgs& a, dim3 grid, hipStream_t stream);
+
 hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream) {
     const uint32_t rows = a.y1 - a.y0;
     if (a.width == 0 || rows == 0 || a.n_cameras == 0) return hipSuccess;
     dim3 grid((a.width + 15) / 16, (rows + 15) / 16, a.n_cameras);
+    RaymarchArgs ag = a;
+    if (a.group_shift) {
+        ag.tiles_x = grid.x;
+        ag.tiles_y = grid.y;
+        ag.groups_x = (grid.x + (1u << a.group_shift) - 1) >> a.group_shift;
+        const uint32_t groups_y = (grid.y + (1u << a.group_shift) - 1) >> a.group_shift;
+        const uint32_t groups = ((ag.groups_x * groups_y + 7u) / 8u) * 8u;
+        grid = dim3(groups << (2 * a.group_shift), 1, a.n_cameras);
+    }
+    return launch_raymarch_grid(ag, grid, stream);
+}
+
+static hipError_t launch_raymarch_grid(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
     const bool linear = a.rp.lod_dist_between_samples == 1.0f;
     if (linear && a.fast_index) {
         if (a.dist) launch_fast<2>(a, grid, stream);

@@ -296,6 +296,31 @@ def test_randomised_sweep_of_the_hand_written_march_loop(pkg, oracle):
                             fovy_degrees=float(rng.uniform(10.0, 120.0)), z_near=float(0.05 * scale)), width=w, height=h)
 
 
+@pytest.mark.parametrize("size", [(160, 120), (333, 217), (17, 500), (1000, 30)])
+def test_every_tile_order_renders_the_same_image(pkg, size):
+    """SDFV_OPT_RAYMARCH_TILE_GROUP only changes WHICH workgroup renders which 16 x 16 tile (XCD-aware groups of tiles, with
+    padding groups at the image's edges that must write nothing): every order leaves the same bits, aux and depth too."""
+    W, H = size
+    g = pkg.make_grid((32, 32, 32))
+    t0, t1 = pkg.alloc_textures(g)
+    pkg.fill_grid(pkg.default_params(), g, t0, t1)
+    rp = pkg.default_render_params(g)
+    cam = pkg.camera_look_at(aspect=W / H)
+    K = pkg._capi
+    ref = None
+    for order in (1, 0, 2, 3, 4, 5):  # launch order first; 0 = auto (grouped for one camera)
+        with pkg.options({K.OPT_RAYMARCH_TILE_GROUP: order}):
+            rgba, depth, aux = pkg.raymarch(rp, t0, t1, cam, W, H, want_aux=True, want_depth=True)
+            band = pkg.raymarch(rp, t0, t1, cam, W, H, y0=H // 3, y1=2 * H // 3)
+        torch.cuda.synchronize()
+        got = (rgba.view(torch.int32).clone(), depth.view(torch.int32).clone(), aux.clone(), band.view(torch.int32).clone())
+        if ref is None:
+            ref = got
+            assert bool((rgba[..., 3] > 0).any())
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), order
+
+
 def test_row_bands_of_the_image_tile_split_tile_the_frame(pkg):
     """parallel.split_rows (config 5's image-tile split): the bands rendered by the "ranks" concatenate to the frame."""
     import importlib

@@ -28,6 +28,7 @@ buf = torch.zeros((n_waves, 4), dtype=torch.int64, device="cuda")
 dist = pkg.commit_distance(g, t0) if "--dist" in sys.argv else None
 for _ in range(200):  # clock ramp
     pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist)
+pkg.set_option(K.OPT_RAYMARCH_TILE_GROUP, 1)  # launch order: the stamp buffer is indexed by the 2-D workgroup grid
 pkg.set_option(K.OPT_TUNING_WAVE_TIMING, buf.data_ptr())
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
@@ -38,6 +39,7 @@ pkg.set_option(K.OPT_TUNING_WAVE_TIMING, 0)
 d = buf.cpu().numpy()
 start, end, it = d[:, 0], d[:, 1], d[:, 2] & 0xffff
 fetch_it = (d[:, 2] >> 16) & 0xffff  # hand-written loop, tuning build: iterations in which some lane entered a new cell
+setup_cyc, loop_cyc = d[:, 3] & 0xffffffff, (d[:, 3] >> 32) & 0xffffffff  # active waves only (culled ones store 0)
 t00 = start.min()
 dur = end - start
 act = it > 0
@@ -50,9 +52,17 @@ summary = {
     "wave_cycles_max": int(dur.max()),
     "cycles_per_iteration_active": {"p10": float(np.percentile(cpi, 10)), "median": float(np.median(cpi)),
                                     "p90": float(np.percentile(cpi, 90))},
+    "phases_of_waves_with_64_or_more_iterations": {
+        "setup_cycles_median": float(np.median(setup_cyc[act & (it >= 64)])),
+        "loop_cycles_median": float(np.median(loop_cyc[act & (it >= 64)])),
+        "after_loop_cycles_median": float(np.median((dur - setup_cyc - loop_cyc)[act & (it >= 64)]))},
+    "phases_of_all_active_waves": {
+        "setup_cycles_median": float(np.median(setup_cyc[act])), "loop_cycles_median": float(np.median(loop_cyc[act])),
+        "after_loop_cycles_median": float(np.median((dur - setup_cyc - loop_cyc)[act]))},
     "fetch_block_iterations_fraction_active": float(fetch_it[act].sum() / max(it[act].sum(), 1)),
     "longest_waves": [{"wave": int(i), "iterations": int(it[i]), "fetch_block_iterations": int(fetch_it[i]), "cycles": int(dur[i]),
-                       "cycles_per_iteration": float(dur[i] / max(it[i], 1)), "start": int(start[i] - t00),
+                       "cycles_per_iteration": float(dur[i] / max(it[i], 1)), "setup": int(setup_cyc[i]), "loop": int(loop_cyc[i]),
+                       "after_loop": int(dur[i] - setup_cyc[i] - loop_cyc[i]), "start": int(start[i] - t00),
                        "end": int(end[i] - t00)} for i in order],
     "hist_iterations": {"edges": [0, 1, 8, 16, 32, 64, 128, 192, 255, 256],
                         "counts": np.histogram(it, bins=[0, 1, 8, 16, 32, 64, 128, 192, 255, 256])[0].tolist()},
