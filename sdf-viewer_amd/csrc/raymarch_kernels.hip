@@ -271,9 +271,9 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 // ---- the march loop in gfx950 assembly -------------------------------------------------------------------------------
 // A frame is as long as its longest wave: ONE grazing ray doing up to 255 dependent iterations alone on its SIMD, where
 // a lone wave issues one instruction every ~6-11 cycles whatever the instruction is.  So the loop is priced per
-// INSTRUCTION, and hipcc's lowering of either C++ form (predicated march_fast: ~74 per iteration; divergent-loop
-// march_simt: ~83, the structurizer's mask bookkeeping) leaves a third of the cost on the table.  This is the same loop
-// written by hand (profiles/r02_raymarch_loop_isa.md lists all three):
+// INSTRUCTION, and hipcc's lowering of either C++ form (the predicated march_fast above: 78 per iteration; the same loop
+// written as a plain divergent loop with breaks: ~83, the structurizer's mask bookkeeping -- tried and removed) leaves
+// half of the cost on the table.  This is the same loop written by hand (profiles/r02_raymarch_loop_isa.md):
 //   * the set of marching lanes IS the EXEC mask: v_cmpx removes the lanes that stop (out-of-bounds test, hit test), so
 //     nothing is predicated and no mask register is maintained; s_cbranch_execz is the wave-level early exit;
 //   * the one-cell cache is tested on the interpolation weights themselves: a = u - floor_cached(u) is the weight if the
@@ -282,7 +282,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 //   * (y, z) components ride in packed-f32 instructions (v_pk_add/mul_f32), the corner values are kept as z-pairs so
 //     that the x and y levels of the trilinear filter are packed as well;
 //   * no per-iteration status or step counters (derived after the loop as in march_fast; the aux variant counts).
-// 42 instructions per iteration on the common path.  Every arithmetic instruction is the one the C++ form performs, in
+// 40 instructions per iteration on the common path (42 for a non-cubic box).  Every arithmetic instruction is the one the C++ form performs, in
 // the same order on the same operands (no fma, no reassociation): results are bit-identical, which the parity tests
 // check against the oracle for every pixel.  Covers: LINEAR filter, power-of-two extents and texture sizes (XF == 2),
 // symmetric box, clamp-for-mirror (fast_index); STRIDE 1 = compact distance volume (one 8-byte load per corner row),
@@ -505,87 +505,6 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
     }
 }
 
-// The same loop as march_fast, written as a plain divergent (SIMT) loop: a lane that stops BREAKS, so the set of marching
-// lanes IS the EXEC mask -- stopped lanes cost no v_cndmask to hold their state, the out-of-bounds and hit tests each
-// shrink EXEC with one compare, and the wave leaves when EXEC is empty (the back edge's s_cbranch_execnz is the ballot).
-// Per iteration of the no-refetch path: ~50 instructions against march_fast's ~74 (profiles/r02_raymarch_loop_isa.md).
-// Values and operation order are those of sample_r() / the oracle, as in march_fast.
-template <int XF, bool SYMM, int STRIDE, bool T>
-__device__ __forceinline__ void march_simt(const RaymarchArgs& a, const float* __restrict__ vol, const Tex& t,
-                                           V3 ray_dir, bool covered, V3& ray_pos, float& dist_from_origin,
-                                           int& status, int& steps, int& iterations) {
-    const float fw_ = (float)t.w, fh_ = (float)t.h, fd_ = (float)t.d;
-    const float kx = a.inv_bsize[0] * fw_, ky = a.inv_bsize[1] * fh_, kz = a.inv_bsize[2] * fd_;  // exact if XF == 2
-    const int wm1 = t.w - 1, hm1 = t.h - 1, dm1 = t.d - 1;
-    const uint32_t sy = (uint32_t)t.w, sz = (uint32_t)t.w * (uint32_t)t.h;
-    if (!covered) return;
-    V3 p = ray_pos;
-    float tt = dist_from_origin;
-    bool hit = false, out_of_bounds = false;
-    float cfu = -4.0f, cfv = -4.0f, cfw = -4.0f;  // never a valid floor(u) of a marching lane
-    float t000 = 0.0f, t100 = 0.0f, t010 = 0.0f, t110 = 0.0f, t001 = 0.0f, t101 = 0.0f, t011 = 0.0f, t111 = 0.0f;
-    int i = 0;
-    for (; i < 255; ++i) {
-        // Stop condition: out of bounds (material.frag:106-109)
-        if (oob_dist<SYMM>(a, p) > 1e-4f) {
-            out_of_bounds = true;
-            break;
-        }
-#ifdef SDFV_TUNING
-        ++iterations;
-#endif
-        float u, v, w;
-        if (XF == 2) {
-            u = (p.x - a.rp.bounds_min[0]) * kx - 0.5f;
-            v = (p.y - a.rp.bounds_min[1]) * ky - 0.5f;
-            w = (p.z - a.rp.bounds_min[2]) * kz - 0.5f;
-        } else {
-            const V3 q = to_p01<XF>(a, p);
-            u = q.x * fw_ - 0.5f; v = q.y * fh_ - 0.5f; w = q.z * fd_ - 0.5f;
-        }
-        const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
-        if (fu != cfu || fv != cfv || fw != cfw) {  // one-cell register cache, as in march_fast
-            cfu = fu; cfv = fv; cfw = fw;
-            const int i0 = (int)fu, j0 = (int)fv, k0 = (int)fw;
-            const uint32_t i0c = (uint32_t)max(i0, 0), i1c = (uint32_t)min(i0 + 1, wm1);
-            const uint32_t j0c = (uint32_t)max(j0, 0) * sy, j1c = (uint32_t)min(j0 + 1, hm1) * sy;
-            const uint32_t k0c = (uint32_t)max(k0, 0) * sz, k1c = (uint32_t)min(k0 + 1, dm1) * sz;
-            const uint32_t r00 = k0c + j0c, r10 = k0c + j1c, r01 = k1c + j0c, r11 = k1c + j1c;
-            if (STRIDE == 1 && wm1 >= 1) {
-                const uint32_t b = (uint32_t)min(max(i0, 0), wm1 - 1);
-                const bool lo_is_x = i0c == b, hi_is_y = i1c == b + 1;
-                typedef float f2 __attribute__((ext_vector_type(2), aligned(4)));
-                const f2 q00 = *reinterpret_cast<const f2*>(vol + (uint64_t)(r00 + b));
-                const f2 q10 = *reinterpret_cast<const f2*>(vol + (uint64_t)(r10 + b));
-                const f2 q01 = *reinterpret_cast<const f2*>(vol + (uint64_t)(r01 + b));
-                const f2 q11 = *reinterpret_cast<const f2*>(vol + (uint64_t)(r11 + b));
-                t000 = lo_is_x ? q00.x : q00.y; t100 = hi_is_y ? q00.y : q00.x;
-                t010 = lo_is_x ? q10.x : q10.y; t110 = hi_is_y ? q10.y : q10.x;
-                t001 = lo_is_x ? q01.x : q01.y; t101 = hi_is_y ? q01.y : q01.x;
-                t011 = lo_is_x ? q11.x : q11.y; t111 = hi_is_y ? q11.y : q11.x;
-            } else {
-                t000 = vol[(uint64_t)(r00 + i0c) * STRIDE]; t100 = vol[(uint64_t)(r00 + i1c) * STRIDE];
-                t010 = vol[(uint64_t)(r10 + i0c) * STRIDE]; t110 = vol[(uint64_t)(r10 + i1c) * STRIDE];
-                t001 = vol[(uint64_t)(r01 + i0c) * STRIDE]; t101 = vol[(uint64_t)(r01 + i1c) * STRIDE];
-                t011 = vol[(uint64_t)(r11 + i0c) * STRIDE]; t111 = vol[(uint64_t)(r11 + i1c) * STRIDE];
-            }
-        }
-        const float sample_dist = trilerp(t000, t100, t010, t110, t001, t101, t011, t111, u - fu, v - fv, w - fw) - 1e-1f;
-        // Stop condition: actually hit the surface (material.frag:117-121)
-        if (sample_dist < 1e-5f) {
-            hit = true;
-            break;
-        }
-        // Move the ray forward by the minimum distance to the surface (material.frag:124-125)
-        p = madd(p, ray_dir, sample_dist);
-        if (T) tt += sample_dist;
-    }
-    ray_pos = p;
-    dist_from_origin = tt;
-    steps = hit ? i + 1 : i;  // tex0 fetches done: the hit's iteration sampled, the out-of-bounds one did not
-    status = hit ? 1 : (out_of_bounds ? -2 : -1);
-}
-
 // three-d 0.18.2 tone_mapping / color_mapping (material.frag:167-168) [not vendored in the reference]
 __device__ __forceinline__ float tone_map(uint32_t type, float c) {
     if (type == 1) c = c / (c + 1.0f);
@@ -764,11 +683,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
 #ifdef SDFV_TUNING
     const unsigned long long t_loop0 = a.wave_timing ? __builtin_readcyclecounter() : 0ull;
 #endif
-#ifdef SDFV_MARCH_SIMT  // the divergent-loop C++ form (hipcc's structurizer makes it longer than the predicated one)
-#define SDFV_MARCH march_simt
-#else
-#define SDFV_MARCH march_fast
-#endif
+#define SDFV_MARCH march_fast  // the C++ loop, where the hand-written one's specialisation does not apply
     if (ASM && MODE == 1) {
         march_asm<SYMM, 4, AUX>(a, reinterpret_cast<const float*>(a.tex0), tex0, ray_dir, covered, ray_pos, dist_from_origin,
                                 status, steps, iterations);
