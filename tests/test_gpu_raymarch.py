@@ -51,10 +51,12 @@ def compare(pkg, oracle, g, t0, t1, h0, h1, cam_kw, width, height, rp_edit=None,
             rgba, depth, aux = pkg.raymarch(rp, t0, t1, cam, width, height, y0=y0, y1=y1, want_aux=True,
                                             want_depth=True, dist=dist if variant.startswith("dist") else None)
             # the depth plane without the 72-byte record must be the same plane
-            _, depth_only = pkg.raymarch(rp, t0, t1, cam, width, height, y0=y0, y1=y1, want_depth=True,
-                                         dist=dist if variant.startswith("dist") else None)
+            rgba_plain, depth_only = pkg.raymarch(rp, t0, t1, cam, width, height, y0=y0, y1=y1, want_depth=True,
+                                                  dist=dist if variant.startswith("dist") else None)
             torch.cuda.synchronize()
         assert torch.equal(depth.view(torch.int32), depth_only.view(torch.int32)), variant
+        # the kernel WITHOUT the aux record (the one bench.py times) writes the same RGBA as the one with it
+        assert torch.equal(rgba.view(torch.int32), rgba_plain.view(torch.int32)), f"{variant}: aux / no-aux RGBA differ"
         assert torch.equal(depth.view(torch.int32), aux[..., -1]), f"{variant}: depth plane != aux.depth"
         got_rgba = rgba[0].cpu().numpy()
         got_aux = aux_to_np(oracle, aux)[0]
