@@ -45,7 +45,7 @@ def count(lines):
 
 def kernel(lines, name):
     start = [i for i, l in enumerate(lines) if l.startswith(name + ":")][0]
-    end = [i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm")][0]
+    end = [i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end")][0]  # (early exits have s_endpgm too)
     return lines[start:end]
 
 
