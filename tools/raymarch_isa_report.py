@@ -72,8 +72,13 @@ def main():
     label = ck[hdr].split(":")[0]
     hi = [i for i in range(hdr, len(ck)) if "s_cbranch_execz" in ck[i] and ck[i].split()[-1] == label][0]
     comp = ck[lo + 1:hi + 1]
-    i14 = [i for i, l in enumerate(comp) if "%bb.14" in l][0]
-    i18 = [i for i, l in enumerate(comp) if re.match(r"\.LBB\d+_18", l)][0]
+    # hipcc's cell fetch: from the block that converts the floors to integers to the first label after the last gather
+    def is_block_start(l):
+        return l.startswith(".LBB") or l.startswith("; %bb.")
+    first_cvt = [i for i, l in enumerate(comp) if "v_cvt_i32_f32" in l][0]
+    i14 = max(i for i in range(first_cvt) if is_block_start(comp[i]))
+    last_load = max(i for i, l in enumerate(comp) if "global_load" in l)
+    i18 = [i for i in range(last_load, len(comp)) if is_block_start(comp[i])][0]
     res = {"hand_common_path": count(hand[i_loop:i_floor] + hand[i_cached:i_back + 1]),
            "hand_fetch_block": count(hand[i_floor:i_cached]),
            "hipcc_common_path": count(comp[:i14] + comp[i18:]), "hipcc_fetch_block_listed": count(comp[i14:i18])}
