@@ -145,9 +145,13 @@ typedef enum sdfv_option {
     SDFV_OPT_RAYMARCH_DISABLE = 3,     /* mask of SDFV_RM_NO_*: exact-arithmetic specialisations left out (default 0) */
     SDFV_OPT_RAYMARCH_KEEP_NORMAL = 4, /* 0 (default) | 1: evaluate sdfNormal per hit although nothing consumes it */
     SDFV_OPT_SLAB_STEP_FORM = 5,       /* sdfv_slab_fill_step: 0 auto (default) | SDFV_STEP_* below */
-    SDFV_OPT_RAYMARCH_TILE_GROUP = 6,  /* raymarch workgroup-tile order: 0 auto (default: XCD-aware groups of 4 x 4 tiles for a
-                                        * single frame, launch order for camera batches) | 1 launch order | v = 2..5: XCD-aware
-                                        * groups of 2^(v-1) x 2^(v-1) tiles (each group's tiles run on one XCD = one L2) */
+    SDFV_OPT_RAYMARCH_TILE_GROUP = 6,  /* raymarch workgroup-tile order: 0 auto (default: for a single frame XCD-aware groups of
+                                        * 2 x 2 tiles with the box-first order below, 4 x 4 where that does not apply; launch order
+                                        * for camera batches) | 1 launch order | v = 2..5: XCD-aware groups of 2^(v-1) x 2^(v-1)
+                                        * tiles (each group's tiles run on one XCD = one L2) */
+    SDFV_OPT_RAYMARCH_BOX_FIRST = 7,   /* 1 (default) | 0: with an XCD-aware tile order and one camera, the groups of tiles under
+                                        * the screen rectangle of the projected bounding box are launched before the others (the
+                                        * frame is as long as its longest wave; those all start at once then).  Order only */
     SDFV_OPT_TUNING_WAVE_TIMING = 100  /* tuning build only (-DSDFV_TUNING): DEVICE address of 32 B per raymarch wave */
 } sdfv_option;
 #define SDFV_RM_NO_FAST_INDEX  1u /* general kernel: full MirroredRepeat, the shader's nested loop */

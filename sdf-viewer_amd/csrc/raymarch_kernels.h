@@ -27,8 +27,13 @@ struct RaymarchArgs {
     uint32_t y0, y1;             // rows rendered by this launch
     uint32_t compute_normal;     // evaluate sdfNormal per hit even when no aux is stored
     uint32_t asm_loop;           // use the hand-written march loop where its specialisation applies (default 1)
-    uint32_t group_shift;        // 0 = tiles in launch order; g > 0: XCD-aware order over groups of 2^g x 2^g tiles
+    uint32_t group_shift;        // 0 = tiles in launch order; g > 0: XCD-aware order over groups of 2^g x 2^g tiles (kGroupAuto: launcher's choice)
     uint32_t tiles_x, tiles_y, groups_x;  // set by the launcher when group_shift > 0
+    // box-first order (single camera, set by the launcher; first_w == 0: off): the groups inside the screen rectangle
+    // [first_gx0, +first_w) x [first_gy0, +first_h) of the projected bounding box are launched before all others.
+    // m_* = ceil(2^32 / d): n / d == mulhi(n, m) for n, d < 2^16
+    uint32_t box_first;          // option: use that order (default 1)
+    uint32_t first_gx0, first_gy0, first_w, first_h, m_groups_x, m_first_w, m_rest_w;
     uint32_t cube_box;           // symmetric box with bounds_max[0] == [1] == [2]: two-instruction out-of-bounds test
     float4* rgba;                // n_cameras x (y1-y0) x width
     sdfv_march_aux* aux;         // same layout or nullptr
@@ -40,6 +45,7 @@ struct RaymarchArgs {
 };
 
 constexpr uint32_t kMaxCamerasPerLaunch = 16;
+constexpr uint32_t kGroupAuto = 255;  // RaymarchArgs::group_shift as handed to launch_raymarch: let the launcher choose
 
 // One round of the march over a z-slab of the grid (multi-GPU: the grid stays sharded, rays move between ranks).
 struct SlabMarchArgs {

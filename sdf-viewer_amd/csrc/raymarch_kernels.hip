@@ -564,11 +564,15 @@ __device__ __forceinline__ void aux_clear(sdfv_march_aux& aux) {
 
 #ifdef SDFV_TUNING
 __device__ __forceinline__ void stamp_wave(const RaymarchArgs& a, uint32_t wave, unsigned long long t_start,
-                                           int iterations, unsigned long long covered_mask) {
+                                           unsigned long long t_start_rt, int iterations,
+                                           unsigned long long covered_mask) {
     const uint64_t wave_id = ((uint64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
     a.wave_timing[wave_id * 4 + 0] = t_start;
     a.wave_timing[wave_id * 4 + 1] = __builtin_readcyclecounter();
-    a.wave_timing[wave_id * 4 + 2] = (unsigned long long)iterations;
+    // bits 32..47 / 48..63: the 100 MHz real-time counter (one clock for the whole device; the cycle counters above are
+    // per XCD) at the wave's start / end, modulo 2^16 ticks
+    a.wave_timing[wave_id * 4 + 2] = (unsigned long long)(uint32_t)iterations | ((t_start_rt & 0xffffull) << 32) |
+                                     ((__builtin_amdgcn_s_memrealtime() & 0xffffull) << 48);
     a.wave_timing[wave_id * 4 + 3] = covered_mask;
 }
 #endif
@@ -623,7 +627,34 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
         const uint32_t g = a.group_shift, per = 1u << (2 * g);
         const uint32_t L = blockIdx.x, xcd = L & 7u, k = L >> 3;
         const uint32_t G = (k >> (2 * g)) * 8u + xcd, t = k & (per - 1u);
-        const uint32_t gx = G % a.groups_x, gy = G / a.groups_x;
+        uint32_t gx, gy;
+        if (a.first_w == 0) {
+            gx = G % a.groups_x;
+            gy = G / a.groups_x;
+        } else {
+            // box-first: the groups under the projected bounding box start first -- the frame is as long as its longest
+            // wave, and those are all there; the groups that only see background fill in behind them
+            auto div = [](uint32_t n, uint32_t d, uint32_t m) { return d == 1 ? n : __umulhi(n, m); };
+            const uint32_t n_in = a.first_w * a.first_h, top = a.first_gy0 * a.groups_x, rest_w = a.groups_x - a.first_w;
+            uint32_t j = G - n_in;
+            if (G < n_in) {
+                const uint32_t r = div(G, a.first_w, a.m_first_w);
+                gx = a.first_gx0 + (G - r * a.first_w);
+                gy = a.first_gy0 + r;
+            } else if (j < top) {
+                gy = div(j, a.groups_x, a.m_groups_x);
+                gx = j - gy * a.groups_x;
+            } else if ((j -= top) < a.first_h * rest_w) {
+                const uint32_t r = div(j, rest_w, a.m_rest_w), c = j - r * rest_w;
+                gy = a.first_gy0 + r;
+                gx = c < a.first_gx0 ? c : c + a.first_w;
+            } else {
+                j -= a.first_h * rest_w;
+                const uint32_t r = div(j, a.groups_x, a.m_groups_x);
+                gy = a.first_gy0 + a.first_h + r;
+                gx = j - r * a.groups_x;
+            }
+        }
         bx = (gx << g) + (t & ((1u << g) - 1u));
         by = (gy << g) + (t >> g);
         if (bx >= a.tiles_x || by >= a.tiles_y) return;  // padding of the last groups
@@ -637,6 +668,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
     const uint64_t out_index = ((uint64_t)cam_idx * (a.y1 - a.y0) + row) * a.width + px;
 #ifdef SDFV_TUNING
     const unsigned long long t_start = a.wave_timing ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long t_start_rt = a.wave_timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #endif
 
     const V3 eye = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
@@ -663,7 +695,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
             }
             if (in_image && a.depth) a.depth[out_index] = 1.0f;
 #ifdef SDFV_TUNING
-            if (a.wave_timing && lane == 0) stamp_wave(a, wave, t_start, 0, 0ull);
+            if (a.wave_timing && lane == 0) stamp_wave(a, wave, t_start, t_start_rt, 0, 0ull);
 #endif
             return;
         }
@@ -794,7 +826,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
     // slot 3: cycles before the march loop (ray set-up) | cycles of the loop << 32; what is left of end - start is the hit's
     // texel gathers and shading
     if (a.wave_timing && lane == 0)
-        stamp_wave(a, wave, t_start, iterations, ((t_loop0 - t_start) & 0xffffffffull) | ((t_loop1 - t_loop0) << 32));
+        stamp_wave(a, wave, t_start, t_start_rt, iterations, ((t_loop0 - t_start) & 0xffffffffull) | ((t_loop1 - t_loop0) << 32));
 #endif
     if (in_image) {
         store_rgba(a.rgba + out_index, rgba);
@@ -1050,18 +1082,61 @@ hipError_t launch_raymarch_slab(const RaymarchArgs& a, const SlabMarchArgs& s, h
 
 static hipError_t launch_raymarch_grid(const RaymarchArgs& a, dim3 grid, hipStream_t stream);
 
+// Screen rectangle (in groups of tiles) of the bounding box seen from camera 0, for the box-first launch order: the eight
+// corners through the same pinhole model as pixel_ray_raw, one pixel of margin.  Order only: any rectangle renders the same
+// image, so a corner behind the camera simply switches the ordering off.
+static void box_first_rectangle(RaymarchArgs& ag, uint32_t groups_y) {
+    const sdfv_camera& cam = ag.cameras[0];
+    float x_lo = 3.0e38f, x_hi = -3.0e38f, y_lo = 3.0e38f, y_hi = -3.0e38f;
+    for (int c = 0; c < 8; ++c) {
+        const float p[3] = {(c & 1 ? ag.rp.bounds_max : ag.rp.bounds_min)[0], (c & 2 ? ag.rp.bounds_max : ag.rp.bounds_min)[1],
+                            (c & 4 ? ag.rp.bounds_max : ag.rp.bounds_min)[2]};
+        const float v[3] = {p[0] - cam.eye[0], p[1] - cam.eye[1], p[2] - cam.eye[2]};
+        const float zc = v[0] * cam.forward[0] + v[1] * cam.forward[1] + v[2] * cam.forward[2];
+        if (!(zc > 1e-6f)) return;
+        const float xc = v[0] * cam.right[0] + v[1] * cam.right[1] + v[2] * cam.right[2];
+        const float yc = v[0] * cam.up[0] + v[1] * cam.up[1] + v[2] * cam.up[2];
+        const float px = (xc / (zc * cam.aspect * cam.tan_half_fovy) + 1.0f) * 0.5f * (float)ag.width;
+        const float py = (1.0f - yc / (zc * cam.tan_half_fovy)) * 0.5f * (float)ag.height - (float)ag.y0;
+        if (!(px == px) || !(py == py)) return;
+        x_lo = fminf(x_lo, px), x_hi = fmaxf(x_hi, px), y_lo = fminf(y_lo, py), y_hi = fmaxf(y_hi, py);
+    }
+    const float edge = (float)(16u << ag.group_shift), gxs = (float)ag.groups_x, gys = (float)groups_y;
+    const float fx0 = fminf(fmaxf(floorf((x_lo - 1.0f) / edge), 0.0f), gxs), fx1 = fminf(fmaxf(floorf((x_hi + 1.0f) / edge) + 1.0f, 0.0f), gxs);
+    const float fy0 = fminf(fmaxf(floorf((y_lo - 1.0f) / edge), 0.0f), gys), fy1 = fminf(fmaxf(floorf((y_hi + 1.0f) / edge) + 1.0f, 0.0f), gys);
+    if (!(fx1 > fx0) || !(fy1 > fy0)) return;  // the box is off screen
+    ag.first_gx0 = (uint32_t)fx0, ag.first_gy0 = (uint32_t)fy0;
+    ag.first_w = (uint32_t)(fx1 - fx0), ag.first_h = (uint32_t)(fy1 - fy0);
+    if (ag.first_w == ag.groups_x && ag.first_h == groups_y) {
+        ag.first_w = 0;  // covers the image: plain order
+        return;
+    }
+    auto magic = [](uint32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + d - 1) / d); };  // d == 1: the kernel does not divide
+    ag.m_groups_x = magic(ag.groups_x), ag.m_first_w = magic(ag.first_w), ag.m_rest_w = magic(ag.groups_x - ag.first_w);
+}
+
 hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream) {
     const uint32_t rows = a.y1 - a.y0;
     if (a.width == 0 || rows == 0 || a.n_cameras == 0) return hipSuccess;
     dim3 grid((a.width + 15) / 16, (rows + 15) / 16, a.n_cameras);
     RaymarchArgs ag = a;
-    if (a.group_shift) {
+    // kGroupAuto (one camera): groups of 2 x 2 tiles with the box-first order where the bounding box projects to a proper
+    // part of the image, otherwise (camera inside the box, box filling the image, order switched off) groups of 4 x 4
+    for (uint32_t shift : {a.group_shift == kGroupAuto ? 1u : a.group_shift, 2u}) {
+        if (shift == 0) break;
+        ag.group_shift = shift;
         ag.tiles_x = grid.x;
         ag.tiles_y = grid.y;
-        ag.groups_x = (grid.x + (1u << a.group_shift) - 1) >> a.group_shift;
-        const uint32_t groups_y = (grid.y + (1u << a.group_shift) - 1) >> a.group_shift;
+        ag.groups_x = (grid.x + (1u << shift) - 1) >> shift;
+        const uint32_t groups_y = (grid.y + (1u << shift) - 1) >> shift;
         const uint32_t groups = ((ag.groups_x * groups_y + 7u) / 8u) * 8u;
-        grid = dim3(groups << (2 * a.group_shift), 1, a.n_cameras);
+        ag.first_w = 0;
+        if (a.box_first && a.n_cameras == 1 && ag.groups_x < 65536u && groups_y < 65536u && groups < 65536u)
+            box_first_rectangle(ag, groups_y);
+        if (a.group_shift != kGroupAuto || ag.first_w != 0 || shift == 2u) {
+            grid = dim3(groups << (2 * shift), 1, a.n_cameras);
+            break;
+        }
     }
     return launch_raymarch_grid(ag, grid, stream);
 }

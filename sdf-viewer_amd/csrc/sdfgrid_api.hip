@@ -384,6 +384,10 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             if (value > 5) break;
             g_options.raymarch_tile_group = (uint32_t)value;
             return SDFV_OK;
+        case SDFV_OPT_RAYMARCH_BOX_FIRST:
+            if (value > 1) break;
+            g_options.raymarch_box_first = (uint32_t)value;
+            return SDFV_OK;
         case SDFV_OPT_SLAB_STEP_FORM: {
             const uint64_t form = value & ~(uint64_t)(SDFV_STEP_UNPACKED | SDFV_STEP_START_EVENT);
             if (form != 0 && form != SDFV_STEP_TWO_LAUNCH && form != SDFV_STEP_ONE_LAUNCH && form != SDFV_STEP_SIDE_BOUNDARY) break;
@@ -412,6 +416,7 @@ int sdfv_get_option(uint32_t option, uint64_t* value) {
         case SDFV_OPT_RAYMARCH_KEEP_NORMAL: *value = g_options.raymarch_keep_normal; return SDFV_OK;
         case SDFV_OPT_SLAB_STEP_FORM: *value = g_options.slab_step_form; return SDFV_OK;
         case SDFV_OPT_RAYMARCH_TILE_GROUP: *value = g_options.raymarch_tile_group; return SDFV_OK;
+        case SDFV_OPT_RAYMARCH_BOX_FIRST: *value = g_options.raymarch_box_first; return SDFV_OK;
         case SDFV_OPT_TUNING_WAVE_TIMING: *value = g_options.wave_timing; return SDFV_OK;
         default: return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown option %u", option);
     }
@@ -833,9 +838,11 @@ int sdfv_raymarch_depth(const sdfv_render_params* rp, const float* tex0, const f
     // aux record asks for it; SDFV_OPT_RAYMARCH_KEEP_NORMAL evaluates it per hit regardless (what it would cost once a
     // directional light uses it).
     a.compute_normal = g_options.raymarch_keep_normal ? 1u : 0u;
-    // tile order: auto = XCD-aware groups of 4 x 4 tiles (64 x 64 pixels) for a single frame -- 5 % shorter at both bench
-    // sizes (tools/tile_group_bench.py) -- and launch order for batches of cameras, which lose 3-8 % with any grouping
-    a.group_shift = g_options.raymarch_tile_group == 0 ? (n_cameras == 1 ? 2u : 0u)
+    // tile order: auto = for a single frame the launcher's XCD-aware choice (groups of 2 x 2 tiles, those under the projected
+    // bounding box first; tools/box_first_bench.py, tools/tile_group_bench.py), launch order for batches of cameras, which
+    // lose 3-8 % with any grouping
+    a.box_first = g_options.raymarch_box_first;
+    a.group_shift = g_options.raymarch_tile_group == 0 ? (n_cameras == 1 ? sdfv::kGroupAuto : 0u)
                                                        : (g_options.raymarch_tile_group == 1 ? 0u : g_options.raymarch_tile_group - 1u);
 #ifdef SDFV_TUNING
     a.wave_timing = reinterpret_cast<unsigned long long*>(g_options.wave_timing);  // 32 B per wave, or 0

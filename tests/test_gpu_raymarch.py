@@ -323,6 +323,39 @@ def test_every_tile_order_renders_the_same_image(pkg, size):
             assert torch.equal(a, b), order
 
 
+@pytest.mark.parametrize("size", [(160, 120), (333, 217), (640, 480), (70, 900), (1920, 1080)])
+def test_box_first_order_covers_every_tile_once(pkg, size):
+    """SDFV_OPT_RAYMARCH_BOX_FIRST reorders the groups of tiles (projected bounding box first): for cameras that see the
+    box anywhere -- centred, cut by each image edge, tiny, filling the image, behind the camera, from inside -- the image
+    written over a sentinel equals the launch-order image bit for bit (every tile rendered, none twice with other
+    results, padding groups silent)."""
+    W, H = size
+    g = pkg.make_grid((32, 32, 32))
+    t0, t1 = pkg.alloc_textures(g)
+    pkg.fill_grid(pkg.default_params(), g, t0, t1)
+    rp = pkg.default_render_params(g)
+    K = pkg._capi
+    views = [dict(), dict(eye=(2.5, 3.0, 5.0), target=(3.0, 0.0, 0.0)), dict(eye=(2.5, 3.0, 5.0), target=(-3.0, 0.0, 0.0)),
+             dict(eye=(2.5, 3.0, 5.0), target=(0.0, 3.0, 0.0)), dict(eye=(2.5, 3.0, 5.0), target=(0.0, -3.5, 0.0)),
+             dict(eye=(25.0, 30.0, 50.0)), dict(eye=(0.9, 1.2, 1.7)), dict(eye=(0.2, 0.1, 0.3), target=(1.0, 0.0, 0.0)),
+             dict(eye=(2.5, 3.0, 5.0), target=(5.0, 6.0, 10.0)), dict(eye=(0.0, 0.0, 4.0), fovy_degrees=100.0),
+             dict(eye=(4.0, 0.0, 0.1), target=(0.0, 0.0, 3.0), fovy_degrees=20.0)]
+    for kw in views:
+        cam = pkg.camera_look_at(aspect=W / H, **kw)
+        with pkg.options({K.OPT_RAYMARCH_TILE_GROUP: 1}):
+            ref = pkg.raymarch(rp, t0, t1, cam, W, H)
+        for group in (0, 2, 3, 4):
+            for rows in ((0, H), (H // 3, 2 * H // 3 + 1)):
+                out = torch.full((1, rows[1] - rows[0], W, 4), float("nan"), dtype=torch.float32, device="cuda")
+                with pkg.options({K.OPT_RAYMARCH_TILE_GROUP: group, K.OPT_RAYMARCH_BOX_FIRST: 1}):
+                    pkg.raymarch(rp, t0, t1, cam, W, H, y0=rows[0], y1=rows[1], out=out)
+                assert torch.equal(out.view(torch.int32), ref[:, rows[0]:rows[1]].view(torch.int32)), (kw, group, rows)
+        out = torch.full((1, H, W, 4), float("nan"), dtype=torch.float32, device="cuda")
+        with pkg.options({K.OPT_RAYMARCH_BOX_FIRST: 0}):
+            pkg.raymarch(rp, t0, t1, cam, W, H, out=out)
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), kw
+
+
 def test_row_bands_of_the_image_tile_split_tile_the_frame(pkg):
     """parallel.split_rows (config 5's image-tile split): the bands rendered by the "ranks" concatenate to the frame."""
     import importlib

@@ -17,6 +17,8 @@ import torch  # noqa: E402
 pkg = importlib.import_module("sdf-viewer_amd")
 K = pkg._capi
 side, W, H = 256, 1920, 1080
+if "--side" in sys.argv:
+    side = int(sys.argv[sys.argv.index("--side") + 1])
 prm = pkg.default_params()
 g = pkg.make_grid((side,) * 3)
 t0, t1 = pkg.alloc_textures(g)
@@ -40,13 +42,19 @@ d = buf.cpu().numpy()
 start, end, it = d[:, 0], d[:, 1], d[:, 2] & 0xffff
 fetch_it = (d[:, 2] >> 16) & 0xffff  # hand-written loop, tuning build: iterations in which some lane entered a new cell
 setup_cyc, loop_cyc = d[:, 3] & 0xffffffff, (d[:, 3] >> 32) & 0xffffffff  # active waves only (culled ones store 0)
-t00 = start.min()
 dur = end - start
+# the cycle counters are per XCD: where a wave lies inside the launch comes from the device-wide 100 MHz counter
+# (16 bits of it at the wave's start and end, 10 ns ticks), relative to the earliest start
+rt0, rt1 = (d[:, 2] >> 32) & 0xffff, (d[:, 2] >> 48) & 0xffff
+rel = lambda t: ((t - rt0[0] + 0x8000) & 0xffff) - 0x8000  # signed distance to wave 0's start
+first = rel(rt0).min()
+start_us, end_us = (rel(rt0) - first) * 0.01, (rel(rt1) - first) * 0.01
+t00 = start.min()
 act = it > 0
 cpi = dur[act] / it[act]
 order = np.argsort(-dur)[:10]
 summary = {
-    "kernel_ms": a.elapsed_time(b), "span_cycles": int(end.max() - t00), "waves": int(n_waves),
+    "kernel_ms": a.elapsed_time(b), "waves": int(n_waves),
     "active_waves": int(act.sum()), "iterations_max": int(it.max()), "iterations_mean_active": float(it[act].mean()),
     "wave_cycles_idle_median": float(np.median(dur[~act])), "wave_cycles_active_median": float(np.median(dur[act])),
     "wave_cycles_max": int(dur.max()),
@@ -62,14 +70,15 @@ summary = {
     "fetch_block_iterations_fraction_active": float(fetch_it[act].sum() / max(it[act].sum(), 1)),
     "longest_waves": [{"wave": int(i), "iterations": int(it[i]), "fetch_block_iterations": int(fetch_it[i]), "cycles": int(dur[i]),
                        "cycles_per_iteration": float(dur[i] / max(it[i], 1)), "setup": int(setup_cyc[i]), "loop": int(loop_cyc[i]),
-                       "after_loop": int(dur[i] - setup_cyc[i] - loop_cyc[i]), "start": int(start[i] - t00),
-                       "end": int(end[i] - t00)} for i in order],
+                       "after_loop": int(dur[i] - setup_cyc[i] - loop_cyc[i]), "start_us": float(start_us[i]),
+                       "end_us": float(end_us[i])} for i in order],
     "hist_iterations": {"edges": [0, 1, 8, 16, 32, 64, 128, 192, 255, 256],
                         "counts": np.histogram(it, bins=[0, 1, 8, 16, 32, 64, 128, 192, 255, 256])[0].tolist()},
     "hist_wave_kcycles": {"edges": [0, 2, 5, 10, 20, 50, 100, 150, 200, 300, 1000],
                           "counts": np.histogram(dur / 1e3, bins=[0, 2, 5, 10, 20, 50, 100, 150, 200, 300, 1000])[0].tolist()},
-    "waves_started_by_fraction_of_span": {str(f): float(np.mean((start - t00) < f * (end.max() - t00)))
-                                          for f in (0.25, 0.5, 0.75)},
+    "launch_us": {"span_first_start_to_last_end": float(end_us.max()), "last_wave_start": float(start_us.max()),
+                  "last_active_wave_start": float(start_us[act].max()),
+                  "active_wave_start_percentiles_10_50_90": [float(v) for v in np.percentile(start_us[act], [10, 50, 90])]},
     "config": {"grid": side, "image": [W, H], "dist_volume": dist is not None},
 }
 # least-squares model of an active wave: cycles = K + C * iterations + F * (iterations that ran the fetch block)
@@ -82,6 +91,8 @@ if fetch_it[act].sum() > 0:
     summary["wave_cycle_model"] = {"form": "cycles = K + C * iterations + F * fetch_block_iterations",
                                    "all_active_waves": {"K": float(coef[0]), "C": float(coef[1]), "F": float(coef[2]), "n": int(act.sum())},
                                    "waves_with_64_or_more_iterations": {"K": float(coef2[0]), "C": float(coef2[1]), "F": float(coef2[2]), "n": int(long.sum())}}
+if "--raw" in sys.argv:  # start, end (XCD-relative), iterations, fetch iterations, set-up and loop cycles per wave
+    np.save(sys.argv[sys.argv.index("--raw") + 1], np.stack([start_us, end_us, dur, it, fetch_it, setup_cyc, loop_cyc], axis=1))
 print(json.dumps(summary, indent=1))
 if "--json" in sys.argv:
     with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
