@@ -74,6 +74,8 @@ def parse_args():
                     help="N>1, 64-camera batch: deal whole cameras to the ranks (default) or give every rank a band of "
                          "rows of every camera (BASELINE.json config 5's image-tile split)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--no-overlapped", action="store_true",
+                    help="N=1: skip the double-buffered (fill of step k+1 beside the march of step k) measurement")
     ap.add_argument("--pipeline", choices=["both", "plain", "fused"], default="both",
                     help="N=1: time both pipelines and report the faster one (default), or only one (profiling runs: "
                          "per-kernel rocprof averages then belong to one kernel variant)")
@@ -375,8 +377,14 @@ def run(redirect):
     local_rank = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # SDFV_BENCH_FORCE_MULTI=1 with WORLD_SIZE 1 (one-GPU test boxes): the N > 1 code path under the REAL backend -- torch's
+    # RCCL process group and the library's own RCCL communicator in one process, the rank its own z-neighbour (periodic
+    # world of 1), every collective of the self-checks on device tensors.  Reported with "loopback": true; never a result.
+    loopback = world == 1 and os.environ.get("SDFV_BENCH_FORCE_MULTI") == "1"
+    multi = world > 1 or loopback
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             # device_id = eager communicator creation, and one collective on an uninitialised buffer to be sure: the
             # process's first RCCL communicator has to exist BEFORE the fill stream launches its first kernel (a
@@ -385,7 +393,7 @@ def run(redirect):
             dist.all_reduce(torch.empty(1, device=device))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    cdev = device if (world > 1 and backend == "nccl") else "cpu"  # where small agreement tensors live
+    cdev = device if (multi and backend == "nccl") else "cpu"  # where small agreement tensors live
 
     wl = WORKLOADS[args.workload]
     side, W, H = wl["side"], wl["width"], wl["height"]
@@ -398,17 +406,17 @@ def run(redirect):
         call per step); should any rank fail to create or use one, EVERY rank falls back to torch.distributed P2P."""
         transport = args.halo_transport
         if transport == "auto":
-            transport = "rccl" if (world > 1 and backend == "nccl") else "torch"
+            transport = "rccl" if (multi and backend == "nccl") else "torch"
         filler = None
         if transport == "rccl":
             try:
-                filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="rccl", dist=slab_dist)
+                filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="rccl", dist=slab_dist, periodic=loopback)
                 filler.step()  # a first step, so that a communicator that cannot exchange shows up here, not mid-run
                 torch.cuda.synchronize()
             except Exception as e:  # noqa: BLE001 -- reported, then decided collectively below
                 filler = None
                 print(f"[bench rank {rank}] library communicator unavailable: {e}", file=sys.stderr, flush=True)
-            if world > 1:
+            if multi:
                 ok = torch.tensor([1 if filler is not None else 0], device=cdev)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if int(ok.item()) == 0:
@@ -417,19 +425,19 @@ def run(redirect):
                     filler = None
         if filler is None:
             transport = "torch"
-            filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="torch", dist=slab_dist)
+            filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="torch", dist=slab_dist, periodic=loopback)
         return filler, transport
 
     # ---------------- the grid: side^3 voxels per rank, z-slab of the weak-scaled global grid ----------------
     gdims = par.weak_scaling_dims(side, world, args.weak_geometry)
-    slab = par.alloc_slab(gdims, rank, world, device, pkg=None if args.no_tuned_placement else pkg)
+    slab = par.alloc_slab(gdims, rank, world, device, pkg=None if args.no_tuned_placement else pkg, periodic=loopback)
     grid = pkg.make_grid(gdims, z_begin=slab.z_begin, z_end=slab.z_end)
     owned0, owned1 = slab.owned0, slab.owned1
     voxels_per_rank = pkg.slab_voxels(grid)
     total_voxels = voxels_per_rank * world  # identical per rank by construction
 
     out = {}
-    if world == 1:
+    if not multi:
         # ---------------- N = 1: two CONSISTENT pipelines over the SAME buffers ----------------
         #   plain: sdfv_fill_grid (32 B/voxel)         -> sdfv_raymarch over tex0.r in place
         #   fused: sdfv_fill_grid_commit (36 B/voxel)  -> sdfv_raymarch_accel over the compact distance volume it wrote
@@ -461,6 +469,41 @@ def run(redirect):
             march_dist_ms, march_dist_ev = region(lambda: pkg.raymarch(rp, owned0, owned1, cam0, W, H, out=rgba, dist=dist_vol),
                                                   K, Wm, torch, dist, 1, device)
             inter_fused_ms = both({"dist": dist_vol}, {"dist": dist_vol})
+        # The fused pipeline software-pipelined over TWO sets of buffers and two streams: the march of step k (latency-bound on
+        # a few long waves, most of the machine idle) runs beside the fill of step k + 1 (HBM-store-bound) -- what the
+        # reference's own frame loop does on one thread in turns (scene/mod.rs:166-200: fill passes and the render of the
+        # state so far alternate within a frame).  Every step still fills a whole grid and marches a whole frame over the grid
+        # ITS fill wrote; nothing is skipped.  Reported beside the sequential pipelines, never as `value`.
+        overlapped = None
+        if args.pipeline in ("both", "fused") and not args.no_overlapped:
+            b0, b1 = torch.empty_like(owned0), torch.empty_like(owned1)
+            bd = torch.empty_like(dist_vol)
+            sets = [(owned0, owned1, dist_vol), (b0, b1, bd)]
+            s_fill, s_march = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device, priority=-1)
+            filled = [torch.cuda.Event(), torch.cuda.Event()]
+            marched = [torch.cuda.Event(), torch.cuda.Event()]
+            state = {"k": 0}
+
+            def overlapped_step():
+                k = state["k"]
+                state["k"] = k + 1
+                t0b, t1b, db = sets[k & 1]
+                if k >= 2:
+                    s_fill.wait_event(marched[k & 1])  # the march of step k - 2 has finished reading this set
+                pkg.fill_grid(prm, grid, t0b, t1b, dist=db, stream=s_fill)
+                filled[k & 1].record(s_fill)
+                s_march.wait_event(filled[k & 1])
+                pkg.raymarch(rp, t0b, t1b, cam0, W, H, out=rgba, dist=db, stream=s_march)
+                marched[k & 1].record(s_march)
+
+            ov_ms = region(overlapped_step, K, Wm, torch, dist, 1, device)[0]
+            torch.cuda.synchronize()
+            same = bool(torch.equal(b0.view(torch.int32), owned0.view(torch.int32)) and torch.equal(bd.view(torch.int32), dist_vol.view(torch.int32)))
+            overlapped = {"ms_per_step": round(ov_ms, 4), "Mvoxels_s": round(voxels_per_rank / ov_ms / 1e3, 1),
+                          "Mrays_s": round(W * H / ov_ms / 1e3, 1), "buffer_sets": 2, "both_sets_identical": same,
+                          "what": "fused pipeline, double-buffered: march of step k on one stream beside the fill of step k + 1 "
+                                  "on another; K full fills + K full frames per K steps; not used for value / ms_per_step"}
+            del b0, b1, bd
         # the separate device-side commit (what a caller pays who filled without the volume and wants it afterwards)
         commit_ms = INF
         if args.pipeline == "both":
@@ -493,6 +536,7 @@ def run(redirect):
         out["pipeline_note"] = ("two consistent pipelines over the same buffers; value, value_rays, ms_per_step and "
                                 "roofline all come from `pipeline` (the faster one end to end); *_interleaved = K steps "
                                 "of fill immediately followed by its march in one timed region")
+        out["pipeline_overlapped"] = overlapped
         out["commit_ms"] = round(commit_ms, 4) if commit_ms != INF else None
         out["commit_note"] = ("sdfv_commit_distance as a pass of its own (device-side SDFViewer::commit for a grid filled "
                               "without the volume); not part of either pipeline")
@@ -538,7 +582,7 @@ def run(redirect):
     # ---------------- N = 1 extras ----------------
     target_512 = None
     halo_loopback = None
-    if world == 1 and not args.no_batch:
+    if not multi and not args.no_batch:
         # the north-star target configuration (>= 70 % of the HBM roofline on the 512^3 fill), whatever --workload is
         if not args.no_target_512:
             try:
@@ -591,7 +635,7 @@ def run(redirect):
     n_batch = 64
     batch_report = None
     if not args.no_batch:
-        if world == 1:
+        if not multi:
             pkg.fill_grid(prm, grid, owned0, owned1, dist=dist_vol)  # the volume of the grid being marched
         batch_cams = pkg.orbit_cameras(n_batch, aspect=W / H)
         if args.batch_split == "rows":
@@ -619,19 +663,19 @@ def run(redirect):
     config4 = None
     verified = None
     sharded_march = None
-    if world > 1:
+    if multi:
         if not args.no_config4:
             # cube geometry at --config4-side^3 voxels per rank: 8 ranks x 512^3 = config 4's 1024^3 (1024 x 1024 slices,
             # 33.5 MB per halo message pair and direction against a 128-slice slab)
             try:
                 cside = args.config4_side
                 cdims = par.weak_scaling_dims(cside, world, "cube")
-                cslab = par.alloc_slab(cdims, rank, world, device, pkg=None if args.no_tuned_placement else pkg)
+                cslab = par.alloc_slab(cdims, rank, world, device, pkg=None if args.no_tuned_placement else pkg, periodic=loopback)
                 cgrid = pkg.make_grid(cdims, z_begin=cslab.z_begin, z_end=cslab.z_end)
                 cdist = torch.empty(tuple(cslab.tex0.shape[:3]), dtype=torch.float32, device=device)
                 c_own = cdist[cslab.ghost_lo:cslab.ghost_lo + (cslab.z_end - cslab.z_begin)]
                 cfiller = par.SlabFiller(pkg, prm, cdims, cslab, rank, world, transport=transport,
-                                         comm=filler.comm, dist=cdist)  # the same communicator serves this slab too
+                                         comm=filler.comm, dist=cdist, periodic=loopback)  # the same communicator serves this slab too
                 cs = max(3, min(K, 10))
                 c_ms, _ = region(cfiller.step, cs, 2, torch, dist, world, device)
                 _, c_kern = region(lambda: pkg.fill_grid(prm, cgrid, cslab.owned0, cslab.owned1, dist=c_own), cs, 1, torch,
@@ -658,9 +702,14 @@ def run(redirect):
                 pkg.fill_grid(prm, pkg.make_grid(gdims), chk0, chk1)
                 torch.cuda.synchronize()
                 ok = torch.equal(full0, chk0) and torch.equal(full1, chk1)
-                lo, hi = slab.z_begin - slab.ghost_lo, slab.z_end + slab.ghost_hi
-                ok = ok and torch.equal(slab.tex0, chk0[lo:hi]) and torch.equal(slab.tex1, chk1[lo:hi])
-                ok = ok and torch.equal(slab_dist, chk0[lo:hi, ..., 0])  # the distance volume the step wrote, ghosts included
+                if loopback:  # periodic world of 1: the ghosts hold the grid's last and first slice
+                    want0, want1 = torch.cat([chk0[-1:], chk0, chk0[:1]]), torch.cat([chk1[-1:], chk1, chk1[:1]])
+                else:
+                    lo, hi = slab.z_begin - slab.ghost_lo, slab.z_end + slab.ghost_hi
+                    want0, want1 = chk0[lo:hi], chk1[lo:hi]
+                ok = ok and torch.equal(slab.tex0, want0) and torch.equal(slab.tex1, want1)
+                ok = ok and torch.equal(slab_dist, want0[..., 0])  # the distance volume the step wrote, ghosts included
+                del want0, want1
                 flag = torch.tensor([1.0 if ok else 0.0], device=cdev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 verified = bool(flag.item() == 1.0)
@@ -668,6 +717,8 @@ def run(redirect):
                 # the consumer of the halo: raymarch the grid where it lies (sharded, rays handed between ranks)
                 # and compare with a march over the whole grid, bit for bit
                 try:
+                    if loopback:
+                        raise RuntimeError("skipped: the loopback slab is periodic, the sharded march is not")
                     ggrid = pkg.make_grid(gdims)
                     grp = pkg.default_render_params(ggrid)
                     sw, sh = 320, 180
@@ -716,12 +767,13 @@ def run(redirect):
             "data": "synthetic (demo SDF defaults on the integer lattice, fixed cameras; no RNG)",
             "sharded_fill_verified": verified,
             "sharded_march": sharded_march,
-            "backend": None if world == 1 else ("rccl" if backend == "nccl" else backend + " (test only)"),
-            "halo_transport": None if world == 1 else {"rccl": "sdfv_slab_fill_step (library RCCL communicator)",
+            "loopback": True if loopback else None,
+            "backend": None if not multi else ("rccl" if backend == "nccl" else backend + " (test only)"),
+            "halo_transport": None if not multi else {"rccl": "sdfv_slab_fill_step (library RCCL communicator)",
                                                        "torch": "torch.distributed batch_isend_irecv"}[transport],
             "config": {"workload": wl["name"], "grid_global": list(gdims), "voxels_per_gpu": voxels_per_rank,
                        "image": [W, H], "cameras_per_gpu": len(my_cams),
-                       "weak_geometry": None if world == 1 else args.weak_geometry,
+                       "weak_geometry": None if not multi else args.weak_geometry,
                        "parallelism": "single GPU" if world == 1 else f"z-slab x{world} + 1-voxel RCCL halo; 1 camera/GPU"},
         }
         line.update(out)
@@ -730,11 +782,11 @@ def run(redirect):
         line["target_512"] = target_512
         line["halo_loopback"] = halo_loopback
         line["config4"] = config4
-        if not args.no_cpu_baseline and world == 1:  # rank 0, N = 1 only
+        if not args.no_cpu_baseline and not multi:  # rank 0, N = 1 only
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_seconds)
         redirect.restore()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         if getattr(filler, "comm", None) is not None:
             torch.cuda.synchronize()
             filler.comm.close()  # the library's RCCL communicator, while every peer is still alive

@@ -68,6 +68,26 @@ def test_bench_line_carries_the_whole_contract():
     assert "note" in rr and rr["avg_launch_ms"] > 0
 
 
+def test_bench_multi_gpu_path_over_rccl_in_loopback():
+    """The N > 1 path under the backend the driver uses (nccl = RCCL), as far as one GPU can take it: world size 1 with
+    SDFV_BENCH_FORCE_MULTI=1 -- torch's RCCL process group AND the library's own RCCL communicator in one process, the rank
+    its own z-neighbour, the fused slab step, config 4's geometry on the same communicator, the collectives of the
+    self-checks on device tensors.  (Two ranks on one device are refused by RCCL: test below.)"""
+    env = dict(os.environ, SDFV_BENCH_FORCE_MULTI="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200),
+               WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "64",
+           "--no-cpu-baseline", "--config4-side", "32", "--prewarm-ms", "5"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["loopback"] is True and d["backend"] == "rccl" and d["n_gpus"] == 1
+    assert d["halo_transport"].startswith("sdfv_slab_fill_step"), (d["halo_transport"], out.stderr[-1500:])
+    assert d["sharded_fill_verified"] is True, (d["sharded_fill_verified"], out.stderr[-1500:])
+    assert d["value"] > 0 and d["value_rays"] > 0 and d["pipeline"] == "fused"
+    assert d["config4"]["value"] > 0, d["config4"]
+    assert "skipped" in str(d["sharded_march"]["verified"])  # a periodic slab; the gloo runs above cover the sharded march
+
+
 def test_two_processes_on_one_gpu_over_the_library_rccl_communicator():
     """two ranks, one device, RCCL (no loopback wrap, no gloo).  RCCL either accepts two ranks on the
     same GPU -- then the fill step's ghosts must equal the neighbour's slices -- or refuses; the refusal is then a

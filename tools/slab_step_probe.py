@@ -66,6 +66,31 @@ def main():
         pkg.fill_grid(prm, grid, slab.owned0, slab.owned1, dist=own_dist)
 
     out = {"steps": steps, "one_launch_capable": comm.one_launch_capable}
+    if "--graph" in sys.argv:
+        # the event form of the step (fork / join by events: capturable) recorded into a HIP graph and
+        # replayed, against the same form enqueued call by call
+        form = K.STEP_SIDE_BOUNDARY | K.STEP_START_EVENT
+        s = torch.cuda.Stream()
+        res = {}
+        with pkg.options({K.OPT_SLAB_STEP_FORM: form}):
+            with torch.cuda.stream(s):
+                res["eager_event_form_ms"] = round(run(lambda: comm.fill_step(prm, grid, slab, dist=dist, stream=s), steps), 4)
+                slab.tex0[0].fill_(-1.0)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(g, stream=s, capture_error_mode="relaxed"):
+                        comm.fill_step(prm, grid, slab, dist=dist, stream=s)
+                    res["graph_ms"] = round(run(g.replay, steps), 4)
+                    res["graph_ghosts_ok"] = ghosts_ok() and bool(torch.equal(dist, slab.tex0[..., 0]))
+                except Exception as e:  # noqa: BLE001
+                    res["graph_error"] = f"{type(e).__name__}: {e}"[:400]
+        res["eager_default_form_ms"] = round(run(step_fused, steps), 4)
+        res["fused_fill_alone_ms"] = round(run(plain_fused, steps), 4)
+        out["graph"] = res
+        comm.close()
+        print(json.dumps(out), flush=True)
+        return
     if "--forms" in sys.argv:
         forms = {"two_launch_unpacked": K.STEP_TWO_LAUNCH | K.STEP_UNPACKED, "two_launch": K.STEP_TWO_LAUNCH,
                  "side_boundary": K.STEP_SIDE_BOUNDARY, "side_boundary_event": K.STEP_SIDE_BOUNDARY | K.STEP_START_EVENT,
