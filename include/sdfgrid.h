@@ -159,6 +159,7 @@ typedef enum sdfv_option {
 #define SDFV_RM_NO_POW2_SIZE   4u /* no fused (1/size)*N scale */
 #define SDFV_RM_NO_SYMMETRIC   8u /* max(min - p, p - max) instead of |p| - max */
 #define SDFV_RM_NO_ASM_LOOP   16u /* the compiler's march loop instead of the hand-written gfx950 one */
+#define SDFV_RM_NO_INTERIOR_FETCH 32u /* hand-written loop: always the clamping cell fetch, never the interior fast path */
 #define SDFV_STEP_TWO_LAUNCH   1u /* boundary slices in a launch of their own, then the interior */
 #define SDFV_STEP_ONE_LAUNCH   2u /* one dense launch whose first workgroups fill the boundary slices and signal */
 #define SDFV_STEP_SIDE_BOUNDARY 3u /* the caller's stream runs the plain dense fill of the whole slab; the communicator's

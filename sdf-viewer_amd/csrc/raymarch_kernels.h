@@ -34,6 +34,7 @@ struct RaymarchArgs {
     // m_* = ceil(2^32 / d): n / d == mulhi(n, m) for n, d < 2^16
     uint32_t box_first;          // option: use that order (default 1)
     uint32_t first_gx0, first_gy0, first_w, first_h, m_groups_x, m_first_w, m_rest_w;
+    uint32_t no_interior_fetch;  // hand-written loop: always take the clamping fetch block (tests, A/B)
     uint32_t cube_box;           // symmetric box with bounds_max[0] == [1] == [2]: two-instruction out-of-bounds test
     float4* rgba;                // n_cameras x (y1-y0) x width
     sdfv_march_aux* aux;         // same layout or nullptr

@@ -294,7 +294,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 #else
 #define SDFV_MARCH_ASM_TUNE(x) ""
 #endif
-#define SDFV_MARCH_ASM_HEAD                                                                                         \
+#define SDFV_MARCH_ASM_HEAD(ROW_SHIFT)                                                                                         \
     "s_mov_b64 s[76:77], exec\n"                                                                                    \
     "s_and_b64 exec, exec, %[cov]\n"                                                                                \
     "s_cbranch_execz .Ldone_%=\n"                                                                                   \
@@ -306,6 +306,15 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "s_add_i32 s75, %[wm1], -1\n"                            /* W - 2 */                                             \
     "s_add_i32 s82, %[lgw], 2\n s_add_i32 s83, %[lgw], 4\n"  /* log2(W) + 2 / + 4: row -> byte offset shifts */      \
     "s_movk_i32 s74, 254\n"                                  /* 255 iterations */                                    \
+    /* interior cells (all eight corners inside the volume, no clamp): the four corner rows are one offset against four  \
+     * bases -- b00 = base, b10 = base + a row, b01 = base + a slice, b11 = both (row shift: s82 for the distance volume, \
+     * s83 for tex0) */                                                                                              \
+    "s_lshl_b32 s64, 1, " ROW_SHIFT "\n"                                                                              \
+    "s_add_i32 s86, %[lgh], " ROW_SHIFT "\n"                                                                          \
+    "s_lshl_b32 s86, 1, s86\n"                                                                                      \
+    "s_add_u32 s68, %[base_lo], s86\n s_addc_u32 s69, %[base_hi], 0\n"   /* b01 */                                   \
+    "s_add_u32 s64, %[base_lo], s64\n s_addc_u32 s65, %[base_hi], 0\n"   /* b10 */                                   \
+    "s_add_u32 s86, s64, s86\n s_addc_u32 s87, s65, 0\n"                 /* b11 */                                   \
     SDFV_MARCH_ASM_TUNE("s_mov_b32 s84, 0\n")                /* tuning build: iterations that ran the fetch block */  \
     "v_mov_b32 v84, 0x7f800000\n v_mov_b32 v86, 0x7f800000\n v_mov_b32 v87, 0x7f800000\n" /* no cell cached */    \
     ".Lloop_%=:\n"
@@ -321,7 +330,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 #define SDFV_MARCH_ASM_OOB4_D "v_max3_f32 v48, v48, v49, v50\n"
 #define SDFV_MARCH_ASM_OOB2_A "v_max3_f32 v48, |v56|, |v58|, |v59|\n"
 #define SDFV_MARCH_ASM_OOB2_D "v_subrev_f32_e32 v48, %[mx], v48\n"
-#define SDFV_MARCH_ASM_TOP(T_STEP, OOB_A, OOB_B, OOB_C, OOB_D)                                                      \
+#define SDFV_MARCH_ASM_TOP(T_STEP, INTERIOR, OOB_A, OOB_B, OOB_C, OOB_D)                                                      \
     OOB_A                                                                                                           \
     "v_subrev_f32_e32 v64, %[minx], v56\n"                                                                          \
     OOB_B                                                                                                           \
@@ -346,6 +355,15 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "v_floor_f32_e32 v84, v64\n v_floor_f32_e32 v86, v66\n v_floor_f32_e32 v87, v67\n"                         \
     "v_cvt_i32_f32_e32 v48, v84\n v_cvt_i32_f32_e32 v49, v86\n v_cvt_i32_f32_e32 v50, v87\n"                      \
     "v_sub_f32_e32 v68, v64, v84\n v_sub_f32_e32 v70, v66, v86\n v_sub_f32_e32 v72, v67, v87\n"             \
+    /* every fetching lane's cell inside the volume (cubic volumes: 0 <= i0, j0, k0 <= N - 2, one unsigned compare)? */ \
+    "v_max3_u32 v51, v48, v49, v50\n"                                                                               \
+    "v_cmp_gt_u32_e32 vcc, %[thresh], v51\n"                                                                        \
+    "s_xor_b64 vcc, vcc, exec\n"                                                                                    \
+    "s_cbranch_scc1 .Lborder_%=\n"                                                                                  \
+    "v_lshl_add_u32 v55, v50, %[lgh], v49\n"                                                                        \
+    "v_lshl_add_u32 v55, v55, %[lgw], v48\n" INTERIOR                                                               \
+    "s_branch .Lcached_%=\n"                                                                                        \
+    ".Lborder_%=:\n"                                                                                                \
     "v_max_i32_e32 v51, 0, v48\n v_max_i32_e32 v53, 0, v49\n v_max_i32_e32 v54, 0, v50\n"  /* i0c, j0c, k0c */       \
     "v_add_u32_e32 v48, 1, v48\n v_add_u32_e32 v49, 1, v49\n v_add_u32_e32 v50, 1, v50\n"                            \
     "v_min_i32_e32 v48, %[wm1], v48\n v_min_i32_e32 v49, %[hm1], v49\n v_min_i32_e32 v50, %[dm1], v50\n" /* i1c.. */  \
@@ -353,6 +371,26 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "v_lshl_add_u32 v45, v54, %[lgh], v49\n"                 /*       (k0c, j1c) */                                  \
     "v_lshl_add_u32 v46, v50, %[lgh], v53\n"                 /*       (k1c, j0c) */                                  \
     "v_lshl_add_u32 v47, v50, %[lgh], v49\n"                 /*       (k1c, j1c) */
+// Interior fetch (v55 = texel index of corner (i0, j0, k0)): no clamps, no selects.
+#define SDFV_MARCH_ASM_INTERIOR_DIST                                                                                \
+    "v_lshlrev_b32_e32 v55, 2, v55\n"                                                                               \
+    "global_load_dwordx2 v[40:41], v55, %[base]\n"           /* (z0, y0): t000, t100 */                             \
+    "global_load_dwordx2 v[42:43], v55, s[64:65]\n"          /* (z0, y1): t010, t110 */                             \
+    "global_load_dwordx2 v[44:45], v55, s[68:69]\n"          /* (z1, y0): t001, t101 */                             \
+    "global_load_dwordx2 v[46:47], v55, s[86:87]\n"          /* (z1, y1): t011, t111 */                             \
+    "s_waitcnt vmcnt(1)\n"                                                                                          \
+    "v_pk_mov_b32 v[76:77], v[40:41], v[44:45] op_sel:[0,0]\n" /* (t000, t001) */                                   \
+    "v_pk_mov_b32 v[78:79], v[40:41], v[44:45] op_sel:[1,1]\n" /* (t100, t101) */                                   \
+    "s_waitcnt vmcnt(0)\n"                                                                                          \
+    "v_pk_mov_b32 v[80:81], v[42:43], v[46:47] op_sel:[0,0]\n" /* (t010, t011) */                                   \
+    "v_pk_mov_b32 v[82:83], v[42:43], v[46:47] op_sel:[1,1]\n" /* (t110, t111) */
+#define SDFV_MARCH_ASM_INTERIOR_TEX0                                                                                \
+    "v_lshlrev_b32_e32 v55, 4, v55\n"                                                                               \
+    "global_load_dword v76, v55, %[base]\n global_load_dword v78, v55, %[base] offset:16\n"                       \
+    "global_load_dword v80, v55, s[64:65]\n global_load_dword v82, v55, s[64:65] offset:16\n"                     \
+    "global_load_dword v77, v55, s[68:69]\n global_load_dword v79, v55, s[68:69] offset:16\n"                     \
+    "global_load_dword v81, v55, s[86:87]\n global_load_dword v83, v55, s[86:87] offset:16\n"                     \
+    "s_waitcnt vmcnt(0)\n"
 // STRIDE 1: x-neighbours are adjacent floats: one 8-byte load per (y, z) row at b = clamp(i0, 0, W - 2); where the clamp
 // folds the two x-corners together both come from the same half (lo_is_x / hi_is_y).
 #define SDFV_MARCH_ASM_FETCH_DIST                                                                                   \
@@ -429,10 +467,10 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     [dx] "v"(ray_dir.x), [dy] "v"(ray_dir.y), [dz] "v"(ray_dir.z), [cov] "s"(cov), [mx] "s"(a.rp.bounds_max[0]),    \
         [my] "s"(a.rp.bounds_max[1]), [mz] "s"(a.rp.bounds_max[2]), [minx] "s"(a.rp.bounds_min[0]),                 \
         [miny] "s"(a.rp.bounds_min[1]), [minz] "s"(a.rp.bounds_min[2]), [kx] "s"(kx), [ky] "s"(ky), [kz] "s"(kz),   \
-        [wm1] "s"(wm1), [hm1] "s"(hm1), [dm1] "s"(dm1), [lgw] "s"(lgw), [lgh] "s"(lgh), [base] "s"(vol)
+        [wm1] "s"(wm1), [hm1] "s"(hm1), [dm1] "s"(dm1), [lgw] "s"(lgw), [lgh] "s"(lgh), [base] "s"(vol), [base_lo] "s"(base_lo), [base_hi] "s"(base_hi), [thresh] "s"(thresh)
 #define SDFV_MARCH_ASM_CLOBBERS                                                                                     \
     "vcc", "scc", "memory", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",    \
-        "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "v40", "v41", "v42", "v43", "v44",  \
+        "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "v40", "v41", "v42", "v43", "v44",  \
         "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",    \
         "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72",   \
         "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85",   \
@@ -449,6 +487,9 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
     const int wm1 = t.w - 1, hm1 = t.h - 1, dm1 = t.d - 1;
     const int lgw = 31 - __builtin_clz((uint32_t)t.w), lgh = 31 - __builtin_clz((uint32_t)t.h);  // sizes are powers of two
     const unsigned long long cov = __ballot(covered);
+    const uint32_t base_lo = (uint32_t)(uintptr_t)vol, base_hi = (uint32_t)((uintptr_t)vol >> 32);
+    // the interior fetch path tests all three cell indices with ONE compare: cubic volumes only (0: never taken)
+    const uint32_t thresh = (t.w == t.h && t.h == t.d && !a.no_interior_fetch) ? (uint32_t)t.w - 1u : 0u;
     unsigned long long ran_out;
     int left = 254;  // the loop's down-counter at exit (tuning build: iterations the wave ran)
     float px = ray_pos.x, py = ray_pos.y, pz = ray_pos.z;
@@ -456,18 +497,18 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
 #define SDFV_MARCH_ASM_OOB_CUBE SDFV_MARCH_ASM_OOB2_A, "", "", SDFV_MARCH_ASM_OOB2_D
 #define SDFV_MARCH_ASM_TOP_(T_STEP, ...) SDFV_MARCH_ASM_TOP(T_STEP, __VA_ARGS__)
 // aux variant: distanceFromOrigin (v74) and the per-ray fetch count (v75) ride along
-#define SDFV_MARCH_ASM_RUN_AUX(FETCH, OOB)                                                                          \
-    asm volatile("v_mov_b32 v74, %[tt]\n v_mov_b32 v75, 0\n" SDFV_MARCH_ASM_HEAD                                    \
-                 SDFV_MARCH_ASM_TOP_("v_add_u32_e32 v75, 1, v75\n", OOB) FETCH SDFV_MARCH_ASM_FILTER                 \
+#define SDFV_MARCH_ASM_RUN_AUX(SHIFT, INTERIOR, FETCH, OOB)                                                         \
+    asm volatile("v_mov_b32 v74, %[tt]\n v_mov_b32 v75, 0\n" SDFV_MARCH_ASM_HEAD(SHIFT)                             \
+                 SDFV_MARCH_ASM_TOP_("v_add_u32_e32 v75, 1, v75\n", INTERIOR, OOB) FETCH SDFV_MARCH_ASM_FILTER       \
                  "v_add_f32_e32 v74, v74, v52\n" SDFV_MARCH_ASM_ADVANCE                                              \
                  "v_mov_b32 %[tt], v74\n v_mov_b32 %[n], v75\n" SDFV_MARCH_ASM_END                                   \
                  : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tt] "+v"(tt), [n] "+v"(n), [ran] "=&s"(ran_out),   \
                    [left] "=&s"(left)                                                                               \
                  : SDFV_MARCH_ASM_OPERANDS                                                                          \
                  : SDFV_MARCH_ASM_CLOBBERS)
-#define SDFV_MARCH_ASM_RUN(FETCH, OOB)                                                                              \
-    asm volatile(SDFV_MARCH_ASM_HEAD SDFV_MARCH_ASM_TOP_("", OOB) FETCH SDFV_MARCH_ASM_FILTER SDFV_MARCH_ASM_ADVANCE \
-                     SDFV_MARCH_ASM_END                                                                             \
+#define SDFV_MARCH_ASM_RUN(SHIFT, INTERIOR, FETCH, OOB)                                                             \
+    asm volatile(SDFV_MARCH_ASM_HEAD(SHIFT) SDFV_MARCH_ASM_TOP_("", INTERIOR, OOB) FETCH SDFV_MARCH_ASM_FILTER      \
+                     SDFV_MARCH_ASM_ADVANCE SDFV_MARCH_ASM_END                                                      \
                  : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [ran] "=&s"(ran_out), [left] "=&s"(left)            \
                  : SDFV_MARCH_ASM_OPERANDS                                                                          \
                  : SDFV_MARCH_ASM_CLOBBERS)
@@ -476,20 +517,20 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
         float tt = dist_from_origin;
         int n = 0;
         if (STRIDE == 1) {
-            if (cube) SDFV_MARCH_ASM_RUN_AUX(SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_CUBE);
-            else SDFV_MARCH_ASM_RUN_AUX(SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_BOX);
+            if (cube) SDFV_MARCH_ASM_RUN_AUX("s82", SDFV_MARCH_ASM_INTERIOR_DIST, SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_CUBE);
+            else SDFV_MARCH_ASM_RUN_AUX("s82", SDFV_MARCH_ASM_INTERIOR_DIST, SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_BOX);
         } else {
-            if (cube) SDFV_MARCH_ASM_RUN_AUX(SDFV_MARCH_ASM_FETCH_TEX0, SDFV_MARCH_ASM_OOB_CUBE);
-            else SDFV_MARCH_ASM_RUN_AUX(SDFV_MARCH_ASM_FETCH_TEX0, SDFV_MARCH_ASM_OOB_BOX);
+            if (cube) SDFV_MARCH_ASM_RUN_AUX("s83", SDFV_MARCH_ASM_INTERIOR_TEX0, SDFV_MARCH_ASM_FETCH_TEX0, SDFV_MARCH_ASM_OOB_CUBE);
+            else SDFV_MARCH_ASM_RUN_AUX("s83", SDFV_MARCH_ASM_INTERIOR_TEX0, SDFV_MARCH_ASM_FETCH_TEX0, SDFV_MARCH_ASM_OOB_BOX);
         }
         dist_from_origin = tt;
         steps = n;
     } else if (STRIDE == 1) {
-        if (cube) SDFV_MARCH_ASM_RUN(SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_CUBE);
-        else SDFV_MARCH_ASM_RUN(SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_BOX);
+        if (cube) SDFV_MARCH_ASM_RUN("s82", SDFV_MARCH_ASM_INTERIOR_DIST, SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_CUBE);
+        else SDFV_MARCH_ASM_RUN("s82", SDFV_MARCH_ASM_INTERIOR_DIST, SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_BOX);
     } else {
-        if (cube) SDFV_MARCH_ASM_RUN(SDFV_MARCH_ASM_FETCH_TEX0, SDFV_MARCH_ASM_OOB_CUBE);
-        else SDFV_MARCH_ASM_RUN(SDFV_MARCH_ASM_FETCH_TEX0, SDFV_MARCH_ASM_OOB_BOX);
+        if (cube) SDFV_MARCH_ASM_RUN("s83", SDFV_MARCH_ASM_INTERIOR_TEX0, SDFV_MARCH_ASM_FETCH_TEX0, SDFV_MARCH_ASM_OOB_CUBE);
+        else SDFV_MARCH_ASM_RUN("s83", SDFV_MARCH_ASM_INTERIOR_TEX0, SDFV_MARCH_ASM_FETCH_TEX0, SDFV_MARCH_ASM_OOB_BOX);
     }
 #ifdef SDFV_TUNING  // left = (iterations that ran the fetch block) << 16 | the down-counter at exit
     iterations = cov ? (min(255, 255 - (int)(short)(left & 0xffff)) | (left & 0xffff0000)) : 0;

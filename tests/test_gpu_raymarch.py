@@ -43,7 +43,9 @@ def compare(pkg, oracle, g, t0, t1, h0, h1, cam_kw, width, height, rp_edit=None,
     K = pkg._capi
     # "fast" / "dist" take the hand-written gfx950 march loop where its specialisation applies (power-of-two grid,
     # symmetric box); "*_c" force the compiler's loop on the same kernels
+    # "*_b": the hand-written loop with its interior fetch path switched off (every cell through the clamping fetch)
     disabled = {"fast": 0, "dist": 0, "fast_c": K.RM_NO_ASM_LOOP, "dist_c": K.RM_NO_ASM_LOOP, "general": K.RM_NO_FAST_INDEX,
+                "fast_b": K.RM_NO_INTERIOR_FETCH, "dist_b": K.RM_NO_INTERIOR_FETCH,
                 "fast_plain": K.RM_NO_SYMMETRIC | K.RM_NO_POW2_SIZE,
                 "fast_div": K.RM_NO_SYMMETRIC | K.RM_NO_POW2_EXTENT}
     for variant, mask in disabled.items():
