@@ -271,6 +271,8 @@ def test_randomised_sweep_of_the_hand_written_march_loop(pkg, oracle):
         dims = tuple(int(rng.choice(sizes)) for _ in range(3))
         if dims[0] * dims[1] * dims[2] > 2 ** 19:
             dims = (dims[0], dims[1], max(2, 2 ** 19 // (dims[0] * dims[1])))
+        if trial % 2 == 0:  # cubic volumes: the loop's interior fetch path (one compare for all three cell indices)
+            dims = (int(rng.choice(sizes[:6])),) * 3
         half = np.array([2.0 ** int(rng.integers(-2, 3)) for _ in range(3)]) if trial % 2 else np.full(3, 2.0 ** int(rng.integers(-2, 3)))
         bb_min, bb_max = tuple(-half), tuple(half)
         scale = float(half.min())
@@ -356,6 +358,48 @@ def test_box_first_order_covers_every_tile_once(pkg, size):
         with pkg.options({K.OPT_RAYMARCH_BOX_FIRST: 0}):
             pkg.raymarch(rp, t0, t1, cam, W, H, out=out)
         assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), kw
+
+
+def test_randomised_tile_orders(pkg):
+    """Seeded sweep over image sizes, row bands, cameras (outside, inside, looking past the box) and tile-order options:
+    every order writes, over a sentinel, the bits the launch order writes."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("SDFV_SOAK_SEED", 99)) + 9000)
+    K = pkg._capi
+    g = pkg.make_grid((32, 32, 32))
+    t0, t1 = pkg.alloc_textures(g)
+    pkg.fill_grid(pkg.default_params(), g, t0, t1)
+    dist = pkg.commit_distance(g, t0)
+    rp = pkg.default_render_params(g)
+    for trial in range(int(os.environ.get("SDFV_SOAK_TRIALS", 12))):
+        W, H = int(rng.integers(1, 900)), int(rng.integers(1, 700))
+        kind = trial % 4
+        if kind == 0:
+            d = rng.normal(size=3)
+            eye, target = d / np.linalg.norm(d) * rng.uniform(1.8, 30.0), rng.uniform(-0.5, 0.5, size=3)
+        elif kind == 1:
+            eye, target = rng.uniform(-0.9, 0.9, size=3), rng.uniform(-2.0, 2.0, size=3)
+        elif kind == 2:
+            d = rng.normal(size=3)
+            eye = d / np.linalg.norm(d) * rng.uniform(2.0, 8.0)
+            target = eye + rng.normal(size=3)  # anywhere: the box may be off screen or behind the camera
+        else:
+            d = rng.normal(size=3)
+            eye, target = d / np.linalg.norm(d) * rng.uniform(2.0, 6.0), rng.uniform(-3.0, 3.0, size=3)
+        cam = pkg.camera_look_at(eye=tuple(float(x) for x in eye), target=tuple(float(x) for x in target),
+                                 fovy_degrees=float(rng.uniform(5.0, 140.0)), aspect=W / H)
+        y0 = int(rng.integers(0, H))
+        y1 = int(rng.integers(y0 + 1, H + 1)) if trial % 3 else H
+        y0 = y0 if trial % 3 else 0
+        use_dist = dist if trial % 2 else None
+        with pkg.options({K.OPT_RAYMARCH_TILE_GROUP: 1}):
+            ref = pkg.raymarch(rp, t0, t1, cam, W, H, y0=y0, y1=y1, dist=use_dist)
+        for group in (0, int(rng.integers(2, 6))):
+            for first in (1, 0):
+                out = torch.full((1, y1 - y0, W, 4), float("nan"), dtype=torch.float32, device="cuda")
+                with pkg.options({K.OPT_RAYMARCH_TILE_GROUP: group, K.OPT_RAYMARCH_BOX_FIRST: first}):
+                    pkg.raymarch(rp, t0, t1, cam, W, H, y0=y0, y1=y1, out=out, dist=use_dist)
+                assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), (trial, W, H, y0, y1, group, first)
 
 
 def test_row_bands_of_the_image_tile_split_tile_the_frame(pkg):

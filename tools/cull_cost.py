@@ -29,4 +29,10 @@ y0, y1 = int(rows.min()) // 16 * 16, min(H, (int(rows.max()) // 16 + 1) * 16)
 res["covered_rows"] = [int(rows.min()), int(rows.max())]; res["covered_cols"] = [int(cols.min()), int(cols.max())]
 band = torch.empty((1, y1 - y0, W, 4), dtype=torch.float32, device="cuda")
 res["rows_with_box_only"] = run(lambda: pkg.raymarch(rp, t0, t1, cam, W, H, y0=y0, y1=y1, out=band, dist=dist))
+# batches: 64 cameras on the orbit, and 64 cameras looking away (every wave culled): what the background costs a batch
+cams = pkg.orbit_cameras(64, aspect=W / H)
+outb = torch.empty((64, H, W, 4), dtype=torch.float32, device="cuda")
+res["batch64_orbit"] = run(lambda: pkg.raymarch(rp, t0, t1, cams, W, H, out=outb, dist=dist), n=5)
+res["batch64_all_culled"] = run(lambda: pkg.raymarch(rp, t0, t1, [away] * 64, W, H, out=outb, dist=dist), n=5)
+res["batch64_memset"] = run(lambda: outb.zero_(), n=5)
 print(json.dumps(res))

@@ -12,6 +12,7 @@ while [ $(date +%s) -lt $END ]; do
         tests/test_gpu_fill.py::test_randomised_parameters_and_grids \
         tests/test_gpu_raymarch.py::test_randomised_cameras_grids_and_boxes \
         tests/test_gpu_raymarch.py::test_randomised_sweep_of_the_hand_written_march_loop \
+        tests/test_gpu_raymarch.py::test_randomised_tile_orders \
         tests/test_gpu_points.py::test_random_points_match_oracle \
         tests/test_gpu_mesh_extract.py::test_randomised_extractions_match_numpy_restatement \
         tests/test_gpu_sharded_march.py::test_randomised_slabs_and_cameras > gpurun_out/soak_last.log 2>&1; then
@@ -20,4 +21,4 @@ while [ $(date +%s) -lt $END ]; do
   fi
   N=$((N + 1))
 done
-echo "soak: $N rounds of 6 sweeps x 40 trials passed, seeds $(( SEED - N + 1 ))..$SEED"
+echo "soak: $N rounds of 7 sweeps x 40 trials passed, seeds $(( SEED - N + 1 ))..$SEED"
