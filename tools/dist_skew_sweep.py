@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""The fused fill (sdfv_fill_grid_commit) streams THREE store bursts: tex0, tex1 and the compact distance volume.  With the
+textures placed by alloc_textures(tuned=True), how does its rate depend on where the distance volume lies?
+python tools/dist_skew_sweep.py [side=512]"""
+import importlib, json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("sdf-viewer_amd")
+side = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+prm = pkg.default_params(); g = pkg.make_grid((side,) * 3)
+t0, t1 = pkg.alloc_textures(g, tuned=True)
+n = side ** 3
+big = torch.empty(n + (80 << 20) // 4, dtype=torch.float32, device="cuda")
+pad = (-big.data_ptr()) % (2 << 20)
+def ms(fn, reps):
+    for _ in range(reps): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+reps = 200 if side <= 256 else 40
+res = {"plain_32B": round(ms(lambda: pkg.fill_grid(prm, g, t0, t1), reps), 4),
+       "tex0_base_mod_64MiB": t0.data_ptr() % (64 << 20), "tex1_minus_tex0": t1.data_ptr() - t0.data_ptr()}
+sw = {}
+for rnd in range(2):
+    for skew in (0, 4096, 64 << 10, 256 << 10, 1 << 20, 2 << 20, 3 << 20, 5 << 20, 8 << 20, 12 << 20, 16 << 20, 17 << 20, 24 << 20, 33 << 20, 48 << 20, 64 << 20):
+        o = (pad + skew) // 4
+        d = big[o:o + n].view(side, side, side)
+        sw.setdefault(str(skew), []).append(round(ms(lambda: pkg.fill_grid(prm, g, t0, t1, dist=d), reps), 4))
+sep = torch.empty((side,) * 3, dtype=torch.float32, device="cuda")
+res["separate_allocation"] = round(ms(lambda: pkg.fill_grid(prm, g, t0, t1, dist=sep), reps), 4)
+res["by_skew_ms"] = sw
+print(json.dumps(res))

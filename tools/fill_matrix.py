@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Dense fill, plain (32 B/voxel) and fused with the distance volume (36 B/voxel): every store policy x index form.
+python tools/fill_matrix.py [side=512]"""
+import importlib, json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("sdf-viewer_amd"); K = pkg._capi
+side = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+prm = pkg.default_params(); g = pkg.make_grid((side,) * 3)
+t0, t1 = pkg.alloc_textures(g, tuned=True)
+d = torch.empty((side,) * 3, dtype=torch.float32, device="cuda")
+def ms(fn, reps):
+    for _ in range(reps): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+reps = 200 if side <= 256 else 40
+res = {}
+for rnd in range(2):
+    for nt in (0, 1, 2):
+        for form in (0, 1, 2):
+            with pkg.options({K.OPT_FILL_NONTEMPORAL: nt, K.OPT_FILL_FORM: form}):
+                res.setdefault(f"plain_nt{nt}_form{form}", []).append(round(ms(lambda: pkg.fill_grid(prm, g, t0, t1), reps), 4))
+                res.setdefault(f"fused_nt{nt}_form{form}", []).append(round(ms(lambda: pkg.fill_grid(prm, g, t0, t1, dist=d), reps), 4))
+print(json.dumps({"side": side, "ms": res}))
