@@ -326,9 +326,9 @@ class NativeStdoutToStderr:
 
 def main():
     # A collective that never completes (a rank lost, P2P unavailable) must not hang the job for ever: after
-    # SDFV_BENCH_WATCHDOG_S seconds (default 1500) a watchdog thread dumps every thread's stack to stderr and exits.
+    # SDFV_BENCH_WATCHDOG_S seconds (default 900) a watchdog thread dumps every thread's stack to stderr and exits.
     import faulthandler
-    watchdog = float(os.environ.get("SDFV_BENCH_WATCHDOG_S", "1500"))
+    watchdog = float(os.environ.get("SDFV_BENCH_WATCHDOG_S", "900"))
     if watchdog > 0:
         faulthandler.dump_traceback_later(watchdog, exit=True)
     with NativeStdoutToStderr() as redirect:
