@@ -626,7 +626,7 @@ def run(redirect):
                     {"error": (r.stderr or r.stdout)[-300:]}
             halo_loopback = loop[str(side)]
             halo_loopback["by_side"] = {k: {kk: v.get(kk) for kk in ("ms_per_step", "plain_fill_ms", "fraction_of_plain_fill_rate",
-                                                                     "ghosts_verified", "error") if kk in v}
+                                                                     "ghosts_verified", "deferred_join", "error") if kk in v}
                                         for k, v in loop.items()}
         except Exception as e:  # noqa: BLE001 -- an extra, never fatal
             halo_loopback = {"error": f"{type(e).__name__}: {e}"}

@@ -167,6 +167,9 @@ typedef enum sdfv_option {
 #define SDFV_STEP_UNPACKED     4u /* flag: 2 messages per texture and neighbour straight into the ghosts (no staging) */
 #define SDFV_STEP_START_EVENT  8u /* flag (side-boundary form): release the communicator's stream with an event recorded
                                    * on the caller's stream instead of the fill launch's own "started" signal */
+#define SDFV_STEP_DEFER_JOIN  16u /* flag (side-boundary forms): the step does NOT make the caller's stream wait for the
+                                   * exchange; sdfv_slab_comm_join() does, whenever the ghost slices are needed.  Steps on the
+                                   * same communicator order themselves after the previous exchange on their own */
 int sdfv_set_option(uint32_t option, uint64_t value); /* unknown option / value out of range: SDFV_ERR_INVALID_ARGUMENT */
 int sdfv_get_option(uint32_t option, uint64_t *value);
 
@@ -403,6 +406,11 @@ int sdfv_slab_fill_step(sdfv_slab_comm *comm, const sdfv_demo_params *params, ui
  * and, once the halo has arrived, tex0.r of the ghost slices. */
 int sdfv_slab_fill_step_commit(sdfv_slab_comm *comm, const sdfv_demo_params *params, uint32_t sdf_id,
                                const sdfv_grid *slab, float *tex0, float *tex1, float *dist, void *stream);
+
+/* Makes `stream` wait for the most recent exchange the communicator has enqueued (a no-op when there is none).  Needed
+ * only after steps taken with SDFV_STEP_DEFER_JOIN: before anything put on `stream` reads the ghost slices of the
+ * textures (or the ghost slices' share of the distance volume).  The owned slices never need it. */
+int sdfv_slab_comm_join(sdfv_slab_comm *comm, void *stream);
 
 #ifdef __cplusplus
 }

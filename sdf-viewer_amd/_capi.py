@@ -137,6 +137,7 @@ PROTOTYPES = {
                                       C.c_void_p, C.c_void_p]),
     "sdfv_slab_fill_step_commit": (C.c_int, [C.c_void_p, C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdfv_slab_comm_join": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 LIGHT_AMBIENT, LIGHT_DIRECTIONAL, MAX_LIGHTS = 0, 1, 4
 # sdfv_option / values (include/sdfgrid.h)
@@ -145,7 +146,7 @@ OPT_RAYMARCH_TILE_GROUP = 6
 OPT_RAYMARCH_BOX_FIRST = 7
 OPT_TUNING_WAVE_TIMING = 100
 RM_NO_FAST_INDEX, RM_NO_POW2_EXTENT, RM_NO_POW2_SIZE, RM_NO_SYMMETRIC, RM_NO_ASM_LOOP, RM_NO_INTERIOR_FETCH = 1, 2, 4, 8, 16, 32
-STEP_TWO_LAUNCH, STEP_ONE_LAUNCH, STEP_SIDE_BOUNDARY, STEP_UNPACKED, STEP_START_EVENT = 1, 2, 3, 4, 8
+STEP_TWO_LAUNCH, STEP_ONE_LAUNCH, STEP_SIDE_BOUNDARY, STEP_UNPACKED, STEP_START_EVENT, STEP_DEFER_JOIN = 1, 2, 3, 4, 8, 16
 FILL_FORM = {"auto": 0, "rows": 1, "flat": 2}
 PLACEMENT_SLACK = 64 << 10
 COMM_ID_BYTES = 128

@@ -390,7 +390,7 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             g_options.raymarch_box_first = (uint32_t)value;
             return SDFV_OK;
         case SDFV_OPT_SLAB_STEP_FORM: {
-            const uint64_t form = value & ~(uint64_t)(SDFV_STEP_UNPACKED | SDFV_STEP_START_EVENT);
+            const uint64_t form = value & ~(uint64_t)(SDFV_STEP_UNPACKED | SDFV_STEP_START_EVENT | SDFV_STEP_DEFER_JOIN);
             if (form != 0 && form != SDFV_STEP_TWO_LAUNCH && form != SDFV_STEP_ONE_LAUNCH && form != SDFV_STEP_SIDE_BOUNDARY) break;
             g_options.slab_step_form = (uint32_t)value;
             return SDFV_OK;

@@ -348,7 +348,12 @@ int sdfv_slab_fill_step_commit(sdfv_slab_comm* c, const sdfv_demo_params* params
     uint32_t form = sdfv::options().slab_step_form;
     bool packed = !(form & SDFV_STEP_UNPACKED);
     const bool start_event = (form & SDFV_STEP_START_EVENT) != 0 || !c->can_wait_value;
-    form &= ~(SDFV_STEP_UNPACKED | SDFV_STEP_START_EVENT);
+    // SDFV_STEP_DEFER_JOIN: `main` is not made to wait for the exchange (sdfv_slab_comm_join does that on demand).  Honoured
+    // by the side-boundary forms only: there the next step's fill on `main` never touches what the exchange still reads
+    // (packed: the sends read the staging block; unpacked: the boundary slices are written by the communicator's stream,
+    // in order behind the previous exchange), and never the ghost slices it writes.
+    const bool defer_join = (form & SDFV_STEP_DEFER_JOIN) != 0;
+    form &= ~(SDFV_STEP_UNPACKED | SDFV_STEP_START_EVENT | SDFV_STEP_DEFER_JOIN);
     uint32_t bps = 0, total = 0;
     if (int rc = sdfv::ordered_fill_blocks(slab, &bps, &total)) return rc;
     if (!exchange || owned < lead + 2 || bps == 0) {  // nothing to hide the exchange behind / shape not supported
@@ -425,7 +430,7 @@ int sdfv_slab_fill_step_commit(sdfv_slab_comm* c, const sdfv_demo_params* params
             SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));
             if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, nb, total, main)) return rc;
         }
-        if (!no_wait) SDFV_HIPC(hipStreamWaitEvent(main, c->halo_done, 0));
+        if (!no_wait && !defer_join) SDFV_HIPC(hipStreamWaitEvent(main, c->halo_done, 0));
         return SDFV_OK;
     }
     if (form == SDFV_STEP_ONE_LAUNCH) {
@@ -452,6 +457,12 @@ int sdfv_slab_fill_step_commit(sdfv_slab_comm* c, const sdfv_demo_params* params
     SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));
     if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, nb, total, main)) return rc;
     SDFV_HIPC(hipStreamWaitEvent(main, c->halo_done, 0));
+    return SDFV_OK;
+}
+
+int sdfv_slab_comm_join(sdfv_slab_comm* c, void* stream) {
+    if (!c) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
+    SDFV_HIPC(hipStreamWaitEvent((hipStream_t)stream, c->halo_done, 0));  // never recorded yet: returns at once
     return SDFV_OK;
 }
 

@@ -218,6 +218,11 @@ class SlabComm:
         self.pkg.check(self.pkg.lib.sdfv_slab_fill_step_commit(self.handle, C.byref(params), sdf_id, g, t0, t1,
                                                                C.c_void_p(dist.data_ptr()), st))
 
+    def join(self, stream=None):
+        """sdfv_slab_comm_join: `stream` waits for the latest exchange (after steps taken with STEP_DEFER_JOIN)."""
+        stream = torch.cuda.current_stream() if stream is None else stream
+        self.pkg.check(self.pkg.lib.sdfv_slab_comm_join(self.handle, C.c_void_p(stream.cuda_stream)))
+
     def close(self):
         if self.handle:
             self.pkg.lib.sdfv_slab_comm_destroy(self.handle)

@@ -122,6 +122,40 @@ def test_fill_step_with_the_fused_commit(pkg, par, oracle, dims, z0, z1, halo, f
         comm.close()
 
 
+@pytest.mark.parametrize("form", ["side_boundary", "side_boundary_event", "side_boundary_unpacked", "two_launch"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_deferred_join(pkg, par, oracle, loop_comm, form, fused):
+    """SDFV_STEP_DEFER_JOIN: steps that do not make the caller's stream wait for their exchange, one sdfv_slab_comm_join
+    before the ghosts are read.  Back-to-back steps with DIFFERENT parameters on a side stream: after the join the slab
+    and its ghosts hold the LAST step's texels (an exchange overtaken by the next fill, or a ghost copy that landed late,
+    would leave the previous parameters' slices).  Forms that cannot defer (two-launch) simply join in the step."""
+    K = pkg._capi
+    dims, z0, z1 = (64, 64, 24), 0, 24
+    slab = par.alloc_slab(dims, 0, 1, "cuda", periodic=True, pkg=pkg)
+    grid = pkg.make_grid(dims, z_begin=z0, z_end=z1)
+    dist = torch.empty(tuple(slab.tex0.shape[:3]), dtype=torch.float32, device="cuda") if fused else None
+    sets = [pkg.default_params(), pkg.default_params(cube_half_side=0.7, sphere_radius=0.9),
+            pkg.default_params(disable_sphere=1), pkg.default_params(cube_material=1, sphere_material=1)]
+    s = torch.cuda.Stream()
+    with pkg.options({K.OPT_SLAB_STEP_FORM: step_forms(pkg)[form] | K.STEP_DEFER_JOIN}):
+        for rounds in (1, 3, 8):
+            with torch.cuda.stream(s):
+                for k in range(rounds):
+                    loop_comm.fill_step(sets[k % len(sets)], grid, slab, stream=s, dist=dist)
+                loop_comm.join(stream=s)
+                got0, got1 = slab.tex0.clone(), slab.tex1.clone()  # on s, behind the join
+                gotd = dist.clone() if fused else None
+            s.synchronize()
+            prm = sets[(rounds - 1) % len(sets)]
+            r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, z0=z0, z1=z1)
+            want0 = np.concatenate([r0[-1:], r0, r0[:1]]).view(np.uint32)
+            want1 = np.concatenate([r1[-1:], r1, r1[:1]]).view(np.uint32)
+            np.testing.assert_array_equal(bits(got0), want0)
+            np.testing.assert_array_equal(bits(got1), want1)
+            if fused:
+                np.testing.assert_array_equal(bits(gotd), want0[..., 0])
+
+
 def test_repeated_steps_on_a_side_stream(pkg, par, oracle, loop_comm):
     """Events and the communicator stream are reused step after step; parameters change between steps."""
     dims = (48, 40, 12)

@@ -34,7 +34,7 @@ def main():
     grid = pkg.make_grid(dims)
     slab = par.alloc_slab(dims, 0, 1, "cuda", periodic=True, pkg=pkg)
 
-    def run(fn, n, warm_s=0.25):
+    def run(fn, n, warm_s=0.25, after=None):
         t_end = time.perf_counter() + warm_s  # device clock ramp, like bench.py's pre-warm
         while time.perf_counter() < t_end:
             fn()
@@ -43,6 +43,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
+        if after is not None:
+            after()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
 
@@ -119,9 +121,18 @@ def main():
         fill_ms = run(plain_fused, steps)
         p_step_ms = run(step, steps)
         p_fill_ms = run(plain, steps)
+        # the same fused steps with SDFV_STEP_DEFER_JOIN: no per-step wait of the caller's stream for the exchange, one
+        # sdfv_slab_comm_join behind the K steps (a streaming caller joins where it reads the ghosts, not after every fill)
+        slab.tex0[0].fill_(-1.0)
+        with pkg.options({K.OPT_SLAB_STEP_FORM: K.STEP_DEFER_JOIN}):
+            d_step_ms = run(step_fused, steps, after=comm.join)
+        d_same = ghosts_ok() and bool(torch.equal(dist, slab.tex0[..., 0]))
         out.update({"ms_per_step": round(step_ms, 4), "plain_fill_ms": round(fill_ms, 4),
                     "fraction_of_plain_fill_rate": round(fill_ms / step_ms, 3), "ghosts_verified": same,
                     "what": "fused step (sdfv_slab_fill_step_commit, 36 B/voxel) against the fused fill alone",
+                    "deferred_join": {"ms_per_step": round(d_step_ms, 4), "fraction_of_plain_fill_rate": round(fill_ms / d_step_ms, 3),
+                                      "ghosts_verified": d_same,
+                                      "what": "SDFV_STEP_DEFER_JOIN: K steps, ONE sdfv_slab_comm_join behind them"},
                     "unfused": {"ms_per_step": round(p_step_ms, 4), "plain_fill_ms": round(p_fill_ms, 4),
                                 "fraction_of_plain_fill_rate": round(p_fill_ms / p_step_ms, 3)},
                     "form": "plain dense fill on the caller's stream; boundary slices -> packed buffers, RCCL, ghost copy "
