@@ -614,10 +614,12 @@ __device__ __forceinline__ void aux_clear(sdfv_march_aux& aux) {
 }
 
 #ifdef SDFV_TUNING
-__device__ __forceinline__ void stamp_wave(const RaymarchArgs& a, uint32_t wave, unsigned long long t_start,
-                                           unsigned long long t_start_rt, int iterations,
+__device__ __forceinline__ void stamp_wave(const RaymarchArgs& a, uint32_t bx, uint32_t by, uint32_t wave,
+                                           unsigned long long t_start, unsigned long long t_start_rt, int iterations,
                                            unsigned long long covered_mask) {
-    const uint64_t wave_id = ((uint64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
+    // indexed by the TILE (whatever workgroup rendered it): stamps of any tile order land in the same slots
+    const uint32_t tiles_x = (a.width + 15) / 16, tiles_y = (a.y1 - a.y0 + 15) / 16;
+    const uint64_t wave_id = ((uint64_t)(blockIdx.z * tiles_y + by) * tiles_x + bx) * 4 + wave;
     a.wave_timing[wave_id * 4 + 0] = t_start;
     a.wave_timing[wave_id * 4 + 1] = __builtin_readcyclecounter();
     // bits 32..47 / 48..63: the 100 MHz real-time counter (one clock for the whole device; the cycle counters above are
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
             }
             if (in_image && a.depth) a.depth[out_index] = 1.0f;
 #ifdef SDFV_TUNING
-            if (a.wave_timing && lane == 0) stamp_wave(a, wave, t_start, t_start_rt, 0, 0ull);
+            if (a.wave_timing && lane == 0) stamp_wave(a, bx, by, wave, t_start, t_start_rt, 0, 0ull);
 #endif
             return;
         }
@@ -877,7 +879,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
     // slot 3: cycles before the march loop (ray set-up) | cycles of the loop << 32; what is left of end - start is the hit's
     // texel gathers and shading
     if (a.wave_timing && lane == 0)
-        stamp_wave(a, wave, t_start, t_start_rt, iterations, ((t_loop0 - t_start) & 0xffffffffull) | ((t_loop1 - t_loop0) << 32));
+        stamp_wave(a, bx, by, wave, t_start, t_start_rt, iterations, ((t_loop0 - t_start) & 0xffffffffull) | ((t_loop1 - t_loop0) << 32));
 #endif
     if (in_image) {
         store_rgba(a.rgba + out_index, rgba);

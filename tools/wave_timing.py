@@ -30,7 +30,8 @@ buf = torch.zeros((n_waves, 4), dtype=torch.int64, device="cuda")
 dist = pkg.commit_distance(g, t0) if "--dist" in sys.argv else None
 for _ in range(200):  # clock ramp
     pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist)
-pkg.set_option(K.OPT_RAYMARCH_TILE_GROUP, 1)  # launch order: the stamp buffer is indexed by the 2-D workgroup grid
+if "--launch-order" in sys.argv:  # default: the product's order (the stamps are indexed by tile, not by workgroup)
+    pkg.set_option(K.OPT_RAYMARCH_TILE_GROUP, 1)
 pkg.set_option(K.OPT_TUNING_WAVE_TIMING, buf.data_ptr())
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
@@ -79,7 +80,8 @@ summary = {
     "launch_us": {"span_first_start_to_last_end": float(end_us.max()), "last_wave_start": float(start_us.max()),
                   "last_active_wave_start": float(start_us[act].max()),
                   "active_wave_start_percentiles_10_50_90": [float(v) for v in np.percentile(start_us[act], [10, 50, 90])]},
-    "config": {"grid": side, "image": [W, H], "dist_volume": dist is not None},
+    "config": {"grid": side, "image": [W, H], "dist_volume": dist is not None,
+               "tile_order": "launch order" if "--launch-order" in sys.argv else "default (box-first, 2 x 2 tile groups)"},
 }
 # least-squares model of an active wave: cycles = K + C * iterations + F * (iterations that ran the fetch block)
 if fetch_it[act].sum() > 0:
