@@ -1,5 +1,5 @@
 // v_pk_mov_b32 operand selection on gfx950, printed: which halves of the two 64-bit sources land in the result for each
-// op_sel / op_sel_hi.  hipcc --offload-arch=gfx950 -O2 tools/ubench/pkmov.hip -o /tmp/pkmov && /tmp/pkmov
+// op_sel / op_sel_hi.  hipcc --offload-arch=gfx950 -O2 tools/ubench/pkmov.hip -o tools/ubench/pkmov && tools/ubench/pkmov
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void k(unsigned* out) {
