@@ -152,7 +152,9 @@ typedef enum sdfv_option {
     SDFV_OPT_RAYMARCH_BOX_FIRST = 7,   /* 1 (default) | 0: with an XCD-aware tile order and one camera, the groups of tiles under
                                         * the screen rectangle of the projected bounding box are launched before the others (the
                                         * frame is as long as its longest wave; those all start at once then).  Order only */
-    SDFV_OPT_TUNING_WAVE_TIMING = 100  /* tuning build only (-DSDFV_TUNING): DEVICE address of 32 B per raymarch wave */
+    SDFV_OPT_TUNING_WAVE_TIMING = 100, /* tuning build only (-DSDFV_TUNING): DEVICE address of 32 B per raymarch wave */
+    SDFV_OPT_TUNING_PRIORITY_MAP = 101 /* tuning build only: DEVICE address of one byte per 16 x 16 raymarch tile (row-major);
+                                        * waves of tiles whose byte is non-zero raise their issue priority at start */
 } sdfv_option;
 #define SDFV_RM_NO_FAST_INDEX  1u /* general kernel: full MirroredRepeat, the shader's nested loop */
 #define SDFV_RM_NO_POW2_EXTENT 2u /* (p - min) / size by IEEE divide instead of the exact reciprocal */

@@ -16,6 +16,7 @@ struct Options {
     uint32_t raymarch_tile_group = 0;  // 0 auto, 1 launch order, v >= 2: XCD-aware order over groups of 2^(v-1) x 2^(v-1) tiles
     uint32_t slab_step_form = 0;     // 0 auto, SDFV_STEP_* otherwise
     unsigned long long wave_timing = 0;  // tuning build only
+    unsigned long long priority_map = 0;  // tuning build only
 };
 const Options& options();
 // Formats the thread-local message sdfv_last_error() returns and hands `code` back.

@@ -40,6 +40,7 @@ struct RaymarchArgs {
     sdfv_march_aux* aux;         // same layout or nullptr
     float* depth;                // gl_FragDepth plane, same pixel layout, or nullptr
 #ifdef SDFV_TUNING
+    const unsigned char* priority_map;  // tuning build only: one byte per tile, non-zero = raise the waves' priority
     unsigned long long* wave_timing;  // tuning build only: per wave {start, end, iterations, covered mask} or nullptr
 #endif
     sdfv_camera cameras[16];

@@ -720,6 +720,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
     const sdfv_camera& cam = a.cameras[cam_idx];
     const uint64_t out_index = ((uint64_t)cam_idx * (a.y1 - a.y0) + row) * a.width + px;
 #ifdef SDFV_TUNING
+    if (a.priority_map && a.priority_map[by * ((a.width + 15) / 16) + bx]) __builtin_amdgcn_s_setprio(3);
     const unsigned long long t_start = a.wave_timing ? __builtin_readcyclecounter() : 0ull;
     const unsigned long long t_start_rt = a.wave_timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #endif

@@ -395,6 +395,13 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             g_options.slab_step_form = (uint32_t)value;
             return SDFV_OK;
         }
+        case SDFV_OPT_TUNING_PRIORITY_MAP:
+#ifdef SDFV_TUNING
+            g_options.priority_map = value;
+            return SDFV_OK;
+#else
+            return fail(SDFV_ERR_INVALID_ARGUMENT, "SDFV_OPT_TUNING_PRIORITY_MAP needs the tuning build (make tuning)");
+#endif
         case SDFV_OPT_TUNING_WAVE_TIMING:
 #ifdef SDFV_TUNING
             g_options.wave_timing = value;
@@ -419,6 +426,7 @@ int sdfv_get_option(uint32_t option, uint64_t* value) {
         case SDFV_OPT_RAYMARCH_TILE_GROUP: *value = g_options.raymarch_tile_group; return SDFV_OK;
         case SDFV_OPT_RAYMARCH_BOX_FIRST: *value = g_options.raymarch_box_first; return SDFV_OK;
         case SDFV_OPT_TUNING_WAVE_TIMING: *value = g_options.wave_timing; return SDFV_OK;
+        case SDFV_OPT_TUNING_PRIORITY_MAP: *value = g_options.priority_map; return SDFV_OK;
         default: return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown option %u", option);
     }
 }
@@ -847,6 +855,7 @@ int sdfv_raymarch_depth(const sdfv_render_params* rp, const float* tex0, const f
                                                        : (g_options.raymarch_tile_group == 1 ? 0u : g_options.raymarch_tile_group - 1u);
 #ifdef SDFV_TUNING
     a.wave_timing = reinterpret_cast<unsigned long long*>(g_options.wave_timing);  // 32 B per wave, or 0
+    a.priority_map = reinterpret_cast<const unsigned char*>(g_options.priority_map);
 #endif
     const uint64_t pixels_per_cam = (uint64_t)(y1 - y0) * width;
     for (uint32_t c0 = 0; c0 < n_cameras; c0 += sdfv::kMaxCamerasPerLaunch) {
