@@ -330,7 +330,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 #define SDFV_MARCH_ASM_OOB4_D "v_max3_f32 v48, v48, v49, v50\n"
 #define SDFV_MARCH_ASM_OOB2_A "v_max3_f32 v48, |v56|, |v58|, |v59|\n"
 #define SDFV_MARCH_ASM_OOB2_D "v_subrev_f32_e32 v48, %[mx], v48\n"
-#define SDFV_MARCH_ASM_TOP(T_STEP, INTERIOR, OOB_A, OOB_B, OOB_C, OOB_D)                                                      \
+#define SDFV_MARCH_ASM_TOP(T_STEP, OOB_A, OOB_B, OOB_C, OOB_D)                                                      \
     OOB_A                                                                                                           \
     "v_subrev_f32_e32 v64, %[minx], v56\n"                                                                          \
     OOB_B                                                                                                           \
@@ -349,7 +349,11 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "v_max3_u32 v48, v68, v70, v72\n"                                                                            \
     "v_cmp_gt_u32_e32 vcc, 0x3f800000, v48\n"                                                                       \
     "s_andn1_saveexec_b64 s[78:79], vcc\n"                   /* exec = lanes whose cell changed */                   \
-    "s_cbranch_execz .Lcached_%=\n"                                                                                 \
+    "s_cbranch_execnz .Lfetch_%=\n"                          /* out of line: the cached case falls through */        \
+    ".Lcached_%=:\n"
+// The cell fetch, out of line behind the loop (one taken branch less in every iteration that stays in its cells).
+#define SDFV_MARCH_ASM_FETCH_PREP(INTERIOR)                                                                         \
+    ".Lfetch_%=:\n"                                                                                                 \
     SDFV_MARCH_ASM_TUNE("s_add_u32 s84, s84, 1\n")                                                                  \
     /* new cell: floor, weights, clamped corner indices (MirroredRepeat == clamp here), row numbers by shifts */    \
     "v_floor_f32_e32 v84, v64\n v_floor_f32_e32 v86, v66\n v_floor_f32_e32 v87, v67\n"                         \
@@ -412,7 +416,8 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "s_waitcnt vmcnt(1)\n"                                                                                          \
     "v_cndmask_b32_e64 v77, v45, v44, s[80:81]\n v_cndmask_b32_e32 v79, v44, v45, vcc\n" /* t001, t101 */          \
     "s_waitcnt vmcnt(0)\n"                                                                                          \
-    "v_cndmask_b32_e64 v81, v47, v46, s[80:81]\n v_cndmask_b32_e32 v83, v46, v47, vcc\n" /* t011, t111 */
+    "v_cndmask_b32_e64 v81, v47, v46, s[80:81]\n v_cndmask_b32_e32 v83, v46, v47, vcc\n" /* t011, t111 */          \
+    "s_branch .Lcached_%=\n"
 // STRIDE 4: tex0.r out of 16-byte texels, one dword load per corner.
 #define SDFV_MARCH_ASM_FETCH_TEX0                                                                                   \
     "v_lshlrev_b32_e32 v51, 4, v51\n v_lshlrev_b32_e32 v48, 4, v48\n"   /* i0c, i1c as byte offsets */               \
@@ -424,11 +429,11 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "global_load_dword v77, v40, %[base]\n global_load_dword v79, v41, %[base]\n"                                  \
     "v_lshl_add_u32 v42, v47, s83, v51\n v_lshl_add_u32 v43, v47, s83, v48\n"                                        \
     "global_load_dword v81, v42, %[base]\n global_load_dword v83, v43, %[base]\n"                                  \
-    "s_waitcnt vmcnt(0)\n"
+    "s_waitcnt vmcnt(0)\n"                                                                                          \
+    "s_branch .Lcached_%=\n"
 // Corner registers as z-pairs: A0 = v[76:77] = (t000, t001), A1 = v[78:79] = (t100, t101), B0 = v[80:81] =
 // (t010, t011), B1 = v[82:83] = (t110, t111); weights (a, 1 - a) as pairs v[68:69], v[70:71], v[72:73].
 #define SDFV_MARCH_ASM_FILTER                                                                                       \
-    ".Lcached_%=:\n"                                                                                                \
     "s_mov_b64 exec, s[78:79]\n"                                                                                    \
     "v_sub_f32_e32 v69, 1.0, v68\n v_sub_f32_e32 v71, 1.0, v70\n v_sub_f32_e32 v73, 1.0, v72\n"                \
     /* mix along x: c = t(x0) * (1 - ax) + t(x1) * ax */                                                            \
@@ -456,6 +461,8 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "v_pk_add_f32 v[58:59], v[58:59], v[50:51]\n"                                                                   \
     "s_add_u32 s74, s74, -1\n"                               /* carry out <=> iterations left */                     \
     "s_cbranch_scc1 .Lloop_%=\n"                                                                                    \
+    "s_branch .Ldone_%=\n"
+#define SDFV_MARCH_ASM_EPILOGUE                                                                                     \
     ".Ldone_%=:\n"                                                                                                  \
     "s_mov_b64 %[ran], exec\n"                               /* lanes still marching after 255 iterations */         \
     "s_mov_b32 %[left], s74\n"                                                                                      \
@@ -499,16 +506,16 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
 // aux variant: distanceFromOrigin (v74) and the per-ray fetch count (v75) ride along
 #define SDFV_MARCH_ASM_RUN_AUX(SHIFT, INTERIOR, FETCH, OOB)                                                         \
     asm volatile("v_mov_b32 v74, %[tt]\n v_mov_b32 v75, 0\n" SDFV_MARCH_ASM_HEAD(SHIFT)                             \
-                 SDFV_MARCH_ASM_TOP_("v_add_u32_e32 v75, 1, v75\n", INTERIOR, OOB) FETCH SDFV_MARCH_ASM_FILTER       \
-                 "v_add_f32_e32 v74, v74, v52\n" SDFV_MARCH_ASM_ADVANCE                                              \
-                 "v_mov_b32 %[tt], v74\n v_mov_b32 %[n], v75\n" SDFV_MARCH_ASM_END                                   \
+                 SDFV_MARCH_ASM_TOP_("v_add_u32_e32 v75, 1, v75\n", OOB) SDFV_MARCH_ASM_FILTER                       \
+                 "v_add_f32_e32 v74, v74, v52\n" SDFV_MARCH_ASM_ADVANCE SDFV_MARCH_ASM_FETCH_PREP(INTERIOR) FETCH    \
+                 SDFV_MARCH_ASM_EPILOGUE "v_mov_b32 %[tt], v74\n v_mov_b32 %[n], v75\n" SDFV_MARCH_ASM_END           \
                  : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tt] "+v"(tt), [n] "+v"(n), [ran] "=&s"(ran_out),   \
                    [left] "=&s"(left)                                                                               \
                  : SDFV_MARCH_ASM_OPERANDS                                                                          \
                  : SDFV_MARCH_ASM_CLOBBERS)
 #define SDFV_MARCH_ASM_RUN(SHIFT, INTERIOR, FETCH, OOB)                                                             \
-    asm volatile(SDFV_MARCH_ASM_HEAD(SHIFT) SDFV_MARCH_ASM_TOP_("", INTERIOR, OOB) FETCH SDFV_MARCH_ASM_FILTER      \
-                     SDFV_MARCH_ASM_ADVANCE SDFV_MARCH_ASM_END                                                      \
+    asm volatile(SDFV_MARCH_ASM_HEAD(SHIFT) SDFV_MARCH_ASM_TOP_("", OOB) SDFV_MARCH_ASM_FILTER SDFV_MARCH_ASM_ADVANCE \
+                     SDFV_MARCH_ASM_FETCH_PREP(INTERIOR) FETCH SDFV_MARCH_ASM_EPILOGUE SDFV_MARCH_ASM_END            \
                  : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [ran] "=&s"(ran_out), [left] "=&s"(left)            \
                  : SDFV_MARCH_ASM_OPERANDS                                                                          \
                  : SDFV_MARCH_ASM_CLOBBERS)

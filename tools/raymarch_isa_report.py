@@ -63,12 +63,13 @@ def main():
     blocks = [[l.strip() for l in asmk[a + 1:b] if l.strip()] for a, b in zip(starts, ends)]
     # the cubic-box variant is the block whose out-of-bounds test starts with v_max3_f32 of absolute values
     hand = [b for b in blocks if any(l.startswith("v_max3_f32") and "|" in l for l in b)][0]
+    # layout: .Lloop ... common path ... back-branch, then (out of line) .Lfetch ... interior ... .Lborder ... , .Ldone
     i_loop = [i for i, l in enumerate(hand) if l.startswith(".Lloop")][0]
-    i_floor = [i for i, l in enumerate(hand) if l.startswith("v_floor")][0]
-    i_cached = [i for i, l in enumerate(hand) if l.startswith(".Lcached")][0]
     i_back = [i for i, l in enumerate(hand) if l.startswith("s_cbranch_scc1") and ".Lloop" in l][0]
+    i_fetch = [i for i, l in enumerate(hand) if l.startswith(".Lfetch")][0]
     i_border = [i for i, l in enumerate(hand) if l.startswith(".Lborder")][0]
     i_test = [i for i, l in enumerate(hand) if l.startswith("s_cbranch_scc1") and ".Lborder" in l][0]
+    i_done = [i for i, l in enumerate(hand) if l.startswith(".Ldone")][0]
     hdr = [i for i, l in enumerate(ck) if "Inner Loop Header" in l][0]
     lo = max(i for i in range(hdr) if ck[i].strip().startswith("s_branch"))
     label = ck[hdr].split(":")[0]
@@ -81,9 +82,9 @@ def main():
     i14 = max(i for i in range(first_cvt) if is_block_start(comp[i]))
     last_load = max(i for i, l in enumerate(comp) if "global_load" in l)
     i18 = [i for i in range(last_load, len(comp)) if is_block_start(comp[i])][0]
-    res = {"hand_common_path": count(hand[i_loop:i_floor] + hand[i_cached:i_back + 1]),
-           "hand_fetch_block_interior_cell": count(hand[i_floor:i_border]),
-           "hand_fetch_block_border_cell": count(hand[i_floor:i_test + 1] + hand[i_border:i_cached]),
+    res = {"hand_common_path": count(hand[i_loop:i_back + 1]),
+           "hand_fetch_block_interior_cell": count(hand[i_fetch:i_border]),
+           "hand_fetch_block_border_cell": count(hand[i_fetch:i_test + 1] + hand[i_border:i_done]),
            "hipcc_common_path": count(comp[:i14] + comp[i18:]), "hipcc_fetch_block_listed": count(comp[i14:i18])}
     for name in (pre + "1EEEvNS_12RaymarchArgsE", pre + "0EEEvNS_12RaymarchArgsE"):
         i = [k for k, l in enumerate(lines) if ".name:" in l and name in l][0]
