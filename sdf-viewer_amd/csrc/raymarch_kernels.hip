@@ -1181,23 +1181,27 @@ hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream) {
     if (a.width == 0 || rows == 0 || a.n_cameras == 0) return hipSuccess;
     dim3 grid((a.width + 15) / 16, (rows + 15) / 16, a.n_cameras);
     RaymarchArgs ag = a;
-    // kGroupAuto (one camera): groups of 2 x 2 tiles with the box-first order where the bounding box projects to a proper
-    // part of the image, otherwise (camera inside the box, box filling the image, order switched off) groups of 4 x 4
-    for (uint32_t shift : {a.group_shift == kGroupAuto ? 1u : a.group_shift, 2u}) {
-        if (shift == 0) break;
+    const dim3 tiles = grid;
+    // the 1-D launch over groups of 2^shift x 2^shift tiles (padded to whole groups, a multiple of 8 of them), with the
+    // box-first rectangle where one exists
+    auto grouped = [&](uint32_t shift) {
         ag.group_shift = shift;
-        ag.tiles_x = grid.x;
-        ag.tiles_y = grid.y;
-        ag.groups_x = (grid.x + (1u << shift) - 1) >> shift;
-        const uint32_t groups_y = (grid.y + (1u << shift) - 1) >> shift;
+        ag.tiles_x = tiles.x;
+        ag.tiles_y = tiles.y;
+        ag.groups_x = (tiles.x + (1u << shift) - 1) >> shift;
+        const uint32_t groups_y = (tiles.y + (1u << shift) - 1) >> shift;
         const uint32_t groups = ((ag.groups_x * groups_y + 7u) / 8u) * 8u;
         ag.first_w = 0;
-        if (a.box_first && a.n_cameras == 1 && ag.groups_x < 65536u && groups_y < 65536u && groups < 65536u)
-            box_first_rectangle(ag, groups_y);
-        if (a.group_shift != kGroupAuto || ag.first_w != 0 || shift == 2u) {
-            grid = dim3(groups << (2 * shift), 1, a.n_cameras);
-            break;
-        }
+        if (a.box_first && a.n_cameras == 1 && groups < 65536u) box_first_rectangle(ag, groups_y);  // 16-bit quotients
+        grid = dim3(groups << (2 * shift), 1, a.n_cameras);
+    };
+    if (a.group_shift == kGroupAuto) {
+        // one camera: groups of 2 x 2 tiles with the box-first order where the bounding box projects to a proper part of the
+        // image, otherwise (camera inside the box, box filling the image, order switched off) groups of 4 x 4
+        grouped(1);
+        if (ag.first_w == 0) grouped(2);
+    } else if (a.group_shift) {
+        grouped(a.group_shift);
     }
     return launch_raymarch_grid(ag, grid, stream);
 }

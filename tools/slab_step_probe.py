@@ -68,6 +68,19 @@ def main():
         pkg.fill_grid(prm, grid, slab.owned0, slab.owned1, dist=own_dist)
 
     out = {"steps": steps, "one_launch_capable": comm.one_launch_capable}
+    if "--graph" in sys.argv and "--graph-child" not in sys.argv:
+        # the capture crashes the process on this image (hipStreamEndCapture): run it in a child and report
+        import subprocess
+        comm.close()
+        r = subprocess.run([sys.executable, "-X", "faulthandler", os.path.abspath(__file__)] + sys.argv[1:] + ["--graph-child"],
+                           capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        out = json.loads(lines[-1]) if lines else {}
+        out["graph_child_returncode"] = r.returncode  # -11: segmentation fault inside the capture
+        if r.returncode != 0:
+            out["graph_child_stderr_tail"] = r.stderr[-600:]
+        print(json.dumps(out), flush=True)
+        return
     if "--graph" in sys.argv:
         # the event form of the step (fork / join by events: capturable) recorded into a HIP graph and
         # replayed, against the same form enqueued call by call
