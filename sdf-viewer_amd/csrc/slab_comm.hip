@@ -185,18 +185,26 @@ int enqueue_exchange_packed(const Rccl* lib, const sdfv_slab_comm* c, const sdfv
     const size_t owned = g->z_end - g->z_begin;
     const size_t lo = c->ghost_lo();
     if (!c->has_lo() && !c->has_hi()) return SDFV_OK;
-    SDFV_RCCL(lib, GroupStart());
+#ifdef SDFV_TUNING  // diagnostics: drop the RCCL group (8) or the ghost copy (16) to price them (results undefined)
+    const bool no_rccl = (sdfv::options().wave_timing & 8) != 0, no_copy = (sdfv::options().wave_timing & 16) != 0;
+#else
+    const bool no_rccl = false, no_copy = false;
+#endif
     int first_error = kNcclSuccess;
     auto post = [&](int r) {
         if (first_error == kNcclSuccess) first_error = r;
     };
+    if (!no_rccl) {
+    SDFV_RCCL(lib, GroupStart());
     if (c->has_lo()) post(lib->Send(c->send_lo(), 2 * c->halo_hi * slice, kNcclFloat, c->lo_peer(), c->comm, stream));
     if (c->has_hi()) post(lib->Send(c->send_hi(), 2 * slice, kNcclFloat, c->hi_peer(), c->comm, stream));
     if (c->has_hi()) post(lib->Recv(c->recv_hi(), 2 * c->halo_hi * slice, kNcclFloat, c->hi_peer(), c->comm, stream));
     if (c->has_lo()) post(lib->Recv(c->recv_lo(), 2 * slice, kNcclFloat, c->lo_peer(), c->comm, stream));
     post(lib->GroupEnd());
+    }
     if (first_error != kNcclSuccess)
         return sdfv::set_error(SDFV_ERR_COMM, "RCCL halo exchange: %s", lib->GetErrorString(first_error));
+    if (no_copy) return SDFV_OK;
     const float* src[4] = {nullptr, nullptr, nullptr, nullptr};
     float* dst[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t n[4] = {0, 0, 0, 0};
@@ -417,6 +425,9 @@ int sdfv_slab_fill_step_commit(sdfv_slab_comm* c, const sdfv_demo_params* params
         }
         if (packed) {
             of.stage_only = true;
+#ifdef SDFV_TUNING
+            if (!(sdfv::options().wave_timing & 4))  // diagnostics: drop the boundary launch
+#endif
             if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, 0, nb, c->comm_stream)) return rc;
             if (int rc = exchange_on(c->comm_stream)) return rc;
             SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));

@@ -22,7 +22,10 @@ def run(fn, n=40, warm=0.15):
     return round((time.perf_counter() - t0) / n * 1e3, 4)
 res = {}
 for rnd in range(2):
-    for name, diag in (("step", 0), ("no_start_event", 1), ("no_final_wait", 2), ("neither", 3)):
+    # bits: 1 no start dependency, 2 no final wait, 4 no boundary launch, 8 no RCCL group, 16 no ghost copy
+    for name, diag in (("step", 0), ("no_start_event", 1), ("no_final_wait", 2), ("neither", 3), ("no_boundary_launch", 4),
+                       ("no_rccl", 8), ("no_ghost_copy", 16), ("no_rccl_no_copy", 24), ("only_the_waits", 28),
+                       ("nothing_but_the_fill", 31)):
         pkg.set_option(K.OPT_TUNING_WAVE_TIMING, diag)
         res.setdefault(name, []).append(run(lambda: comm.fill_step(prm, grid, slab)))
     pkg.set_option(K.OPT_TUNING_WAVE_TIMING, 0)
