@@ -42,7 +42,9 @@ int ordered_fill_blocks(const sdfv_grid* slab, uint32_t* per_slice, uint32_t* to
 int fill_slab_ordered(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* slab, float* o0, float* o1,
                       const OrderedFill& of, uint32_t block_begin, uint32_t block_end, void* stream);
 // dst[i] = src[i] over up to four segments of `n` 16-byte texels (ghost slices out of the packed receive buffers).
-int copy_texel_segments(const float* const src[4], float* const dst[4], const size_t n[4], void* stream);
+// r_out (or its entries) may be NULL; r_out[i] receives the first component of segment i's texels as a compact array
+int copy_texel_segments(const float* const src[4], float* const dst[4], const size_t n[4], float* const r_out[4],
+                        void* stream);
 // sdfv_fill_grid whose first workgroup stores `value` to `signal` (signal memory) as soon as the launch starts.
 int fill_grid_signalling_start(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, float* tex0,
                                float* tex1, float* dist, uint32_t* signal, uint32_t value, void* stream);

@@ -71,6 +71,7 @@ struct CopySegments {
     const float4* src[4];
     float4* dst[4];
     uint32_t n[4];  // texels
+    float* r_out[4];  // optional: the texels' first component as a compact array (the distance volume's ghost slices)
 };
 hipError_t launch_copy_segments(const CopySegments& c, hipStream_t stream);
 // slab_d slices z_begin + k * z_step in ONE launch (the two boundary slices of a slab: slab_d = 2).

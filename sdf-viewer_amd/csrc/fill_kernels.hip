@@ -233,7 +233,12 @@ __global__ __launch_bounds__(kBlock) void copy_segments_kernel(CopySegments c) {
     const uint32_t n = c.n[seg];
     const float4* __restrict__ src = c.src[seg];
     float4* __restrict__ dst = c.dst[seg];
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) dst[i] = src[i];
+    float* __restrict__ r_out = c.r_out[seg];  // block-uniform
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float4 t = src[i];
+        dst[i] = t;
+        if (r_out) r_out[i] = t.x;
+    }
 }
 
 // One visited voxel of a LoadingManager pass: update_required (scene/sdf/mod.rs:184-190) and, when it holds, the

@@ -293,7 +293,8 @@ int fill_slab_ordered(const sdfv_demo_params* params, uint32_t sdf_id, const sdf
     return SDFV_OK;
 }
 
-int copy_texel_segments(const float* const src[4], float* const dst[4], const size_t n[4], void* stream) {
+int copy_texel_segments(const float* const src[4], float* const dst[4], const size_t n[4], float* const r_out[4],
+                        void* stream) {
     CopySegments c;
     memset(&c, 0, sizeof(c));
     for (int i = 0; i < 4; ++i) {
@@ -301,6 +302,7 @@ int copy_texel_segments(const float* const src[4], float* const dst[4], const si
         c.src[i] = reinterpret_cast<const float4*>(src[i]);
         c.dst[i] = reinterpret_cast<float4*>(dst[i]);
         c.n[i] = (uint32_t)n[i];
+        c.r_out[i] = r_out ? r_out[i] : nullptr;
     }
     SDFV_HIP(launch_copy_segments(c, (hipStream_t)stream));
     return SDFV_OK;

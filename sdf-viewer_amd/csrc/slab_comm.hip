@@ -179,8 +179,10 @@ int enqueue_exchange_direct(const Rccl* lib, const sdfv_slab_comm* c, const sdfv
 
 // One ncclGroup over the packed staging buffers (filled by the boundary workgroups of the ordered fill): ONE message per
 // neighbour and direction carrying both textures' slices, then one launch that copies the received slices into the ghosts.
+// dist (optional): the slab's compact distance volume incl. ghost slices -- the copy out of the receive buffers writes the
+// ghost slices' share (tex0.r) in the same pass
 int enqueue_exchange_packed(const Rccl* lib, const sdfv_slab_comm* c, const sdfv_grid* g, float* tex0, float* tex1,
-                            hipStream_t stream) {
+                            float* dist, hipStream_t stream) {
     const size_t slice = c->slice_f();
     const size_t owned = g->z_end - g->z_begin;
     const size_t lo = c->ghost_lo();
@@ -207,16 +209,19 @@ int enqueue_exchange_packed(const Rccl* lib, const sdfv_slab_comm* c, const sdfv
     if (no_copy) return SDFV_OK;
     const float* src[4] = {nullptr, nullptr, nullptr, nullptr};
     float* dst[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* r_out[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t n[4] = {0, 0, 0, 0};
     if (c->has_hi()) {  // [tex0 halo_hi slices | tex1 halo_hi slices] from above -> the upper ghosts
         src[0] = c->recv_hi();                          dst[0] = tex0 + (lo + owned) * slice; n[0] = c->halo_hi * c->stage_slice;
+        if (dist) r_out[0] = dist + (lo + owned) * (slice / 4);
         src[1] = c->recv_hi() + c->halo_hi * slice;     dst[1] = tex1 + (lo + owned) * slice; n[1] = c->halo_hi * c->stage_slice;
     }
     if (c->has_lo()) {  // [tex0 slice | tex1 slice] from below -> the lower ghost
         src[2] = c->recv_lo();                          dst[2] = tex0; n[2] = c->stage_slice;
+        if (dist) r_out[2] = dist;
         src[3] = c->recv_lo() + slice;                  dst[3] = tex1; n[3] = c->stage_slice;
     }
-    return sdfv::copy_texel_segments(src, dst, n, stream);
+    return sdfv::copy_texel_segments(src, dst, n, r_out, stream);
 }
 
 }  // namespace
@@ -394,8 +399,8 @@ int sdfv_slab_fill_step_commit(sdfv_slab_comm* c, const sdfv_demo_params* params
     }
     const uint32_t nb = (lead + 1) * bps;  // the boundary workgroups: what the neighbours wait for
     auto exchange_on = [&](hipStream_t st) -> int {
-        if (int rc = packed ? enqueue_exchange_packed(lib, c, slab, tex0, tex1, st) : enqueue_exchange_direct(lib, c, slab, tex0, tex1, st))
-            return rc;
+        if (packed) return enqueue_exchange_packed(lib, c, slab, tex0, tex1, dist, st);  // ghost copy + their distances in one launch
+        if (int rc = enqueue_exchange_direct(lib, c, slab, tex0, tex1, st)) return rc;
         return ghost_distances(st);
     };
 
