@@ -99,8 +99,9 @@ def check_config4(world=8, side=1024, threads=None, log=print):
     return bad
 
 
-def random_sweep(n, seed=1, log=print):
-    """n random parameter sets and cameras at configs[1]'s full size; -> number of runs with any difference."""
+def random_sweep(n, seed=1, log=print, side=256):
+    """n random parameter sets and cameras at configs[1]'s (side 256) or configs[2]'s (512) full size; -> number of runs
+    with any difference."""
     rng = np.random.default_rng(seed)
     failures = 0
     for k in range(n):
@@ -110,7 +111,7 @@ def random_sweep(n, seed=1, log=print):
                   disable_sphere=int(rng.integers(0, 5) == 0))
         v = rng.normal(size=3)
         eye = tuple(float(x) for x in v / np.linalg.norm(v) * rng.uniform(0.3, 6.0))
-        bad, diff, err = check(256, log=lambda m: None, eye=eye, **kw)
+        bad, diff, err = check(side, log=lambda m: None, eye=eye, **kw)
         ok = bad == 0 and not any(diff.values()) and err <= 1e-4
         failures += 0 if ok else 1
         log(f"run {k}: {kw} eye {tuple(round(e, 2) for e in eye)} -> texture words {bad}, aux {sum(diff.values())}, rgba {err:.2g}"
@@ -121,7 +122,8 @@ def random_sweep(n, seed=1, log=print):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "sweep":
         n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-        bad = random_sweep(n, log=lambda m: print(m, flush=True))
+        side = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+        bad = random_sweep(n, seed=1 if side == 256 else 2, log=lambda m: print(m, flush=True), side=side)
         print(f"sweep: {n} random full-size runs, {bad} with differences", flush=True)
         return
     for side in [int(a) for a in sys.argv[1:]] or [256, 512, 1024]:
