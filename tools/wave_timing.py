@@ -19,6 +19,8 @@ K = pkg._capi
 side, W, H = 256, 1920, 1080
 if "--side" in sys.argv:
     side = int(sys.argv[sys.argv.index("--side") + 1])
+if "--4k" in sys.argv:
+    W, H = 3840, 2160
 prm = pkg.default_params()
 g = pkg.make_grid((side,) * 3)
 t0, t1 = pkg.alloc_textures(g)
