@@ -153,6 +153,9 @@ typedef enum sdfv_option {
                                         * the screen rectangle of the projected bounding box are launched before the others (the
                                         * frame is as long as its longest wave; those all start at once then).  Order only */
     SDFV_OPT_TUNING_WAVE_TIMING = 100, /* tuning build only (-DSDFV_TUNING): DEVICE address of 32 B per raymarch wave */
+    SDFV_OPT_TUNING_TILE_ORDER = 102,  /* tuning build only: DEVICE address of tiles_x * tiles_y uint32 tile numbers (row-major
+                                        * tile index by * tiles_x + bx): workgroup L of a single-camera launch renders tile
+                                        * order[L] (an oracle for longest-first scheduling experiments) */
     SDFV_OPT_TUNING_PRIORITY_MAP = 101 /* tuning build only: DEVICE address of one byte per 16 x 16 raymarch tile (row-major);
                                         * waves of tiles whose byte is non-zero raise their issue priority at start */
 } sdfv_option;

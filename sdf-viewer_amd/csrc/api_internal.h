@@ -17,6 +17,7 @@ struct Options {
     uint32_t slab_step_form = 0;     // 0 auto, SDFV_STEP_* otherwise
     unsigned long long wave_timing = 0;  // tuning build only
     unsigned long long priority_map = 0;  // tuning build only
+    unsigned long long tile_order = 0;    // tuning build only
 };
 const Options& options();
 // Formats the thread-local message sdfv_last_error() returns and hands `code` back.

@@ -680,6 +680,13 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
     // 8x8 pixel tile per wave, 2x2 waves per workgroup
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t bx = blockIdx.x, by = blockIdx.y;
+#ifdef SDFV_TUNING
+    if (a.tile_order) {  // 1-D launch over the tiles, in the order given
+        const uint32_t tiles_x = (a.width + 15) / 16, t = a.tile_order[blockIdx.x];
+        bx = t % tiles_x;
+        by = t / tiles_x;
+    } else
+#endif
     if (a.group_shift) {
         // XCD-aware order (a.group_shift = g): the launch is 1-D over workgroups; workgroup L runs on XCD L % 8 (observed
         // placement, used for speed only).  The image is cut into groups of 2^g x 2^g tiles; group number G goes to XCD
@@ -1182,6 +1189,12 @@ hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream) {
     dim3 grid((a.width + 15) / 16, (rows + 15) / 16, a.n_cameras);
     RaymarchArgs ag = a;
     const dim3 tiles = grid;
+#ifdef SDFV_TUNING
+    if (a.tile_order) {
+        ag.group_shift = 0;
+        return launch_raymarch_grid(ag, dim3(tiles.x * tiles.y, 1, 1), stream);
+    }
+#endif
     // the 1-D launch over groups of 2^shift x 2^shift tiles (padded to whole groups, a multiple of 8 of them), with the
     // box-first rectangle where one exists
     auto grouped = [&](uint32_t shift) {
