@@ -210,3 +210,13 @@ def test_headers_compile_as_plain_c_and_the_library_links(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_integration_guide_binds_every_entry_point():
+    """INTEGRATION.md shows the reference-side binding for every function include/sdfgrid.h declares."""
+    import re
+    header = open(os.path.join(ROOT, "include", "sdfgrid.h")).read()
+    guide = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    declared = set(re.findall(r"\b(sdfv_[a-z0-9_]+)\s*\(", header))
+    missing = sorted(f for f in declared if f not in guide)
+    assert not missing, missing
