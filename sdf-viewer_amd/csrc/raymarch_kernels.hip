@@ -287,7 +287,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 // check against the oracle for every pixel.  Covers: LINEAR filter, power-of-two extents and texture sizes (XF == 2),
 // symmetric box, clamp-for-mirror (fast_index); STRIDE 1 = compact distance volume (one 8-byte load per corner row),
 // STRIDE 4 = tex0.r in place.  Byte offsets are 32-bit: the launcher checks the volume's size.
-// Registers: v40-v87 and s64-s85 are this block's (declared as clobbers; low enough that the kernel stays at 96
+// Registers: v24-v71 and s64-s87 are this block's (declared as clobbers; low enough that the kernel stays at 96
 // VGPRs = 5 waves per SIMD); operands stay where hipcc put them.
 #ifdef SDFV_TUNING
 #define SDFV_MARCH_ASM_TUNE(x) x
@@ -298,8 +298,8 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "s_mov_b64 s[76:77], exec\n"                                                                                    \
     "s_and_b64 exec, exec, %[cov]\n"                                                                                \
     "s_cbranch_execz .Ldone_%=\n"                                                                                   \
-    "v_mov_b32 v56, %[px]\n v_mov_b32 v58, %[py]\n v_mov_b32 v59, %[pz]\n"                                           \
-    "v_mov_b32 v60, %[dx]\n v_mov_b32 v62, %[dy]\n v_mov_b32 v63, %[dz]\n"                                        \
+    "v_mov_b32 v40, %[px]\n v_mov_b32 v42, %[py]\n v_mov_b32 v43, %[pz]\n"                                           \
+    "v_mov_b32 v44, %[dx]\n v_mov_b32 v46, %[dy]\n v_mov_b32 v47, %[dz]\n"                                        \
     "s_mov_b32 s66, %[miny]\n s_mov_b32 s67, %[minz]\n"      /* (miny, minz) */                                      \
     "s_mov_b32 s70, %[ky]\n s_mov_b32 s71, %[kz]\n"          /* (ky, kz) */                                          \
     "s_mov_b32 s72, 0xbf000000\n s_mov_b32 s73, 0xbf000000\n" /* (-0.5, -0.5) */                                     \
@@ -316,7 +316,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "s_add_u32 s64, %[base_lo], s64\n s_addc_u32 s65, %[base_hi], 0\n"   /* b10 */                                   \
     "s_add_u32 s86, s64, s86\n s_addc_u32 s87, s65, 0\n"                 /* b11 */                                   \
     SDFV_MARCH_ASM_TUNE("s_mov_b32 s84, 0\n")                /* tuning build: iterations that ran the fetch block */  \
-    "v_mov_b32 v84, 0x7f800000\n v_mov_b32 v86, 0x7f800000\n v_mov_b32 v87, 0x7f800000\n" /* no cell cached */    \
+    "v_mov_b32 v68, 0x7f800000\n v_mov_b32 v70, 0x7f800000\n v_mov_b32 v71, 0x7f800000\n" /* no cell cached */    \
     ".Lloop_%=:\n"
 // One iteration, top half.  Two independent chains are interleaved so that a lone wave rarely issues an instruction
 // that waits for the one before it: (A) out of bounds? max(|p| - max) > 1e-4 (material.frag:106-109) -> v_cmpx removes
@@ -324,30 +324,30 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 // relative to the cached cell: all three in [0, 1) <=> the cell is unchanged.
 // OOB4 / OOB2: the out-of-bounds distance max(|p| - max) in four instructions, or in two when the box is a cube
 // (max_x == max_y == max_z = m): max3(|p|) - m -- identical bits, rounding is monotonic so max and "- m" commute.
-#define SDFV_MARCH_ASM_OOB4_A "v_sub_f32_e64 v48, |v56|, %[mx]\n"
-#define SDFV_MARCH_ASM_OOB4_B "v_sub_f32_e64 v49, |v58|, %[my]\n"
-#define SDFV_MARCH_ASM_OOB4_C "v_sub_f32_e64 v50, |v59|, %[mz]\n"
-#define SDFV_MARCH_ASM_OOB4_D "v_max3_f32 v48, v48, v49, v50\n"
-#define SDFV_MARCH_ASM_OOB2_A "v_max3_f32 v48, |v56|, |v58|, |v59|\n"
-#define SDFV_MARCH_ASM_OOB2_D "v_subrev_f32_e32 v48, %[mx], v48\n"
+#define SDFV_MARCH_ASM_OOB4_A "v_sub_f32_e64 v32, |v40|, %[mx]\n"
+#define SDFV_MARCH_ASM_OOB4_B "v_sub_f32_e64 v33, |v42|, %[my]\n"
+#define SDFV_MARCH_ASM_OOB4_C "v_sub_f32_e64 v34, |v43|, %[mz]\n"
+#define SDFV_MARCH_ASM_OOB4_D "v_max3_f32 v32, v32, v33, v34\n"
+#define SDFV_MARCH_ASM_OOB2_A "v_max3_f32 v32, |v40|, |v42|, |v43|\n"
+#define SDFV_MARCH_ASM_OOB2_D "v_subrev_f32_e32 v32, %[mx], v32\n"
 #define SDFV_MARCH_ASM_TOP(T_STEP, OOB_A, OOB_B, OOB_C, OOB_D)                                                      \
     OOB_A                                                                                                           \
-    "v_subrev_f32_e32 v64, %[minx], v56\n"                                                                          \
+    "v_subrev_f32_e32 v48, %[minx], v40\n"                                                                          \
     OOB_B                                                                                                           \
-    "v_pk_add_f32 v[66:67], v[58:59], s[66:67] neg_lo:[0,1] neg_hi:[0,1]\n"                                         \
+    "v_pk_add_f32 v[50:51], v[42:43], s[66:67] neg_lo:[0,1] neg_hi:[0,1]\n"                                         \
     OOB_C                                                                                                           \
-    "v_mul_f32_e32 v64, %[kx], v64\n"                                                                               \
-    "v_pk_mul_f32 v[66:67], v[66:67], s[70:71]\n"                                                                   \
+    "v_mul_f32_e32 v48, %[kx], v48\n"                                                                               \
+    "v_pk_mul_f32 v[50:51], v[50:51], s[70:71]\n"                                                                   \
     OOB_D                                                                                                           \
-    "v_add_f32_e32 v64, -0.5, v64\n"                                                                                \
-    "v_pk_add_f32 v[66:67], v[66:67], s[72:73]\n"                                                                   \
-    "v_cmpx_nlt_f32_e32 vcc, 0x38d1b717, v48\n"              /* exec &= !(1e-4 < oob) */                             \
+    "v_add_f32_e32 v48, -0.5, v48\n"                                                                                \
+    "v_pk_add_f32 v[50:51], v[50:51], s[72:73]\n"                                                                   \
+    "v_cmpx_nlt_f32_e32 vcc, 0x38d1b717, v32\n"              /* exec &= !(1e-4 < oob) */                             \
     "s_cbranch_execz .Ldone_%=\n"                                                                                   \
-    "v_sub_f32_e32 v68, v64, v84\n"                                                                              \
-    "v_sub_f32_e32 v70, v66, v86\n"                                                                              \
-    "v_sub_f32_e32 v72, v67, v87\n" T_STEP                                                                       \
-    "v_max3_u32 v48, v68, v70, v72\n"                                                                            \
-    "v_cmp_gt_u32_e32 vcc, 0x3f800000, v48\n"                                                                       \
+    "v_sub_f32_e32 v52, v48, v68\n"                                                                              \
+    "v_sub_f32_e32 v54, v50, v70\n"                                                                              \
+    "v_sub_f32_e32 v56, v51, v71\n" T_STEP                                                                       \
+    "v_max3_u32 v32, v52, v54, v56\n"                                                                            \
+    "v_cmp_gt_u32_e32 vcc, 0x3f800000, v32\n"                                                                       \
     "s_andn1_saveexec_b64 s[78:79], vcc\n"                   /* exec = lanes whose cell changed */                   \
     "s_cbranch_execnz .Lfetch_%=\n"                          /* out of line: the cached case falls through */        \
     ".Lcached_%=:\n"
@@ -356,109 +356,109 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     ".Lfetch_%=:\n"                                                                                                 \
     SDFV_MARCH_ASM_TUNE("s_add_u32 s84, s84, 1\n")                                                                  \
     /* new cell: floor, weights, clamped corner indices (MirroredRepeat == clamp here), row numbers by shifts */    \
-    "v_floor_f32_e32 v84, v64\n v_floor_f32_e32 v86, v66\n v_floor_f32_e32 v87, v67\n"                         \
-    "v_cvt_i32_f32_e32 v48, v84\n v_cvt_i32_f32_e32 v49, v86\n v_cvt_i32_f32_e32 v50, v87\n"                      \
-    "v_sub_f32_e32 v68, v64, v84\n v_sub_f32_e32 v70, v66, v86\n v_sub_f32_e32 v72, v67, v87\n"             \
+    "v_floor_f32_e32 v68, v48\n v_floor_f32_e32 v70, v50\n v_floor_f32_e32 v71, v51\n"                         \
+    "v_cvt_i32_f32_e32 v32, v68\n v_cvt_i32_f32_e32 v33, v70\n v_cvt_i32_f32_e32 v34, v71\n"                      \
+    "v_sub_f32_e32 v52, v48, v68\n v_sub_f32_e32 v54, v50, v70\n v_sub_f32_e32 v56, v51, v71\n"             \
     /* every fetching lane's cell inside the volume (cubic volumes: 0 <= i0, j0, k0 <= N - 2, one unsigned compare)? */ \
-    "v_max3_u32 v51, v48, v49, v50\n"                                                                               \
-    "v_cmp_gt_u32_e32 vcc, %[thresh], v51\n"                                                                        \
+    "v_max3_u32 v35, v32, v33, v34\n"                                                                               \
+    "v_cmp_gt_u32_e32 vcc, %[thresh], v35\n"                                                                        \
     "s_xor_b64 vcc, vcc, exec\n"                                                                                    \
     "s_cbranch_scc1 .Lborder_%=\n"                                                                                  \
-    "v_lshl_add_u32 v55, v50, %[lgh], v49\n"                                                                        \
-    "v_lshl_add_u32 v55, v55, %[lgw], v48\n" INTERIOR                                                               \
+    "v_lshl_add_u32 v39, v34, %[lgh], v33\n"                                                                        \
+    "v_lshl_add_u32 v39, v39, %[lgw], v32\n" INTERIOR                                                               \
     "s_branch .Lcached_%=\n"                                                                                        \
     ".Lborder_%=:\n"                                                                                                \
-    "v_max_i32_e32 v51, 0, v48\n v_max_i32_e32 v53, 0, v49\n v_max_i32_e32 v54, 0, v50\n"  /* i0c, j0c, k0c */       \
-    "v_add_u32_e32 v48, 1, v48\n v_add_u32_e32 v49, 1, v49\n v_add_u32_e32 v50, 1, v50\n"                            \
-    "v_min_i32_e32 v48, %[wm1], v48\n v_min_i32_e32 v49, %[hm1], v49\n v_min_i32_e32 v50, %[dm1], v50\n" /* i1c.. */  \
-    "v_lshl_add_u32 v44, v54, %[lgh], v53\n"                 /* rows: (k0c, j0c) */                                  \
-    "v_lshl_add_u32 v45, v54, %[lgh], v49\n"                 /*       (k0c, j1c) */                                  \
-    "v_lshl_add_u32 v46, v50, %[lgh], v53\n"                 /*       (k1c, j0c) */                                  \
-    "v_lshl_add_u32 v47, v50, %[lgh], v49\n"                 /*       (k1c, j1c) */
-// Interior fetch (v55 = texel index of corner (i0, j0, k0)): no clamps, no selects.
+    "v_max_i32_e32 v35, 0, v32\n v_max_i32_e32 v37, 0, v33\n v_max_i32_e32 v38, 0, v34\n"  /* i0c, j0c, k0c */       \
+    "v_add_u32_e32 v32, 1, v32\n v_add_u32_e32 v33, 1, v33\n v_add_u32_e32 v34, 1, v34\n"                            \
+    "v_min_i32_e32 v32, %[wm1], v32\n v_min_i32_e32 v33, %[hm1], v33\n v_min_i32_e32 v34, %[dm1], v34\n" /* i1c.. */  \
+    "v_lshl_add_u32 v28, v38, %[lgh], v37\n"                 /* rows: (k0c, j0c) */                                  \
+    "v_lshl_add_u32 v29, v38, %[lgh], v33\n"                 /*       (k0c, j1c) */                                  \
+    "v_lshl_add_u32 v30, v34, %[lgh], v37\n"                 /*       (k1c, j0c) */                                  \
+    "v_lshl_add_u32 v31, v34, %[lgh], v33\n"                 /*       (k1c, j1c) */
+// Interior fetch (v39 = texel index of corner (i0, j0, k0)): no clamps, no selects.
 #define SDFV_MARCH_ASM_INTERIOR_DIST                                                                                \
-    "v_lshlrev_b32_e32 v55, 2, v55\n"                                                                               \
-    "global_load_dwordx2 v[40:41], v55, %[base]\n"           /* (z0, y0): t000, t100 */                             \
-    "global_load_dwordx2 v[42:43], v55, s[64:65]\n"          /* (z0, y1): t010, t110 */                             \
-    "global_load_dwordx2 v[44:45], v55, s[68:69]\n"          /* (z1, y0): t001, t101 */                             \
-    "global_load_dwordx2 v[46:47], v55, s[86:87]\n"          /* (z1, y1): t011, t111 */                             \
+    "v_lshlrev_b32_e32 v39, 2, v39\n"                                                                               \
+    "global_load_dwordx2 v[24:25], v39, %[base]\n"           /* (z0, y0): t000, t100 */                             \
+    "global_load_dwordx2 v[26:27], v39, s[64:65]\n"          /* (z0, y1): t010, t110 */                             \
+    "global_load_dwordx2 v[28:29], v39, s[68:69]\n"          /* (z1, y0): t001, t101 */                             \
+    "global_load_dwordx2 v[30:31], v39, s[86:87]\n"          /* (z1, y1): t011, t111 */                             \
     "s_waitcnt vmcnt(1)\n"                                                                                          \
-    "v_pk_mov_b32 v[76:77], v[40:41], v[44:45] op_sel:[0,0]\n" /* (t000, t001) */                                   \
-    "v_pk_mov_b32 v[78:79], v[40:41], v[44:45] op_sel:[1,1]\n" /* (t100, t101) */                                   \
+    "v_pk_mov_b32 v[60:61], v[24:25], v[28:29] op_sel:[0,0]\n" /* (t000, t001) */                                   \
+    "v_pk_mov_b32 v[62:63], v[24:25], v[28:29] op_sel:[1,1]\n" /* (t100, t101) */                                   \
     "s_waitcnt vmcnt(0)\n"                                                                                          \
-    "v_pk_mov_b32 v[80:81], v[42:43], v[46:47] op_sel:[0,0]\n" /* (t010, t011) */                                   \
-    "v_pk_mov_b32 v[82:83], v[42:43], v[46:47] op_sel:[1,1]\n" /* (t110, t111) */
+    "v_pk_mov_b32 v[64:65], v[26:27], v[30:31] op_sel:[0,0]\n" /* (t010, t011) */                                   \
+    "v_pk_mov_b32 v[66:67], v[26:27], v[30:31] op_sel:[1,1]\n" /* (t110, t111) */
 #define SDFV_MARCH_ASM_INTERIOR_TEX0                                                                                \
-    "v_lshlrev_b32_e32 v55, 4, v55\n"                                                                               \
-    "global_load_dword v76, v55, %[base]\n global_load_dword v78, v55, %[base] offset:16\n"                       \
-    "global_load_dword v80, v55, s[64:65]\n global_load_dword v82, v55, s[64:65] offset:16\n"                     \
-    "global_load_dword v77, v55, s[68:69]\n global_load_dword v79, v55, s[68:69] offset:16\n"                     \
-    "global_load_dword v81, v55, s[86:87]\n global_load_dword v83, v55, s[86:87] offset:16\n"                     \
+    "v_lshlrev_b32_e32 v39, 4, v39\n"                                                                               \
+    "global_load_dword v60, v39, %[base]\n global_load_dword v62, v39, %[base] offset:16\n"                       \
+    "global_load_dword v64, v39, s[64:65]\n global_load_dword v66, v39, s[64:65] offset:16\n"                     \
+    "global_load_dword v61, v39, s[68:69]\n global_load_dword v63, v39, s[68:69] offset:16\n"                     \
+    "global_load_dword v65, v39, s[86:87]\n global_load_dword v67, v39, s[86:87] offset:16\n"                     \
     "s_waitcnt vmcnt(0)\n"
 // STRIDE 1: x-neighbours are adjacent floats: one 8-byte load per (y, z) row at b = clamp(i0, 0, W - 2); where the clamp
 // folds the two x-corners together both come from the same half (lo_is_x / hi_is_y).
 #define SDFV_MARCH_ASM_FETCH_DIST                                                                                   \
-    "v_min_i32_e32 v52, s75, v51\n"                          /* b = min(i0c, W - 2) */                               \
-    "v_lshlrev_b32_e32 v55, 2, v52\n"                                                                               \
-    "v_lshl_add_u32 v44, v44, s82, v55\n v_lshl_add_u32 v45, v45, s82, v55\n"                                        \
-    "v_lshl_add_u32 v46, v46, s82, v55\n v_lshl_add_u32 v47, v47, s82, v55\n"                                        \
-    "global_load_dwordx2 v[40:41], v44, %[base]\n"           /* (z0, y0) */                                          \
-    "global_load_dwordx2 v[42:43], v45, %[base]\n"           /* (z0, y1) */                                          \
-    "global_load_dwordx2 v[44:45], v46, %[base]\n"           /* (z1, y0) */                                          \
-    "global_load_dwordx2 v[46:47], v47, %[base]\n"           /* (z1, y1) */                                          \
-    "v_cmp_eq_u32_e64 s[80:81], v51, v52\n"                  /* lo_is_x */                                           \
-    "v_add_u32_e32 v52, 1, v52\n"                                                                                   \
-    "v_cmp_eq_u32_e32 vcc, v48, v52\n"                       /* hi_is_y */                                           \
+    "v_min_i32_e32 v36, s75, v35\n"                          /* b = min(i0c, W - 2) */                               \
+    "v_lshlrev_b32_e32 v39, 2, v36\n"                                                                               \
+    "v_lshl_add_u32 v28, v28, s82, v39\n v_lshl_add_u32 v29, v29, s82, v39\n"                                        \
+    "v_lshl_add_u32 v30, v30, s82, v39\n v_lshl_add_u32 v31, v31, s82, v39\n"                                        \
+    "global_load_dwordx2 v[24:25], v28, %[base]\n"           /* (z0, y0) */                                          \
+    "global_load_dwordx2 v[26:27], v29, %[base]\n"           /* (z0, y1) */                                          \
+    "global_load_dwordx2 v[28:29], v30, %[base]\n"           /* (z1, y0) */                                          \
+    "global_load_dwordx2 v[30:31], v31, %[base]\n"           /* (z1, y1) */                                          \
+    "v_cmp_eq_u32_e64 s[80:81], v35, v36\n"                  /* lo_is_x */                                           \
+    "v_add_u32_e32 v36, 1, v36\n"                                                                                   \
+    "v_cmp_eq_u32_e32 vcc, v32, v36\n"                       /* hi_is_y */                                           \
     "s_waitcnt vmcnt(3)\n"                                                                                          \
-    "v_cndmask_b32_e64 v76, v41, v40, s[80:81]\n v_cndmask_b32_e32 v78, v40, v41, vcc\n" /* t000, t100 */          \
+    "v_cndmask_b32_e64 v60, v25, v24, s[80:81]\n v_cndmask_b32_e32 v62, v24, v25, vcc\n" /* t000, t100 */          \
     "s_waitcnt vmcnt(2)\n"                                                                                          \
-    "v_cndmask_b32_e64 v80, v43, v42, s[80:81]\n v_cndmask_b32_e32 v82, v42, v43, vcc\n" /* t010, t110 */          \
+    "v_cndmask_b32_e64 v64, v27, v26, s[80:81]\n v_cndmask_b32_e32 v66, v26, v27, vcc\n" /* t010, t110 */          \
     "s_waitcnt vmcnt(1)\n"                                                                                          \
-    "v_cndmask_b32_e64 v77, v45, v44, s[80:81]\n v_cndmask_b32_e32 v79, v44, v45, vcc\n" /* t001, t101 */          \
+    "v_cndmask_b32_e64 v61, v29, v28, s[80:81]\n v_cndmask_b32_e32 v63, v28, v29, vcc\n" /* t001, t101 */          \
     "s_waitcnt vmcnt(0)\n"                                                                                          \
-    "v_cndmask_b32_e64 v81, v47, v46, s[80:81]\n v_cndmask_b32_e32 v83, v46, v47, vcc\n" /* t011, t111 */          \
+    "v_cndmask_b32_e64 v65, v31, v30, s[80:81]\n v_cndmask_b32_e32 v67, v30, v31, vcc\n" /* t011, t111 */          \
     "s_branch .Lcached_%=\n"
 // STRIDE 4: tex0.r out of 16-byte texels, one dword load per corner.
 #define SDFV_MARCH_ASM_FETCH_TEX0                                                                                   \
-    "v_lshlrev_b32_e32 v51, 4, v51\n v_lshlrev_b32_e32 v48, 4, v48\n"   /* i0c, i1c as byte offsets */               \
-    "v_lshl_add_u32 v40, v44, s83, v51\n v_lshl_add_u32 v41, v44, s83, v48\n"                                        \
-    "global_load_dword v76, v40, %[base]\n global_load_dword v78, v41, %[base]\n"                                  \
-    "v_lshl_add_u32 v42, v45, s83, v51\n v_lshl_add_u32 v43, v45, s83, v48\n"                                        \
-    "global_load_dword v80, v42, %[base]\n global_load_dword v82, v43, %[base]\n"                                  \
-    "v_lshl_add_u32 v40, v46, s83, v51\n v_lshl_add_u32 v41, v46, s83, v48\n"                                        \
-    "global_load_dword v77, v40, %[base]\n global_load_dword v79, v41, %[base]\n"                                  \
-    "v_lshl_add_u32 v42, v47, s83, v51\n v_lshl_add_u32 v43, v47, s83, v48\n"                                        \
-    "global_load_dword v81, v42, %[base]\n global_load_dword v83, v43, %[base]\n"                                  \
+    "v_lshlrev_b32_e32 v35, 4, v35\n v_lshlrev_b32_e32 v32, 4, v32\n"   /* i0c, i1c as byte offsets */               \
+    "v_lshl_add_u32 v24, v28, s83, v35\n v_lshl_add_u32 v25, v28, s83, v32\n"                                        \
+    "global_load_dword v60, v24, %[base]\n global_load_dword v62, v25, %[base]\n"                                  \
+    "v_lshl_add_u32 v26, v29, s83, v35\n v_lshl_add_u32 v27, v29, s83, v32\n"                                        \
+    "global_load_dword v64, v26, %[base]\n global_load_dword v66, v27, %[base]\n"                                  \
+    "v_lshl_add_u32 v24, v30, s83, v35\n v_lshl_add_u32 v25, v30, s83, v32\n"                                        \
+    "global_load_dword v61, v24, %[base]\n global_load_dword v63, v25, %[base]\n"                                  \
+    "v_lshl_add_u32 v26, v31, s83, v35\n v_lshl_add_u32 v27, v31, s83, v32\n"                                        \
+    "global_load_dword v65, v26, %[base]\n global_load_dword v67, v27, %[base]\n"                                  \
     "s_waitcnt vmcnt(0)\n"                                                                                          \
     "s_branch .Lcached_%=\n"
-// Corner registers as z-pairs: A0 = v[76:77] = (t000, t001), A1 = v[78:79] = (t100, t101), B0 = v[80:81] =
-// (t010, t011), B1 = v[82:83] = (t110, t111); weights (a, 1 - a) as pairs v[68:69], v[70:71], v[72:73].
+// Corner registers as z-pairs: A0 = v[60:61] = (t000, t001), A1 = v[62:63] = (t100, t101), B0 = v[64:65] =
+// (t010, t011), B1 = v[66:67] = (t110, t111); weights (a, 1 - a) as pairs v[52:53], v[54:55], v[56:57].
 #define SDFV_MARCH_ASM_FILTER                                                                                       \
     "s_mov_b64 exec, s[78:79]\n"                                                                                    \
-    "v_sub_f32_e32 v69, 1.0, v68\n v_sub_f32_e32 v71, 1.0, v70\n v_sub_f32_e32 v73, 1.0, v72\n"                \
+    "v_sub_f32_e32 v53, 1.0, v52\n v_sub_f32_e32 v55, 1.0, v54\n v_sub_f32_e32 v57, 1.0, v56\n"                \
     /* mix along x: c = t(x0) * (1 - ax) + t(x1) * ax */                                                            \
-    "v_pk_mul_f32 v[50:51], v[78:79], v[68:69] op_sel_hi:[1,0]\n"                                                \
-    "v_pk_mul_f32 v[54:55], v[82:83], v[68:69] op_sel_hi:[1,0]\n"                                                \
-    "v_pk_mul_f32 v[48:49], v[76:77], v[68:69] op_sel:[0,1] op_sel_hi:[1,1]\n"                                   \
-    "v_pk_mul_f32 v[52:53], v[80:81], v[68:69] op_sel:[0,1] op_sel_hi:[1,1]\n"                                   \
-    "v_pk_add_f32 v[48:49], v[48:49], v[50:51]\n"            /* (c00, c01) */                                        \
-    "v_pk_add_f32 v[52:53], v[52:53], v[54:55]\n"            /* (c10, c11) */                                        \
+    "v_pk_mul_f32 v[34:35], v[62:63], v[52:53] op_sel_hi:[1,0]\n"                                                \
+    "v_pk_mul_f32 v[38:39], v[66:67], v[52:53] op_sel_hi:[1,0]\n"                                                \
+    "v_pk_mul_f32 v[32:33], v[60:61], v[52:53] op_sel:[0,1] op_sel_hi:[1,1]\n"                                   \
+    "v_pk_mul_f32 v[36:37], v[64:65], v[52:53] op_sel:[0,1] op_sel_hi:[1,1]\n"                                   \
+    "v_pk_add_f32 v[32:33], v[32:33], v[34:35]\n"            /* (c00, c01) */                                        \
+    "v_pk_add_f32 v[36:37], v[36:37], v[38:39]\n"            /* (c10, c11) */                                        \
     /* mix along y */                                                                                               \
-    "v_pk_mul_f32 v[48:49], v[48:49], v[70:71] op_sel:[0,1] op_sel_hi:[1,1]\n"                                     \
-    "v_pk_mul_f32 v[52:53], v[52:53], v[70:71] op_sel_hi:[1,0]\n"                                                  \
-    "v_pk_add_f32 v[48:49], v[48:49], v[52:53]\n"            /* (c0, c1) */                                          \
+    "v_pk_mul_f32 v[32:33], v[32:33], v[54:55] op_sel:[0,1] op_sel_hi:[1,1]\n"                                     \
+    "v_pk_mul_f32 v[36:37], v[36:37], v[54:55] op_sel_hi:[1,0]\n"                                                  \
+    "v_pk_add_f32 v[32:33], v[32:33], v[36:37]\n"            /* (c0, c1) */                                          \
     /* mix along z, then sample_dist = r - 0.1 */                                                                   \
-    "v_pk_mul_f32 v[48:49], v[48:49], v[72:73] op_sel:[0,1] op_sel_hi:[1,0]\n" /* (c0 * (1 - az), c1 * az) */      \
-    "v_add_f32_e32 v52, v48, v49\n"                                                                                 \
-    "v_add_f32_e32 v52, 0xbdcccccd, v52\n"                                                                          \
+    "v_pk_mul_f32 v[32:33], v[32:33], v[56:57] op_sel:[0,1] op_sel_hi:[1,0]\n" /* (c0 * (1 - az), c1 * az) */      \
+    "v_add_f32_e32 v36, v32, v33\n"                                                                                 \
+    "v_add_f32_e32 v36, 0xbdcccccd, v36\n"                                                                          \
     /* hit?  (material.frag:117-121) */                                                                             \
-    "v_cmpx_ngt_f32_e32 vcc, 0x3727c5ac, v52\n"              /* exec &= !(1e-5 > sample_dist) */
+    "v_cmpx_ngt_f32_e32 vcc, 0x3727c5ac, v36\n"              /* exec &= !(1e-5 > sample_dist) */
 #define SDFV_MARCH_ASM_ADVANCE                                                                                      \
     /* advance the rays that go on (material.frag:124-125) */                                                       \
-    "v_mul_f32_e32 v48, v60, v52\n"                                                                                \
-    "v_pk_mul_f32 v[50:51], v[62:63], v[52:53] op_sel_hi:[1,0]\n"                                                  \
-    "v_add_f32_e32 v56, v56, v48\n"                                                                                 \
-    "v_pk_add_f32 v[58:59], v[58:59], v[50:51]\n"                                                                   \
+    "v_mul_f32_e32 v32, v44, v36\n"                                                                                \
+    "v_pk_mul_f32 v[34:35], v[46:47], v[36:37] op_sel_hi:[1,0]\n"                                                  \
+    "v_add_f32_e32 v40, v40, v32\n"                                                                                 \
+    "v_pk_add_f32 v[42:43], v[42:43], v[34:35]\n"                                                                   \
     "s_add_u32 s74, s74, -1\n"                               /* carry out <=> iterations left */                     \
     "s_cbranch_scc1 .Lloop_%=\n"                                                                                    \
     "s_branch .Ldone_%=\n"
@@ -468,7 +468,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "s_mov_b32 %[left], s74\n"                                                                                      \
     SDFV_MARCH_ASM_TUNE("s_lshl_b32 s84, s84, 16\n s_and_b32 %[left], %[left], 0xffff\n s_or_b32 %[left], %[left], s84\n") \
     "s_and_b64 exec, s[76:77], %[cov]\n"                                                                            \
-    "v_mov_b32 %[px], v56\n v_mov_b32 %[py], v58\n v_mov_b32 %[pz], v59\n"
+    "v_mov_b32 %[px], v40\n v_mov_b32 %[py], v42\n v_mov_b32 %[pz], v43\n"
 #define SDFV_MARCH_ASM_END "s_mov_b64 exec, s[76:77]\n"
 #define SDFV_MARCH_ASM_OPERANDS                                                                                     \
     [dx] "v"(ray_dir.x), [dy] "v"(ray_dir.y), [dz] "v"(ray_dir.z), [cov] "s"(cov), [mx] "s"(a.rp.bounds_max[0]),    \
@@ -477,11 +477,11 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
         [wm1] "s"(wm1), [hm1] "s"(hm1), [dm1] "s"(dm1), [lgw] "s"(lgw), [lgh] "s"(lgh), [base] "s"(vol), [base_lo] "s"(base_lo), [base_hi] "s"(base_hi), [thresh] "s"(thresh)
 #define SDFV_MARCH_ASM_CLOBBERS                                                                                     \
     "vcc", "scc", "memory", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",    \
-        "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "v40", "v41", "v42", "v43", "v44",  \
-        "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",    \
-        "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72",   \
-        "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85",   \
-        "v86", "v87"
+        "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "v24", "v25", "v26", "v27", "v28",  \
+        "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43",    \
+        "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56",   \
+        "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69",   \
+        "v70", "v71"
 
 template <bool SYMM_UNUSED, int STRIDE, bool T>
 __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __restrict__ vol, const Tex& t,
@@ -503,12 +503,12 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
 #define SDFV_MARCH_ASM_OOB_BOX SDFV_MARCH_ASM_OOB4_A, SDFV_MARCH_ASM_OOB4_B, SDFV_MARCH_ASM_OOB4_C, SDFV_MARCH_ASM_OOB4_D
 #define SDFV_MARCH_ASM_OOB_CUBE SDFV_MARCH_ASM_OOB2_A, "", "", SDFV_MARCH_ASM_OOB2_D
 #define SDFV_MARCH_ASM_TOP_(T_STEP, ...) SDFV_MARCH_ASM_TOP(T_STEP, __VA_ARGS__)
-// aux variant: distanceFromOrigin (v74) and the per-ray fetch count (v75) ride along
+// aux variant: distanceFromOrigin (v58) and the per-ray fetch count (v59) ride along
 #define SDFV_MARCH_ASM_RUN_AUX(SHIFT, INTERIOR, FETCH, OOB)                                                         \
-    asm volatile("v_mov_b32 v74, %[tt]\n v_mov_b32 v75, 0\n" SDFV_MARCH_ASM_HEAD(SHIFT)                             \
-                 SDFV_MARCH_ASM_TOP_("v_add_u32_e32 v75, 1, v75\n", OOB) SDFV_MARCH_ASM_FILTER                       \
-                 "v_add_f32_e32 v74, v74, v52\n" SDFV_MARCH_ASM_ADVANCE SDFV_MARCH_ASM_FETCH_PREP(INTERIOR) FETCH    \
-                 SDFV_MARCH_ASM_EPILOGUE "v_mov_b32 %[tt], v74\n v_mov_b32 %[n], v75\n" SDFV_MARCH_ASM_END           \
+    asm volatile("v_mov_b32 v58, %[tt]\n v_mov_b32 v59, 0\n" SDFV_MARCH_ASM_HEAD(SHIFT)                             \
+                 SDFV_MARCH_ASM_TOP_("v_add_u32_e32 v59, 1, v59\n", OOB) SDFV_MARCH_ASM_FILTER                       \
+                 "v_add_f32_e32 v58, v58, v36\n" SDFV_MARCH_ASM_ADVANCE SDFV_MARCH_ASM_FETCH_PREP(INTERIOR) FETCH    \
+                 SDFV_MARCH_ASM_EPILOGUE "v_mov_b32 %[tt], v58\n v_mov_b32 %[n], v59\n" SDFV_MARCH_ASM_END           \
                  : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tt] "+v"(tt), [n] "+v"(n), [ran] "=&s"(ran_out),   \
                    [left] "=&s"(left)                                                                               \
                  : SDFV_MARCH_ASM_OPERANDS                                                                          \
@@ -838,7 +838,11 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
         // The fast kernels know the hit point is within 1e-4 of the box; the normal's taps are h further out,
         // a.fast_normal says whether floor(u) still stays in [-1, N-1] for them.
         const float4 raw0 = sample_rgba<LINEAR, XF, FAST>(a, tex0, ray_pos);  // == the march's last sample
-        const float4 raw1 = sample_rgba<LINEAR, XF, FAST>(a, tex1, ray_pos);  // material.frag:154
+        // one texture's eight 16-byte corners at a time: both sets in flight together would cost 32 more VGPRs than the rest
+        // of the kernel needs (one wave per SIMD less)
+        V3 pos1 = ray_pos;
+        asm volatile("" : "+v"(pos1.x) : "v"(raw0.x), "v"(raw0.y), "v"(raw0.z), "v"(raw0.w));  // same value, after raw0
+        const float4 raw1 = sample_rgba<LINEAR, XF, FAST>(a, tex1, pos1);  // material.frag:154
         rgba = shade(a, raw0, raw1);
         if (a.depth) {  // gl_FragDepth, material.frag:180-181
             const float* m = cam.bvp;
