@@ -156,6 +156,8 @@ typedef enum sdfv_option {
     SDFV_OPT_TUNING_TILE_ORDER = 102,  /* tuning build only: DEVICE address of tiles_x * tiles_y uint32 tile numbers (row-major
                                         * tile index by * tiles_x + bx): workgroup L of a single-camera launch renders tile
                                         * order[L] (an oracle for longest-first scheduling experiments) */
+    SDFV_OPT_TUNING_RAYMARCH_LDS = 103, /* tuning build only: bytes of (unused) dynamic LDS per raymarch workgroup, which caps
+                                        * the resident waves per SIMD (occupancy A/B runs in one binary) */
     SDFV_OPT_TUNING_PRIORITY_MAP = 101 /* tuning build only: DEVICE address of one byte per 16 x 16 raymarch tile (row-major);
                                         * waves of tiles whose byte is non-zero raise their issue priority at start */
 } sdfv_option;

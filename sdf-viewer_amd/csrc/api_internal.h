@@ -18,6 +18,7 @@ struct Options {
     unsigned long long wave_timing = 0;  // tuning build only
     unsigned long long priority_map = 0;  // tuning build only
     unsigned long long tile_order = 0;    // tuning build only
+    unsigned long long raymarch_lds = 0;  // tuning build only
 };
 const Options& options();
 // Formats the thread-local message sdfv_last_error() returns and hands `code` back.

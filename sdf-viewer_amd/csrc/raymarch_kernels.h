@@ -40,6 +40,7 @@ struct RaymarchArgs {
     sdfv_march_aux* aux;         // same layout or nullptr
     float* depth;                // gl_FragDepth plane, same pixel layout, or nullptr
 #ifdef SDFV_TUNING
+    uint32_t tuning_lds_bytes;   // tuning build only: dynamic LDS per workgroup (occupancy cap for A/B runs)
     const uint32_t* tile_order;  // tuning build only: workgroup L renders tile tile_order[L] (single camera)
     const unsigned char* priority_map;  // tuning build only: one byte per tile, non-zero = raise the waves' priority
     unsigned long long* wave_timing;  // tuning build only: per wave {start, end, iterations, covered mask} or nullptr

@@ -287,7 +287,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 // check against the oracle for every pixel.  Covers: LINEAR filter, power-of-two extents and texture sizes (XF == 2),
 // symmetric box, clamp-for-mirror (fast_index); STRIDE 1 = compact distance volume (one 8-byte load per corner row),
 // STRIDE 4 = tex0.r in place.  Byte offsets are 32-bit: the launcher checks the volume's size.
-// Registers: v24-v71 and s64-s87 are this block's (declared as clobbers; low enough that the kernel stays at 96
+// Registers: v24-v71 (less v41, v45, v49, v69) and s64-s87 are this block's (declared as clobbers; low enough that the kernel stays at 96
 // VGPRs = 5 waves per SIMD); operands stay where hipcc put them.
 #ifdef SDFV_TUNING
 #define SDFV_MARCH_ASM_TUNE(x) x
@@ -298,8 +298,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "s_mov_b64 s[76:77], exec\n"                                                                                    \
     "s_and_b64 exec, exec, %[cov]\n"                                                                                \
     "s_cbranch_execz .Ldone_%=\n"                                                                                   \
-    "v_mov_b32 v40, %[px]\n v_mov_b32 v42, %[py]\n v_mov_b32 v43, %[pz]\n"                                           \
-    "v_mov_b32 v44, %[dx]\n v_mov_b32 v46, %[dy]\n v_mov_b32 v47, %[dz]\n"                                        \
+    /* position v40, v[42:43] and direction v44, v[46:47] ARE the operands px..dz (explicit register variables) */      \
     "s_mov_b32 s66, %[miny]\n s_mov_b32 s67, %[minz]\n"      /* (miny, minz) */                                      \
     "s_mov_b32 s70, %[ky]\n s_mov_b32 s71, %[kz]\n"          /* (ky, kz) */                                          \
     "s_mov_b32 s72, 0xbf000000\n s_mov_b32 s73, 0xbf000000\n" /* (-0.5, -0.5) */                                     \
@@ -468,19 +467,18 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "s_mov_b32 %[left], s74\n"                                                                                      \
     SDFV_MARCH_ASM_TUNE("s_lshl_b32 s84, s84, 16\n s_and_b32 %[left], %[left], 0xffff\n s_or_b32 %[left], %[left], s84\n") \
     "s_and_b64 exec, s[76:77], %[cov]\n"                                                                            \
-    "v_mov_b32 %[px], v40\n v_mov_b32 %[py], v42\n v_mov_b32 %[pz], v43\n"
+    "s_nop 0\n"
 #define SDFV_MARCH_ASM_END "s_mov_b64 exec, s[76:77]\n"
 #define SDFV_MARCH_ASM_OPERANDS                                                                                     \
-    [dx] "v"(ray_dir.x), [dy] "v"(ray_dir.y), [dz] "v"(ray_dir.z), [cov] "s"(cov), [mx] "s"(a.rp.bounds_max[0]),    \
+    [dx] "v"(dirx), [dy] "v"(diry), [dz] "v"(dirz), [cov] "s"(cov), [mx] "s"(a.rp.bounds_max[0]),    \
         [my] "s"(a.rp.bounds_max[1]), [mz] "s"(a.rp.bounds_max[2]), [minx] "s"(a.rp.bounds_min[0]),                 \
         [miny] "s"(a.rp.bounds_min[1]), [minz] "s"(a.rp.bounds_min[2]), [kx] "s"(kx), [ky] "s"(ky), [kz] "s"(kz),   \
         [wm1] "s"(wm1), [hm1] "s"(hm1), [dm1] "s"(dm1), [lgw] "s"(lgw), [lgh] "s"(lgh), [base] "s"(vol), [base_lo] "s"(base_lo), [base_hi] "s"(base_hi), [thresh] "s"(thresh)
 #define SDFV_MARCH_ASM_CLOBBERS                                                                                     \
     "vcc", "scc", "memory", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",    \
         "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "v24", "v25", "v26", "v27", "v28",  \
-        "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43",    \
-        "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56",   \
-        "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69",   \
+        "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v48", "v50", "v51", "v52",    \
+        "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68",   \
         "v70", "v71"
 
 template <bool SYMM_UNUSED, int STRIDE, bool T>
@@ -499,7 +497,14 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
     const uint32_t thresh = (t.w == t.h && t.h == t.d && !a.no_interior_fetch) ? (uint32_t)t.w - 1u : 0u;
     unsigned long long ran_out;
     int left = 254;  // the loop's down-counter at exit (tuning build: iterations the wave ran)
-    float px = ray_pos.x, py = ray_pos.y, pz = ray_pos.z;
+    // The block's position and direction registers are the operands themselves (explicit register variables: no copies in
+    // or out, and six registers fewer than operands + copies): (py, pz) and (dy, dz) must be aligned pairs for v_pk_*.
+    register float px asm("v40") = ray_pos.x;
+    register float py asm("v42") = ray_pos.y;
+    register float pz asm("v43") = ray_pos.z;
+    register float dirx asm("v44") = ray_dir.x;
+    register float diry asm("v46") = ray_dir.y;
+    register float dirz asm("v47") = ray_dir.z;
 #define SDFV_MARCH_ASM_OOB_BOX SDFV_MARCH_ASM_OOB4_A, SDFV_MARCH_ASM_OOB4_B, SDFV_MARCH_ASM_OOB4_C, SDFV_MARCH_ASM_OOB4_D
 #define SDFV_MARCH_ASM_OOB_CUBE SDFV_MARCH_ASM_OOB2_A, "", "", SDFV_MARCH_ASM_OOB2_D
 #define SDFV_MARCH_ASM_TOP_(T_STEP, ...) SDFV_MARCH_ASM_TOP(T_STEP, __VA_ARGS__)
@@ -674,9 +679,13 @@ __device__ __forceinline__ bool box_fragment_ray(const RaymarchArgs& a, V3 eye, 
 #ifndef SDFV_RM_MIN_WAVES
 #define SDFV_RM_MIN_WAVES 1
 #endif
-template <int MODE, bool LINEAR, int XF, bool SYMM, bool AUX, bool ASM = false>
+// NORMAL: sdfNormal's four taps are compiled in (always with the aux record; without it only for
+// SDFV_OPT_RAYMARCH_KEEP_NORMAL).  A compile-time switch: the taps' 32 gathers with 64-bit addresses would otherwise set the
+// register count of the kernel that never runs them (79 -> 72 VGPRs = one more wave per SIMD).
+template <int MODE, bool LINEAR, int XF, bool SYMM, bool AUX, bool ASM = false, bool NORMAL = AUX>
 __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(RaymarchArgs a) {
     constexpr bool FAST = MODE != 0;
+    static_assert(NORMAL || !AUX, "the aux record carries the normal");
     // 8x8 pixel tile per wave, 2x2 waves per workgroup
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t bx = blockIdx.x, by = blockIdx.y;
@@ -850,7 +859,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
             const float hw = m[3] * ray_pos.x + m[7] * ray_pos.y + m[11] * ray_pos.z + m[15];
             frag_depth = hz / hw;
         }
-        if (AUX || a.compute_normal) {
+        if (NORMAL) {
             // sdfNormal, material.frag:73-80
             const float sxn = (float)tex0.w / a.rp.lod_dist_between_samples;
             const float syn = (float)tex0.h / a.rp.lod_dist_between_samples;
@@ -1109,12 +1118,19 @@ __global__ __launch_bounds__(256) void raymarch_slab_kernel(RaymarchArgs a, Slab
     }
 }
 
+#ifdef SDFV_TUNING  // unused dynamic LDS per workgroup: caps the waves per SIMD for occupancy A/B runs
+#define SDFV_RM_LDS(a) ((a).tuning_lds_bytes)
+#else
+#define SDFV_RM_LDS(a) 0
+#endif
 template <int MODE, bool LINEAR, int XF, bool SYMM>
 void launch_aux(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
     if (a.aux)
-        hipLaunchKernelGGL((raymarch_kernel<MODE, LINEAR, XF, SYMM, true>), grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((raymarch_kernel<MODE, LINEAR, XF, SYMM, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
+    else if (a.compute_normal)
+        hipLaunchKernelGGL((raymarch_kernel<MODE, LINEAR, XF, SYMM, false, false, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
     else
-        hipLaunchKernelGGL((raymarch_kernel<MODE, LINEAR, XF, SYMM, false>), grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((raymarch_kernel<MODE, LINEAR, XF, SYMM, false>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
 }
 
 template <int MODE>
@@ -1124,8 +1140,10 @@ void launch_fast(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
     // the hand-written loop: its specialisation (power-of-two extents and sizes, symmetric box) and 32-bit byte offsets
     const uint64_t texels = (uint64_t)a.rp.tex_size[0] * a.rp.tex_size[1] * a.rp.tex_size[2];
     if (xf == 2 && symm && a.asm_loop && a.rp.tex_size[0] >= 2 && texels <= (MODE == 2 ? (1ull << 30) : (1ull << 28))) {
-        if (a.aux) hipLaunchKernelGGL((raymarch_kernel<MODE, true, 2, true, true, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((raymarch_kernel<MODE, true, 2, true, false, true>), grid, dim3(256), 0, stream, a);
+        if (a.aux) hipLaunchKernelGGL((raymarch_kernel<MODE, true, 2, true, true, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
+        else if (a.compute_normal)
+            hipLaunchKernelGGL((raymarch_kernel<MODE, true, 2, true, false, true, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
+        else hipLaunchKernelGGL((raymarch_kernel<MODE, true, 2, true, false, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
         return;
     }
     if (xf == 2 && symm) launch_aux<MODE, true, 2, true>(a, grid, stream);

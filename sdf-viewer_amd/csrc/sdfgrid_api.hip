@@ -397,6 +397,14 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             g_options.slab_step_form = (uint32_t)value;
             return SDFV_OK;
         }
+        case SDFV_OPT_TUNING_RAYMARCH_LDS:
+#ifdef SDFV_TUNING
+            if (value > 65536) break;
+            g_options.raymarch_lds = value;
+            return SDFV_OK;
+#else
+            return fail(SDFV_ERR_INVALID_ARGUMENT, "SDFV_OPT_TUNING_RAYMARCH_LDS needs the tuning build (make tuning)");
+#endif
         case SDFV_OPT_TUNING_TILE_ORDER:
 #ifdef SDFV_TUNING
             g_options.tile_order = value;
@@ -437,6 +445,7 @@ int sdfv_get_option(uint32_t option, uint64_t* value) {
         case SDFV_OPT_TUNING_WAVE_TIMING: *value = g_options.wave_timing; return SDFV_OK;
         case SDFV_OPT_TUNING_PRIORITY_MAP: *value = g_options.priority_map; return SDFV_OK;
         case SDFV_OPT_TUNING_TILE_ORDER: *value = g_options.tile_order; return SDFV_OK;
+        case SDFV_OPT_TUNING_RAYMARCH_LDS: *value = g_options.raymarch_lds; return SDFV_OK;
         default: return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown option %u", option);
     }
 }
@@ -866,6 +875,7 @@ int sdfv_raymarch_depth(const sdfv_render_params* rp, const float* tex0, const f
 #ifdef SDFV_TUNING
     a.wave_timing = reinterpret_cast<unsigned long long*>(g_options.wave_timing);  // 32 B per wave, or 0
     a.priority_map = reinterpret_cast<const unsigned char*>(g_options.priority_map);
+    a.tuning_lds_bytes = (uint32_t)g_options.raymarch_lds;
     a.tile_order = n_cameras == 1 ? reinterpret_cast<const uint32_t*>(g_options.tile_order) : nullptr;
 #endif
     const uint64_t pixels_per_cam = (uint64_t)(y1 - y0) * width;
