@@ -144,10 +144,10 @@ LIGHT_AMBIENT, LIGHT_DIRECTIONAL, MAX_LIGHTS = 0, 1, 4
 OPT_FILL_NONTEMPORAL, OPT_FILL_FORM, OPT_RAYMARCH_DISABLE, OPT_RAYMARCH_KEEP_NORMAL, OPT_SLAB_STEP_FORM = 1, 2, 3, 4, 5
 OPT_RAYMARCH_TILE_GROUP = 6
 OPT_RAYMARCH_BOX_FIRST = 7
+OPT_RAYMARCH_WAVES_PER_SIMD = 8
 OPT_TUNING_WAVE_TIMING = 100
 OPT_TUNING_PRIORITY_MAP = 101
 OPT_TUNING_TILE_ORDER = 102
-OPT_TUNING_RAYMARCH_LDS = 103
 RM_NO_FAST_INDEX, RM_NO_POW2_EXTENT, RM_NO_POW2_SIZE, RM_NO_SYMMETRIC, RM_NO_ASM_LOOP, RM_NO_INTERIOR_FETCH = 1, 2, 4, 8, 16, 32
 STEP_TWO_LAUNCH, STEP_ONE_LAUNCH, STEP_SIDE_BOUNDARY, STEP_UNPACKED, STEP_START_EVENT, STEP_DEFER_JOIN = 1, 2, 3, 4, 8, 16
 FILL_FORM = {"auto": 0, "rows": 1, "flat": 2}

@@ -13,12 +13,12 @@ struct Options {
     uint32_t raymarch_disable = 0;   // SDFV_RM_NO_*
     bool raymarch_keep_normal = false;
     uint32_t raymarch_box_first = 1;   // single frames: groups under the projected bounding box are launched first
+    uint32_t raymarch_waves_per_simd = 0;  // 0 = no cap
     uint32_t raymarch_tile_group = 0;  // 0 auto, 1 launch order, v >= 2: XCD-aware order over groups of 2^(v-1) x 2^(v-1) tiles
     uint32_t slab_step_form = 0;     // 0 auto, SDFV_STEP_* otherwise
     unsigned long long wave_timing = 0;  // tuning build only
     unsigned long long priority_map = 0;  // tuning build only
     unsigned long long tile_order = 0;    // tuning build only
-    unsigned long long raymarch_lds = 0;  // tuning build only
 };
 const Options& options();
 // Formats the thread-local message sdfv_last_error() returns and hands `code` back.

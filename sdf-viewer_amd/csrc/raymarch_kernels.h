@@ -35,12 +35,12 @@ struct RaymarchArgs {
     uint32_t box_first;          // option: use that order (default 1)
     uint32_t first_gx0, first_gy0, first_w, first_h, m_groups_x, m_first_w, m_rest_w;
     uint32_t no_interior_fetch;  // hand-written loop: always take the clamping fetch block (tests, A/B)
+    uint32_t lds_cap_bytes;      // unused dynamic LDS per workgroup: caps the resident waves per SIMD (0 = no cap)
     uint32_t cube_box;           // symmetric box with bounds_max[0] == [1] == [2]: two-instruction out-of-bounds test
     float4* rgba;                // n_cameras x (y1-y0) x width
     sdfv_march_aux* aux;         // same layout or nullptr
     float* depth;                // gl_FragDepth plane, same pixel layout, or nullptr
 #ifdef SDFV_TUNING
-    uint32_t tuning_lds_bytes;   // tuning build only: dynamic LDS per workgroup (occupancy cap for A/B runs)
     const uint32_t* tile_order;  // tuning build only: workgroup L renders tile tile_order[L] (single camera)
     const unsigned char* priority_map;  // tuning build only: one byte per tile, non-zero = raise the waves' priority
     unsigned long long* wave_timing;  // tuning build only: per wave {start, end, iterations, covered mask} or nullptr

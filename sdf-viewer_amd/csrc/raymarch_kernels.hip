@@ -1118,11 +1118,8 @@ __global__ __launch_bounds__(256) void raymarch_slab_kernel(RaymarchArgs a, Slab
     }
 }
 
-#ifdef SDFV_TUNING  // unused dynamic LDS per workgroup: caps the waves per SIMD for occupancy A/B runs
-#define SDFV_RM_LDS(a) ((a).tuning_lds_bytes)
-#else
-#define SDFV_RM_LDS(a) 0
-#endif
+// unused dynamic LDS per workgroup (SDFV_OPT_RAYMARCH_WAVES_PER_SIMD): 160 KB per CU, one wave of a workgroup per SIMD
+#define SDFV_RM_LDS(a) ((a).lds_cap_bytes)
 template <int MODE, bool LINEAR, int XF, bool SYMM>
 void launch_aux(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
     if (a.aux)

@@ -397,14 +397,10 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             g_options.slab_step_form = (uint32_t)value;
             return SDFV_OK;
         }
-        case SDFV_OPT_TUNING_RAYMARCH_LDS:
-#ifdef SDFV_TUNING
-            if (value > 65536) break;
-            g_options.raymarch_lds = value;
+        case SDFV_OPT_RAYMARCH_WAVES_PER_SIMD:
+            if (value == 1 || value > 7) break;
+            g_options.raymarch_waves_per_simd = (uint32_t)value;
             return SDFV_OK;
-#else
-            return fail(SDFV_ERR_INVALID_ARGUMENT, "SDFV_OPT_TUNING_RAYMARCH_LDS needs the tuning build (make tuning)");
-#endif
         case SDFV_OPT_TUNING_TILE_ORDER:
 #ifdef SDFV_TUNING
             g_options.tile_order = value;
@@ -445,7 +441,7 @@ int sdfv_get_option(uint32_t option, uint64_t* value) {
         case SDFV_OPT_TUNING_WAVE_TIMING: *value = g_options.wave_timing; return SDFV_OK;
         case SDFV_OPT_TUNING_PRIORITY_MAP: *value = g_options.priority_map; return SDFV_OK;
         case SDFV_OPT_TUNING_TILE_ORDER: *value = g_options.tile_order; return SDFV_OK;
-        case SDFV_OPT_TUNING_RAYMARCH_LDS: *value = g_options.raymarch_lds; return SDFV_OK;
+        case SDFV_OPT_RAYMARCH_WAVES_PER_SIMD: *value = g_options.raymarch_waves_per_simd; return SDFV_OK;
         default: return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown option %u", option);
     }
 }
@@ -869,13 +865,16 @@ int sdfv_raymarch_depth(const sdfv_render_params* rp, const float* tex0, const f
     // tile order: auto = for a single frame the launcher's XCD-aware choice (groups of 2 x 2 tiles, those under the projected
     // bounding box first; tools/box_first_bench.py, tools/tile_group_bench.py), launch order for batches of cameras, which
     // lose 3-8 % with any grouping
+    // w waves per SIMD = w workgroups per CU: each asks for a w-th of the CU's 160 KB of LDS (less a little for rounding)
+    const uint32_t w = g_options.raymarch_waves_per_simd;
+    a.lds_cap_bytes = (w >= 2 && w <= 6) ? (160u * 1024u) / w - 1024u : 0u;
+    if (a.lds_cap_bytes > 65536u) a.lds_cap_bytes = 65536u;  // the launch limit without an opt-in: 2 waves per SIMD
     a.box_first = g_options.raymarch_box_first;
     a.group_shift = g_options.raymarch_tile_group == 0 ? (n_cameras == 1 ? sdfv::kGroupAuto : 0u)
                                                        : (g_options.raymarch_tile_group == 1 ? 0u : g_options.raymarch_tile_group - 1u);
 #ifdef SDFV_TUNING
     a.wave_timing = reinterpret_cast<unsigned long long*>(g_options.wave_timing);  // 32 B per wave, or 0
     a.priority_map = reinterpret_cast<const unsigned char*>(g_options.priority_map);
-    a.tuning_lds_bytes = (uint32_t)g_options.raymarch_lds;
     a.tile_order = n_cameras == 1 ? reinterpret_cast<const uint32_t*>(g_options.tile_order) : nullptr;
 #endif
     const uint64_t pixels_per_cam = (uint64_t)(y1 - y0) * width;

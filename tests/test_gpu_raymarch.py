@@ -402,6 +402,29 @@ def test_randomised_tile_orders(pkg):
                 assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), (trial, W, H, y0, y1, group, first)
 
 
+def test_occupancy_cap_changes_nothing_but_speed(pkg):
+    """SDFV_OPT_RAYMARCH_WAVES_PER_SIMD asks for unused dynamic LDS per workgroup: every value renders the same bits, with
+    and without the aux record, single frames and batches, over tex0.r and over the distance volume."""
+    K = pkg._capi
+    g = pkg.make_grid((64, 64, 64))
+    t0, t1 = pkg.alloc_textures(g)
+    pkg.fill_grid(pkg.default_params(), g, t0, t1)
+    dist = pkg.commit_distance(g, t0)
+    rp = pkg.default_render_params(g)
+    W, H = 400, 300
+    cams = pkg.orbit_cameras(3, aspect=W / H)
+    ref = pkg.raymarch(rp, t0, t1, cams, W, H, want_aux=True, want_depth=True, dist=dist)
+    ref0 = pkg.raymarch(rp, t0, t1, cams[0], W, H)
+    for waves in (2, 3, 4, 5, 6, 7):
+        with pkg.options({K.OPT_RAYMARCH_WAVES_PER_SIMD: waves}):
+            got = pkg.raymarch(rp, t0, t1, cams, W, H, want_aux=True, want_depth=True, dist=dist)
+            got0 = pkg.raymarch(rp, t0, t1, cams[0], W, H)
+        torch.cuda.synchronize()
+        assert torch.equal(got[0].view(torch.int32), ref[0].view(torch.int32)) and torch.equal(got[2], ref[2]), waves
+        assert torch.equal(got[1].view(torch.int32), ref[1].view(torch.int32)), waves
+        assert torch.equal(got0.view(torch.int32), ref0.view(torch.int32)), waves
+
+
 def test_row_bands_of_the_image_tile_split_tile_the_frame(pkg):
     """parallel.split_rows (config 5's image-tile split): the bands rendered by the "ranks" concatenate to the frame."""
     import importlib

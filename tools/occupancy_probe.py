@@ -1,11 +1,10 @@
 #!/usr/bin/env python3
-"""Tuning build: the raymarch kernel's resident waves per SIMD capped by unused dynamic LDS (SDFV_OPT_TUNING_RAYMARCH_LDS),
-single frames and batches, one binary.  160 KB of LDS per CU, workgroups of 4 waves (one per SIMD): B bytes per workgroup
-allow floor(160 KB / B) workgroups = waves per SIMD (the register file allows 7).  python tools/occupancy_probe.py [side=256]"""
+"""The raymarch kernel's resident waves per SIMD capped by unused dynamic LDS (SDFV_OPT_RAYMARCH_WAVES_PER_SIMD), single
+frames and batches, one binary.  160 KB of LDS per CU, workgroups of 4 waves (one per SIMD): a w-th of it per workgroup
+allows w workgroups = w waves per SIMD (the register file allows 7).  python tools/occupancy_probe.py [side=256]"""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["SDFGRID_LIBRARY"] = os.path.join(ROOT, "sdf-viewer_amd", "libsdfgrid_tuning.so")
 import torch
 pkg = importlib.import_module("sdf-viewer_amd"); K = pkg._capi
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 256
@@ -21,13 +20,13 @@ def run(fn, n, warm=0.2):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return round((time.perf_counter() - t) / n * 1e3, 4)
 res = {}
-caps = {7: 0, 6: 160 * 1024 // 6 - 512, 5: 160 * 1024 // 5 - 512, 4: 160 * 1024 // 4 - 512, 3: 160 * 1024 // 3 - 1024}
+caps = {7: 0, 6: 6, 5: 5, 4: 4, 3: 3}
 for ncam in (1, 16, 64):
     cams = pkg.orbit_cameras(ncam, aspect=W / H)
     out = torch.empty((ncam, H, W, 4), dtype=torch.float32, device="cuda")
     for rnd in range(2):
         for waves, lds in caps.items():
-            pkg.set_option(K.OPT_TUNING_RAYMARCH_LDS, lds)
+            pkg.set_option(K.OPT_RAYMARCH_WAVES_PER_SIMD, lds)
             res.setdefault(f"cams{ncam}_waves{waves}", []).append(run(lambda: pkg.raymarch(rp, t0, t1, cams, W, H, out=out, dist=dist), 40 if ncam == 1 else 5))
-pkg.set_option(K.OPT_TUNING_RAYMARCH_LDS, 0)
-print(json.dumps({"side": side, "lds_bytes_per_workgroup": caps, "ms": res}))
+pkg.set_option(K.OPT_RAYMARCH_WAVES_PER_SIMD, 0)
+print(json.dumps({"side": side, "ms": res}))
