@@ -18,7 +18,7 @@ import ctypes as C
 from dataclasses import dataclass
 
 import torch
-import torch.distributed as dist
+import torch.distributed as c10d  # not `dist`: that name is the distance volume in this package's signatures
 
 
 def slab_range(depth, rank, world):
@@ -89,7 +89,7 @@ def alloc_slab(dims, rank, world, device, fill_value=None, periodic=False, pkg=N
 def _needs_host_staging(t, group=None):
     """gloo cannot send/recv device tensors: when the path is exercised over gloo with GPU tensors (two ranks
     sharing the one GPU of a test box) the slices are staged through host memory.  Never taken with nccl/RCCL."""
-    return t.is_cuda and dist.get_backend(group) == "gloo"
+    return t.is_cuda and c10d.get_backend(group) == "gloo"
 
 
 def halo_exchange(slab, rank, world, group=None):
@@ -107,16 +107,16 @@ def halo_exchange(slab, rank, world, group=None):
 
     def send(block, peer):
         nonlocal sent
-        ops.append(dist.P2POp(dist.isend, block.cpu() if staged else block, peer, group))
+        ops.append(c10d.P2POp(c10d.isend, block.cpu() if staged else block, peer, group))
         sent += block.numel() * 4
 
     def recv(block, peer):
         if staged:
             buf = torch.empty(block.shape, dtype=block.dtype)
-            ops.append(dist.P2POp(dist.irecv, buf, peer, group))
+            ops.append(c10d.P2POp(c10d.irecv, buf, peer, group))
             copies.append((block, buf))
         else:
-            ops.append(dist.P2POp(dist.irecv, block, peer, group))
+            ops.append(c10d.P2POp(c10d.irecv, block, peer, group))
 
     lo = slab.ghost_lo
     for t in (slab.tex0, slab.tex1):
@@ -129,7 +129,7 @@ def halo_exchange(slab, rank, world, group=None):
             recv(t[lo + n_owned:lo + n_owned + slab.ghost_hi], rank + 1)
         if rank > 0:
             recv(t[0:lo], rank - 1)
-    for req in dist.batch_isend_irecv(ops):
+    for req in c10d.batch_isend_irecv(ops):
         req.wait()
     for dst, buf in copies:
         dst.copy_(buf)
@@ -149,13 +149,13 @@ class SlabComm:
         self.pkg, self.rank, self.world, self.periodic, self.halo_hi = pkg, rank, world, periodic, halo_hi
         self.handle = None
         assert halo_hi in (1, 2)
-        on_gpu = world > 1 and dist.get_backend(group) == "nccl"
+        on_gpu = world > 1 and c10d.get_backend(group) == "nccl"
         dev = "cuda" if on_gpu else "cpu"
 
         def agree(ok, what):
             if world > 1:
                 t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+                c10d.all_reduce(t, op=c10d.ReduceOp.MIN, group=group)
                 everyone = bool(t.item())
             else:
                 everyone = ok
@@ -168,7 +168,7 @@ class SlabComm:
         agree(rc == 0, "sdfv_slab_comm_unique_id")
         if world > 1:
             t = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
-            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            c10d.broadcast(t, src=c10d.get_global_rank(group, 0) if group is not None else 0, group=group)
             ident = (C.c_ubyte * capi.COMM_ID_BYTES)(*t.cpu().tolist())
         handle = C.c_void_p()
         flags = (capi.COMM_PERIODIC if periodic else 0) | (capi.COMM_HALO2 if halo_hi == 2 else 0)
@@ -253,7 +253,7 @@ class SlabFiller:
         self.dist = dist  # optional compact distance volume of the slab incl. ghosts: every step is the fused fill
         self.rank, self.world, self.sdf_id, self.group = rank, world, sdf_id, group
         if transport == "auto":
-            transport = "rccl" if (world > 1 and slab.tex0.is_cuda and dist.get_backend(group) == "nccl") else "torch"
+            transport = "rccl" if (world > 1 and slab.tex0.is_cuda and c10d.get_backend(group) == "nccl") else "torch"
         self.transport = transport
         # comm: an existing SlabComm to reuse (one communicator serves any number of slabs; the caller closes it)
         self.comm = (comm or SlabComm(pkg, rank, world, group, periodic=periodic, halo_hi=slab.halo_hi)) \
@@ -353,20 +353,20 @@ def _exchange_rays(down, up, rank, world, group):
     recv_n = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in peers]
     ops = []
     for (p, _), sn, rn in zip(peers, send_n, recv_n):
-        ops += [dist.P2POp(dist.isend, sn, p, group), dist.P2POp(dist.irecv, rn, p, group)]
-    for req in dist.batch_isend_irecv(ops):
+        ops += [c10d.P2POp(c10d.isend, sn, p, group), c10d.P2POp(c10d.irecv, rn, p, group)]
+    for req in c10d.batch_isend_irecv(ops):
         req.wait()
     ops, bufs = [], []
     for (p, t), rn in zip(peers, recv_n):
         n = int(rn.item())
         if t.shape[0]:
-            ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t.contiguous(), p, group))
+            ops.append(c10d.P2POp(c10d.isend, t.cpu() if staged else t.contiguous(), p, group))
         if n:
             buf = torch.empty((n, t.shape[1]), dtype=t.dtype, device=cdev)
-            ops.append(dist.P2POp(dist.irecv, buf, p, group))
+            ops.append(c10d.P2POp(c10d.irecv, buf, p, group))
             bufs.append(buf)
     if ops:
-        for req in dist.batch_isend_irecv(ops):
+        for req in c10d.batch_isend_irecv(ops):
             req.wait()
     if not bufs:
         return torch.empty((0, down.shape[1]), dtype=down.dtype, device=dev)
@@ -401,7 +401,7 @@ def raymarch_sharded(pkg, rp, grid, slab, camera, width, height, rank, world, gr
             return t
         bits = t.view(torch.int32)
         h = bits.cpu() if staged else bits
-        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        c10d.all_reduce(h, op=c10d.ReduceOp.SUM, group=group)
         return (h.to(t.device) if staged else h).view(t.dtype)
 
     rgba = merge(m.rgba)
@@ -422,7 +422,7 @@ def gather_replica(slab, dims, world, group=None):
         padded = torch.zeros((deepest, dims[1], dims[0], 4), dtype=owned.dtype, device=dev)
         padded[:owned.shape[0]] = owned
         parts = [torch.empty_like(padded) for _ in range(world)]
-        dist.all_gather(parts, padded, group=group)
+        c10d.all_gather(parts, padded, group=group)
         outs.append(torch.cat([p[:z1 - z0] for p, (z0, z1) in zip(parts, ranges)], dim=0).to(owned.device))
     return outs[0], outs[1]
 
@@ -450,7 +450,7 @@ def gather_rows(band, height, rank, world, dst=0, group=None, tile=16):
     padded = torch.zeros((band.shape[0], deepest) + tuple(band.shape[2:]), dtype=band.dtype, device=dev)
     padded[:, :band.shape[1]] = band
     parts = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-    dist.gather(padded, parts, dst=dst, group=group)
+    c10d.gather(padded, parts, dst=dst, group=group)
     if rank != dst:
         return None
     return torch.cat([p[:, :y1 - y0] for p, (y0, y1) in zip(parts, ranges)], dim=1).to(band.device)
@@ -468,7 +468,7 @@ def gather_images(rgba, n_cameras, rank, world, dst=0, group=None):
     padded = torch.zeros((max(counts),) + tuple(rgba.shape[1:]), dtype=rgba.dtype, device=dev)
     padded[:rgba.shape[0]] = rgba
     parts = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-    dist.gather(padded, parts, dst=dst, group=group)
+    c10d.gather(padded, parts, dst=dst, group=group)
     if rank != dst:
         return None
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0).to(rgba.device)

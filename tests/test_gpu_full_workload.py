@@ -18,9 +18,14 @@ def load_tool():
     return mod
 
 
+@pytest.mark.parametrize("pipeline", ["plain", "fused"])
 @pytest.mark.parametrize("side", [256, 512])
-def test_whole_grid_and_whole_frame(pkg, oracle, side):
-    bad_words, aux_diff, rgba_err = load_tool().check(side, log=lambda m: None)
+def test_whole_grid_and_whole_frame(pkg, oracle, side, pipeline):
+    """Both pipelines bench.py times, with the kernel instantiations it times (default options): plain = sdfv_fill_grid +
+    the no-aux march over tex0.r; fused = sdfv_fill_grid_commit (nt texture stores, distance volume in the same launch) +
+    the no-aux hand-written march over that volume in box-first order.  Textures (and the volume) word for word, the
+    no-aux RGBA on every pixel against the oracle and bit for bit against the aux kernel's."""
+    bad_words, aux_diff, rgba_err = load_tool().check(side, log=lambda m: None, pipeline=pipeline)
     assert bad_words == 0
     assert all(v == 0 for v in aux_diff.values()), aux_diff
     assert rgba_err <= RGBA_TOL
@@ -34,6 +39,15 @@ def test_config4_grid_as_eight_slabs_on_one_gpu(pkg, oracle):
     assert load_tool().check_config4(log=lambda m: None) == 0
 
 
+def test_config4_slabs_through_the_fused_step_in_rccl_loopback(pkg, oracle):
+    """Config 4's eight slabs of 1024^3, each through sdfv_slab_fill_step_commit (what bench.py --gpus N times per rank) on
+    the library's RCCL communicator in loopback, default options: textures, distance volume and ghosts."""
+    import torch
+    if torch.cuda.mem_get_info()[0] < 24 << 30:
+        pytest.skip("needs 24 GB of free HBM")
+    assert load_tool().check_config4_fused(log=lambda m: None) == 0
+
+
 def test_config5_batch_of_64_cameras(pkg, oracle):
     """BASELINE.json config 5's shape on one GPU: 64 orbit cameras x 1080p over the 256^3 grid in ONE call; every
     frame within tolerance of the oracle's, four of them also bit for bit before shading."""
@@ -43,12 +57,22 @@ def test_config5_batch_of_64_cameras(pkg, oracle):
     prm = pkg.default_params()
     g = pkg.make_grid((256, 256, 256))
     t0, t1 = pkg.alloc_textures(g)
-    pkg.fill_grid(prm, g, t0, t1)
-    dist = pkg.commit_distance(g, t0)
+    dist = torch.empty((256, 256, 256), dtype=torch.float32, device=t0.device)
+    pkg.fill_grid(prm, g, t0, t1, dist=dist)  # the fused fill: the volume bench.py's batch marches over
     rp = pkg.default_render_params(g)
     cams = pkg.orbit_cameras(n, aspect=W / H)
     rgba = pkg.raymarch(rp, t0, t1, cams, W, H, dist=dist)
+    # config 5 as BASELINE names it -- the image-tile split: the 8 ranks' row bands of every camera (split_rows), each
+    # band one call like bench.py --batch-split rows makes per rank; assembled they are the whole-image batch bit for bit
+    import importlib
+    par = importlib.import_module("sdf-viewer_amd.parallel")
+    banded = torch.empty_like(rgba)
+    for r in range(8):
+        y0, y1 = par.split_rows(H, r, 8)
+        banded[:, y0:y1] = pkg.raymarch(rp, t0, t1, cams, W, H, y0=y0, y1=y1, dist=dist)
     torch.cuda.synchronize()
+    assert torch.equal(banded.view(torch.int32), rgba.view(torch.int32))
+    del banded
     h0, h1 = t0.cpu().numpy(), t1.cpu().numpy()
     orp = oracle.copy_struct(oracle.RenderParams, rp)
     worst = 0.0

@@ -104,3 +104,53 @@ def test_two_processes_on_one_gpu_over_the_library_rccl_communicator():
         for r in d["ranks_out"]:
             assert r["result"] is not None and r["result"]["stage"] in ("comm_create", "unique_id"), d
             assert r["result"]["rc"] == -5 and "RCCL" in r["result"]["error"], d
+
+
+def _auto_transport_worker(rank, world, port, q):
+    """SlabFiller(transport="auto") with CUDA tensors, a distance volume and world > 1: the constructor asks the process
+    group for its backend (a parameter named `dist` once shadowed the torch.distributed alias right there)."""
+    import importlib
+    import torch
+    import torch.distributed as c10d
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    c10d.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module("sdf-viewer_amd")
+        par = importlib.import_module("sdf-viewer_amd.parallel")
+        torch.cuda.set_device(0)
+        dims = (64, 32, 24)
+        prm = pkg.default_params()
+        slab = par.alloc_slab(dims, rank, world, "cuda", fill_value=-7.0)
+        vol = torch.full(tuple(slab.tex0.shape[:3]), -7.0, dtype=torch.float32, device="cuda")
+        filler = par.SlabFiller(pkg, prm, dims, slab, rank, world, transport="auto", dist=vol)
+        for _ in range(2):
+            filler.step()
+        torch.cuda.synchronize()
+        full = pkg.make_grid(dims)
+        f0, f1 = pkg.alloc_textures(full)
+        pkg.fill_grid(prm, full, f0, f1)
+        lo, hi = slab.z_begin - slab.ghost_lo, slab.z_end + slab.ghost_hi
+        ok = filler.transport == "torch"  # gloo: the torch transport is what "auto" must resolve to
+        ok &= torch.equal(slab.tex0.view(torch.int32), f0[lo:hi].view(torch.int32))
+        ok &= torch.equal(slab.tex1.view(torch.int32), f1[lo:hi].view(torch.int32))
+        ok &= torch.equal(vol.view(torch.int32), f0[lo:hi, ..., 0].contiguous().view(torch.int32))
+        q.put((rank, bool(ok)))
+    finally:
+        c10d.destroy_process_group()
+
+
+def test_slab_filler_auto_transport_with_distance_volume_two_ranks():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_auto_transport_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results), results
