@@ -70,15 +70,20 @@ def parse_args():
                          "distance between them inside one block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the extra 64-camera batch (profiling runs)")
-    ap.add_argument("--batch-split", choices=["cameras", "rows"], default="cameras",
-                    help="N>1, 64-camera batch: deal whole cameras to the ranks (default) or give every rank a band of "
-                         "rows of every camera (BASELINE.json config 5's image-tile split)")
+    ap.add_argument("--batch-split", choices=["both", "cameras", "rows"], default="both",
+                    help="N>1, 64-camera batch: rows = every rank renders a band of rows of every camera (BASELINE.json "
+                         "config 5's image-tile split), cameras = whole cameras dealt to the ranks; default: both are timed, "
+                         "`batch_raymarch` is the image-tile split and carries the camera split beside it")
+    ap.add_argument("--per-step-samples", type=int, default=50,
+                    help="launches timed one by one with HIP events for ms_per_step_median / p95 (outside the K-step regions)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-overlapped", action="store_true",
                     help="N=1: skip the double-buffered (fill of step k+1 beside the march of step k) measurement")
     ap.add_argument("--pipeline", choices=["both", "plain", "fused"], default="both",
                     help="N=1: time both pipelines and report the faster one (default), or only one (profiling runs: "
                          "per-kernel rocprof averages then belong to one kernel variant)")
+    ap.add_argument("--no-progressive", action="store_true",
+                    help="N=1: skip the progressive / changed_box block (LoadingManager passes, SURVEY 8(f)1)")
     ap.add_argument("--no-target-512", action="store_true", help="N=1: skip the 512^3 fill block (north-star target config)")
     ap.add_argument("--no-config4", action="store_true", help="N>1: skip the cube-geometry block (BASELINE config 4)")
     ap.add_argument("--config4-side", type=int, default=512,
@@ -87,6 +92,13 @@ def parse_args():
 
 
 PREWARM_S = 0.25  # --prewarm-ms
+
+
+def STAGE(name):
+    """Registers the collective stage about to block (parallel.enter_stage) for the watchdog's report."""
+    par = sys.modules.get("sdf-viewer_amd.parallel")
+    if par is not None:
+        par.enter_stage("bench.py " + name)
 
 
 def prewarm(fn, torch, dist=None, world=1, device=None, seconds=None):
@@ -106,9 +118,11 @@ def prewarm(fn, torch, dist=None, world=1, device=None, seconds=None):
     one = max(time.perf_counter() - t0, 1e-5)
     n = min(2000, int(seconds / one) + 1)
     if world > 1:
+        STAGE("prewarm: all_reduce(MAX) of the call count")
         t = torch.tensor([n], dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         n = int(t.item())
+    STAGE("prewarm: running")
     for _ in range(n):
         fn()
     torch.cuda.synchronize()
@@ -118,8 +132,10 @@ def timed_region(fn, steps, torch, dist, world, device):
     """EXACTLY `steps` calls of fn bracketed by barrier + synchronize on both sides; MAX over ranks.
     Also returns the HIP-event time of the region on the launch stream (kernel time incl. launch gaps)."""
     if world > 1:
+        STAGE("timed_region: barrier before")
         dist.barrier()
     torch.cuda.synchronize()
+    STAGE("timed_region: K steps + synchronize")
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
@@ -128,10 +144,12 @@ def timed_region(fn, steps, torch, dist, world, device):
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:
+        STAGE("timed_region: barrier after")
         dist.barrier()
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     if world > 1:
+        STAGE("timed_region: all_reduce(MAX) of the times")
         t = torch.tensor([dt, ev_ms], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, ev_ms = float(t[0]), float(t[1])
@@ -237,7 +255,7 @@ def cpu_baseline(workload, budget_s):
     all_rays = frames * W * H / all_rays_dt / 1e6
     return {"value": round(fill_mvox, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
             "sample": f"{loads} complete load(s) of the {side}^3 grid in LoadingManager order, 2 passes "
-                      f"({loads * n_vox} voxels, {fill_dt:.1f} s), oracle/grid_fill.c gcc -O2 -ffp-contract=off, 1 thread",
+                      f"({loads * n_vox} voxels, {fill_dt:.1f} s), oracle/grid_fill.c gcc -O3 -ffp-contract=off, 1 thread",
             "all_cores": {"value": round(all_mvox, 3), "unit": "Mvoxels/s", "cores": threads,
                           "sample": f"{n_all} dense fill(s) of the {side}^3 grid, OpenMP over z ({all_dt:.1f} s); "
                                     f"{threads} = usable cores (affinity {len(os.sched_getaffinity(0))}, cgroup quota applied)"},
@@ -297,6 +315,128 @@ def raymarch_traffic_report(workload_key, launch_ms, path_key="product_path", tr
     return rep
 
 
+def progressive_block(pkg, torch, prm, sides, reps=7):
+    """SURVEY 8(f)1 under the bench's measurement discipline: the LoadingManager passes (loading.rs:50-76) with
+    update_required (scene/sdf/mod.rs:184-190) on the device, over textures that travel with their distance volume
+    (sdfv_fill_grid_pass_dist).  Per case: median ms over `reps` runs (HIP events; the state is re-created, untimed, before
+    every run), visited voxels, updated voxels, and the fraction of the HBM roofline on SURVEY 8(d)'s incremental figure,
+    36 B per UPDATED voxel (4 B read + 32 B written) + 4 B per voxel that is visited only."""
+    import ctypes as C
+    AIR = pkg.AIR_DIST
+    out = {}
+    for side in sides:
+        g = pkg.make_grid((side,) * 3)
+        t0, t1 = pkg.alloc_textures(g)
+        dist = torch.empty((side,) * 3, dtype=torch.float32, device=t0.device)
+        n = side ** 3
+
+        def fresh():
+            pkg.grid_init(g, t0, t1)
+            dist.fill_(AIR)
+
+        def loaded():
+            pkg.fill_grid(prm, g, t0, t1, dist=dist)
+
+        def timed(fn, setup):
+            ts = []
+            for _ in range(reps):
+                setup()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                fn()
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b))
+            return sorted(ts)[len(ts) // 2]
+
+        def passes(steps, box=None):
+            return lambda: [pkg.fill_grid_pass(prm, g, st, t0, t1, changed_box=box, dist=dist) for st in steps]
+
+        def visited(steps):
+            return sum((-(-side // st)) ** 3 for st in steps)
+
+        def case(ms, vis, upd, what):
+            bytes_ = 36 * upd + 4 * (vis - upd)
+            return {"ms": round(ms, 4), "visited_voxels": vis, "updated_voxels": upd,
+                    "Mvoxels_s_updated": round(upd / ms / 1e3, 1) if upd else 0.0,
+                    "algorithmic_bytes": bytes_, "frac": round(bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "what": what}
+
+        whole = (-1.0, -1.0, -1.0, 1.0, 1.0, 1.0)
+        eighth = (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5)
+        # voxels of the 1/8 box: coordinates idx/(N-1)*2-1 in [-0.5, 0.5] per axis
+        in_box_axis = sum(1 for i in range(side) if -0.5 <= (i / (side - 1)) * 2.0 - 1.0 <= 0.5)
+        res = {}
+        res["fresh_load_2_passes"] = case(timed(passes((2, 1)), fresh), visited((2, 1)), n,
+                                          "the reference's DEFAULT load (cli/mod.rs:13-18): step 2 then step 1 over a fresh grid")
+        res["fresh_pass_step_2"] = case(timed(passes((2,)), fresh), visited((2,)), visited((2,)), "first pass of that load alone")
+
+        def after_step2():
+            fresh()
+            pkg.fill_grid_pass(prm, g, 2, t0, t1, dist=dist)
+        res["fresh_pass_step_1_after_step_2"] = case(timed(passes((1,)), after_step2), n, n - visited((2,)), "second pass of that load alone")
+        res["fresh_pass_step_1"] = case(timed(passes((1,)), fresh), n, n, "a single step-1 pass over a fresh grid")
+        res["edit_full_box_3_passes"] = case(timed(passes((4, 2, 1), whole), loaded), visited((4, 2, 1)), visited((4, 2, 1)),
+                                             "parameter edit whose changed_box is the whole bounding box (what the demo reports): "
+                                             "steps 4, 2, 1 rewrite everything they visit")
+        res["edit_eighth_box_3_passes"] = case(timed(passes((4, 2, 1), eighth), loaded), visited((4, 2, 1)),
+                                               sum((-(-in_box_axis // st)) ** 3 for st in (4, 2, 1)),
+                                               "changed_box = [-0.5, 0.5]^3 (1/8 of the volume); updated count approximate for step > 1")
+        res["noop_pass_step_1"] = case(timed(passes((1,)), loaded), n, 0, "step-1 pass over a loaded grid, no box: reads the volume, writes nothing")
+        res["dense_fused_fill_ms"] = round(timed(lambda: pkg.fill_grid(prm, g, t0, t1, dist=dist), lambda: None), 4)
+        out[str(side)] = res
+        del t0, t1, dist
+    out["note"] = ("sdfv_fill_grid_pass_dist; frac = (36 B x updated + 4 B x visited-only voxels) / ms / 8 TB/s; every intermediate "
+                   "state is bit-identical to the oracle's LoadingManager loop (tests/test_gpu_fill.py)")
+    return out
+
+
+def batch_valu_roofline(workload_key, world, ms_per_batch):
+    """The 64-camera batch fills the machine with short waves and is bound by VALU ISSUE, not by HBM: one wave64 VALU
+    instruction occupies its SIMD's issue port for 4 cycles (16 lanes per cycle), so a SIMD retires at most clock / 4 wave
+    instructions per second.  frac = (VALU wave-instructions of one batch, PMC SQ_INSTS_VALU, committed pass) /
+    (1024 SIMDs x clock / 4 x batch time)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "raymarch_batch_valu.json")))[workload_key]
+    except Exception:  # noqa: BLE001
+        return None
+    simds, clock = 1024 * world, float(d.get("clock_GHz", 2.4))
+    peak = simds * clock * 1e9 / 4.0
+    rate = d["valu_wave_instructions_per_batch"] / (ms_per_batch * 1e-3)
+    return {"bound": "valu issue", "valu_wave_instructions_per_batch": d["valu_wave_instructions_per_batch"],
+            "achieved": round(rate / 1e12, 3), "peak": round(peak / 1e12, 3), "unit": "T wave-instructions/s",
+            "frac": round(rate / peak, 4), "simds": simds, "clock_GHz": clock, "source": d.get("source"),
+            "note": "wave64 VALU instruction = 4 issue cycles on its SIMD; peak = SIMDs x clock / 4"}
+
+
+def raymarch_rank_cameras_report(workload_key, world, launch_ms):
+    """N > 1: every rank marches ONE camera of the `world`-camera orbit (camera r = camera r * 64 / world of the 64-camera
+    orbit when world divides 64) over its replica.  SURVEY 8(d)'s compulsory / nominal bytes of exactly those cameras come
+    from the per-camera entries of profiles/raymarch_model_bytes.json's batch model; achieved = their sum / the (max over
+    ranks) launch time, against `world` x 8 TB/s."""
+    rep = {"kernel": "raymarch_kernel", "bound": "latency (<=255 dependent gathers per ray), not hbm",
+           "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "avg_launch_ms": round(launch_ms, 5), "traffic": None}
+    try:
+        model = json.load(open(os.path.join(ROOT, "profiles", "raymarch_model_bytes.json")))
+        per_cam = model[f"{workload_key}_batch64"]["per_camera"]
+        if 64 % world:
+            raise KeyError(f"{world} does not divide the 64-camera orbit the model was made for")
+        mine = [per_cam[r * 64 // world] for r in range(world)]
+    except Exception as e:  # noqa: BLE001
+        rep.update({"achieved": None, "frac": None, "note": f"no per-camera byte model for this configuration: {type(e).__name__}: {e}"})
+        return rep
+    sec = launch_ms * 1e-3
+    comp = sum(c["compulsory_bytes"] for c in mine)
+    nominal = sum(c["nominal_gather_bytes"] for c in mine)
+    rep.update({"compulsory_bytes": comp, "nominal_gather_bytes": nominal,
+                "product_path_compulsory_bytes": sum(c["product_path_compulsory_bytes"] for c in mine),
+                "achieved": round(comp / sec / 1e9, 1), "frac": round(comp / sec / 1e9 / (HBM_PEAK_GBS * world), 4),
+                "nominal_gather_GBs": round(nominal / sec / 1e9, 1),
+                "cameras": [{"orbit_index": r * 64 // world, "hits": c["hits"], "sum_steps": c["sum_steps"]} for r, c in enumerate(mine)],
+                "note": "SURVEY 8(d) over the ranks' cameras (one each): compulsory = 16 B x (unique tex0 + tex1 texels of that "
+                        "camera's frame) + 16 B x W*H, summed over ranks; peak = n_gpus x 8 TB/s; no PMC pass exists for N > 1"})
+    return rep
+
+
 class NativeStdoutToStderr:
     """RCCL prints a version banner to the C-level stdout when its first communicator comes up (buffered, so it lands
     after anything Python has printed).  The contract is ONE JSON line on stdout: while the benchmark runs, file
@@ -328,12 +468,29 @@ def main():
     # A collective that never completes (a rank lost, P2P unavailable) must not hang the job for ever: after
     # SDFV_BENCH_WATCHDOG_S seconds (default 900) a watchdog thread dumps every thread's stack to stderr and exits.
     import faulthandler
+    import threading
     watchdog = float(os.environ.get("SDFV_BENCH_WATCHDOG_S", "900"))
+    done = threading.Event()
+
+    def bark():
+        # names the collective stage this rank is stuck in (parallel.enter_stage: every blocking stage of the multi-GPU
+        # path registers itself first), then every thread's stack, then exits: a hang on real xGMI is attributable in one run
+        if done.wait(watchdog):
+            return
+        try:
+            par = sys.modules.get("sdf-viewer_amd.parallel")
+            name, age, count = par.current_stage() if par else ("(parallel not imported)", 0.0, 0)
+            print(f"[bench rank {os.environ.get('RANK', '0')}/{os.environ.get('WORLD_SIZE', '1')}] WATCHDOG after {watchdog:.0f} s: "
+                  f"stuck in stage #{count} '{name}' for {age:.1f} s", file=sys.stderr, flush=True)
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        finally:
+            os._exit(3)
+
     if watchdog > 0:
-        faulthandler.dump_traceback_later(watchdog, exit=True)
+        threading.Thread(target=bark, daemon=True).start()
     with NativeStdoutToStderr() as redirect:
         run(redirect)
-    faulthandler.cancel_dump_traceback_later()
+    done.set()
 
 
 def region(fn, steps, warmup, torch, dist, world, device):
@@ -345,12 +502,45 @@ def region(fn, steps, warmup, torch, dist, world, device):
     return dt / steps * 1e3, ev_ms / steps
 
 
+def per_step_stats(fn, n, torch, warm=5):
+    """"hipEvent around the kernel, >= 20 iterations after warm-up, median".  n calls of fn, each bracketed
+    by its own pair of HIP events on the launch stream (n + 1 events, one between consecutive calls) -> the distribution
+    the K-step mean hides (box / placement / clock spread).  Outside the timed regions; never `value`."""
+    if n <= 0:
+        return None
+    for _ in range(warm):
+        fn()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    evs[0].record()
+    for i in range(n):
+        fn()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n))
+    q = lambda f: ms[min(n - 1, int(f * n))]  # noqa: E731
+    return {"samples": n, "median": round(ms[n // 2] if n % 2 else 0.5 * (ms[n // 2 - 1] + ms[n // 2]), 5),
+            "p95": round(q(0.95), 5), "min": round(ms[0], 5), "max": round(ms[-1], 5),
+            "note": "one HIP-event pair per launch (includes the event's own packet: ~1-2 us more than back-to-back launches)"}
+
+
+FILL_8D_PEAK_MVOX = HBM_PEAK_GBS * 1e9 / FILL_BYTES_PER_VOXEL / 1e6  # 250 000 Mvoxels/s = 8 TB/s at SURVEY 8(d)'s 32 B/voxel
+
+
 def fill_roofline(kern_ms, voxels, bytes_per_voxel, traffic):
-    gbs = bytes_per_voxel * voxels / (kern_ms * 1e-3) / 1e9
+    """the fill's algorithmic bytes are 32 B/voxel (tex0 + tex1), whatever else the launch stores.  achieved /
+    frac are on that figure (frac = Mvoxels/s / 250 000, the scale the north-star target is worded on); the fused launch
+    also stores the compact distance volume (36 B/voxel on the bus): achieved_bus / frac_bus say how busy the bus is."""
+    gbs = FILL_BYTES_PER_VOXEL * voxels / (kern_ms * 1e-3) / 1e9
+    bus = bytes_per_voxel * voxels / (kern_ms * 1e-3) / 1e9
     return {"kernel": "fill_dense_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_voxel": bytes_per_voxel,
-            "algorithmic_bytes_per_launch": bytes_per_voxel * voxels, "avg_launch_ms": round(kern_ms, 5),
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_8d": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "algorithmic_bytes_per_voxel": FILL_BYTES_PER_VOXEL,
+            "algorithmic_bytes_per_launch": FILL_BYTES_PER_VOXEL * voxels,
+            "bus_bytes_per_voxel": bytes_per_voxel, "achieved_bus": round(bus, 1), "frac_bus": round(bus / HBM_PEAK_GBS, 4),
+            "frac_note": "frac = frac_8d = 32 B/voxel x voxels / launch time / 8 TB/s (SURVEY 8d; = Mvoxels/s / 250 000); "
+                         "frac_bus counts every byte the launch stores (36 B/voxel when it also writes the distance volume)",
+            "avg_launch_ms": round(kern_ms, 5),
             "avg_launch_note": "HIP events around K back-to-back launches / K: includes the ~6 us gap between "
                                "launches, which rocprofv3's kernel-only average leaves out (8 % at 256^3, under 1 % at 512^3)"}
 
@@ -385,6 +575,7 @@ def run(redirect):
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        STAGE(f"init_process_group({backend}, rank {rank} of {world}) + first all_reduce")
         if backend == "nccl":
             # device_id = eager communicator creation, and one collective on an uninitialised buffer to be sure: the
             # process's first RCCL communicator has to exist BEFORE the fill stream launches its first kernel (a
@@ -410,13 +601,16 @@ def run(redirect):
         filler = None
         if transport == "rccl":
             try:
+                STAGE("make_filler: SlabFiller(transport=rccl) -> SlabComm.__init__")
                 filler = par.SlabFiller(pkg, prm, gdims, slab, rank, world, transport="rccl", dist=slab_dist, periodic=loopback)
+                STAGE("make_filler: first sdfv_slab_fill_step_commit over the library communicator + synchronize")
                 filler.step()  # a first step, so that a communicator that cannot exchange shows up here, not mid-run
                 torch.cuda.synchronize()
             except Exception as e:  # noqa: BLE001 -- reported, then decided collectively below
                 filler = None
                 print(f"[bench rank {rank}] library communicator unavailable: {e}", file=sys.stderr, flush=True)
             if multi:
+                STAGE("make_filler: all_reduce(MIN) agreeing on the library communicator")
                 ok = torch.tensor([1 if filler is not None else 0], device=cdev)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if int(ok.item()) == 0:
@@ -514,14 +708,16 @@ def run(redirect):
                       "ms_per_step": round(fill_plain_ms + march_tex0_ms, 4),
                       "ms_per_step_interleaved": round(inter_plain_ms, 4),
                       "Mvoxels_s": round(voxels_per_rank / fill_plain_ms / 1e3, 1), "Mrays_s": round(W * H / march_tex0_ms / 1e3, 1),
-                      "fill_frac_of_hbm_peak": round(32 * voxels_per_rank / (fill_plain_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                      "fill_frac_of_hbm_peak": round(32 * voxels_per_rank / (fill_plain_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "fill_frac_8d": round(32 * voxels_per_rank / (fill_plain_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "fused": {"fill": "sdfv_fill_grid_commit (36 B/voxel: textures + compact distance volume)",
                       "march": "sdfv_raymarch_accel over the distance volume",
                       "ms_fill": round(fill_fused_ms, 4), "ms_raymarch": round(march_dist_ms, 4),
                       "ms_per_step": round(fill_fused_ms + march_dist_ms, 4),
                       "ms_per_step_interleaved": round(inter_fused_ms, 4),
                       "Mvoxels_s": round(voxels_per_rank / fill_fused_ms / 1e3, 1), "Mrays_s": round(W * H / march_dist_ms / 1e3, 1),
-                      "fill_frac_of_hbm_peak": round(36 * voxels_per_rank / (fill_fused_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                      "fill_frac_of_hbm_peak": round(36 * voxels_per_rank / (fill_fused_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "fill_frac_8d": round(32 * voxels_per_rank / (fill_fused_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
         chosen = "fused" if fill_fused_ms + march_dist_ms < fill_plain_ms + march_tex0_ms else "plain"
         if chosen == "fused":
@@ -530,6 +726,23 @@ def run(redirect):
             fill_ms, march_ms, kern_ms, march_ev, bpv = fill_plain_ms, march_tex0_ms, fill_plain_ev, march_tex0_ev, 32
         fill_mvox = voxels_per_rank / fill_ms / 1e3
         march_mrays = W * H / march_ms / 1e3
+        # the distribution behind the two means (SURVEY 8d asks for the median): launches timed one by one
+        if chosen == "fused":
+            st_fill = per_step_stats(lambda: pkg.fill_grid(prm, grid, owned0, owned1, dist=dist_vol), args.per_step_samples, torch)
+            st_march = per_step_stats(lambda: pkg.raymarch(rp, owned0, owned1, cam0, W, H, out=rgba, dist=dist_vol),
+                                      args.per_step_samples, torch)
+        else:
+            st_fill = per_step_stats(lambda: pkg.fill_grid(prm, grid, owned0, owned1), args.per_step_samples, torch)
+            st_march = per_step_stats(lambda: pkg.raymarch(rp, owned0, owned1, cam0, W, H, out=rgba), args.per_step_samples, torch)
+        if st_fill and st_march:
+            out["ms_per_step_median"] = round(st_fill["median"] + st_march["median"], 4)
+            out["ms_per_step_p95"] = round(st_fill["p95"] + st_march["p95"], 4)
+            out["per_step"] = {"fill": st_fill, "raymarch": st_march,
+                               "Mvoxels_s_median": round(voxels_per_rank / st_fill["median"] / 1e3, 1),
+                               "Mrays_s_median": round(W * H / st_march["median"] / 1e3, 1),
+                               "frac_8d_median": round(voxels_per_rank / st_fill["median"] / 1e3 / FILL_8D_PEAK_MVOX, 4),
+                               "note": "ms_per_step_median / _p95 = fill + raymarch of `pipeline`, each launch between its own "
+                                       "pair of HIP events; value / ms_per_step stay the K-step means of the contract"}
         out["pipeline"] = chosen
         out["pipeline_plain"] = pipes["plain"] if args.pipeline in ("both", "plain") else None
         out["pipeline_fused"] = pipes["fused"] if args.pipeline in ("both", "fused") else None
@@ -577,7 +790,12 @@ def run(redirect):
         out["pipeline_note"] = ("N > 1: value = z-slab fill step = the fused fill per rank (textures + distance volume, "
                                 "36 B/voxel) incl. the RCCL halo exchange: N x the work of pipeline_fused at N = 1; value_rays "
                                 "= one camera per rank over a replica, marched over the distance volume that fill wrote")
-        out["roofline_raymarch"] = raymarch_traffic_report(None, march_ev)
+        out["roofline_raymarch"] = raymarch_rank_cameras_report(args.workload, world, march_ev)
+        # what RCCL itself says about the library communicator the step ran on (None under the torch transport)
+        comm = getattr(filler, "comm", None)
+        out["rccl_ranks"] = None if comm is None else comm.rccl_ranks[1]
+        out["rccl_rank_of_rank0"] = None if comm is None else comm.rccl_ranks[0]
+        out["torch_world_size"] = dist.get_world_size()
 
     # ---------------- N = 1 extras ----------------
     target_512 = None
@@ -601,9 +819,14 @@ def run(redirect):
                               "Mvoxels_s": round(n512 / t_ms / 1e3, 1), "avg_launch_ms": round(t_ev, 5),
                               "achieved_GBs": round(32 * n512 / (t_ev * 1e-3) / 1e9, 1),
                               "frac": round(32 * n512 / (t_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                              "fused_commit": {"ms_fill": round(f_ms, 4),
+                              "frac_8d": round(32 * n512 / (t_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "per_launch": per_step_stats(lambda: pkg.fill_grid(prm, t_grid, t_slab.owned0, t_slab.owned1),
+                                                           min(args.per_step_samples, 30), torch, warm=2),
+                              "fused_commit": {"ms_fill": round(f_ms, 4), "Mvoxels_s": round(n512 / f_ms / 1e3, 1),
                                                "achieved_GBs": round(36 * n512 / (f_ev * 1e-3) / 1e9, 1),
-                                               "frac": round(36 * n512 / (f_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                                               "frac": round(36 * n512 / (f_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                               "frac_8d": round(32 * n512 / (f_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                               "frac_note": "frac: 36 B/voxel on the bus; frac_8d: SURVEY 8(d)'s 32 B/voxel"},
                               "texture_placement": placement_note(args, t_slab), "target_frac": 0.70,
                               "note": "north_star: >= 70 % HBM-roofline Mvoxels/s on the demo SDF 512^3 grid fill at 1 GPU; "
                                       "32 B/voxel algorithmic, HIP events over the timed launches"}
@@ -631,6 +854,13 @@ def run(redirect):
         except Exception as e:  # noqa: BLE001 -- an extra, never fatal
             halo_loopback = {"error": f"{type(e).__name__}: {e}"}
 
+    progressive = None
+    if not multi and not args.no_batch and not args.no_progressive:
+        try:
+            progressive = progressive_block(pkg, torch, prm, sorted({side, 512}))
+        except Exception as e:  # noqa: BLE001 -- an extra, never fatal
+            progressive = {"error": f"{type(e).__name__}: {e}"}
+
     # ---------------- config 5 shape: a batch of 64 cameras, split over the ranks (extra, not `value`) ----------------
     n_batch = 64
     batch_report = None
@@ -638,26 +868,39 @@ def run(redirect):
         if not multi:
             pkg.fill_grid(prm, grid, owned0, owned1, dist=dist_vol)  # the volume of the grid being marched
         batch_cams = pkg.orbit_cameras(n_batch, aspect=W / H)
-        if args.batch_split == "rows":
-            mine = batch_cams
-            by0, by1 = par.split_rows(H, rank, world)
-        else:
-            mine = [batch_cams[i] for i in par.split_cameras(n_batch, rank, world)]
-            by0, by1 = 0, H
-        batch_out = torch.empty((len(mine), by1 - by0, W, 4), dtype=torch.float32, device=device)
-
-        def batch_step():
-            pkg.raymarch(rp, r0, r1, mine, W, H, y0=by0, y1=by1, out=batch_out, dist=dist_vol)
-
-        batch_step()
         batch_steps = max(2, min(K, 5))
-        batch_dt, _ = timed_region(batch_step, batch_steps, torch, dist, world, device)
-        batch_report = {"cameras": n_batch, "image": [W, H], "cameras_per_gpu": len(mine),
-                        "rows_per_gpu": by1 - by0, "split": args.batch_split if world > 1 else None,
-                        "value": round(n_batch * W * H * batch_steps / batch_dt / 1e6, 1), "unit": "Mrays/s",
-                        "ms_per_batch": round(batch_dt / batch_steps * 1e3, 4),
-                        "note": "BASELINE.json configs[4] shape (64-camera orbit) over the same grid, distance-volume march"}
-        del batch_out
+
+        def time_split(split):
+            """rows = BASELINE config 5 as named (image-tile split: a band of rows of EVERY camera per rank, cut on the
+            kernel's 16-row tiles); cameras = whole cameras dealt to the ranks.  At N = 1 both are the same call."""
+            if split == "rows":
+                mine = batch_cams
+                by0, by1 = par.split_rows(H, rank, world)
+            else:
+                mine = [batch_cams[i] for i in par.split_cameras(n_batch, rank, world)]
+                by0, by1 = 0, H
+            batch_out = torch.empty((len(mine), by1 - by0, W, 4), dtype=torch.float32, device=device)
+
+            def batch_step():
+                pkg.raymarch(rp, r0, r1, mine, W, H, y0=by0, y1=by1, out=batch_out, dist=dist_vol)
+
+            batch_step()
+            batch_dt, _ = timed_region(batch_step, batch_steps, torch, dist, world, device)
+            return {"split": split if world > 1 else None, "cameras_per_gpu": len(mine), "rows_per_gpu": by1 - by0,
+                    "value": round(n_batch * W * H * batch_steps / batch_dt / 1e6, 1), "unit": "Mrays/s",
+                    "ms_per_batch": round(batch_dt / batch_steps * 1e3, 4)}
+
+        splits = ["rows"] if world == 1 else (["rows", "cameras"] if args.batch_split == "both" else [args.batch_split])
+        reports = {sp: time_split(sp) for sp in splits}
+        batch_report = {"cameras": n_batch, "image": [W, H]}
+        batch_report.update(reports[splits[0]])
+        if len(splits) > 1:
+            batch_report["camera_split"] = reports["cameras"]
+        batch_report["note"] = ("BASELINE.json configs[4] shape (64-camera orbit) over the same grid, distance-volume march; "
+                                "top level = the image-tile split config 5 names (rows), camera_split = whole cameras per rank")
+        # the batch is issue-bound, not HBM-bound: VALU wave-instructions per batch / (SIMDs x clock / 4 cycles per wave64
+        # VALU instruction) -- the roofline that actually bounds it (counts: profiles/raymarch_batch_valu.json)
+        batch_report["roofline_raymarch_batch"] = batch_valu_roofline(args.workload, world, batch_report["ms_per_batch"])
 
     # ---------------- N > 1 extras: BASELINE config 4's geometry, and the self-checks ----------------
     config4 = None
@@ -775,11 +1018,13 @@ def run(redirect):
                        "image": [W, H], "cameras_per_gpu": len(my_cams),
                        "weak_geometry": None if not multi else args.weak_geometry,
                        "parallelism": "single GPU" if world == 1 else f"z-slab x{world} + 1-voxel RCCL halo; 1 camera/GPU"},
+            "keys_note": "N = 1 and N > 1 lines carry the same contract keys; N > 1 adds rccl_ranks, torch_world_size, config4",
         }
         line.update(out)
         line["raymarch_kernel_ms"] = round(march_ev, 4)
         line["batch_raymarch"] = batch_report
         line["target_512"] = target_512
+        line["progressive"] = progressive
         line["halo_loopback"] = halo_loopback
         line["config4"] = config4
         if not args.no_cpu_baseline and not multi:  # rank 0, N = 1 only

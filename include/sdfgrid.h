@@ -144,7 +144,8 @@ typedef enum sdfv_option {
     SDFV_OPT_FILL_FORM = 2,            /* 0 auto (default) | 1 row-chunk form | 2 flat form of the dense fill */
     SDFV_OPT_RAYMARCH_DISABLE = 3,     /* mask of SDFV_RM_NO_*: exact-arithmetic specialisations left out (default 0) */
     SDFV_OPT_RAYMARCH_KEEP_NORMAL = 4, /* 0 (default) | 1: evaluate sdfNormal per hit although nothing consumes it */
-    SDFV_OPT_SLAB_STEP_FORM = 5,       /* sdfv_slab_fill_step: 0 auto (default) | SDFV_STEP_* below */
+    SDFV_OPT_SLAB_STEP_FORM = 5,       /* sdfv_slab_fill_step: 0 auto (default: packed messages for slabs below 2^26 voxels, per-texture
+                                        * messages from there) | SDFV_STEP_SIDE_BOUNDARY, optionally with the SDFV_STEP_* flags below */
     SDFV_OPT_RAYMARCH_TILE_GROUP = 6,  /* raymarch workgroup-tile order: 0 auto (default: for a single frame XCD-aware groups of
                                         * 2 x 2 tiles with the box-first order below, 4 x 4 where that does not apply; launch order
                                         * for camera batches) | 1 launch order | v = 2..5: XCD-aware groups of 2^(v-1) x 2^(v-1)
@@ -169,14 +170,18 @@ typedef enum sdfv_option {
 #define SDFV_RM_NO_SYMMETRIC   8u /* max(min - p, p - max) instead of |p| - max */
 #define SDFV_RM_NO_ASM_LOOP   16u /* the compiler's march loop instead of the hand-written gfx950 one */
 #define SDFV_RM_NO_INTERIOR_FETCH 32u /* hand-written loop: always the clamping cell fetch, never the interior fast path */
-#define SDFV_STEP_TWO_LAUNCH   1u /* boundary slices in a launch of their own, then the interior */
-#define SDFV_STEP_ONE_LAUNCH   2u /* one dense launch whose first workgroups fill the boundary slices and signal */
-#define SDFV_STEP_SIDE_BOUNDARY 3u /* the caller's stream runs the plain dense fill of the whole slab; the communicator's
-                                    * stream computes the boundary slices once more, into the packed send buffers only */
-#define SDFV_STEP_UNPACKED     4u /* flag: 2 messages per texture and neighbour straight into the ghosts (no staging) */
-#define SDFV_STEP_START_EVENT  8u /* flag (side-boundary form): release the communicator's stream with an event recorded
-                                   * on the caller's stream instead of the fill launch's own "started" signal */
-#define SDFV_STEP_DEFER_JOIN  16u /* flag (side-boundary forms): the step does NOT make the caller's stream wait for the
+#define SDFV_STEP_SIDE_BOUNDARY 3u /* the one step form (values 1 and 2, round 2's two-launch / one-launch forms, lost every
+                                    * measurement and are gone): the caller's stream runs the plain dense fill of the whole
+                                    * slab; the communicator's stream computes the boundary slices once more, into the packed
+                                    * send buffers only, exchanges, and copies what it received into the ghosts */
+#define SDFV_STEP_UNPACKED     4u /* flag: 2 messages per texture and neighbour straight out of / into the textures (no
+                                   * staging): the communicator's stream fills the boundary slices in place, the caller's
+                                   * stream everything else */
+#define SDFV_STEP_START_EVENT  8u /* flag: release the communicator's stream with an event recorded on the caller's stream
+                                   * instead of the fill launch's own "started" signal (the fallback where
+                                   * hipStreamWaitValue32 is unavailable) */
+#define SDFV_STEP_DEFER_JOIN  16u /* flag (packed messages only; ignored with per-texture messages, where the communicator's
+                                   * stream writes OWNED slices): the step does NOT make the caller's stream wait for the
                                    * exchange; sdfv_slab_comm_join() does, whenever the ghost slices are needed.  Steps on the
                                    * same communicator order themselves after the previous exchange on their own */
 int sdfv_set_option(uint32_t option, uint64_t value); /* unknown option / value out of range: SDFV_ERR_INVALID_ARGUMENT */
@@ -389,23 +394,25 @@ int sdfv_slab_comm_unique_id(unsigned char id_out[SDFV_COMM_ID_BYTES]);
 int sdfv_slab_comm_create(const unsigned char id[SDFV_COMM_ID_BYTES], int rank, int world, uint32_t flags,
                           sdfv_slab_comm **out);
 int sdfv_slab_comm_destroy(sdfv_slab_comm *comm);
-/* Ghost slices this rank's textures carry below / above the owned slices, and whether the one-launch step is available
- * on this device (hipStreamWaitValue32).  Any output pointer may be NULL. */
-int sdfv_slab_comm_info(const sdfv_slab_comm *comm, uint32_t *ghost_lo, uint32_t *ghost_hi, uint32_t *one_launch_capable);
+/* Ghost slices this rank's textures carry below / above the owned slices, and whether the step can be released by the
+ * fill launch's own start signal on this device (hipStreamWaitValue32; otherwise the event form is used).  Any output
+ * pointer may be NULL. */
+int sdfv_slab_comm_info(const sdfv_slab_comm *comm, uint32_t *ghost_lo, uint32_t *ghost_hi, uint32_t *wait_value_capable);
+/* What RCCL itself says about the communicator: ncclCommUserRank / ncclCommCount -- the number of ranks RCCL actually
+ * connected (what a reader of a multi-GPU measurement needs to know first).  Either output pointer may be NULL. */
+int sdfv_slab_comm_ranks(const sdfv_slab_comm *comm, int *rank, int *world);
 /* The halo exchange alone, enqueued on `stream` (one ncclGroup of up to 4 sends + 4 receives straight on the textures:
  * the first 1 (2 with SDFV_COMM_HALO2) owned slices down, the last owned slice up). DEVICE pointers. */
 int sdfv_slab_halo_exchange(sdfv_slab_comm *comm, const sdfv_grid *slab, float *tex0, float *tex1, void *stream);
 /* One fill step of this rank = sdfv_fill_grid over the owned slab + the halo exchange, with the exchange hidden
- * behind the fill.  Default form (SDFV_STEP_SIDE_BOUNDARY): `stream` runs the plain dense fill of the whole slab -- the
- * same single launch as sdfv_fill_grid, nothing before it -- while the communicator's high-priority stream, released by
- * an event recorded on `stream` at the start of the step, (1) computes the boundary slices (the first 1 or 2 and the
- * last owned one: under 1 % of the slab, computed twice) straight into packed send buffers, (2) exchanges ONE RCCL
- * message per neighbour and direction carrying both textures' slices, (3) copies the received slices into the ghosts;
- * `stream` then waits for that chain, which is shorter than the fill it runs under.  SDFV_OPT_SLAB_STEP_FORM selects
- * the other forms that were measured: boundary workgroups as a launch of their own on `stream` + event
- * (two-launch), or ONE launch in boundary-first workgroup order whose first workgroups publish and signal the
- * communicator's stream through hipStreamWaitValue32 (one-launch); both with packed or per-texture messages.  Slabs
- * too thin to have an interior, or whose rows do not fill whole workgroups, are filled and then exchanged.  On return
+ * behind the fill: `stream` runs the plain dense fill of the whole slab -- the same single launch as sdfv_fill_grid,
+ * nothing before it -- while the communicator's high-priority stream, released by the fill launch's own start signal (or
+ * by an event recorded on `stream`), (1) computes the boundary slices (the first 1 or 2 and the last owned one: under
+ * 1 % of the slab, computed twice) straight into packed send buffers, (2) exchanges ONE RCCL message per neighbour and
+ * direction carrying both textures' slices, (3) copies the received slices into the ghosts; `stream` then waits for
+ * that chain, which is shorter than the fill it runs under.  From 2^26 voxels per slab the messages go per texture
+ * straight out of / into the textures instead (SDFV_STEP_UNPACKED; SDFV_OPT_SLAB_STEP_FORM pins either).  Slabs too
+ * thin to have an interior, or whose rows do not fill whole workgroups, are filled and then exchanged.  On return
  * everything is enqueued; work later put on `stream` sees owned and ghost slices complete. */
 int sdfv_slab_fill_step(sdfv_slab_comm *comm, const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *slab,
                         float *tex0, float *tex1, void *stream);
@@ -418,7 +425,8 @@ int sdfv_slab_fill_step_commit(sdfv_slab_comm *comm, const sdfv_demo_params *par
 
 /* Makes `stream` wait for the most recent exchange the communicator has enqueued (a no-op when there is none).  Needed
  * only after steps taken with SDFV_STEP_DEFER_JOIN: before anything put on `stream` reads the ghost slices of the
- * textures (or the ghost slices' share of the distance volume).  The owned slices never need it. */
+ * textures (or the ghost slices' share of the distance volume).  The owned slices never need it: the flag is honoured
+ * only where the caller's stream fills every owned slice itself (packed messages). */
 int sdfv_slab_comm_join(sdfv_slab_comm *comm, void *stream);
 
 #ifdef __cplusplus

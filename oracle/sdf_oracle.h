@@ -18,7 +18,7 @@
  * Each of those is an isolated function below (srgb_u8_to_linear, shade_*, trilinear_*).
  *
  * Every function cites the reference file:line it follows (paths relative to /root/reference).
- * Build: plain C11, -O2 -ffp-contract=off (Rust never contracts a*b+c), scalar fp32, no fast-math.
+ * Build: plain C11, -O3 -ffp-contract=off (Rust never contracts a*b+c), scalar fp32, no fast-math.
  */
 #ifndef SDF_ORACLE_H
 #define SDF_ORACLE_H

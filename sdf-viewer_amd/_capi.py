@@ -132,6 +132,7 @@ PROTOTYPES = {
     "sdfv_slab_comm_create": (C.c_int, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
     "sdfv_slab_comm_destroy": (C.c_int, [C.c_void_p]),
     "sdfv_slab_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "sdfv_slab_comm_ranks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sdfv_slab_halo_exchange": (C.c_int, [C.c_void_p, C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_slab_fill_step": (C.c_int, [C.c_void_p, C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
@@ -149,7 +150,7 @@ OPT_TUNING_WAVE_TIMING = 100
 OPT_TUNING_PRIORITY_MAP = 101
 OPT_TUNING_TILE_ORDER = 102
 RM_NO_FAST_INDEX, RM_NO_POW2_EXTENT, RM_NO_POW2_SIZE, RM_NO_SYMMETRIC, RM_NO_ASM_LOOP, RM_NO_INTERIOR_FETCH = 1, 2, 4, 8, 16, 32
-STEP_TWO_LAUNCH, STEP_ONE_LAUNCH, STEP_SIDE_BOUNDARY, STEP_UNPACKED, STEP_START_EVENT, STEP_DEFER_JOIN = 1, 2, 3, 4, 8, 16
+STEP_SIDE_BOUNDARY, STEP_UNPACKED, STEP_START_EVENT, STEP_DEFER_JOIN = 3, 4, 8, 16
 FILL_FORM = {"auto": 0, "rows": 1, "flat": 2}
 PLACEMENT_SLACK = 64 << 10
 COMM_ID_BYTES = 128

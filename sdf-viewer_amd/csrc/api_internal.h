@@ -26,17 +26,13 @@ int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3
 // The first and the last slice of `slab` (the ones the z-neighbours need) in one launch; o0/o1 address the first
 // owned slice.  Same texels as sdfv_fill_grid over those two slices.  Requires at least two owned slices.
 // Dense fill of `slab` in boundary-first workgroup order (fill_kernels.h): the `lead` first slices and the last one come
-// first, optionally copied into the packed staging buffers and followed by the arrival/signal protocol.
+// first, optionally copied into the packed staging buffers.
 struct OrderedFill {
     uint32_t lead = 1;
     bool stage_only = false;  // write the packed copies only (the textures are another launch's)
     float* dist = nullptr;    // compact distance volume of the owned slices (fused commit), or nullptr
     float* stage_lo = nullptr;
     float* stage_hi = nullptr;
-    uint32_t* arrive = nullptr;
-    uint32_t arrive_target = 0;
-    uint32_t* signal = nullptr;
-    uint32_t signal_value = 0;
 };
 // Workgroups per slice and in total of that order for this slab; per_slice = 0: the shape does not allow it.
 int ordered_fill_blocks(const sdfv_grid* slab, uint32_t* per_slice, uint32_t* total);

@@ -30,14 +30,12 @@ struct FillArgs {
     // that fill them come FIRST in dispatch order, the interior follows in memory order.
     uint32_t order_bps;      // workgroups per slice (0 = plain memory order)
     uint32_t order_lead;     // leading boundary slices: 1 (one-voxel halo) or 2 (two ghost slices on the upper side)
-    uint32_t block_base;     // first logical workgroup of this launch (two-launch form: boundary, then the rest)
+    uint32_t block_base;     // first logical workgroup of this launch (the boundary workgroups and the rest are separate launches)
     uint32_t stage_only;     // boundary workgroups write the packed copies only, not the textures (another launch does)
     float4* stage_lo;        // packed copy of the lead slices for the lower neighbour: [tex0 lead slices | tex1 lead slices]
     float4* stage_hi;        // packed copy of the last slice for the upper neighbour:  [tex0 slice | tex1 slice]
-    uint32_t* arrive;        // arrival counter of the boundary workgroups (monotonic, wraps) or nullptr = no signal
-    uint32_t arrive_target;  // counter value that means "all boundary workgroups of this step have published"
-    uint32_t* signal;        // word the communicator's stream waits on (hipStreamWaitValue32)
-    uint32_t signal_value;
+    uint32_t* signal;        // plain (not ordered) launches: word the first workgroup stores signal_value to when the launch
+    uint32_t signal_value;   // starts -- the communicator's stream waits on it (hipStreamWaitValue32); nullptr = none
 };
 
 struct PassArgs {

@@ -63,15 +63,7 @@ __device__ __forceinline__ OrderedBlock ordered_block(const FillArgs& a, uint32_
     return r;
 }
 
-// Write-through store (sc0 sc1): the texel goes to memory, not just to this XCD's L2, so that a kernel on any other XCD
-// (the exchange) reads it once the wave's vmcnt has drained -- without the L2-wide write-back a release fence costs.
-__device__ __forceinline__ void store_texel_wt(float4* dst, const float4& v) {
-    v4f t = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(t) : "memory");
-}
-
 // The boundary workgroups' packed copies (one message per neighbour and direction instead of one per texture).
-template <bool WT>
 __device__ __forceinline__ void store_staged(const FillArgs& a, const OrderedBlock& ob, uint64_t o, const float4& v0,
                                              const float4& v1) {
     const uint64_t slice = (uint64_t)a.W * a.H;
@@ -87,33 +79,8 @@ __device__ __forceinline__ void store_staged(const FillArgs& a, const OrderedBlo
         d1 = a.stage_lo + a.order_lead * slice + o;
     }
     if (!d0) return;
-    if (WT) {
-        store_texel_wt(d0, v0);
-        store_texel_wt(d1, v1);
-    } else {
-        *d0 = v0;
-        *d1 = v1;
-    }
-}
-
-// A boundary workgroup publishes its texels to the whole device (the exchange that follows reads them from other
-// XCDs, whose L2s are not coherent with this one) and arrives; the last arrival releases the communicator's stream.
-// Two ways, by what the exchange reads: the packed copies were stored write-through (every wave drains its stores,
-// then one arrival per workgroup -- no fence); texels the exchange reads in place (per-texture messages) sit in this
-// XCD's L2 and need the agent-scope release, i.e. a write-back of the L2's dirty lines.
-__device__ __forceinline__ void publish_boundary(const FillArgs& a) {
-    const bool staged = a.stage_lo || a.stage_hi;
-    if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (!staged) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        const uint32_t old = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1u == a.arrive_target)
-            __hip_atomic_store(a.signal, a.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    *d0 = v0;
+    *d1 = v1;
 }
 
 template <int TX, bool NT, typename Cfg, bool ORDERED = false>
@@ -158,14 +125,7 @@ __global__ __launch_bounds__(kBlock) void fill_dense_kernel(FillArgs a) {
         store_texel<NT>(a.tex1 + o, v1);
         if (a.dist) a.dist[o] = v0.x;  // wave-uniform: +4 B/voxel instead of a second pass over tex0
     }
-    if (ORDERED && ob.boundary) {  // wave-uniform
-        if (a.arrive) {
-            store_staged<true>(a, ob, o, v0, v1);
-            publish_boundary(a);
-        } else {
-            store_staged<false>(a, ob, o, v0, v1);
-        }
-    }
+    if (ORDERED && ob.boundary) store_staged(a, ob, o, v0, v1);  // wave-uniform
 }
 
 // Flat form of the dense kernel for widths that do not fill the row-chunk form's lanes (W not a multiple of the
@@ -217,14 +177,7 @@ __global__ __launch_bounds__(kBlock) void fill_dense_flat_kernel(FillArgs a) {
         store_texel<NT>(a.tex1 + at, v1t);
         if (a.dist) a.dist[at] = v0t.x;
     }
-    if (ORDERED && ob.boundary) {  // wave-uniform
-        if (a.arrive) {
-            store_staged<true>(a, ob, at, v0t, v1t);
-            publish_boundary(a);
-        } else {
-            store_staged<false>(a, ob, at, v0t, v1t);
-        }
-    }
+    if (ORDERED && ob.boundary) store_staged(a, ob, at, v0t, v1t);  // wave-uniform
 }
 
 // Ghost slices out of the packed receive buffers (one launch for up to four contiguous copies).

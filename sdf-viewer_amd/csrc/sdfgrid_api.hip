@@ -285,10 +285,6 @@ int fill_slab_ordered(const sdfv_demo_params* params, uint32_t sdf_id, const sdf
     a.dist = of.dist;
     a.stage_lo = reinterpret_cast<float4*>(of.stage_lo);
     a.stage_hi = reinterpret_cast<float4*>(of.stage_hi);
-    a.arrive = of.arrive;
-    a.arrive_target = of.arrive_target;
-    a.signal = of.signal;
-    a.signal_value = of.signal_value;
     SDFV_HIP(launch_fill_dense_ordered(a, block_begin, block_end, (hipStream_t)stream));
     return SDFV_OK;
 }
@@ -393,7 +389,7 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             return SDFV_OK;
         case SDFV_OPT_SLAB_STEP_FORM: {
             const uint64_t form = value & ~(uint64_t)(SDFV_STEP_UNPACKED | SDFV_STEP_START_EVENT | SDFV_STEP_DEFER_JOIN);
-            if (form != 0 && form != SDFV_STEP_TWO_LAUNCH && form != SDFV_STEP_ONE_LAUNCH && form != SDFV_STEP_SIDE_BOUNDARY) break;
+            if (form != 0 && form != SDFV_STEP_SIDE_BOUNDARY) break;
             g_options.slab_step_form = (uint32_t)value;
             return SDFV_OK;
         }

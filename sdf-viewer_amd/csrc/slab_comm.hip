@@ -31,6 +31,8 @@ struct Rccl {
     int (*GetUniqueId)(NcclUniqueId*) = nullptr;
     int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
     int (*CommDestroy)(NcclComm) = nullptr;
+    int (*CommCount)(const NcclComm, int*) = nullptr;
+    int (*CommUserRank)(const NcclComm, int*) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
@@ -58,6 +60,8 @@ const Rccl* rccl() {
         ok = bind(r.handle, "ncclGetUniqueId", r.GetUniqueId) && ok;
         ok = bind(r.handle, "ncclCommInitRank", r.CommInitRank) && ok;
         ok = bind(r.handle, "ncclCommDestroy", r.CommDestroy) && ok;
+        ok = bind(r.handle, "ncclCommCount", r.CommCount) && ok;
+        ok = bind(r.handle, "ncclCommUserRank", r.CommUserRank) && ok;
         ok = bind(r.handle, "ncclGroupStart", r.GroupStart) && ok;
         ok = bind(r.handle, "ncclGroupEnd", r.GroupEnd) && ok;
         ok = bind(r.handle, "ncclSend", r.Send) && ok;
@@ -99,10 +103,9 @@ struct sdfv_slab_comm {
     // packed messages: one block holding [send_lo | send_hi | recv_hi | recv_lo], sized for stage_slice texels per slice
     float* stage = nullptr;
     size_t stage_slice = 0;
-    // one-launch form: arrival counter of the boundary workgroups and the word the communicator's stream waits on
-    uint32_t* arrive = nullptr;
+    // the word the fill launch stores the step number to when it starts, and the communicator's stream waits on
     uint32_t* signal = nullptr;
-    uint32_t arrive_total = 0, step = 0;
+    uint32_t step = 0;
     bool can_wait_value = false;
 
     bool has_lo() const { return periodic || rank > 0; }
@@ -273,13 +276,11 @@ int sdfv_slab_comm_create(const unsigned char id[SDFV_COMM_ID_BYTES], int rank, 
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, prio_high);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->boundary_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->halo_done, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->arrive, sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(c->arrive, 0, sizeof(uint32_t));
     if (e != hipSuccess) {
         sdfv_slab_comm_destroy(c);
         return sdfv::set_error(SDFV_ERR_HIP, "communicator stream/events: %s", hipGetErrorString(e));
     }
-    // The one-launch step needs hipStreamWaitValue32 on a word of signal memory; without either, the two-launch form.
+    // The start signal needs hipStreamWaitValue32 on a word of signal memory; without either, the event form.
     int dev = 0, can = 0;
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can &&
@@ -304,17 +305,28 @@ int sdfv_slab_comm_destroy(sdfv_slab_comm* c) {
     if (c->halo_done) (void)hipEventDestroy(c->halo_done);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->stage) (void)hipFree(c->stage);
-    if (c->arrive) (void)hipFree(c->arrive);
     if (c->signal) (void)hipFree(c->signal);
     delete c;
     return SDFV_OK;
 }
 
-int sdfv_slab_comm_info(const sdfv_slab_comm* c, uint32_t* ghost_lo, uint32_t* ghost_hi, uint32_t* one_launch_capable) {
+int sdfv_slab_comm_info(const sdfv_slab_comm* c, uint32_t* ghost_lo, uint32_t* ghost_hi, uint32_t* wait_value_capable) {
     if (!c) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "communicator is NULL");
     if (ghost_lo) *ghost_lo = c->ghost_lo();
     if (ghost_hi) *ghost_hi = c->ghost_hi();
-    if (one_launch_capable) *one_launch_capable = c->can_wait_value ? 1u : 0u;
+    if (wait_value_capable) *wait_value_capable = c->can_wait_value ? 1u : 0u;
+    return SDFV_OK;
+}
+
+int sdfv_slab_comm_ranks(const sdfv_slab_comm* c, int* rank, int* world) {
+    if (!c) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "communicator is NULL");
+    const Rccl* lib;
+    if (int rc = need_rccl(lib)) return rc;
+    int n = 0, r = -1;
+    SDFV_RCCL(lib, CommCount(c->comm, &n));
+    SDFV_RCCL(lib, CommUserRank(c->comm, &r));
+    if (rank) *rank = r;
+    if (world) *world = n;
     return SDFV_OK;
 }
 
@@ -357,15 +369,11 @@ int sdfv_slab_fill_step_commit(sdfv_slab_comm* c, const sdfv_demo_params* params
     };
     const uint32_t lead = c->halo_hi;
 
-    // Which form: the ordered fill needs whole workgroups per slice and an interior to hide the exchange behind.
+    // Which form: the boundary launch needs whole workgroups per slice and an interior to hide the exchange behind.
     uint32_t form = sdfv::options().slab_step_form;
     bool packed = !(form & SDFV_STEP_UNPACKED);
     const bool start_event = (form & SDFV_STEP_START_EVENT) != 0 || !c->can_wait_value;
-    // SDFV_STEP_DEFER_JOIN: `main` is not made to wait for the exchange (sdfv_slab_comm_join does that on demand).  Honoured
-    // by the side-boundary forms only: there the next step's fill on `main` never touches what the exchange still reads
-    // (packed: the sends read the staging block; unpacked: the boundary slices are written by the communicator's stream,
-    // in order behind the previous exchange), and never the ghost slices it writes.
-    const bool defer_join = (form & SDFV_STEP_DEFER_JOIN) != 0;
+    const bool want_defer = (form & SDFV_STEP_DEFER_JOIN) != 0;
     form &= ~(SDFV_STEP_UNPACKED | SDFV_STEP_START_EVENT | SDFV_STEP_DEFER_JOIN);
     uint32_t bps = 0, total = 0;
     if (int rc = sdfv::ordered_fill_blocks(slab, &bps, &total)) return rc;
@@ -376,17 +384,15 @@ int sdfv_slab_fill_step_commit(sdfv_slab_comm* c, const sdfv_demo_params* params
         if (int rc = enqueue_exchange_direct(lib, c, slab, tex0, tex1, main)) return rc;
         return ghost_distances(main);
     }
-    bool unpacked_auto = false;
-    if (form == 0) {
-        // Measured in loopback (tools/slab_step_probe.py): packed messages halve the exchange kernel's time, which is what
-        // a short fill (256^3: 80 us) needs to hide it; a long fill (512^3: 580 us) hides either and is disturbed
-        // less by per-texture messages straight into the ghosts (no staging stores, no ghost copy: 16 MB less traffic).
-        form = SDFV_STEP_SIDE_BOUNDARY;
-        unpacked_auto = (uint64_t)slice_texels * owned >= (1ull << 26);
-    }
-    if (unpacked_auto) packed = false;
-    if (form == SDFV_STEP_ONE_LAUNCH && !c->can_wait_value)
-        return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "the one-launch step needs hipStreamWaitValue32 on this device");
+    // Measured in loopback (tools/slab_step_probe.py): packed messages halve the exchange kernel's time, which is what
+    // a short fill (256^3: 80 us) needs to hide it; a long fill (512^3: 580 us) hides either and is disturbed
+    // less by per-texture messages straight into the ghosts (no staging stores, no ghost copy: 16 MB less traffic).
+    if (form == 0 && (uint64_t)slice_texels * owned >= (1ull << 26)) packed = false;
+    // SDFV_STEP_DEFER_JOIN: `main` is not made to wait for the exchange (sdfv_slab_comm_join does that on demand).  Only
+    // with packed messages: there `main` fills every owned slice itself and the exchange touches nothing but the staging
+    // block and the ghosts.  With per-texture messages the communicator's stream writes the OWNED boundary slices, which
+    // work put on `main` after the step may read -- that form always joins.
+    const bool defer_join = want_defer && packed;
     if (packed)
         if (int rc = ensure_staging(c, slice_texels)) return rc;
 
@@ -404,75 +410,48 @@ int sdfv_slab_fill_step_commit(sdfv_slab_comm* c, const sdfv_demo_params* params
         return ghost_distances(st);
     };
 
-    if (form == SDFV_STEP_SIDE_BOUNDARY) {
-        // `main` runs the plain dense fill, nothing before it.  The communicator's stream starts when `main` reaches
-        // this step (work enqueued earlier on `main` may still be reading what the exchange overwrites), computes the
-        // boundary slices into the packed send buffers only, exchanges, and copies the received slices into the ghosts.
+    // `main` runs the plain dense fill, nothing before it.  The communicator's stream starts when `main` reaches
+    // this step (work enqueued earlier on `main` may still be reading what the exchange overwrites), computes the
+    // boundary slices into the packed send buffers only, exchanges, and copies the received slices into the ghosts.
 #ifdef SDFV_TUNING  // diagnostics of the tuning build: drop one of the two stream dependencies to price it (results undefined)
-        const bool no_start = (sdfv::options().wave_timing & 1) != 0, no_wait = (sdfv::options().wave_timing & 2) != 0;
+    const bool no_start = (sdfv::options().wave_timing & 1) != 0, no_wait = (sdfv::options().wave_timing & 2) != 0;
 #else
-        const bool no_start = false, no_wait = false;
+    const bool no_start = false, no_wait = false;
 #endif
-        // How the communicator's stream learns that `main` has reached this step: the packed form's fill launch says so
-        // itself (its first workgroup stores the step number to a word of signal memory the moment the launch starts,
-        // and the communicator's stream waits on that word) -- no event is recorded on `main`, which then carries
-        // nothing but the fill and the final wait; otherwise an event.
-        const bool signal_start = packed && !start_event;
-        if (signal_start) {
-            // the fill goes first in host order: should the two streams ever share a hardware queue, the launch that signals
-            // is ahead of the packet that waits for it
-            c->step += 1;
-            if (int rc = sdfv::fill_grid_signalling_start(params, sdf_id, slab, o0, o1, od, c->signal, c->step, main)) return rc;
-            SDFV_HIPC(hipStreamWaitValue32(c->comm_stream, c->signal, c->step, hipStreamWaitValueGte, 0xffffffffu));
-        } else if (!no_start) {
-            SDFV_HIPC(hipEventRecord(c->boundary_done, main));
-            SDFV_HIPC(hipStreamWaitEvent(c->comm_stream, c->boundary_done, 0));
-        }
-        if (packed) {
-            of.stage_only = true;
-#ifdef SDFV_TUNING
-            if (!(sdfv::options().wave_timing & 4))  // diagnostics: drop the boundary launch
-#endif
-            if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, 0, nb, c->comm_stream)) return rc;
-            if (int rc = exchange_on(c->comm_stream)) return rc;
-            SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));
-            if (!signal_start)
-                if (int rc = sdfv_fill_grid_commit(params, sdf_id, slab, o0, o1, od, main)) return rc;
-        } else {
-            // per-texture messages straight out of / into the textures: the communicator's stream fills the boundary
-            // slices in place, `main` everything else (the same ordered grid, split between the two streams)
-            if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, 0, nb, c->comm_stream)) return rc;
-            if (int rc = exchange_on(c->comm_stream)) return rc;
-            SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));
-            if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, nb, total, main)) return rc;
-        }
-        if (!no_wait && !defer_join) SDFV_HIPC(hipStreamWaitEvent(main, c->halo_done, 0));
-        return SDFV_OK;
-    }
-    if (form == SDFV_STEP_ONE_LAUNCH) {
-        // ONE dense launch: its first workgroups fill the boundary slices, publish them and signal; the communicator's
-        // stream waits on that word, not on the kernel, so the exchange runs under the rest of the same launch.
-        c->arrive_total += nb;  // wraps; the kernel compares for equality
+    // How the communicator's stream learns that `main` has reached this step: the packed form's fill launch says so
+    // itself (its first workgroup stores the step number to a word of signal memory the moment the launch starts,
+    // and the communicator's stream waits on that word) -- no event is recorded on `main`, which then carries
+    // nothing but the fill and the final wait; otherwise an event.
+    const bool signal_start = packed && !start_event;
+    if (signal_start) {
+        // the fill goes first in host order: should the two streams ever share a hardware queue, the launch that signals
+        // is ahead of the packet that waits for it
         c->step += 1;
-        of.arrive = c->arrive;
-        of.arrive_target = c->arrive_total;
-        of.signal = c->signal;
-        of.signal_value = c->step;
-        if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, 0, total, main)) return rc;
+        if (int rc = sdfv::fill_grid_signalling_start(params, sdf_id, slab, o0, o1, od, c->signal, c->step, main)) return rc;
         SDFV_HIPC(hipStreamWaitValue32(c->comm_stream, c->signal, c->step, hipStreamWaitValueGte, 0xffffffffu));
+    } else if (!no_start) {
+        SDFV_HIPC(hipEventRecord(c->boundary_done, main));
+        SDFV_HIPC(hipStreamWaitEvent(c->comm_stream, c->boundary_done, 0));
+    }
+    if (packed) {
+        of.stage_only = true;
+#ifdef SDFV_TUNING
+        if (!(sdfv::options().wave_timing & 4))  // diagnostics: drop the boundary launch
+#endif
+        if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, 0, nb, c->comm_stream)) return rc;
         if (int rc = exchange_on(c->comm_stream)) return rc;
         SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));
-        SDFV_HIPC(hipStreamWaitEvent(main, c->halo_done, 0));
-        return SDFV_OK;
+        if (!signal_start)
+            if (int rc = sdfv_fill_grid_commit(params, sdf_id, slab, o0, o1, od, main)) return rc;
+    } else {
+        // per-texture messages straight out of / into the textures: the communicator's stream fills the boundary
+        // slices in place, `main` everything else (the same boundary-first grid, split between the two streams)
+        if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, 0, nb, c->comm_stream)) return rc;
+        if (int rc = exchange_on(c->comm_stream)) return rc;
+        SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));
+        if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, nb, total, main)) return rc;
     }
-    // Two launches of the same ordered grid: the boundary workgroups, then (overlapping the exchange) the rest.
-    if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, 0, nb, main)) return rc;
-    SDFV_HIPC(hipEventRecord(c->boundary_done, main));
-    SDFV_HIPC(hipStreamWaitEvent(c->comm_stream, c->boundary_done, 0));
-    if (int rc = exchange_on(c->comm_stream)) return rc;
-    SDFV_HIPC(hipEventRecord(c->halo_done, c->comm_stream));
-    if (int rc = sdfv::fill_slab_ordered(params, sdf_id, slab, o0, o1, of, nb, total, main)) return rc;
-    SDFV_HIPC(hipStreamWaitEvent(main, c->halo_done, 0));
+    if (!no_wait && !defer_join) SDFV_HIPC(hipStreamWaitEvent(main, c->halo_done, 0));
     return SDFV_OK;
 }
 

@@ -15,10 +15,26 @@ host time per exchange, more than the 256^3 fill takes on the GPU -- tools/halo_
 the first on GPUs with the nccl backend and the second everywhere else (gloo tests).
 """
 import ctypes as C
+import time
 from dataclasses import dataclass
 
 import torch
 import torch.distributed as c10d  # not `dist`: that name is the distance volume in this package's signatures
+
+
+# Every collective stage names itself before it blocks, so that a hang on first contact with real xGMI (a peer that never
+# joins, P2P unavailable) is attributable in ONE run: bench.py's watchdog prints current_stage() of the rank that is stuck.
+_stage = {"name": "idle", "since": time.monotonic(), "count": 0}
+
+
+def enter_stage(name):
+    _stage["name"], _stage["since"] = name, time.monotonic()
+    _stage["count"] += 1
+
+
+def current_stage():
+    """-> (name of the collective stage this rank entered last, seconds since, stages entered so far)"""
+    return _stage["name"], time.monotonic() - _stage["since"], _stage["count"]
 
 
 def slab_range(depth, rank, world):
@@ -129,8 +145,10 @@ def halo_exchange(slab, rank, world, group=None):
             recv(t[lo + n_owned:lo + n_owned + slab.ghost_hi], rank + 1)
         if rank > 0:
             recv(t[0:lo], rank - 1)
+    enter_stage(f"halo_exchange: batch_isend_irecv of {len(ops)} ops with ranks {rank - 1}/{rank + 1}")
     for req in c10d.batch_isend_irecv(ops):
         req.wait()
+    enter_stage("halo_exchange: done")
     for dst, buf in copies:
         dst.copy_(buf)
     return sent
@@ -154,6 +172,7 @@ class SlabComm:
 
         def agree(ok, what):
             if world > 1:
+                enter_stage(f"SlabComm.__init__: agreement all_reduce after {what}")
                 t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
                 c10d.all_reduce(t, op=c10d.ReduceOp.MIN, group=group)
                 everyone = bool(t.item())
@@ -167,11 +186,13 @@ class SlabComm:
         rc = pkg.lib.sdfv_slab_comm_unique_id(ident) if rank == 0 else 0
         agree(rc == 0, "sdfv_slab_comm_unique_id")
         if world > 1:
+            enter_stage("SlabComm.__init__: broadcast of the 128-byte RCCL id from rank 0")
             t = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
             c10d.broadcast(t, src=c10d.get_global_rank(group, 0) if group is not None else 0, group=group)
             ident = (C.c_ubyte * capi.COMM_ID_BYTES)(*t.cpu().tolist())
         handle = C.c_void_p()
         flags = (capi.COMM_PERIODIC if periodic else 0) | (capi.COMM_HALO2 if halo_hi == 2 else 0)
+        enter_stage(f"SlabComm.__init__: sdfv_slab_comm_create = ncclCommInitRank(rank {rank} of {world}) on the library's communicator")
         rc = pkg.lib.sdfv_slab_comm_create(ident, rank, world, flags, C.byref(handle))
         if rc == 0:
             self.handle = handle
@@ -180,6 +201,7 @@ class SlabComm:
         except Exception:
             self.close()
             raise
+        enter_stage("SlabComm.__init__: done")
 
     @property
     def ghost_lo(self):
@@ -190,7 +212,14 @@ class SlabComm:
         return self.halo_hi if (self.periodic or self.rank < self.world - 1) else 0
 
     @property
-    def one_launch_capable(self):
+    def rccl_ranks(self):
+        """(rank, world) as RCCL reports them for the library's communicator (ncclCommUserRank, ncclCommCount)."""
+        r, n = C.c_int(-1), C.c_int(0)
+        self.pkg.check(self.pkg.lib.sdfv_slab_comm_ranks(self.handle, C.byref(r), C.byref(n)))
+        return int(r.value), int(n.value)
+
+    @property
+    def wait_value_capable(self):
         v = C.c_uint32(0)
         self.pkg.check(self.pkg.lib.sdfv_slab_comm_info(self.handle, None, None, C.byref(v)))
         return bool(v.value)
@@ -354,6 +383,7 @@ def _exchange_rays(down, up, rank, world, group):
     ops = []
     for (p, _), sn, rn in zip(peers, send_n, recv_n):
         ops += [c10d.P2POp(c10d.isend, sn, p, group), c10d.P2POp(c10d.irecv, rn, p, group)]
+    enter_stage(f"_exchange_rays: ray counts with {[p for p, _ in peers]}")
     for req in c10d.batch_isend_irecv(ops):
         req.wait()
     ops, bufs = [], []
@@ -366,8 +396,10 @@ def _exchange_rays(down, up, rank, world, group):
             ops.append(c10d.P2POp(c10d.irecv, buf, p, group))
             bufs.append(buf)
     if ops:
+        enter_stage(f"_exchange_rays: ray payloads ({len(ops)} ops)")
         for req in c10d.batch_isend_irecv(ops):
             req.wait()
+    enter_stage("_exchange_rays: done")
     if not bufs:
         return torch.empty((0, down.shape[1]), dtype=down.dtype, device=dev)
     return torch.cat([b.to(dev) for b in bufs], dim=0)
@@ -401,6 +433,7 @@ def raymarch_sharded(pkg, rp, grid, slab, camera, width, height, rank, world, gr
             return t
         bits = t.view(torch.int32)
         h = bits.cpu() if staged else bits
+        enter_stage("raymarch_sharded: all_reduce (integer sum of bit patterns) of the ranks' images")
         c10d.all_reduce(h, op=c10d.ReduceOp.SUM, group=group)
         return (h.to(t.device) if staged else h).view(t.dtype)
 
@@ -422,6 +455,7 @@ def gather_replica(slab, dims, world, group=None):
         padded = torch.zeros((deepest, dims[1], dims[0], 4), dtype=owned.dtype, device=dev)
         padded[:owned.shape[0]] = owned
         parts = [torch.empty_like(padded) for _ in range(world)]
+        enter_stage("gather_replica: all_gather of the slabs")
         c10d.all_gather(parts, padded, group=group)
         outs.append(torch.cat([p[:z1 - z0] for p, (z0, z1) in zip(parts, ranges)], dim=0).to(owned.device))
     return outs[0], outs[1]
@@ -450,6 +484,7 @@ def gather_rows(band, height, rank, world, dst=0, group=None, tile=16):
     padded = torch.zeros((band.shape[0], deepest) + tuple(band.shape[2:]), dtype=band.dtype, device=dev)
     padded[:, :band.shape[1]] = band
     parts = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    enter_stage("gather_rows: gather of the row bands")
     c10d.gather(padded, parts, dst=dst, group=group)
     if rank != dst:
         return None
@@ -468,6 +503,7 @@ def gather_images(rgba, n_cameras, rank, world, dst=0, group=None):
     padded = torch.zeros((max(counts),) + tuple(rgba.shape[1:]), dtype=rgba.dtype, device=dev)
     padded[:rgba.shape[0]] = rgba
     parts = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    enter_stage("gather_images: gather of the cameras' images")
     c10d.gather(padded, parts, dst=dst, group=group)
     if rank != dst:
         return None

@@ -12,16 +12,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,geometry", [(2, "slab"), (4, "cube")])
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+@pytest.mark.parametrize("world,geometry", [(2, "slab"), (4, "cube"), (8, "slab"), (8, "cube")])
 def test_bench_weak_scaling_path_two_ranks_one_gpu(world, geometry):
+    """2, 4 and 8 ranks (the driver's SCALE run uses 1, 2, 4, 8) sharing the box's one GPU over gloo, both weak geometries."""
     env = dict(os.environ, SDFV_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     port = 29600 + world + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "64", "--no-cpu-baseline",
-           "--config4-side", "32", "--prewarm-ms", "5",
-           "--weak-geometry", geometry, "--batch-split", "rows" if geometry == "cube" else "cameras"]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+           "--config4-side", "32", "--prewarm-ms", "5", "--per-step-samples", "4",
+           "--weak-geometry", geometry]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
@@ -29,10 +34,18 @@ def test_bench_weak_scaling_path_two_ranks_one_gpu(world, geometry):
     assert d["config"]["voxels_per_gpu"] == 64 ** 3
     gx, gy, gz = d["config"]["grid_global"]
     assert gx * gy * gz == world * 64 ** 3
-    assert (gx, gy, gz) == ((64, 64, 64 * world) if geometry == "slab" else (64, 128, 128))
+    cube = {2: (64, 64, 128), 4: (64, 128, 128), 8: (128, 128, 128)}[world]
+    assert (gx, gy, gz) == ((64, 64, 64 * world) if geometry == "slab" else cube)
     assert d["value"] > 0 and d["value_rays"] > 0
+    # the N > 1 line = the N = 1 contract + config4 + what RCCL saw (None here: gloo carries the halo, not the library's RCCL)
+    for key in CONTRACT_KEYS + ("config4", "rccl_ranks", "torch_world_size", "roofline_raymarch", "batch_raymarch"):
+        assert key in d, key
+    assert d["rccl_ranks"] is None and d["torch_world_size"] == world
+    assert d["roofline"]["frac_8d"] > 0 and d["roofline"]["algorithmic_bytes_per_voxel"] == 32
+    # config 5 as BASELINE names it (image-tile split) is the batch's top level, the camera split rides beside it
     b = d["batch_raymarch"]
-    assert b["value"] > 0 and (b["rows_per_gpu"] == 512 // world if geometry == "cube" else b["cameras_per_gpu"] == 64 // world)
+    assert b["value"] > 0 and b["split"] == "rows" and b["rows_per_gpu"] == 512 // world and b["cameras_per_gpu"] == 64
+    assert b["camera_split"]["value"] > 0 and b["camera_split"]["cameras_per_gpu"] == 64 // world
     assert d["sharded_fill_verified"] is True  # gathered slabs == dense fill, ghost slices == neighbour's slices
     c4 = d["config4"]  # the cube geometry next to the default one, in the same line
     assert c4["value"] > 0 and c4["voxels_per_gpu"] == 32 ** 3 and len(c4["grid_global"]) == 3, c4
@@ -47,8 +60,7 @@ def test_bench_line_carries_the_whole_contract():
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+    for key in CONTRACT_KEYS + ("cpu_baseline", "ms_per_step_median", "ms_per_step_p95", "per_step"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and "workload" in d["config"]
@@ -60,10 +72,15 @@ def test_bench_line_carries_the_whole_contract():
     # one consistent pipeline: value / value_rays / ms_per_step / roofline all come from `pipeline`
     pipe = d["pipeline_" + d["pipeline"]]
     assert d["pipeline"] in ("plain", "fused") and abs(pipe["ms_per_step"] - d["ms_per_step"]) < 1e-3
-    assert d["roofline"]["algorithmic_bytes_per_voxel"] == (36 if d["pipeline"] == "fused" else 32)
+    # the roofline is priced on 32 B/voxel whatever the launch stores; the bus figure rides beside it
+    assert d["roofline"]["algorithmic_bytes_per_voxel"] == 32 and d["roofline"]["frac"] == d["roofline"]["frac_8d"]
+    assert d["roofline"]["bus_bytes_per_voxel"] == (36 if d["pipeline"] == "fused" else 32)
+    assert abs(d["roofline"]["frac_8d"] * 36 / 32 - d["roofline"]["frac_bus"]) < 2e-3 or d["pipeline"] == "plain"
+    assert d["per_step"]["fill"]["median"] > 0 and d["per_step"]["raymarch"]["p95"] >= d["per_step"]["raymarch"]["median"]
     other = d["pipeline_fused" if d["pipeline"] == "plain" else "pipeline_plain"]
     assert pipe["ms_per_step"] <= other["ms_per_step"]
     assert d["target_512"]["frac"] > 0 and d["target_512"]["grid"] == [512, 512, 512]
+    assert d["target_512"]["frac_8d"] == d["target_512"]["frac"] and 0 < d["target_512"]["fused_commit"]["frac_8d"] < d["target_512"]["fused_commit"]["frac"]
     rr = d["roofline_raymarch"]
     assert "note" in rr and rr["avg_launch_ms"] > 0
 
@@ -85,6 +102,7 @@ def test_bench_multi_gpu_path_over_rccl_in_loopback():
     assert d["sharded_fill_verified"] is True, (d["sharded_fill_verified"], out.stderr[-1500:])
     assert d["value"] > 0 and d["value_rays"] > 0 and d["pipeline"] == "fused"
     assert d["config4"]["value"] > 0, d["config4"]
+    assert d["rccl_ranks"] == 1 and d["rccl_rank_of_rank0"] == 0 and d["torch_world_size"] == 1  # ncclCommCount of the library communicator
     assert "skipped" in str(d["sharded_march"]["verified"])  # a periodic slab; the gloo runs above cover the sharded march
 
 

@@ -42,22 +42,22 @@ def step_forms(pkg):
     K = pkg._capi
     return {"auto": 0, "side_boundary": K.STEP_SIDE_BOUNDARY, "side_boundary_event": K.STEP_SIDE_BOUNDARY | K.STEP_START_EVENT,
             "side_boundary_unpacked": K.STEP_SIDE_BOUNDARY | K.STEP_UNPACKED,
-            "one_launch": K.STEP_ONE_LAUNCH, "one_launch_unpacked": K.STEP_ONE_LAUNCH | K.STEP_UNPACKED,
-            "two_launch": K.STEP_TWO_LAUNCH, "two_launch_unpacked": K.STEP_TWO_LAUNCH | K.STEP_UNPACKED}
+            "side_boundary_unpacked_event": K.STEP_SIDE_BOUNDARY | K.STEP_UNPACKED | K.STEP_START_EVENT}
 
 
 # (40, 24, *) and (33, 7, *), (130, 5, 3): rows that do not fill whole workgroups -> fill, then exchange;
 # (64, 64, 64), (128, 8, 10), (256, 4, 7): the row-chunk form of the boundary-first order; (48, 16, 12): its flat form
-@pytest.mark.parametrize("form", ["auto", "side_boundary", "side_boundary_event", "side_boundary_unpacked", "one_launch", "one_launch_unpacked", "two_launch", "two_launch_unpacked"])
+ALL_FORMS = ["auto", "side_boundary", "side_boundary_event", "side_boundary_unpacked", "side_boundary_unpacked_event"]
+
+
+@pytest.mark.parametrize("form", ALL_FORMS)
 @pytest.mark.parametrize("dims,z0,z1", [((40, 24, 16), 0, 16), ((40, 24, 16), 5, 12), ((33, 7, 9), 0, 2),
                                         ((33, 7, 9), 4, 5), ((64, 64, 64), 0, 64), ((130, 5, 3), 0, 3),
                                         ((128, 8, 10), 2, 9), ((256, 4, 7), 0, 7), ((48, 16, 12), 3, 12),
                                         ((64, 64, 64), 10, 13)])
 def test_fill_step_fills_slab_and_ghosts(pkg, par, oracle, loop_comm, dims, z0, z1, form):
-    """Every form of the step (boundary-first single launch with the in-kernel signal / two launches with an event;
-    packed messages / one message per texture) leaves the same texels: owned slices = the oracle's, ghosts = the wrap."""
-    if "one_launch" in form and not loop_comm.one_launch_capable:
-        pytest.skip("hipStreamWaitValue32 not available on this device")
+    """Every form of the step (released by the fill's start signal / by an event; packed messages / one message per
+    texture) leaves the same texels: owned slices = the oracle's, ghosts = the wrap."""
     prm = pkg.default_params()
     slab = par.alloc_slab((dims[0], dims[1], z1 - z0), 0, 1, "cuda", fill_value=-7.0, periodic=True)
     slab.z_begin, slab.z_end = z0, z1
@@ -69,15 +69,13 @@ def test_fill_step_fills_slab_and_ghosts(pkg, par, oracle, loop_comm, dims, z0, 
     check_slab(oracle, pkg, prm, dims, z0, z1, slab)
 
 
-@pytest.mark.parametrize("form", ["auto", "side_boundary_unpacked", "one_launch", "one_launch_unpacked", "two_launch", "two_launch_unpacked"])
+@pytest.mark.parametrize("form", ALL_FORMS)
 @pytest.mark.parametrize("dims,z0,z1", [((64, 32, 12), 0, 12), ((64, 32, 12), 4, 8), ((40, 24, 16), 2, 9), ((64, 8, 9), 3, 5)])
 def test_two_slice_upper_halo(pkg, par, oracle, dims, z0, z1, form):
     """SDFV_COMM_HALO2: two ghost slices above the owned ones (what sdfNormal's taps need in the sharded march); every rank
     sends its first TWO owned slices down.  Fill step and the exchange alone."""
     comm = par.SlabComm(pkg, 0, 1, periodic=True, halo_hi=2)
     try:
-        if "one_launch" in form and not comm.one_launch_capable:
-            pytest.skip("hipStreamWaitValue32 not available on this device")
         prm = pkg.default_params(cube_half_side=0.8)
         slab = par.alloc_slab((dims[0], dims[1], z1 - z0), 0, 1, "cuda", fill_value=-7.0, periodic=True, halo_hi=2)
         assert slab.ghost_hi == 2 and slab.tex0.shape[0] == (z1 - z0) + 3
@@ -97,7 +95,7 @@ def test_two_slice_upper_halo(pkg, par, oracle, dims, z0, z1, form):
         comm.close()
 
 
-@pytest.mark.parametrize("form", ["auto", "side_boundary_event", "side_boundary_unpacked", "one_launch", "two_launch", "two_launch_unpacked"])
+@pytest.mark.parametrize("form", ALL_FORMS)
 @pytest.mark.parametrize("dims,z0,z1,halo", [((64, 32, 12), 0, 12, 1), ((64, 32, 12), 3, 9, 2), ((40, 24, 16), 2, 9, 1),
                                              ((128, 8, 10), 0, 10, 2)])
 def test_fill_step_with_the_fused_commit(pkg, par, oracle, dims, z0, z1, halo, form):
@@ -105,8 +103,6 @@ def test_fill_step_with_the_fused_commit(pkg, par, oracle, dims, z0, z1, halo, f
     fill's own pass, ghost slices once the halo is in): dist == tex0.r on every slice of the allocation, textures as ever."""
     comm = par.SlabComm(pkg, 0, 1, periodic=True, halo_hi=halo)
     try:
-        if "one_launch" in form and not comm.one_launch_capable:
-            pytest.skip("hipStreamWaitValue32 not available on this device")
         prm = pkg.default_params(sphere_radius=0.9)
         slab = par.alloc_slab((dims[0], dims[1], z1 - z0), 0, 1, "cuda", fill_value=-7.0, periodic=True, halo_hi=halo)
         slab.z_begin, slab.z_end = z0, z1
@@ -122,13 +118,14 @@ def test_fill_step_with_the_fused_commit(pkg, par, oracle, dims, z0, z1, halo, f
         comm.close()
 
 
-@pytest.mark.parametrize("form", ["side_boundary", "side_boundary_event", "side_boundary_unpacked", "two_launch"])
+@pytest.mark.parametrize("form", ["side_boundary", "side_boundary_event", "side_boundary_unpacked"])
 @pytest.mark.parametrize("fused", [False, True])
 def test_deferred_join(pkg, par, oracle, loop_comm, form, fused):
     """SDFV_STEP_DEFER_JOIN: steps that do not make the caller's stream wait for their exchange, one sdfv_slab_comm_join
     before the ghosts are read.  Back-to-back steps with DIFFERENT parameters on a side stream: after the join the slab
     and its ghosts hold the LAST step's texels (an exchange overtaken by the next fill, or a ghost copy that landed late,
-    would leave the previous parameters' slices).  Forms that cannot defer (two-launch) simply join in the step."""
+    would leave the previous parameters' slices).  The form that cannot defer (per-texture messages: the communicator's
+    stream writes owned slices) simply joins in the step."""
     K = pkg._capi
     dims, z0, z1 = (64, 64, 24), 0, 24
     slab = par.alloc_slab(dims, 0, 1, "cuda", periodic=True, pkg=pkg)
@@ -154,6 +151,32 @@ def test_deferred_join(pkg, par, oracle, loop_comm, form, fused):
             np.testing.assert_array_equal(bits(got1), want1)
             if fused:
                 np.testing.assert_array_equal(bits(gotd), want0[..., 0])
+
+
+@pytest.mark.parametrize("dims", [(64, 64, 24), (512, 512, 256)])
+def test_owned_slices_need_no_join_in_any_form(pkg, par, loop_comm, dims):
+    """include/sdfgrid.h: after a step taken with SDFV_STEP_DEFER_JOIN "the owned slices never need" sdfv_slab_comm_join.
+    With per-texture messages the communicator's stream fills the owned boundary slices, so that form must not defer
+    (it did, and a read of the owned slices on the caller's stream raced with the boundary fill).  Sentinel
+    slab, one deferred step, the owned slices copied on the SAME stream with no join: they equal a plain fill.  512 x 512 x
+    256 = 2^26 voxels is where per-texture messages become the default."""
+    K = pkg._capi
+    prm = pkg.default_params()
+    grid = pkg.make_grid(dims)
+    c0, c1 = pkg.alloc_textures(grid)
+    pkg.fill_grid(prm, grid, c0, c1)
+    s = torch.cuda.Stream()
+    for form in (K.STEP_SIDE_BOUNDARY | K.STEP_UNPACKED, 0, K.STEP_SIDE_BOUNDARY):
+        slab = par.alloc_slab(dims, 0, 1, "cuda", fill_value=-7.0, periodic=True)
+        torch.cuda.synchronize()
+        with pkg.options({K.OPT_SLAB_STEP_FORM: form | K.STEP_DEFER_JOIN}), torch.cuda.stream(s):
+            loop_comm.fill_step(prm, grid, slab, stream=s)
+            got0, got1 = slab.owned0.clone(), slab.owned1.clone()  # on s, NO join
+            loop_comm.join(stream=s)
+        s.synchronize()
+        assert torch.equal(got0.view(torch.int32), c0.view(torch.int32)), form
+        assert torch.equal(got1.view(torch.int32), c1.view(torch.int32)), form
+        del slab, got0, got1
 
 
 def test_repeated_steps_on_a_side_stream(pkg, par, oracle, loop_comm):

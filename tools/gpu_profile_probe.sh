@@ -1,0 +1,21 @@
+#!/bin/bash
+# The run the bench LINE describes, under the profiler: default bench.py options (texture-placement probe ON, both
+# pipelines), kernel trace + stats; tools/kernel_trace_avg.py then separates the whole-grid launches from the probe's
+# short ones by grid size.  usage: tools/gpu_profile_probe.sh <tag> [workload]
+TAG=${1:-probe}
+WL=${2:-256}
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+CMD="python bench.py --steps 20 --warmup 3 --workload $WL --no-cpu-baseline --no-batch --no-overlapped"
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $CMD > $OUT/trace.log 2>&1
+{
+  echo "# rocprofv3 --kernel-trace --stats -- $CMD   (placement probe ON: the line bench.py prints describes this run)"
+  grep '^{' $OUT/trace.log | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('# bench line:', json.dumps({k: d[k] for k in ('value','value_rays','ms_per_step','ms_per_step_fill','ms_per_step_raymarch','pipeline','texture_placement','raymarch_kernel_ms')})); print('# roofline:', json.dumps(d['roofline']))"
+  cat $OUT/trace/trace_kernel_stats.csv
+  echo
+  echo "# per (kernel, grid size): whole-grid launches vs the placement probe's first-slices launches"
+  python tools/kernel_trace_avg.py $OUT/trace
+} > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt

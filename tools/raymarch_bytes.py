@@ -47,9 +47,21 @@ def model(side, W, H, eyes, threads):
     t0, t1 = oracle.fill_dense(prm, dims, threads=threads)
     rp = oracle.default_render_params(dims)
     maps, tot = None, None
+    per_camera = []
     for eye in eyes:
         cam = oracle.camera_look_at(eye=eye, aspect=W / H)
         maps, c = oracle.raymarch_touch(rp, t0, t1, cam, W, H, threads=threads, maps=maps)
+        if len(eyes) > 1:
+            # the same camera on its own (bench.py --gpus N marches ONE orbit camera per rank: N > 1 lines take their
+            # byte model from these entries instead of reporting none)
+            own, _ = oracle.raymarch_touch(rp, t0, t1, cam, W, H, threads=threads, maps=None)
+            m, h0, h1 = int(own["march0"].sum()), int(own["hit0"].sum()), int(own["hit1"].sum())
+            all0 = int((own["march0"] | own["hit0"] | own["normal0"]).sum())
+            per_camera.append({"eye": [round(e, 6) for e in eye], "hits": c["hits"], "sum_steps": c["sum_steps"],
+                               "covered": c["covered"], "max_steps": c["max_steps"],
+                               "compulsory_bytes": 16 * (all0 + h1) + 16 * W * H,
+                               "nominal_gather_bytes": 128 * (c["sum_steps"] + 5 * c["hits"]) + 16 * W * H,
+                               "product_path_compulsory_bytes": 4 * m + 16 * (h0 + h1) + 16 * W * H})
         if tot is None:
             tot = c
         else:
@@ -84,6 +96,8 @@ def model(side, W, H, eyes, threads):
         },
         "output_bytes": out_bytes,
     }
+    if per_camera:
+        res["per_camera"] = per_camera
     return res
 
 

@@ -67,7 +67,7 @@ def main():
     def plain_fused():
         pkg.fill_grid(prm, grid, slab.owned0, slab.owned1, dist=own_dist)
 
-    out = {"steps": steps, "one_launch_capable": comm.one_launch_capable}
+    out = {"steps": steps, "wait_value_capable": comm.wait_value_capable}
     if "--graph" in sys.argv and "--graph-child" not in sys.argv:
         # the capture crashes the process on this image (hipStreamEndCapture): run it in a child and report
         import subprocess
@@ -107,11 +107,8 @@ def main():
         print(json.dumps(out), flush=True)
         return
     if "--forms" in sys.argv:
-        forms = {"two_launch_unpacked": K.STEP_TWO_LAUNCH | K.STEP_UNPACKED, "two_launch": K.STEP_TWO_LAUNCH,
-                 "side_boundary": K.STEP_SIDE_BOUNDARY, "side_boundary_event": K.STEP_SIDE_BOUNDARY | K.STEP_START_EVENT,
+        forms = {"side_boundary": K.STEP_SIDE_BOUNDARY, "side_boundary_event": K.STEP_SIDE_BOUNDARY | K.STEP_START_EVENT,
                  "side_boundary_unpacked": K.STEP_SIDE_BOUNDARY | K.STEP_UNPACKED}
-        if comm.one_launch_capable:
-            forms.update({"one_launch_unpacked": K.STEP_ONE_LAUNCH | K.STEP_UNPACKED, "one_launch": K.STEP_ONE_LAUNCH})
         res = {k: [] for k in forms}
         res["plain_fill"] = []
         for rnd in range(3):
