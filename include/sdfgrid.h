@@ -153,10 +153,11 @@ typedef enum sdfv_option {
     SDFV_OPT_RAYMARCH_BOX_FIRST = 7,   /* 1 (default) | 0: with an XCD-aware tile order and one camera, the groups of tiles under
                                         * the screen rectangle of the projected bounding box are launched before the others (the
                                         * frame is as long as its longest wave; those all start at once then).  Order only */
-    SDFV_OPT_RAYMARCH_WAVES_PER_SIMD = 8, /* 0 (default: what the register file allows, 7 for the kernels without aux record) |
-                                        * 2..7: cap on the raymarch kernel's resident waves per SIMD (unused dynamic LDS).
-                                        * Batches and close-ups want the maximum; a single large frame whose box covers part
-                                        * of the image is latency-bound and can gain from 3-4.  Speed only */
+    SDFV_OPT_RAYMARCH_WAVES_PER_SIMD = 8, /* resident waves per SIMD of the raymarch kernel (unused dynamic LDS caps them): 0 (default)
+                                        * = the launcher's rule: 4 for a single frame over a volume larger than the Infinity Cache
+                                        * whose projected bounding box holds 1x .. 3.5x the machine's wave slots (latency-bound on
+                                        * its long waves: 1440p over 512^3 -17 %, 4K -6 %), otherwise no cap | 2..6: that cap |
+                                        * 7: never cap (what the register file allows).  Speed only */
     SDFV_OPT_TUNING_WAVE_TIMING = 100, /* tuning build only (-DSDFV_TUNING): DEVICE address of 32 B per raymarch wave */
     SDFV_OPT_TUNING_TILE_ORDER = 102,  /* tuning build only: DEVICE address of tiles_x * tiles_y uint32 tile numbers (row-major
                                         * tile index by * tiles_x + bx): workgroup L of a single-camera launch renders tile

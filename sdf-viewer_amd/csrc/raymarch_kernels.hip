@@ -847,8 +847,9 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
         // The fast kernels know the hit point is within 1e-4 of the box; the normal's taps are h further out,
         // a.fast_normal says whether floor(u) still stays in [-1, N-1] for them.
         const float4 raw0 = sample_rgba<LINEAR, XF, FAST>(a, tex0, ray_pos);  // == the march's last sample
-        // one texture's eight 16-byte corners at a time: both sets in flight together would cost 32 more VGPRs than the rest
-        // of the kernel needs (one wave per SIMD less)
+        // one texture's eight 16-byte corners at a time: both sets in flight together cost 6 more VGPRs (78: one wave per
+        // SIMD less) and buy nothing even for single frames, which are not occupancy-limited -- measured 1 % SLOWER on
+        // every view at 1080p / 256^3 and 4K / 512^3 (round 3 A/B, profiles/r03_hit_path_ab.json)
         V3 pos1 = ray_pos;
         asm volatile("" : "+v"(pos1.x) : "v"(raw0.x), "v"(raw0.y), "v"(raw0.z), "v"(raw0.w));  // same value, after raw0
         const float4 raw1 = sample_rgba<LINEAR, XF, FAST>(a, tex1, pos1);  // material.frag:154
@@ -1202,6 +1203,38 @@ static void box_first_rectangle(RaymarchArgs& ag, uint32_t groups_y) {
     ag.m_groups_x = magic(ag.groups_x), ag.m_first_w = magic(ag.first_w), ag.m_rest_w = magic(ag.groups_x - ag.first_w);
 }
 
+// Resident waves per SIMD for this launch (7 = what the register file allows = no cap).
+//
+// A frame is as long as its longest wave.  While every wave that can be active is resident at once, a long wave shares its
+// CU's gather path with up to 27 others and advances at a fraction of its lone speed; with fewer resident waves the ones that
+// started first (box-first order: those under the box) finish sooner and the rest fill in behind them.  That only pays when
+// (i) the frame is bound by its long waves, not by throughput -- a box covering a small multiple of the machine, not the
+// whole image; (ii) a gather that misses L2 is expensive -- a marched volume larger than the Infinity Cache; smaller ones
+// (256^3: 64 MB) move by +-3 % either way (tools/occupancy_rule_bench.py, profiles/r03_occupancy_rule.json: 13 views x
+// 1080p/256^3, 1440p/512^3, 4K/512^3 x every cap).  What the launcher knows: the screen rectangle of the projected bounding
+// box (box-first order) in waves, the machine's wave slots, the volume's bytes.  Rule: cap at 4 when the rectangle holds
+// between 1x and 3.5x the slots at 7 per SIMD and the volume exceeds the last-level cache; no cap otherwise (camera
+// inside, box filling the image, batches of cameras, small volumes, a box of a few tiles).  Speed only.
+static uint32_t occupancy_rule(const RaymarchArgs& ag) {
+    if (ag.waves_per_simd >= 2 && ag.waves_per_simd <= 6) return ag.waves_per_simd;  // the caller's cap
+    if (ag.waves_per_simd == 7) return 7;
+    if (ag.n_cameras != 1 || ag.first_w == 0 || ag.group_shift == 0 || ag.wave_slots_per_simd_unit == 0) return 7;
+    const uint64_t texels = (uint64_t)ag.rp.tex_size[0] * ag.rp.tex_size[1] * ag.rp.tex_size[2];
+    const uint64_t volume_bytes = texels * (ag.dist ? 4u : 16u);
+    if (ag.last_level_cache_bytes == 0 || volume_bytes <= ag.last_level_cache_bytes) return 7;
+    const uint64_t rect_waves = (uint64_t)ag.first_w * ag.first_h * (4ull << (2 * ag.group_shift));  // 4 waves per 16 x 16 tile
+    const uint64_t slots7 = 7ull * ag.wave_slots_per_simd_unit;
+    if (rect_waves < slots7 || 2 * rect_waves > 7 * slots7) return 7;
+    return 4;
+}
+
+// w waves per SIMD = w workgroups per CU: each asks for a w-th of the CU's 160 KB of LDS (less a little for rounding)
+static uint32_t lds_cap_for(uint32_t w) {
+    uint32_t bytes = (w >= 2 && w <= 6) ? (160u * 1024u) / w - 1024u : 0u;
+    if (bytes > 65536u) bytes = 65536u;  // the launch limit without an opt-in: 2 waves per SIMD
+    return bytes;
+}
+
 hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream) {
     const uint32_t rows = a.y1 - a.y0;
     if (a.width == 0 || rows == 0 || a.n_cameras == 0) return hipSuccess;
@@ -1211,6 +1244,7 @@ hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream) {
 #ifdef SDFV_TUNING
     if (a.tile_order) {
         ag.group_shift = 0;
+        ag.lds_cap_bytes = lds_cap_for(occupancy_rule(ag));  // no rectangle here: the caller's cap or none
         return launch_raymarch_grid(ag, dim3(tiles.x * tiles.y, 1, 1), stream);
     }
 #endif
@@ -1235,6 +1269,7 @@ hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream) {
     } else if (a.group_shift) {
         grouped(a.group_shift);
     }
+    ag.lds_cap_bytes = lds_cap_for(occupancy_rule(ag));
     return launch_raymarch_grid(ag, grid, stream);
 }
 

@@ -134,6 +134,35 @@ int current_device() {
     return d;
 }
 
+// What the raymarch launcher needs to know about the device it launches on (cached per host thread and device): the
+// hand-written march loop is gfx950 machine code, the XCD-aware tile order assumes workgroup L -> XCD L % xcds, and the
+// occupancy rule counts wave slots.
+struct DeviceFacts {
+    int device = -2;
+    bool gfx950 = false;
+    uint32_t cus = 0, xcds = 0;
+    uint64_t last_level_cache_bytes = 0;
+};
+const DeviceFacts& device_facts() {
+    thread_local DeviceFacts f;
+    const int now = current_device();
+    if (f.device == now) return f;
+    f = DeviceFacts();
+    f.device = now;
+    hipDeviceProp_t prop;
+    if (now >= 0 && hipGetDeviceProperties(&prop, now) == hipSuccess) {
+        f.gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+        f.cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 0u;
+        int x = 0;
+        if (hipDeviceGetAttribute(&x, hipDeviceAttributeNumberOfXccs, now) == hipSuccess && x > 0) f.xcds = (uint32_t)x;
+        // MI355X: 256 MB of Infinity Cache behind the eight 4 MB L2s (MI355X_MICROARCH.md); HIP reports the L2 only
+        f.last_level_cache_bytes = f.gfx950 ? (256ull << 20) : (uint64_t)(prop.l2CacheSize > 0 ? prop.l2CacheSize : 0);
+    } else {
+        (void)hipGetLastError();
+    }
+    return f;
+}
+
 struct MeshScratch {
     void* p = nullptr;
     size_t bytes = 0;
@@ -394,7 +423,7 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             return SDFV_OK;
         }
         case SDFV_OPT_RAYMARCH_WAVES_PER_SIMD:
-            if (value == 1 || value > 7) break;
+            if (value == 1 || value > 7) break;  // 0 auto (the launcher's rule) | 2..6 cap | 7 never cap
             g_options.raymarch_waves_per_simd = (uint32_t)value;
             return SDFV_OK;
         case SDFV_OPT_TUNING_TILE_ORDER:
@@ -863,10 +892,17 @@ int sdfv_raymarch_depth(const sdfv_render_params* rp, const float* tex0, const f
     // lose 3-8 % with any grouping
     // w waves per SIMD = w workgroups per CU: each asks for a w-th of the CU's 160 KB of LDS (less a little for rounding)
     const uint32_t w = g_options.raymarch_waves_per_simd;
-    a.lds_cap_bytes = (w >= 2 && w <= 6) ? (160u * 1024u) / w - 1024u : 0u;
-    if (a.lds_cap_bytes > 65536u) a.lds_cap_bytes = 65536u;  // the launch limit without an opt-in: 2 waves per SIMD
+    a.waves_per_simd = w;  // 0 = the launcher's occupancy rule (launch_raymarch), 7 = never cap, 2..6 = that cap
     a.box_first = g_options.raymarch_box_first;
-    a.group_shift = g_options.raymarch_tile_group == 0 ? (n_cameras == 1 ? sdfv::kGroupAuto : 0u)
+    // The device's facts gate what is machine- or topology-specific: the hand-written loop is gfx950 code (anything else
+    // takes the compiler's loop, bit-identical), and the XCD-aware tile orders assume the observed workgroup -> XCD
+    // placement L % 8 of an eight-XCD part (speed only; launch order elsewhere).
+    const DeviceFacts& dev = device_facts();
+    if (!dev.gfx950) a.asm_loop = 0;
+    a.wave_slots_per_simd_unit = dev.cus * 4u;  // SIMDs: resident waves at w per SIMD = w * this
+    a.last_level_cache_bytes = dev.last_level_cache_bytes;
+    const bool xcd_order_ok = dev.xcds == 8;
+    a.group_shift = g_options.raymarch_tile_group == 0 ? (n_cameras == 1 && xcd_order_ok ? sdfv::kGroupAuto : 0u)
                                                        : (g_options.raymarch_tile_group == 1 ? 0u : g_options.raymarch_tile_group - 1u);
 #ifdef SDFV_TUNING
     a.wave_timing = reinterpret_cast<unsigned long long*>(g_options.wave_timing);  // 32 B per wave, or 0

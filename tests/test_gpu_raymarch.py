@@ -415,7 +415,7 @@ def test_occupancy_cap_changes_nothing_but_speed(pkg):
     cams = pkg.orbit_cameras(3, aspect=W / H)
     ref = pkg.raymarch(rp, t0, t1, cams, W, H, want_aux=True, want_depth=True, dist=dist)
     ref0 = pkg.raymarch(rp, t0, t1, cams[0], W, H)
-    for waves in (2, 3, 4, 5, 6, 7):
+    for waves in (0, 2, 3, 4, 5, 6, 7):  # 0 = the launcher's own rule
         with pkg.options({K.OPT_RAYMARCH_WAVES_PER_SIMD: waves}):
             got = pkg.raymarch(rp, t0, t1, cams, W, H, want_aux=True, want_depth=True, dist=dist)
             got0 = pkg.raymarch(rp, t0, t1, cams[0], W, H)
@@ -423,6 +423,26 @@ def test_occupancy_cap_changes_nothing_but_speed(pkg):
         assert torch.equal(got[0].view(torch.int32), ref[0].view(torch.int32)) and torch.equal(got[2], ref[2]), waves
         assert torch.equal(got[1].view(torch.int32), ref[1].view(torch.int32)), waves
         assert torch.equal(got0.view(torch.int32), ref0.view(torch.int32)), waves
+
+
+def test_launcher_occupancy_rule_at_the_sizes_it_fires(pkg):
+    """The launcher's rule caps the resident waves (4 per SIMD) for a single frame over a volume larger than the Infinity
+    Cache whose projected box holds 1x .. 3.5x the machine's wave slots: 1440p over 512^3 with the default camera is such a
+    launch, its close-up and its 64^3 sibling are not.  Whatever it decides, the image is the uncapped one bit for bit."""
+    K = pkg._capi
+    prm = pkg.default_params()
+    g = pkg.make_grid((512, 512, 512))
+    t0, t1 = pkg.alloc_textures(g)
+    dist = torch.empty((512, 512, 512), dtype=torch.float32, device="cuda")
+    pkg.fill_grid(prm, g, t0, t1, dist=dist)
+    rp = pkg.default_render_params(g)
+    for (W, H), eye in (((2560, 1440), (2.5, 3.0, 5.0)), ((3840, 2160), (2.5, 3.0, 5.0)), ((2560, 1440), (1.2, 1.5, 2.4))):
+        cam = pkg.camera_look_at(eye=eye, aspect=W / H)
+        for use_dist in (dist, None):
+            auto = pkg.raymarch(rp, t0, t1, cam, W, H, dist=use_dist)
+            with pkg.options({K.OPT_RAYMARCH_WAVES_PER_SIMD: 7}):
+                free = pkg.raymarch(rp, t0, t1, cam, W, H, dist=use_dist)
+            assert torch.equal(auto.view(torch.int32), free.view(torch.int32)), (W, H, eye)
 
 
 def test_row_bands_of_the_image_tile_split_tile_the_frame(pkg):
