@@ -349,8 +349,14 @@ def progressive_block(pkg, torch, prm, sides, reps=7):
                 ts.append(a.elapsed_time(b))
             return sorted(ts)[len(ts) // 2]
 
-        def passes(steps, box=None):
-            return lambda: [pkg.fill_grid_pass(prm, g, st, t0, t1, changed_box=box, dist=dist) for st in steps]
+        FRESH, SAME = pkg._capi.PASS_FRESH_GRID, pkg._capi.PASS_SAME_LOAD
+
+        def passes(steps, box=None, flagged=False):
+            # flagged: what host/sdf_viewer.cpp's LoadingManager tells the library (sdfv_fill_grid_pass_ex): the first pass
+            # of a load sees a fresh grid, the later ones revisit what the same load wrote -- nothing is read
+            return lambda: [pkg.fill_grid_pass(prm, g, st, t0, t1, changed_box=box, dist=dist,
+                                               flags=((FRESH | SAME) if k == 0 else SAME) if flagged else 0)
+                            for k, st in enumerate(steps)]
 
         def visited(steps):
             return sum((-(-side // st)) ** 3 for st in steps)
@@ -366,9 +372,17 @@ def progressive_block(pkg, torch, prm, sides, reps=7):
         # voxels of the 1/8 box: coordinates idx/(N-1)*2-1 in [-0.5, 0.5] per axis
         in_box_axis = sum(1 for i in range(side) if -0.5 <= (i / (side - 1)) * 2.0 - 1.0 <= 0.5)
         res = {}
-        res["fresh_load_2_passes"] = case(timed(passes((2, 1)), fresh), visited((2, 1)), n,
-                                          "the reference's DEFAULT load (cli/mod.rs:13-18): step 2 then step 1 over a fresh grid")
-        res["fresh_pass_step_2"] = case(timed(passes((2,)), fresh), visited((2,)), visited((2,)), "first pass of that load alone")
+        res["fresh_load_2_passes"] = case(timed(passes((2, 1), flagged=True), fresh), visited((2, 1)), n,
+                                          "the reference's DEFAULT load (cli/mod.rs:13-18): step 2 then step 1 over a fresh grid, as "
+                                          "SDFViewer::update enqueues it (sdfv_fill_grid_pass_ex with the LoadingManager's knowledge: "
+                                          "store-only; the intermediate LOD-2 state is produced)")
+        res["fresh_load_2_passes"]["algorithmic_bytes"] = 36 * (n + visited((2,)))  # no reads; the step-2 lattice is written twice
+        res["fresh_load_2_passes"]["frac"] = round(36 * (n + visited((2,))) / (res["fresh_load_2_passes"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        res["fresh_pass_step_2_flagged"] = case(timed(passes((2,), flagged=True), fresh), visited((2,)), visited((2,)),
+                                                "first pass of that load alone (whole visited rows written: 1/4 of the textures)")
+        res["fresh_load_2_passes_unflagged"] = case(timed(passes((2, 1)), fresh), visited((2, 1)), n,
+                                                    "the same load through sdfv_fill_grid_pass_dist (update_required read from the volume)")
+        res["fresh_pass_step_2"] = case(timed(passes((2,)), fresh), visited((2,)), visited((2,)), "first pass, unflagged")
 
         def after_step2():
             fresh()

@@ -241,6 +241,26 @@ int sdfv_fill_grid_pass(const sdfv_demo_params *params, uint32_t sdf_id, const s
 int sdfv_fill_grid_pass_dist(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid, uint32_t step,
                              const float *changed_box, float *tex0, float *tex1, float *dist, void *stream);
 
+/* The same pass with what the CALLER knows about the grid (flags; 0 = sdfv_fill_grid_pass_dist).  Whenever update_required
+ * is known to hold for every visited voxel the pass reads nothing: at step 1 it is the dense fill (+ the distance volume),
+ * at larger steps a store-only strided pass.  The library finds one such case itself -- a changed_box that contains every
+ * voxel of the slab (what the demo reports on any parameter edit, demo/mod.rs:135-144) -- the flags name the two a host
+ * that drives a LoadingManager knows (host/sdf_viewer.cpp does):
+ *   SDFV_PASS_FRESH_GRID  every voxel of the slab holds new_voxels' initial state [AIR_DIST; 4] (scene/sdf/mod.rs:76-77,
+ *                         sdfv_grid_init) on entry: the FIRST pass of a load.  The voxels between the visited ones are then
+ *                         known as well, and a pass with step 2..8 writes the visited rows whole (visited x: the sample,
+ *                         the others: the AIR texel they hold) -- whole 128-byte lines instead of one texel in every
+ *                         `step`, no read-modify-write of partly written lines.
+ *   SDFV_PASS_SAME_LOAD   every stored (non-AIR) voxel the pass visits was written by an earlier pass of the SAME load --
+ *                         same SDF, same parameters, no changed box since -- so rewriting it stores the bits it holds:
+ *                         the later passes of a load (loading.rs:50-76 revisits what coarser passes sampled).
+ * The textures after the call are those sdfv_fill_grid_pass_dist leaves, bit for bit, provided the flags are true; a false
+ * flag overwrites voxels the reference would have kept. */
+#define SDFV_PASS_FRESH_GRID 1u
+#define SDFV_PASS_SAME_LOAD  2u
+int sdfv_fill_grid_pass_ex(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid, uint32_t step,
+                           const float *changed_box, float *tex0, float *tex1, float *dist, uint32_t flags, void *stream);
+
 /* ---- batched point sampling (the "Batched sampling" TODO, src/sdf/mod.rs:39) ---- */
 /* points: DEVICE, n x 3 floats.  out: DEVICE, n x sdfv_sample.  SDFSurface::sample(p, distance_only). */
 int sdfv_sample_points(const sdfv_demo_params *params, uint32_t sdf_id, const float *points, size_t n,

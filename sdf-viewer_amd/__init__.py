@@ -169,13 +169,14 @@ def fill_grid(params, grid, tex0, tex1, sdf_id=SDF_DEMO, stream=None, dist=None)
                                     _stream_ptr(stream)))
 
 
-def fill_grid_pass(params, grid, step, tex0, tex1, changed_box=None, sdf_id=SDF_DEMO, stream=None, dist=None):
+def fill_grid_pass(params, grid, step, tex0, tex1, changed_box=None, sdf_id=SDF_DEMO, stream=None, dist=None, flags=0):
     """One LoadingManager pass (loading.rs:50-76) with update_required (scene/sdf/mod.rs:184-190).  `dist`: the
-    textures' compact distance volume, read instead of tex0 and kept in sync (sdfv_fill_grid_pass_dist)."""
+    textures' compact distance volume, read instead of tex0 and kept in sync (sdfv_fill_grid_pass_dist).  `flags`:
+    _capi.PASS_FRESH_GRID / PASS_SAME_LOAD -- what the caller knows about the grid (sdfv_fill_grid_pass_ex)."""
     box = None if changed_box is None else (C.c_float * 6)(*[float(x) for x in changed_box])
-    check(lib.sdfv_fill_grid_pass_dist(C.byref(params), sdf_id, C.byref(grid), int(step), box, _dev_ptr(tex0, "tex0"),
-                                       _dev_ptr(tex1, "tex1"), None if dist is None else _dev_ptr(dist, "dist"),
-                                       _stream_ptr(stream)))
+    check(lib.sdfv_fill_grid_pass_ex(C.byref(params), sdf_id, C.byref(grid), int(step), box, _dev_ptr(tex0, "tex0"),
+                                     _dev_ptr(tex1, "tex1"), None if dist is None else _dev_ptr(dist, "dist"), int(flags),
+                                     _stream_ptr(stream)))
 
 
 def sample_points(params, points, distance_only=False, sdf_id=SDF_DEMO, stream=None):

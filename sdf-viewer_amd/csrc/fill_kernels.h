@@ -38,6 +38,13 @@ struct FillArgs {
     uint32_t signal_value;   // starts -- the communicator's stream waits on it (hipStreamWaitValue32); nullptr = none
 };
 
+// Exact division of a 32-bit index by a launch constant (fill_kernels.hip div_u32).
+struct DivU32 {
+    unsigned long long magic;  // floor((2^64 - 1) / d) + 1
+    uint32_t shift;            // log2(d) when d is a power of two
+    uint32_t pow2;
+};
+
 struct PassArgs {
     uint32_t step;
     uint32_t nx, ny, nz;     // visited voxels per axis in this slab
@@ -48,6 +55,11 @@ struct PassArgs {
     float approx_margin[3];  // set by the launcher: bound on |estimate - exact voxel coordinate|, with slack
     float* dist;             // optional compact copy of tex0.r, in sync with tex0: read for update_required
                              // instead of the 16-byte texel and rewritten with it (nullptr = read tex0 itself)
+    uint32_t all_required;   // update_required is known to hold for every visited voxel: nothing is read
+    uint32_t fresh;          // every voxel of the slab holds [AIR_DIST; 4] on entry (first pass of a fresh load)
+    // set by the launcher:
+    uint32_t n_visited;      // nx * ny * nz
+    DivU32 div_nx, div_ny, div_w;
 };
 
 struct FillLaunch {
@@ -74,7 +86,8 @@ struct CopySegments {
 hipError_t launch_copy_segments(const CopySegments& c, hipStream_t stream);
 // slab_d slices z_begin + k * z_step in ONE launch (the two boundary slices of a slab: slab_d = 2).
 hipError_t launch_fill_slices(const FillArgs& a, hipStream_t stream);
-hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& p, hipStream_t stream);
+// dense_cfg: store policy / index form of the dense kernel, which an all-required step-1 pass is
+hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& p, const FillLaunch& dense_cfg, hipStream_t stream);
 hipError_t launch_commit_distance(const float* tex0, float* dist, uint64_t n_voxels, hipStream_t stream);
 hipError_t launch_grid_init(float* tex0, float* tex1, uint64_t n_voxels, float air, hipStream_t stream);
 

@@ -194,41 +194,38 @@ __global__ __launch_bounds__(kBlock) void copy_segments_kernel(CopySegments c) {
     }
 }
 
-// One visited voxel of a LoadingManager pass: update_required (scene/sdf/mod.rs:184-190) and, when it holds, the
-// rewrite of both texels.  `is_air` = the stored tex0.r equals AIR_DIST (read by the caller from tex0 or from the
-// distance volume).
-__device__ __forceinline__ void pass_voxel(const FillArgs& a, const PassArgs& p, uint32_t x, uint32_t y, uint32_t z,
-                                           uint64_t flat, bool is_air) {
-    if (!is_air) {
-        // Most visited voxels of a loaded grid need nothing: leave before paying three correctly rounded divides.
-        if (!p.has_box) return;
-        // Cheap estimate of the voxel's coordinates (one multiply-add per axis); the exact ones differ from it by
-        // less than approx_margin, so a voxel whose estimate is further than that outside the box is outside it.
-        const float ex = (float)x * p.approx_scale[0] + a.bb_min[0];
-        const float ey = (float)y * p.approx_scale[1] + a.bb_min[1];
-        const float ez = (float)z * p.approx_scale[2] + a.bb_min[2];
-        if (ex < p.box[0] - p.approx_margin[0] || ex > p.box[3] + p.approx_margin[0] ||
-            ey < p.box[1] - p.approx_margin[1] || ey > p.box[4] + p.approx_margin[1] ||
-            ez < p.box[2] - p.approx_margin[2] || ez > p.box[5] + p.approx_margin[2])
-            return;
-    }
-    const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
-    const float py = voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]);
-    const float pz = voxel_coord(z, a.dm1[2], a.bb_size[2], a.bb_min[2]);
-    bool update_required = is_air;
-    if (p.has_box) {
-        update_required = update_required ||
-                          (px >= p.box[0] && px <= p.box[3] && py >= p.box[1] && py <= p.box[4] &&
-                           pz >= p.box[2] && pz <= p.box[5]);
-    }
-    if (!update_required) return;
-    // No LDS staging of the colour table in the pass kernels: most workgroups of a pass over a loaded grid have
-    // nothing to update and would pay the staging and its barrier for nothing; the few lookups read the 1 KiB table
-    // through the caches.
+// Exact v / d for v < 2^32 (DivU32 made by the launcher): a shift for powers of two, otherwise the 64-bit multiply-high
+// with M = floor((2^64 - 1) / d) + 1 the flat dense kernel uses.  All fields are wave-uniform (SGPRs): one scalar branch.
+__device__ __forceinline__ uint32_t div_u32(uint32_t v, const DivU32& d) {
+    if (d.pow2) return v >> d.shift;
+    const unsigned long long t = ((unsigned long long)v * (uint32_t)d.magic) >> 32;
+    return (uint32_t)(((unsigned long long)v * (uint32_t)(d.magic >> 32) + t) >> 32);
+}
+
+// update_required (scene/sdf/mod.rs:184-190) for one visited voxel whose stored tex0.r is not AIR_DIST: inside the
+// changed box?  A cheap estimate of the coordinates (one multiply-add per axis; the exact ones differ from it by less than
+// approx_margin) rejects what is clearly outside before anyone pays for three correctly rounded divides.
+__device__ __forceinline__ bool maybe_in_box(const FillArgs& a, const PassArgs& p, uint32_t x, uint32_t y, uint32_t z) {
+    const float ex = (float)x * p.approx_scale[0] + a.bb_min[0];
+    const float ey = (float)y * p.approx_scale[1] + a.bb_min[1];
+    const float ez = (float)z * p.approx_scale[2] + a.bb_min[2];
+    return !(ex < p.box[0] - p.approx_margin[0] || ex > p.box[3] + p.approx_margin[0] ||
+             ey < p.box[1] - p.approx_margin[1] || ey > p.box[4] + p.approx_margin[1] ||
+             ez < p.box[2] - p.approx_margin[2] || ez > p.box[5] + p.approx_margin[2]);
+}
+
+// The rewrite of one voxel that update_required holds for.  No LDS staging of the colour table in the pass kernels: most
+// workgroups of a pass over a loaded grid have nothing to update and would pay the staging and its barrier for nothing; the
+// few lookups (the "normal" material only) read the 1 KiB table through the caches.
+template <typename Cfg>
+__device__ __forceinline__ void pass_store(const FillArgs& a, const PassArgs& p, float px, float py, float pz, uint64_t flat) {
     const LdsLut lut{c_srgb_lut};
     float4 v0, v1;
-    fill_voxel<RuntimeCfg>(a.prm, a.sdf_id, px, py, pz, lut, a.air_dist, v0, v1);
-    a.tex0[flat] = v0;
+    fill_voxel<Cfg>(a.prm, a.sdf_id, px, py, pz, lut, a.air_dist, v0, v1);
+    // Texture stores stream past L2 (nt), like the fused dense fill's: nothing re-reads them before the march's few texels
+    // under the hits, while the volume -- which this very pass READS -- keeps the cache.  tools/ubench/rw_mix.hip: a
+    // 4 B/voxel read stream next to the 36 B/voxel store stream costs 0.108 ms with plain stores and 0.094 with nt at 256^3.
+    store_texel<true>(a.tex0 + flat, v0);
     if (p.dist) {
         // The volume's contract: the textures were initialised / filled by this library, so tex1.a holds AIR_DIST
         // everywhere (update() never writes it, scene/sdf/mod.rs:205-208) and need not be read back.
@@ -239,29 +236,34 @@ __device__ __forceinline__ void pass_voxel(const FillArgs& a, const PassArgs& p,
         // stores make the memory side read-modify-write the line; ~10 % slower on the step-1 pass)
         v1.w = reinterpret_cast<const float*>(a.tex1 + flat)[3];
     }
-    a.tex1[flat] = v1;
+    store_texel<true>(a.tex1 + flat, v1);
 }
 
-// One LoadingManager pass: one thread per visited voxel (x, y, z multiples of `step`; z is GLOBAL), workgroups in
-// memory order like the dense kernel.  Reads tex0.r (or the distance volume's entry) for update_required.
+// One LoadingManager pass, any step: one thread per visited voxel (x, y, z multiples of `step`; z is GLOBAL), workgroups in
+// memory order like the dense kernel.  Reads tex0.r (or the distance volume's entry) for update_required; with
+// p.all_required (the launcher knows that it holds for every visited voxel) nothing is read at all.
+template <typename Cfg>
 __global__ __launch_bounds__(kBlock) void fill_pass_kernel(FillArgs a, PassArgs p) {
-    const uint64_t n = (uint64_t)p.nx * p.ny * p.nz;
-    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    uint32_t ix, r;
-    if (n <= 0xffffffffull) {  // wave-uniform; 32-bit divisions cost a handful of instructions, 64-bit ones ~100
-        const uint32_t i32 = (uint32_t)i;
-        r = i32 / p.nx;
-        ix = i32 - r * p.nx;
-    } else {
-        r = (uint32_t)(i / p.nx);
-        ix = (uint32_t)(i - (uint64_t)r * p.nx);
-    }
-    const uint32_t iz = r / p.ny, iy = r - iz * p.ny;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // < 2^32 visited voxels: checked by the launcher
+    if (i >= p.n_visited) return;
+    const uint32_t r = div_u32(i, p.div_nx), ix = i - r * p.nx;
+    const uint32_t iz = div_u32(r, p.div_ny), iy = r - iz * p.ny;
     const uint32_t x = ix * p.step, y = iy * p.step, z = p.z_first + iz * p.step;  // global z
     const uint64_t flat = ((uint64_t)(z - a.z_begin) * a.H + y) * a.W + x;
-    const bool is_air = (p.dist ? p.dist[flat] : a.tex0[flat].x) == a.air_dist;
-    pass_voxel(a, p, x, y, z, flat, is_air);
+    if (!p.all_required) {
+        const bool is_air = (p.dist ? p.dist[flat] : a.tex0[flat].x) == a.air_dist;
+        // most visited voxels of a loaded grid need nothing: leave before paying three correctly rounded divides
+        if (!is_air && (!p.has_box || !maybe_in_box(a, p, x, y, z))) return;
+        const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
+        const float py = voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]);
+        const float pz = voxel_coord(z, a.dm1[2], a.bb_size[2], a.bb_min[2]);
+        if (!is_air && !(px >= p.box[0] && px <= p.box[3] && py >= p.box[1] && py <= p.box[4] && pz >= p.box[2] && pz <= p.box[5]))
+            return;
+        pass_store<Cfg>(a, p, px, py, pz, flat);
+        return;
+    }
+    pass_store<Cfg>(a, p, voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]), voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]),
+                    voxel_coord(z, a.dm1[2], a.bb_size[2], a.bb_min[2]), flat);
 }
 
 // The step-1 pass over a grid with its distance volume.  A pass over a loaded grid is bound by per-wave latency (one
@@ -269,9 +271,13 @@ __global__ __launch_bounds__(kBlock) void fill_pass_kernel(FillArgs a, PassArgs 
 // the volume and a wave with nothing to do leaves after that single load (a quarter of the waves, a quarter of the
 // time).  Where there is work, the wave's 256 voxels are processed in four rounds of 64 CONSECUTIVE voxels (lane l
 // takes voxel 64*j + l of the span, its flag fetched from the lane that loaded it), so texel stores stay coalesced.
-// Needs W % 4 == 0, a 16-byte aligned volume and fewer than 2^32 visited voxels.
+// A pass that updates most of what it visits (a fresh grid) is bound by VALU issue before it is bound by bytes, so the
+// per-voxel path is the dense kernel's: index arithmetic by shifts / multiply-high (no integer division), the row's
+// (y, z) coordinates -- two correctly rounded divides -- recomputed only when a round enters a new row, compile-time
+// packed materials for the default configuration.  Needs W % 4 == 0, a 16-byte aligned volume, < 2^32 voxels.
+template <typename Cfg>
 __global__ __launch_bounds__(kBlock) void fill_pass_quad_kernel(FillArgs a, PassArgs p) {
-    const uint32_t n_vox = a.W * p.ny * p.nz;  // visited voxels of the slab (step 1: all of them)
+    const uint32_t n_vox = p.n_visited;  // visited voxels of the slab (step 1: all of them)
     const uint32_t q = blockIdx.x * kBlock + threadIdx.x;  // this lane's quad of voxels [4q, 4q + 4)
     const uint32_t lane = threadIdx.x & 63;
     uint32_t air_bits = 0;
@@ -282,15 +288,63 @@ __global__ __launch_bounds__(kBlock) void fill_pass_quad_kernel(FillArgs a, Pass
     }
     if (!p.has_box && __ballot(air_bits != 0) == 0ull) return;  // wave-uniform: nothing to update in these 256 voxels
     const uint32_t span0 = (q - lane) * 4;  // first voxel of the wave's span (flat index within the slab)
+    uint32_t row_cached = 0xffffffffu;
+    float py = 0.0f, pz = 0.0f;
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) {
         const uint32_t bits = (uint32_t)__shfl((int)air_bits, (int)(j * 16 + (lane >> 2)));
         const uint32_t v = span0 + j * 64 + lane;
-        if (v >= n_vox) continue;
-        const uint32_t r = v / a.W, x = v - r * a.W;
-        const uint32_t zl = r / a.H, y = r - zl * a.H;
-        pass_voxel(a, p, x, y, p.z_first + zl, v, ((bits >> (lane & 3)) & 1u) != 0);
+        const bool is_air = ((bits >> (lane & 3)) & 1u) != 0;
+        const uint32_t r = div_u32(v, p.div_nx), x = v - r * a.W;   // step 1: nx == W
+        const uint32_t zl = div_u32(r, p.div_ny), y = r - zl * a.H;  //         ny == H
+        const uint32_t z = p.z_first + zl;
+        bool work = v < n_vox && (is_air || (p.has_box && maybe_in_box(a, p, x, y, z)));
+        if (__ballot(work) == 0ull) continue;  // wave-uniform
+        if (__ballot(work && r != row_cached) != 0ull) {  // wave-uniform: some lane entered a new row
+            row_cached = r;
+            py = voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]);
+            pz = voxel_coord(z, a.dm1[2], a.bb_size[2], a.bb_min[2]);
+        }
+        if (!work) continue;
+        const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
+        if (!is_air && !(px >= p.box[0] && px <= p.box[3] && py >= p.box[1] && py <= p.box[4] && pz >= p.box[2] && pz <= p.box[5]))
+            continue;
+        pass_store<Cfg>(a, p, px, py, pz, v);
     }
+}
+
+// A pass with step >= 2 in which update_required holds for every visited voxel (nothing to decide, see PassArgs::all_required),
+// written as WHOLE ROWS: one thread per voxel of a visited row (rows: y and global z multiples of step), memory order.  Lanes
+// on the visited lattice store their sample; the lanes between them re-store what the voxel holds -- over a FRESH grid
+// (every voxel is new_voxels' [AIR_DIST; 4], scene/sdf/mod.rs:76-77) that is a constant and nothing is read at all,
+// otherwise the texel is loaded and written back.  Either way the memory side sees whole 128-byte lines instead of one
+// 16-byte texel in every `step`: a strided pass of single texels makes it read-modify-write every line it touches, one
+// texel at a time (step 2 over a 256^3 grid: 0.087 ms for 75 MB of samples -- as long as the dense fill of the whole grid).
+template <typename Cfg, bool FRESH>
+__global__ __launch_bounds__(kBlock) void fill_pass_rows_kernel(FillArgs a, PassArgs p) {
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;  // < 2^32: checked by the launcher
+    if (t >= a.W * p.ny * p.nz) return;
+    const uint32_t r = div_u32(t, p.div_w), x = t - r * a.W;
+    const uint32_t iz = div_u32(r, p.div_ny), iy = r - iz * p.ny;
+    const uint32_t y = iy * p.step, z = p.z_first + iz * p.step;
+    const uint64_t flat = ((uint64_t)(z - a.z_begin) * a.H + y) * a.W + x;
+    float4 v0 = make_float4(a.air_dist, a.air_dist, a.air_dist, a.air_dist), v1 = v0;
+    const bool visited = (x & (p.step - 1)) == 0;
+    if (visited) {
+        const LdsLut lut{c_srgb_lut};
+        fill_voxel<Cfg>(a.prm, a.sdf_id, voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]),
+                        voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]), voxel_coord(z, a.dm1[2], a.bb_size[2], a.bb_min[2]),
+                        lut, a.air_dist, v0, v1);
+        // tex1.a is not update()'s to touch (scene/sdf/mod.rs:205-208): AIR_DIST in a fresh grid and under the volume's
+        // contract, otherwise whatever the voxel holds
+        if (!FRESH && !p.dist) v1.w = reinterpret_cast<const float*>(a.tex1 + flat)[3];
+    } else if (!FRESH) {
+        v0 = a.tex0[flat];
+        v1 = a.tex1[flat];
+    }
+    store_texel<true>(a.tex0 + flat, v0);
+    store_texel<true>(a.tex1 + flat, v1);
+    if (p.dist) p.dist[flat] = v0.x;  // every lane: the volume equals tex0.r (its contract), so whole lines here too
 }
 
 __global__ __launch_bounds__(kBlock) void grid_init_kernel(float4* tex0, float4* tex1, uint64_t n, float air) {
@@ -459,7 +513,16 @@ hipError_t launch_fill_dense(const FillArgs& a, const FillLaunch& cfg, hipStream
     return launch_dense_tx<256>(a, cfg, stream);
 }
 
-hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& pass, hipStream_t stream) {
+static DivU32 make_div(uint32_t d) {
+    DivU32 v;
+    v.pow2 = d != 0 && (d & (d - 1)) == 0;
+    v.shift = 0;
+    while (v.pow2 && (1u << v.shift) < d) ++v.shift;
+    v.magic = d > 1 ? (~0ull / d) + 1ull : 0ull;  // d == 1 is a power of two: the multiply is never taken
+    return v;
+}
+
+hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& pass, const FillLaunch& dense_cfg, hipStream_t stream) {
     PassArgs p = pass;
     for (int i = 0; i < 3; ++i) {
         // |idx * (size / dm1) + min  -  ((idx / dm1) * size + min)| is a few ulp of the largest intermediate
@@ -468,16 +531,42 @@ hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& pass, hipStream_t
         p.approx_margin[i] = 64.0f * 1.1920929e-7f * (fabsf(a.bb_size[i]) + fabsf(a.bb_min[i]));
         if (!(a.dm1[i] > 0.0f) || !(p.approx_margin[i] >= 0.0f)) p.approx_margin[i] = INFINITY;  // never filter
     }
-    uint64_t n = (uint64_t)p.nx * p.ny * p.nz;
+    const uint64_t n = (uint64_t)p.nx * p.ny * p.nz;
     if (n == 0) return hipSuccess;
-    const bool quad = p.step == 1 && p.dist && a.W % 4 == 0 && ((uintptr_t)p.dist & 15) == 0 && n < (1ull << 32);
-    if (quad) n = (n + 3) / 4;
-    const uint64_t blocks = (n + kBlock - 1) / kBlock;
-    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    if (quad)
-        hipLaunchKernelGGL(fill_pass_quad_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, stream, a, p);
-    else
-        hipLaunchKernelGGL(fill_pass_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, stream, a, p);
+    const bool dflt = is_default_config(a);
+    if (p.all_required && p.step == 1) {
+        // every voxel of the slab is rewritten and nothing needs reading: that IS the dense fill (+ its distance volume)
+        FillArgs d = a;
+        d.dist = p.dist;
+        return launch_fill_dense(d, dense_cfg, stream);
+    }
+    if (n >= (1ull << 32) || (uint64_t)a.W * p.ny * p.nz >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit lattice indices
+    p.n_visited = (uint32_t)n;
+    p.div_nx = make_div(p.nx);
+    p.div_ny = make_div(p.ny);
+    p.div_w = make_div(a.W);
+    if (p.all_required && p.step <= 8) {
+        // whole visited rows: one of every `step` texels computed, the rest re-stored (a constant over a fresh grid)
+        const uint32_t blocks = (uint32_t)(((uint64_t)a.W * p.ny * p.nz + kBlock - 1) / kBlock);
+        if (p.fresh) {
+            if (dflt) hipLaunchKernelGGL((fill_pass_rows_kernel<DefaultCfg, true>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
+            else hipLaunchKernelGGL((fill_pass_rows_kernel<RuntimeCfg, true>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
+        } else {
+            if (dflt) hipLaunchKernelGGL((fill_pass_rows_kernel<DefaultCfg, false>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
+            else hipLaunchKernelGGL((fill_pass_rows_kernel<RuntimeCfg, false>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
+        }
+        return hipGetLastError();
+    }
+    const bool quad = p.step == 1 && p.dist && a.W % 4 == 0 && ((uintptr_t)p.dist & 15) == 0;
+    const uint64_t threads = quad ? (n + 3) / 4 : n;
+    const uint32_t blocks = (uint32_t)((threads + kBlock - 1) / kBlock);
+    if (quad) {
+        if (dflt) hipLaunchKernelGGL(fill_pass_quad_kernel<DefaultCfg>, dim3(blocks), dim3(kBlock), 0, stream, a, p);
+        else hipLaunchKernelGGL(fill_pass_quad_kernel<RuntimeCfg>, dim3(blocks), dim3(kBlock), 0, stream, a, p);
+    } else {
+        if (dflt) hipLaunchKernelGGL(fill_pass_kernel<DefaultCfg>, dim3(blocks), dim3(kBlock), 0, stream, a, p);
+        else hipLaunchKernelGGL(fill_pass_kernel<RuntimeCfg>, dim3(blocks), dim3(kBlock), 0, stream, a, p);
+    }
     return hipGetLastError();
 }
 

@@ -672,12 +672,13 @@ int sdfv_fill_grid(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_g
     return sdfv_fill_grid_commit(params, sdf_id, grid, tex0, tex1, nullptr, stream);
 }
 
-int sdfv_fill_grid_pass_dist(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, uint32_t step,
-                             const float* changed_box, float* tex0, float* tex1, float* dist, void* stream) {
+int sdfv_fill_grid_pass_ex(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, uint32_t step,
+                           const float* changed_box, float* tex0, float* tex1, float* dist, uint32_t flags, void* stream) {
     if (int rc = check_params(params, sdf_id)) return rc;
     if (int rc = check_grid(grid)) return rc;
     if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
     if (step == 0 || (step & (step - 1))) return fail(SDFV_ERR_INVALID_ARGUMENT, "step %u is not a power of two", step);
+    if (flags & ~(SDFV_PASS_FRESH_GRID | SDFV_PASS_SAME_LOAD)) return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown pass flags 0x%x", flags);
     if (int rc = check_texel_alignment(tex0, tex1)) return rc;
     if ((uintptr_t)dist & 3) return fail(SDFV_ERR_INVALID_ARGUMENT, "dist must be 4-byte aligned");
     if (int rc = need_device()) return rc;
@@ -692,8 +693,33 @@ int sdfv_fill_grid_pass_dist(const sdfv_demo_params* params, uint32_t sdf_id, co
     p.has_box = changed_box != nullptr;
     p.dist = dist;
     if (changed_box) memcpy(p.box, changed_box, sizeof(p.box));
-    SDFV_HIP(sdfv::launch_fill_pass(a, p, (hipStream_t)stream));
+    // Does update_required (scene/sdf/mod.rs:184-190) hold for EVERY visited voxel?  Then the pass reads nothing.
+    //  * the caller says so (flags): a fresh grid is all AIR_DIST; within one load a stored voxel already holds what this pass
+    //    would write;
+    //  * the changed box contains every voxel of the slab -- decided on the voxels' own first and last coordinates per axis
+    //    (the kernels' arithmetic: idx / (dim - 1) * size + min, three roundings; monotonic in idx, so the ends decide; a NaN
+    //    coordinate fails the comparison and keeps the general path).  The demo reports its whole bounding box on every
+    //    parameter edit (demo/mod.rs:135-144), so its edits take this path.
+    bool covers = changed_box != nullptr;
+    for (int i = 0; i < 3 && covers; ++i) {
+        const uint32_t first_idx = i == 2 ? grid->z_begin : 0u, last_idx = i == 2 ? grid->z_end - 1 : grid->dims[i] - 1;
+        float first = (float)first_idx / a.dm1[i];
+        first = first * a.bb_size[i];
+        first = first + a.bb_min[i];
+        float last = (float)last_idx / a.dm1[i];
+        last = last * a.bb_size[i];
+        last = last + a.bb_min[i];
+        covers = first >= changed_box[i] && first <= changed_box[3 + i] && last >= changed_box[i] && last <= changed_box[3 + i];
+    }
+    p.fresh = (flags & SDFV_PASS_FRESH_GRID) ? 1u : 0u;
+    p.all_required = (flags != 0 || covers) ? 1u : 0u;
+    SDFV_HIP(sdfv::launch_fill_pass(a, p, fill_launch_config(dist != nullptr), (hipStream_t)stream));
     return SDFV_OK;
+}
+
+int sdfv_fill_grid_pass_dist(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, uint32_t step,
+                             const float* changed_box, float* tex0, float* tex1, float* dist, void* stream) {
+    return sdfv_fill_grid_pass_ex(params, sdf_id, grid, step, changed_box, tex0, tex1, dist, 0u, stream);
 }
 
 int sdfv_fill_grid_pass(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, uint32_t step,

@@ -138,7 +138,16 @@ sdfv_grid SDFViewer::grid() const {
 size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_time) {
     // Check whether the SDF self-reports updates.  (:130-141)
     bool just_changed_box = false;
+    // the passes of ONE load share one SDF and one set of parameters: a different device SDF (or parameter block) than the
+    // one the load began with, or any reported change, ends it
+    if (const auto dev_now = sdf.device_sdf()) {
+        if (!load_sdf_ || memcmp(&*load_sdf_, &*dev_now, sizeof(*dev_now)) != 0) {
+            if (!fresh_) same_load_ = false;
+            load_sdf_ = *dev_now;
+        }
+    }
     if (auto new_box = sdf.changed()) {
+        same_load_ = false;
         changed_box = changed_box ? merge_bounding_boxes(*changed_box, *new_box) : *new_box;
         changed_box_while_loading = loading_mgr.len() > 0 || changed_box_while_loading;
         just_changed_box = true;
@@ -213,8 +222,13 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
             box[3] = (*changed_box)[1].x; box[4] = (*changed_box)[1].y; box[5] = (*changed_box)[1].z;
             box_ptr = box;
         }
-        if (sdfv_fill_grid_pass_dist(&dev->params, dev->sdf_id, &g, (uint32_t)step, box_ptr, tex0_device(),
-                                     tex1_device(), dist_synced_ ? material.dist->f32() : nullptr, stream) != 0) {
+        // What this LoadingManager knows about the grid (sdfv_fill_grid_pass_ex): the first pass of a load over the grid
+        // new_voxels initialised sees AIR_DIST everywhere; the later passes of that load revisit only what ITS earlier
+        // passes wrote (same SDF, same parameters -- a changed box or another SDF ends the load, see set below).
+        uint32_t flags = 0;
+        if (same_load_ && !changed_box) flags = (fresh_ ? SDFV_PASS_FRESH_GRID : 0u) | SDFV_PASS_SAME_LOAD;
+        if (sdfv_fill_grid_pass_ex(&dev->params, dev->sdf_id, &g, (uint32_t)step, box_ptr, tex0_device(), tex1_device(),
+                                   dist_synced_ ? material.dist->f32() : nullptr, flags, stream) != 0) {
             error_ = sdfv_last_error();
             break;
         }

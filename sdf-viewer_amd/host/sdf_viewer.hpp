@@ -109,6 +109,8 @@ class SDFViewer {
     SDFViewer(std::array<size_t, 3> voxels, const BoundingBox& bb, size_t passes);
     std::string error_;
     bool fresh_ = true;  // both textures still hold new_voxels' AIR_DIST everywhere
+    bool same_load_ = true;  // every pass so far belongs to ONE load: the SDF and parameters of load_sdf_, no change reported
+    std::optional<DeviceSDF> load_sdf_;  // what that load samples
     bool dist_synced_ = false;  // material.dist exists and mirrors tex0.r (kept so by every fill)
     std::shared_ptr<DeviceBuffer> block_;  // owns tex0 and tex1 when they share one tuned allocation
 };

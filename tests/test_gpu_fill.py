@@ -346,3 +346,122 @@ def test_tuned_texture_placement(pkg, oracle):
     o0, o1 = C.c_size_t(), C.c_size_t()
     assert pkg.lib.sdfv_tune_texture_placement(C.byref(g), C.c_void_p(small.data_ptr()), 4096, C.byref(o0), C.byref(o1), None) == -1
     assert b"smaller than" in pkg.lib.sdfv_last_error()
+
+
+@pytest.mark.parametrize("dims,z_range", [((64, 32, 16), (0, 16)), ((37, 20, 29), (0, 29)), ((40, 12, 29), (7, 22)),
+                                          ((8, 3, 5), (1, 4)), ((256, 8, 6), (0, 6)), ((130, 5, 9), (2, 9))])
+@pytest.mark.parametrize("use_dist", [False, True])
+def test_fresh_load_with_the_callers_knowledge_reads_nothing(pkg, oracle, dims, z_range, use_dist):
+    """sdfv_fill_grid_pass_ex: the first pass of a load flagged SDFV_PASS_FRESH_GRID (writes the visited rows whole: the
+    samples and, between them, the AIR texels the fresh grid holds), the later ones SDFV_PASS_SAME_LOAD (store-only; step 1
+    = the dense fill).  Every intermediate state -- both textures and the volume -- equals the unflagged passes' and the
+    oracle's LoadingManager loop stopped at the pass boundary; non-default parameters too (RuntimeCfg kernels)."""
+    K = pkg._capi
+    bb = ((-1.0, -0.75, -1.0), (1.0, 1.0, 0.5))
+    g = pkg.make_grid(dims, *bb, *z_range)
+    for prm in (pkg.default_params(), pkg.default_params(cube_material=1, sphere_radius=0.8, disable_sphere=0)):
+        for steps in ((4, 2, 1), (2, 1), (8, 1), (1,)):
+            a0, a1 = pkg.alloc_textures(g)
+            b0, b1 = pkg.alloc_textures(g)
+            pkg.grid_init(g, a0, a1)
+            pkg.grid_init(g, b0, b1)
+            da = pkg.commit_distance(g, a0) if use_dist else None
+            db = pkg.commit_distance(g, b0) if use_dist else None
+            for k, step in enumerate(steps):
+                pkg.fill_grid_pass(prm, g, step, a0, a1, dist=da)
+                pkg.fill_grid_pass(prm, g, step, b0, b1, dist=db,
+                                   flags=(K.PASS_FRESH_GRID | K.PASS_SAME_LOAD) if k == 0 else K.PASS_SAME_LOAD)
+                torch.cuda.synchronize()
+                assert torch.equal(a0.view(torch.int32), b0.view(torch.int32)), (steps, step)
+                assert torch.equal(a1.view(torch.int32), b1.view(torch.int32)), (steps, step)
+                if use_dist:
+                    assert torch.equal(db, b0[..., 0]) and torch.equal(da, db), (steps, step)
+            r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, *bb, *z_range)
+            assert_bits_equal(b0, r0)
+            assert_bits_equal(b1, r1)
+
+
+def test_fresh_flagged_load_against_the_oracles_loading_manager(pkg, oracle):
+    """The flagged passes against the ORACLE's loop (not just against the unflagged kernels) at every pass boundary."""
+    K = pkg._capi
+    prm = pkg.default_params()
+    oprm = oracle.params_from(prm)
+    dims = (24, 18, 13)
+    g = pkg.make_grid(dims)
+    t0, t1 = pkg.alloc_textures(g)
+    pkg.grid_init(g, t0, t1)
+    dist = pkg.commit_distance(g, t0)
+    r0, r1 = oracle.grid_init(dims)
+    lm = oracle.lm_new(dims, 3)
+    for k, step in enumerate((4, 2, 1)):
+        pkg.fill_grid_pass(prm, g, step, t0, t1, dist=dist, flags=(K.PASS_FRESH_GRID if k == 0 else 0) | K.PASS_SAME_LOAD)
+        n = -(-dims[0] // step) * -(-dims[1] // step) * -(-dims[2] // step)
+        assert oracle.viewer_update(oprm, dims, lm, r0, r1, max_iterations=n) == n
+        torch.cuda.synchronize()
+        assert_bits_equal(t0, r0)
+        assert_bits_equal(t1, r1)
+        assert torch.equal(dist, t0[..., 0])
+
+
+@pytest.mark.parametrize("use_dist", [False, True])
+def test_changed_box_that_contains_every_voxel_takes_the_store_only_path(pkg, oracle, use_dist):
+    """A parameter edit whose changed box is the whole bounding box (what the demo reports, demo/mod.rs:135-144): the library
+    sees that the box contains every voxel coordinate and reads nothing.  Every pass boundary against the oracle's loop with
+    the same box; then a box that misses the LAST voxel of each axis by one ulp (general path), same check."""
+    dims = (32, 20, 24)
+    bb = ((-1.0, -0.9, -1.3), (0.7, 1.0, 0.4))
+    g = pkg.make_grid(dims, *bb)
+    prm, edited = pkg.default_params(), pkg.default_params(cube_half_side=0.5, sphere_radius=0.6)
+    whole = bb[0] + bb[1]
+    short = bb[0] + tuple(float(np.nextafter(np.float32(v), np.float32(-10.0))) for v in bb[1])
+    for box in (whole, short):
+        t0, t1 = pkg.alloc_textures(g)
+        dist = torch.empty(tuple(t0.shape[:-1]), dtype=torch.float32, device="cuda") if use_dist else None
+        pkg.fill_grid(prm, g, t0, t1, dist=dist)
+        r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, *bb)
+        lm = oracle.lm_new(dims, 3)
+        for step in (4, 2, 1):
+            pkg.fill_grid_pass(edited, g, step, t0, t1, changed_box=box, dist=dist)
+            n = -(-dims[0] // step) * -(-dims[1] // step) * -(-dims[2] // step)
+            oracle.viewer_update(oracle.params_from(edited), dims, lm, r0, r1, changed_box=box, max_iterations=n,
+                                 bb_min=bb[0], bb_max=bb[1])
+            torch.cuda.synchronize()
+            assert_bits_equal(t0, r0)
+            assert_bits_equal(t1, r1)
+            if use_dist:
+                assert torch.equal(dist, t0[..., 0])
+    # the short box really left the last voxels alone: they still hold the first parameters' texels
+    first = oracle.fill_dense(oracle.params_from(prm), dims, *bb)[0]
+    assert (t0.cpu().numpy()[-1, -1, -1].view(np.uint32) == first[-1, -1, -1].view(np.uint32)).all()
+
+
+def test_full_size_progressive_load_states(pkg, oracle):
+    """256^3: the reference's default 2-pass load through the flagged passes (what SDFViewer::update enqueues), the
+    intermediate state against the oracle's loop, the final one against the dense fill."""
+    K = pkg._capi
+    side = 256
+    dims = (side,) * 3
+    prm = pkg.default_params()
+    g = pkg.make_grid(dims)
+    t0, t1 = pkg.alloc_textures(g)
+    pkg.grid_init(g, t0, t1)
+    dist = pkg.commit_distance(g, t0)
+    pkg.fill_grid_pass(prm, g, 2, t0, t1, dist=dist, flags=K.PASS_FRESH_GRID | K.PASS_SAME_LOAD)
+    torch.cuda.synchronize()
+    r0, r1 = oracle.grid_init(dims)
+    lm = oracle.lm_new(dims, 2)
+    oracle.viewer_update(oracle.params_from(prm), dims, lm, r0, r1, max_iterations=(side // 2) ** 3)
+    assert_bits_equal(t0, r0)
+    assert_bits_equal(t1, r1)
+    assert torch.equal(dist, t0[..., 0])
+    pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=dist, flags=K.PASS_SAME_LOAD)
+    torch.cuda.synchronize()
+    d0, d1 = gpu_fill(pkg, prm, dims)
+    assert torch.equal(t0, d0) and torch.equal(t1, d1) and torch.equal(dist, d0[..., 0])
+    # and the unflagged passes (update_required read from the volume) from the same start
+    pkg.grid_init(g, t0, t1)
+    pkg.commit_distance(g, t0, dist=dist)
+    for step in (2, 1):
+        pkg.fill_grid_pass(prm, g, step, t0, t1, dist=dist)
+    torch.cuda.synchronize()
+    assert torch.equal(t0, d0) and torch.equal(t1, d1) and torch.equal(dist, d0[..., 0])
