@@ -982,7 +982,11 @@ def run(redirect):
                     scam = pkg.camera_look_at(eye=(1.5, 2.0, 3.5), aspect=sw / sh)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    got = par.raymarch_sharded(pkg, grp, grid, slab, scam, sw, sh, rank, world)
+                    # under RCCL the whole march runs inside the library (sdfv_slab_march: `world` rounds + the ray exchange
+                    # enqueued in one call, no host round trip); over gloo (tests) torch.distributed carries the rays
+                    lib_comm = getattr(filler, "comm", None) if transport == "rccl" else None
+                    STAGE("sharded march self-check (" + ("sdfv_slab_march over the library communicator" if lib_comm else "torch.distributed rounds") + ")")
+                    got = par.raymarch_sharded(pkg, grp, grid, slab, scam, sw, sh, rank, world, comm=lib_comm)
                     torch.cuda.synchronize()
                     sharded_march_ms = (time.perf_counter() - t0) * 1e3
                     want = pkg.raymarch(grp, chk0, chk1, scam, sw, sh)[0]
@@ -991,6 +995,8 @@ def run(redirect):
                     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                     sharded_march = {"verified": bool(flag.item() == 1.0), "image": [sw, sh], "rounds": world,
                                      "ms": round(sharded_march_ms, 3),
+                                     "transport": "sdfv_slab_march (library RCCL communicator, no host round trip per round)" if lib_comm
+                                                  else "torch.distributed (counter read-back + count exchange per round)",
                                      "note": "sdfv_raymarch_slab over the sharded grid vs sdfv_raymarch over the whole "
                                              "grid, bit for bit; not part of the timed regions"}
                 except Exception as e:  # noqa: BLE001

@@ -375,6 +375,22 @@ int sdfv_raymarch_slab(const sdfv_render_params *rp, const sdfv_grid *slab, uint
                        sdfv_march_aux *aux, sdfv_ray_state *out_down, sdfv_ray_state *out_up, uint32_t capacity,
                        uint32_t *counters, void *stream);
 
+/* The same round with NOTHING for the host to read between rounds: ray lists are fixed-capacity buffers with their count
+ * in band -- SDFV_RAY_BUFFER_HEADER_BYTES of header (word 0: the count, written by the round that fills the buffer) followed
+ * by `capacity` sdfv_ray_state entries; sdfv_ray_buffer_bytes(capacity) bytes, DEVICE, 4-byte aligned.  in_lo / in_hi: the
+ * buffers the lower / upper neighbour filled as its out_up / out_down (either may be NULL: no such neighbour); first_round
+ * != 0: every pixel's primary ray instead (in_lo = in_hi = NULL).  out_down / out_up are cleared by the call itself.
+ * `overflow` (DEVICE word, may be NULL) is set to 1 when a ray did not fit into `capacity` (width * height always suffices).
+ * A whole march is `world` such rounds per rank with the buffers moved between neighbours by any stream-ordered copy
+ * (sdfv_slab_march below does it over RCCL); capture-safe, no synchronisation. */
+#define SDFV_RAY_BUFFER_HEADER_BYTES 16u
+size_t sdfv_ray_buffer_bytes(uint32_t capacity);
+int sdfv_raymarch_slab_round(const sdfv_render_params *rp, const sdfv_grid *slab, uint32_t ghost_lo, uint32_t ghost_hi,
+                             const float *tex0, const float *tex1, const sdfv_camera *camera, uint32_t width,
+                             uint32_t height, const void *in_lo, const void *in_hi, int first_round, float *rgba,
+                             sdfv_march_aux *aux, void *out_down, void *out_up, uint32_t capacity, uint32_t *overflow,
+                             void *stream);
+
 /* ---- host-buffer conveniences (allocate, run, copy back, synchronise; PCIe-inclusive) ---- */
 int sdfv_fill_grid_host(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid,
                         float *tex0_host, float *tex1_host);
@@ -443,6 +459,25 @@ int sdfv_slab_fill_step(sdfv_slab_comm *comm, const sdfv_demo_params *params, ui
  * and, once the halo has arrived, tex0.r of the ghost slices. */
 int sdfv_slab_fill_step_commit(sdfv_slab_comm *comm, const sdfv_demo_params *params, uint32_t sdf_id,
                                const sdfv_grid *slab, float *tex0, float *tex1, float *dist, void *stream);
+
+/* The whole sharded march of one frame over the communicator, enqueued in ONE call: `world` rounds of
+ * sdfv_raymarch_slab_round back to back on `stream`, between them one RCCL group per rank that sends its two ray buffers
+ * (whole, fixed size: the count is in their header) to the z-neighbours and receives theirs.  No counter read-back, no host
+ * round trip, nothing synchronises.  tex0 / tex1: the slab allocation as sdfv_slab_fill_step leaves it (ghosts filled; the
+ * communicator must not be periodic).  scratch: DEVICE, 16-byte aligned, sdfv_slab_march_scratch_bytes(capacity) bytes (four
+ * ray buffers); capacity: rays a list can hold -- width * height always suffices, a message is 16 + 24 * capacity bytes per
+ * neighbour and round whatever it carries, so a caller that knows its views can bound it.  status: DEVICE, 2 words --
+ * [0] = 1 if any list overflowed (the image is then incomplete: repeat with a larger capacity), [1] = rays left over after
+ * the last round (0 otherwise).  SDFV_MARCH_MERGE: afterwards the ranks' images (each pixel written by the one rank its ray
+ * ended on, zero bits elsewhere) are summed as integers in place (ncclAllReduce), so every rank holds the whole frame --
+ * bit-identical to sdfv_raymarch over the whole grid (aux.normal as described for sdfv_raymarch_slab; aux.depth of pixels no
+ * rank reports stays 0 in the merged record, as with sdfv_raymarch_slab). */
+#define SDFV_MARCH_MERGE 1u
+size_t sdfv_slab_march_scratch_bytes(uint32_t capacity);
+int sdfv_slab_march(sdfv_slab_comm *comm, const sdfv_render_params *rp, const sdfv_grid *slab, const float *tex0,
+                    const float *tex1, const sdfv_camera *camera, uint32_t width, uint32_t height, float *rgba,
+                    sdfv_march_aux *aux, void *scratch, size_t scratch_bytes, uint32_t capacity, uint32_t flags,
+                    uint32_t *status, void *stream);
 
 /* Makes `stream` wait for the most recent exchange the communicator has enqueued (a no-op when there is none).  Needed
  * only after steps taken with SDFV_STEP_DEFER_JOIN: before anything put on `stream` reads the ghost slices of the

@@ -306,6 +306,23 @@ def raymarch_slab(rp, grid, ghost_lo, ghost_hi, tex0, tex1, camera, width, heigh
                                  int(out_down.shape[0]), C.c_void_p(counters.data_ptr()), _stream_ptr(stream)))
 
 
+def ray_buffer(capacity, device="cuda"):
+    """A fixed-capacity ray list with its count in band (sdfv_ray_buffer_bytes): int32 words, header first."""
+    words = lib.sdfv_ray_buffer_bytes(int(capacity)) // 4
+    return torch.zeros(words, dtype=torch.int32, device=device)
+
+
+def raymarch_slab_round(rp, grid, ghost_lo, ghost_hi, tex0, tex1, camera, width, height, rgba, out_down, out_up, capacity,
+                        in_lo=None, in_hi=None, first_round=False, aux=None, overflow=None, stream=None):
+    """One round of the sharded march with device-side counts (sdfv_raymarch_slab_round): nothing to read back.
+    in_lo / in_hi / out_down / out_up: ray_buffer() tensors."""
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+    check(lib.sdfv_raymarch_slab_round(C.byref(rp), C.byref(grid), int(ghost_lo), int(ghost_hi), _dev_ptr(tex0, "tex0"),
+                                       _dev_ptr(tex1, "tex1"), C.byref(camera), width, height, p(in_lo), p(in_hi),
+                                       1 if first_round else 0, _dev_ptr(rgba, "rgba"), p(aux), p(out_down), p(out_up),
+                                       int(capacity), p(overflow), _stream_ptr(stream)))
+
+
 def commit_distance(grid, tex0, dist=None, stream=None):
     """Device-side commit: compact copy of tex0.r for the raymarch (sdfv_commit_distance)."""
     if dist is None:

@@ -130,6 +130,15 @@ PROTOTYPES = {
     "sdfv_raymarch_slab": (C.c_int, [C.POINTER(RenderParams), C.POINTER(Grid), C.c_uint32, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "sdfv_ray_buffer_bytes": (C.c_size_t, [C.c_uint32]),
+    "sdfv_raymarch_slab_round": (C.c_int, [C.POINTER(RenderParams), C.POINTER(Grid), C.c_uint32, C.c_uint32, C.c_void_p,
+                                           C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                           C.c_void_p]),
+    "sdfv_slab_march_scratch_bytes": (C.c_size_t, [C.c_uint32]),
+    "sdfv_slab_march": (C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.POINTER(Grid), C.c_void_p, C.c_void_p,
+                                  C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                  C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "sdfv_slab_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "sdfv_slab_comm_create": (C.c_int, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
     "sdfv_slab_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -157,6 +166,8 @@ PASS_FRESH_GRID, PASS_SAME_LOAD = 1, 2
 FILL_FORM = {"auto": 0, "rows": 1, "flat": 2}
 PLACEMENT_SLACK = 64 << 10
 COMM_ID_BYTES = 128
+RAY_BUFFER_HEADER_BYTES = 16
+MARCH_MERGE = 1
 COMM_PERIODIC = 1
 COMM_HALO2 = 2
 

@@ -59,10 +59,17 @@ struct SlabMarchArgs {
     uint32_t z_lo, z_count;        // resident slices [z_lo, z_lo + z_count) (owned + ghosts); tex0/tex1 address z_lo
     uint32_t own_begin, own_end;   // owned slices: this rank marches a ray while clamp(floor(w), 0, D-1) is in here
     const sdfv_ray_state* in;      // continuation round: rays handed over by the neighbours; nullptr = first round
-    uint32_t n_in;
+    uint32_t n_in;                 // ... their number, known to the host (sdfv_raymarch_slab)
+    // continuation round whose counts live on the DEVICE (sdfv_raymarch_slab_round: no read-back between rounds): up to two
+    // ray buffers {count, ...header..., states[]}; thread t takes ray t of the first while t < its count, then of the second
+    const uint32_t* in_count[2];   // nullptr = not used (with in == nullptr and both null: first round)
+    const sdfv_ray_state* in_rays[2];
+    uint32_t max_in;               // threads launched for such a round (>= the two counts' sum; <= width * height)
     sdfv_ray_state* out_down;      // rays leaving through the low / high face of the slab
     sdfv_ray_state* out_up;
-    uint32_t* counters;            // [0] rays in out_down, [1] rays in out_up (atomically appended)
+    uint32_t* count_down;          // rays in out_down / out_up (atomically appended)
+    uint32_t* count_up;
+    uint32_t* overflow;            // optional: set to 1 when a ray did not fit into `capacity`
     uint32_t capacity;             // entries each out list can hold
 };
 hipError_t launch_raymarch_slab(const RaymarchArgs& a, const SlabMarchArgs& s, hipStream_t stream);

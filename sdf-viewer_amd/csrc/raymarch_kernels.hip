@@ -958,7 +958,8 @@ __device__ __forceinline__ float4 fetch_rgba(const float4* data, const Footprint
 
 template <int XF, bool AUX>
 __global__ __launch_bounds__(256) void raymarch_slab_kernel(RaymarchArgs a, SlabMarchArgs s) {
-    const bool first_round = s.in == nullptr;
+    const bool device_counts = s.in_count[0] != nullptr || s.in_count[1] != nullptr;
+    const bool first_round = s.in == nullptr && !device_counts;
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
     const sdfv_camera& cam = a.cameras[0];
     uint32_t px, py;
@@ -973,8 +974,20 @@ __global__ __launch_bounds__(256) void raymarch_slab_kernel(RaymarchArgs a, Slab
         py = (tile / tiles_x) * 8 + (lane >> 3);
         live = px < a.width && py < a.height;
     } else {
-        live = gid < s.n_in;
-        const sdfv_ray_state st = s.in[live ? gid : 0];
+        sdfv_ray_state st{};
+        if (device_counts) {
+            // the neighbours' ray buffers as they arrived: their counts are read here, on the device
+            const uint32_t n0 = s.in_count[0] ? min(*s.in_count[0], s.capacity) : 0u;
+            const uint32_t n1 = s.in_count[1] ? min(*s.in_count[1], s.capacity) : 0u;
+            live = gid < n0 + n1;
+            if (live) st = gid < n0 ? s.in_rays[0][gid] : s.in_rays[1][gid - n0];
+        } else {
+            live = gid < s.n_in;
+            st = s.in[live ? gid : 0];
+        }
+        // a continuation round is launched for the most rays that COULD arrive (their number is only known on the device):
+        // waves beyond the lists leave before the ray set-up
+        if (__ballot(live) == 0ull) return;
         px = st.pixel % a.width;
         py = st.pixel / a.width;
         i = (int)st.iteration;
@@ -1025,7 +1038,8 @@ __global__ __launch_bounds__(256) void raymarch_slab_kernel(RaymarchArgs a, Slab
         if (k0c < (int)s.own_begin || k0c >= (int)s.own_end) {
             // the cell belongs to a z-neighbour: hand the ray over exactly as it is
             const int dir = k0c < (int)s.own_begin ? 0 : 1;
-            const uint32_t at = atomicAdd(&s.counters[dir], 1u);
+            const uint32_t at = atomicAdd(dir == 0 ? s.count_down : s.count_up, 1u);
+            if (at >= s.capacity && s.overflow) *s.overflow = 1u;  // the caller's capacity was too small: the image is incomplete
             if (at < s.capacity) {
                 sdfv_ray_state st;
                 st.pixel = pixel;
@@ -1154,8 +1168,10 @@ void launch_fast(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
 }  // namespace
 
 hipError_t launch_raymarch_slab(const RaymarchArgs& a, const SlabMarchArgs& s, hipStream_t stream) {
-    const uint64_t threads = s.in ? (uint64_t)s.n_in
-                                  : (uint64_t)((a.width + 7) / 8) * ((a.height + 7) / 8) * 64;  // whole 8x8 tiles
+    const bool device_counts = s.in_count[0] || s.in_count[1];
+    const uint64_t threads = device_counts ? (uint64_t)s.max_in
+                             : s.in ? (uint64_t)s.n_in
+                                    : (uint64_t)((a.width + 7) / 8) * ((a.height + 7) / 8) * 64;  // whole 8x8 tiles
     if (threads == 0) return hipSuccess;
     const dim3 grid((uint32_t)((threads + 255) / 256));
     if (a.pow2_extent) {

@@ -320,10 +320,14 @@ int fill_slab_ordered(const sdfv_demo_params* params, uint32_t sdf_id, const sdf
 
 int copy_texel_segments(const float* const src[4], float* const dst[4], const size_t n[4], float* const r_out[4],
                         void* stream) {
+    if (int rc = need_device()) return rc;
     CopySegments c;
     memset(&c, 0, sizeof(c));
     for (int i = 0; i < 4; ++i) {
         if (n[i] >= (1ull << 32)) return fail(SDFV_ERR_INVALID_ARGUMENT, "segment too large");
+        if (n[i] == 0) continue;
+        if (int rc = check_texel_alignment(src[i], dst[i])) return rc;  // the kernel moves float4 texels
+        if (r_out && ((uintptr_t)r_out[i] & 3)) return fail(SDFV_ERR_INVALID_ARGUMENT, "r_out must be 4-byte aligned");
         c.src[i] = reinterpret_cast<const float4*>(src[i]);
         c.dst[i] = reinterpret_cast<float4*>(dst[i]);
         c.n[i] = (uint32_t)n[i];
@@ -334,6 +338,10 @@ int copy_texel_segments(const float* const src[4], float* const dst[4], const si
 }
 
 int extract_distance(const float* tex0, float* dist, size_t n, void* stream) {
+    if (n == 0) return SDFV_OK;
+    if (int rc = check_texel_alignment(tex0)) return rc;  // read as float4 texels
+    if ((uintptr_t)dist & 3) return fail(SDFV_ERR_INVALID_ARGUMENT, "dist must be 4-byte aligned");
+    if (int rc = need_device()) return rc;
     SDFV_HIP(launch_commit_distance(tex0, dist, n, (hipStream_t)stream));
     return SDFV_OK;
 }
@@ -948,13 +956,11 @@ int sdfv_raymarch_depth(const sdfv_render_params* rp, const float* tex0, const f
     return SDFV_OK;
 }
 
-int sdfv_raymarch_slab(const sdfv_render_params* rp, const sdfv_grid* slab, uint32_t ghost_lo, uint32_t ghost_hi,
-                       const float* tex0, const float* tex1, const sdfv_camera* camera, uint32_t width, uint32_t height,
-                       const sdfv_ray_state* in_states, uint32_t n_in, float* rgba, sdfv_march_aux* aux,
-                       sdfv_ray_state* out_down, sdfv_ray_state* out_up, uint32_t capacity, uint32_t* counters,
-                       void* stream) {
-    if (!rp || !slab || !tex0 || !tex1 || !camera || !rgba || !out_down || !out_up || !counters)
-        return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
+// Argument checks and RaymarchArgs / SlabMarchArgs shared by the two forms of a round of the sharded march.
+static int slab_round_args(const sdfv_render_params* rp, const sdfv_grid* slab, uint32_t ghost_lo, uint32_t ghost_hi,
+                           const float* tex0, const float* tex1, const sdfv_camera* camera, uint32_t width, uint32_t height,
+                           float* rgba, sdfv_march_aux* aux, sdfv::RaymarchArgs& a, sdfv::SlabMarchArgs& s) {
+    if (!rp || !slab || !tex0 || !tex1 || !camera || !rgba) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
     if (int rc = check_grid(slab)) return rc;
     if (int rc = check_lights(rp)) return rc;
     if (int rc = check_texel_alignment(tex0, tex1, rgba)) return rc;
@@ -973,9 +979,7 @@ int sdfv_raymarch_slab(const sdfv_render_params* rp, const sdfv_grid* slab, uint
     if ((uint64_t)width * height >= (1ull << 32)) return fail(SDFV_ERR_INVALID_ARGUMENT, "image too large");
     const uint64_t resident = (uint64_t)slab->dims[0] * slab->dims[1] * (ghost_lo + (slab->z_end - slab->z_begin) + ghost_hi);
     if (resident >= (1ull << 32)) return fail(SDFV_ERR_INVALID_ARGUMENT, "slab too large for 32-bit texel indexing");
-    if (in_states == nullptr && n_in != 0) return fail(SDFV_ERR_INVALID_ARGUMENT, "n_in without in_states");
     if (int rc = need_device()) return rc;
-    sdfv::RaymarchArgs a;
     derive_raymarch_args(rp, a);
     if (!a.fast_index)
         return fail(SDFV_ERR_INVALID_ARGUMENT, "box too small for the sharded march: 1e-4 * N / size must be <= 0.25");
@@ -989,18 +993,74 @@ int sdfv_raymarch_slab(const sdfv_render_params* rp, const sdfv_grid* slab, uint
     a.cameras[0] = *camera;
     a.rgba = reinterpret_cast<float4*>(rgba);
     a.aux = aux;
-    sdfv::SlabMarchArgs s{};
+    s = sdfv::SlabMarchArgs{};
     s.z_lo = slab->z_begin - ghost_lo;
     s.z_count = ghost_lo + (slab->z_end - slab->z_begin) + ghost_hi;
     s.own_begin = slab->z_begin;
     s.own_end = slab->z_end;
+    return SDFV_OK;
+}
+
+int sdfv_raymarch_slab(const sdfv_render_params* rp, const sdfv_grid* slab, uint32_t ghost_lo, uint32_t ghost_hi,
+                       const float* tex0, const float* tex1, const sdfv_camera* camera, uint32_t width, uint32_t height,
+                       const sdfv_ray_state* in_states, uint32_t n_in, float* rgba, sdfv_march_aux* aux,
+                       sdfv_ray_state* out_down, sdfv_ray_state* out_up, uint32_t capacity, uint32_t* counters,
+                       void* stream) {
+    if (!out_down || !out_up || !counters) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (in_states == nullptr && n_in != 0) return fail(SDFV_ERR_INVALID_ARGUMENT, "n_in without in_states");
+    sdfv::RaymarchArgs a;
+    sdfv::SlabMarchArgs s;
+    if (int rc = slab_round_args(rp, slab, ghost_lo, ghost_hi, tex0, tex1, camera, width, height, rgba, aux, a, s)) return rc;
     s.in = in_states;
     s.n_in = n_in;
     s.out_down = out_down;
     s.out_up = out_up;
-    s.counters = counters;
+    s.count_down = counters;
+    s.count_up = counters + 1;
     s.capacity = capacity;
     if (in_states && n_in == 0) return SDFV_OK;  // nothing arrived this round
+    SDFV_HIP(sdfv::launch_raymarch_slab(a, s, (hipStream_t)stream));
+    return SDFV_OK;
+}
+
+size_t sdfv_ray_buffer_bytes(uint32_t capacity) { return SDFV_RAY_BUFFER_HEADER_BYTES + (size_t)capacity * sizeof(sdfv_ray_state); }
+
+int sdfv_raymarch_slab_round(const sdfv_render_params* rp, const sdfv_grid* slab, uint32_t ghost_lo, uint32_t ghost_hi,
+                             const float* tex0, const float* tex1, const sdfv_camera* camera, uint32_t width, uint32_t height,
+                             const void* in_lo, const void* in_hi, int first_round, float* rgba, sdfv_march_aux* aux,
+                             void* out_down, void* out_up, uint32_t capacity, uint32_t* overflow, void* stream) {
+    if (!out_down || !out_up) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL ray buffer");
+    if (((uintptr_t)in_lo | (uintptr_t)in_hi | (uintptr_t)out_down | (uintptr_t)out_up | (uintptr_t)overflow) & 3)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "ray buffers must be 4-byte aligned");
+    if (first_round && (in_lo || in_hi)) return fail(SDFV_ERR_INVALID_ARGUMENT, "the first round takes no incoming rays");
+    sdfv::RaymarchArgs a;
+    sdfv::SlabMarchArgs s;
+    if (int rc = slab_round_args(rp, slab, ghost_lo, ghost_hi, tex0, tex1, camera, width, height, rgba, aux, a, s)) return rc;
+    auto count_of = [](const void* b) { return reinterpret_cast<const uint32_t*>(b); };
+    auto rays_of = [](const void* b) {
+        return reinterpret_cast<const sdfv_ray_state*>(static_cast<const char*>(b) + SDFV_RAY_BUFFER_HEADER_BYTES);
+    };
+    // this round's outgoing lists start empty: their headers are cleared on the stream, ahead of the kernel
+    SDFV_HIP(hipMemsetAsync(out_down, 0, SDFV_RAY_BUFFER_HEADER_BYTES, (hipStream_t)stream));
+    SDFV_HIP(hipMemsetAsync(out_up, 0, SDFV_RAY_BUFFER_HEADER_BYTES, (hipStream_t)stream));
+    if (!first_round) {
+        if (!in_lo && !in_hi) return SDFV_OK;  // a rank without neighbours has nothing to continue
+        s.in_count[0] = in_lo ? count_of(in_lo) : nullptr;
+        s.in_rays[0] = in_lo ? rays_of(in_lo) : nullptr;
+        s.in_count[1] = in_hi ? count_of(in_hi) : nullptr;
+        s.in_rays[1] = in_hi ? rays_of(in_hi) : nullptr;
+        // every pixel's ray is in exactly one place, so the two lists together hold at most width * height rays
+        const uint64_t most = (uint64_t)capacity * ((in_lo ? 1u : 0u) + (in_hi ? 1u : 0u));
+        const uint64_t pixels = (uint64_t)width * height;
+        s.max_in = (uint32_t)(most < pixels ? most : pixels);
+        if (s.max_in == 0) return SDFV_OK;
+    }
+    s.out_down = const_cast<sdfv_ray_state*>(rays_of(out_down));
+    s.out_up = const_cast<sdfv_ray_state*>(rays_of(out_up));
+    s.count_down = reinterpret_cast<uint32_t*>(out_down);
+    s.count_up = reinterpret_cast<uint32_t*>(out_up);
+    s.overflow = overflow;
+    s.capacity = capacity;
     SDFV_HIP(sdfv::launch_raymarch_slab(a, s, (hipStream_t)stream));
     return SDFV_OK;
 }

@@ -21,6 +21,7 @@ namespace {
 // The slice of rccl.h this file needs (/opt/rocm/include/rccl/rccl.h; the ABI is NCCL's).
 constexpr int kNcclSuccess = 0;
 constexpr int kNcclFloat = 7;  // ncclFloat32
+constexpr int kNcclInt8 = 0, kNcclInt32 = 2, kNcclSum = 0;
 struct NcclUniqueId {
     char internal[SDFV_COMM_ID_BYTES];
 };
@@ -37,6 +38,7 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     const char* load_error = nullptr;
 };
@@ -66,6 +68,7 @@ const Rccl* rccl() {
         ok = bind(r.handle, "ncclGroupEnd", r.GroupEnd) && ok;
         ok = bind(r.handle, "ncclSend", r.Send) && ok;
         ok = bind(r.handle, "ncclRecv", r.Recv) && ok;
+        ok = bind(r.handle, "ncclAllReduce", r.AllReduce) && ok;
         ok = bind(r.handle, "ncclGetErrorString", r.GetErrorString) && ok;
         if (!ok) r.load_error = "librccl.so.1 lacks an ncclSend/ncclRecv entry point";
         return r;
@@ -454,6 +457,61 @@ int sdfv_slab_fill_step_commit(sdfv_slab_comm* c, const sdfv_demo_params* params
     if (!no_wait && !defer_join) SDFV_HIPC(hipStreamWaitEvent(main, c->halo_done, 0));
     return SDFV_OK;
 }
+
+// The sharded march with nobody in the loop but the stream: `world` rounds enqueued back to back -- a round's kernel, then ONE
+// RCCL group that ships the two fixed-capacity ray buffers (count in their header) to the z-neighbours and receives theirs.
+// No counter is read back, nothing synchronises; every rank enqueues the same sequence, so the groups match.
+int sdfv_slab_march(sdfv_slab_comm* c, const sdfv_render_params* rp, const sdfv_grid* slab, const float* tex0,
+                    const float* tex1, const sdfv_camera* camera, uint32_t width, uint32_t height, float* rgba,
+                    sdfv_march_aux* aux, void* scratch, size_t scratch_bytes, uint32_t capacity, uint32_t flags,
+                    uint32_t* status, void* stream) {
+    if (!c || !scratch || !status) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (c->periodic) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "the sharded march needs a non-periodic communicator");
+    if (flags & ~SDFV_MARCH_MERGE) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", flags);
+    if (capacity == 0) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "capacity is 0");
+    const size_t one = sdfv_ray_buffer_bytes(capacity);
+    const size_t one_aligned = (one + 255) & ~(size_t)255;
+    if (((uintptr_t)scratch & 15) || scratch_bytes < 4 * one_aligned)
+        return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "scratch: 16-byte aligned, at least sdfv_slab_march_scratch_bytes(capacity)");
+    const Rccl* lib;
+    if (int rc = need_rccl(lib)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    char* base = static_cast<char*>(scratch);
+    void *out_down = base, *out_up = base + one_aligned, *in_lo = base + 2 * one_aligned, *in_hi = base + 3 * one_aligned;
+    const bool lo = c->rank > 0, hi = c->rank < c->world - 1;
+    SDFV_HIPC(hipMemsetAsync(status, 0, 2 * sizeof(uint32_t), st));
+    for (int round = 0; round < c->world; ++round) {
+        if (int rc = sdfv_raymarch_slab_round(rp, slab, c->ghost_lo(), c->ghost_hi(), tex0, tex1, camera, width, height,
+                                              round == 0 ? nullptr : (lo ? in_lo : nullptr), round == 0 ? nullptr : (hi ? in_hi : nullptr),
+                                              round == 0, rgba, aux, out_down, out_up, capacity, status, st))
+            return rc;
+        if (round == c->world - 1 || (!lo && !hi)) break;  // z is monotonic along a ray: after `world` rounds every ray has ended
+        SDFV_RCCL(lib, GroupStart());
+        int first_error = kNcclSuccess;
+        auto post = [&](int r) {
+            if (first_error == kNcclSuccess) first_error = r;
+        };
+        // whole buffers, header and all: the count travels in band, the size of a message never depends on it
+        if (lo) post(lib->Send(out_down, one, kNcclInt8, c->lo_peer(), c->comm, st));
+        if (hi) post(lib->Send(out_up, one, kNcclInt8, c->hi_peer(), c->comm, st));
+        if (hi) post(lib->Recv(in_hi, one, kNcclInt8, c->hi_peer(), c->comm, st));
+        if (lo) post(lib->Recv(in_lo, one, kNcclInt8, c->lo_peer(), c->comm, st));
+        post(lib->GroupEnd());
+        if (first_error != kNcclSuccess)
+            return sdfv::set_error(SDFV_ERR_COMM, "RCCL ray exchange: %s", lib->GetErrorString(first_error));
+    }
+    // status[1]: rays still waiting in this rank's outgoing lists after the last round (0 unless a list overflowed earlier)
+    SDFV_HIPC(hipMemcpyAsync(status + 1, out_down, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    if (flags & SDFV_MARCH_MERGE) {
+        // every pixel was written by exactly one rank and is all-zero bits elsewhere: the integer sum of the bit patterns IS
+        // the image (a float sum would turn -0.0 into +0.0; RCCL has no bitwise OR)
+        SDFV_RCCL(lib, AllReduce(rgba, rgba, (size_t)width * height * 4, kNcclInt32, kNcclSum, c->comm, st));
+        if (aux) SDFV_RCCL(lib, AllReduce(aux, aux, (size_t)width * height * (sizeof(sdfv_march_aux) / 4), kNcclInt32, kNcclSum, c->comm, st));
+    }
+    return SDFV_OK;
+}
+
+size_t sdfv_slab_march_scratch_bytes(uint32_t capacity) { return 4 * ((sdfv_ray_buffer_bytes(capacity) + 255) & ~(size_t)255); }
 
 int sdfv_slab_comm_join(sdfv_slab_comm* c, void* stream) {
     if (!c) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");

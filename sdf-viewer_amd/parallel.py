@@ -84,8 +84,9 @@ class SlabTextures:
 def alloc_slab(dims, rank, world, device, fill_value=None, periodic=False, pkg=None, halo_hi=1):
     """pkg given (and a GPU device): the two textures share one block and sdfv_tune_texture_placement chooses the
     distance between them (see pkg.alloc_textures(tuned=True)).
-    halo_hi = 2: two ghost slices on the upper side (what sdfNormal's taps need in the sharded march; the library's
-    own communicator and the fill step use the one-voxel halo, halo_exchange() below handles either)."""
+    halo_hi = 2: two ghost slices on the upper side (what sdfNormal's taps need in the sharded march): the library's
+    communicator fills them when created with SDFV_COMM_HALO2 (SlabComm(halo_hi=2)), halo_exchange() below handles either
+    depth over torch.distributed."""
     z0, z1 = slab_range(dims[2], rank, world)
     glo = 1 if (periodic or rank > 0) else 0
     ghi = halo_hi if periodic else min(halo_hi, dims[2] - z1)
@@ -246,6 +247,28 @@ class SlabComm:
             tuple(dist.shape) == tuple(slab.tex0.shape[:3])
         self.pkg.check(self.pkg.lib.sdfv_slab_fill_step_commit(self.handle, C.byref(params), sdf_id, g, t0, t1,
                                                                C.c_void_p(dist.data_ptr()), st))
+
+    def march(self, rp, grid, slab, camera, width, height, want_aux=False, capacity=None, merge=True, stream=None):
+        """sdfv_slab_march: the whole sharded march of one frame enqueued in one call -- `world` rounds back to back, the ray
+        buffers (count in band) exchanged over this communicator, optionally the integer all-reduce that merges the ranks'
+        images.  Nothing is read back in between.  -> (rgba [H, W, 4], aux or None, status int32[2] DEVICE tensor:
+        [overflow flag, rays left over]); the caller checks status when it synchronises anyway."""
+        pkg = self.pkg
+        dev = slab.tex0.device
+        capacity = width * height if capacity is None else int(capacity)
+        n = pkg.lib.sdfv_slab_march_scratch_bytes(capacity)
+        scratch = torch.empty(n // 4, dtype=torch.int32, device=dev)
+        rgba = torch.empty((height, width, 4), dtype=torch.float32, device=dev)
+        aux = torch.empty((height, width, pkg.AUX_FLOATS), dtype=torch.int32, device=dev) if want_aux else None
+        status = torch.zeros(2, dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream() if stream is None else stream
+        pkg.check(pkg.lib.sdfv_slab_march(self.handle, C.byref(rp), C.byref(grid), C.c_void_p(slab.tex0.data_ptr()),
+                                          C.c_void_p(slab.tex1.data_ptr()), C.byref(camera), width, height,
+                                          C.c_void_p(rgba.data_ptr()), None if aux is None else C.c_void_p(aux.data_ptr()),
+                                          C.c_void_p(scratch.data_ptr()), n, capacity, pkg._capi.MARCH_MERGE if merge else 0,
+                                          C.c_void_p(status.data_ptr()), C.c_void_p(stream.cuda_stream)))
+        self._march_scratch = scratch  # alive until the stream has run the rounds
+        return rgba, (merge_sharded_aux(aux) if (want_aux and merge) else aux), status
 
     def join(self, stream=None):
         """sdfv_slab_comm_join: `stream` waits for the latest exchange (after steps taken with STEP_DEFER_JOIN)."""
@@ -414,11 +437,19 @@ def merge_sharded_aux(aux_sum):
     return out
 
 
-def raymarch_sharded(pkg, rp, grid, slab, camera, width, height, rank, world, group=None, want_aux=False):
+def raymarch_sharded(pkg, rp, grid, slab, camera, width, height, rank, world, group=None, want_aux=False, comm=None):
     """Raymarch of a grid that stays z-sharded across the ranks (slab + ghosts as left by the halo exchange).
     Every rank gets the full image (all-reduce of the per-rank images' bit patterns: each pixel is written by one rank).
     Returns rgba [H, W, 4] (+ the merged aux image); bit-identical to pkg.raymarch over the whole grid, except that
-    aux.normal stays (0, 0, 0)."""
+    aux.normal stays (0, 0, 0).  comm: a (non-periodic) SlabComm -- the whole march then runs inside the library over its
+    RCCL communicator (sdfv_slab_march: no host round trip per round); otherwise torch.distributed carries the rays, with a
+    counter read-back and a count exchange per round (the gloo / CPU-test transport)."""
+    if comm is not None and comm.handle and not comm.periodic:
+        rgba, aux, status = comm.march(rp, grid, slab, camera, width, height, want_aux=want_aux)
+        overflow, left = (int(v) for v in status.tolist())  # synchronises: the caller wants the image now
+        if overflow or left:
+            raise pkg.SdfvError(-1, f"sdfv_slab_march: ray lists overflowed ({overflow}) / {left} rays left over")
+        return (rgba, aux) if want_aux else rgba
     m = ShardedMarch(pkg, rp, grid, slab, camera, width, height, want_aux)
     incoming = None
     for _ in range(world):

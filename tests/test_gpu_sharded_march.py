@@ -201,3 +201,136 @@ def test_second_upper_ghost_slice_gives_the_normals(pkg, par, dims, world, eye):
     ga, wa = got_aux.cpu().numpy(), want_aux[0].cpu().numpy()
     np.testing.assert_array_equal(ga, wa)                    # every word, normals included
     assert (wa[..., 14:17] != 0).any()
+
+
+def run_lockstep_inband(pkg, rp, slabs, grids, cam, W, H, capacity, want_aux=True):
+    """The march as sdfv_slab_march runs it -- rounds back to back, fixed-capacity ray buffers with the count in band, no
+    counter read-back -- with all ranks on the one GPU and a device-to-device copy of the WHOLE buffer standing in for the
+    ncclSend / ncclRecv pair.  Everything between the first launch and the last is enqueue-only."""
+    world = len(slabs)
+    dev = slabs[0].tex0.device
+    rgba = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(world)]
+    aux = [torch.empty((H, W, pkg.AUX_FLOATS), dtype=torch.int32, device=dev) if want_aux else None for _ in range(world)]
+    out_down = [pkg.ray_buffer(capacity) for _ in range(world)]
+    out_up = [pkg.ray_buffer(capacity) for _ in range(world)]
+    in_lo = [pkg.ray_buffer(capacity) for _ in range(world)]
+    in_hi = [pkg.ray_buffer(capacity) for _ in range(world)]
+    overflow = torch.zeros(world, dtype=torch.int32, device=dev)
+
+    def enqueue():
+        overflow.zero_()
+        for rnd in range(world):
+            for r in range(world):
+                pkg.raymarch_slab_round(rp, grids[r], slabs[r].ghost_lo, slabs[r].ghost_hi, slabs[r].tex0, slabs[r].tex1, cam,
+                                        W, H, rgba[r], out_down[r], out_up[r], capacity,
+                                        in_lo=None if (rnd == 0 or r == 0) else in_lo[r],
+                                        in_hi=None if (rnd == 0 or r == world - 1) else in_hi[r],
+                                        first_round=rnd == 0, aux=aux[r], overflow=overflow[r:r + 1])
+            if rnd == world - 1:
+                break
+            for r in range(world):  # the exchange: whole buffers, whatever they hold
+                if r > 0:
+                    in_lo[r].copy_(out_up[r - 1])
+                if r < world - 1:
+                    in_hi[r].copy_(out_down[r + 1])
+
+    return enqueue, rgba, aux, out_down, out_up, overflow
+
+
+def merged(pkg, par, rgba, aux):
+    img = rgba[0].view(torch.int32).clone()
+    rec = aux[0].clone() if aux[0] is not None else None
+    for r in range(1, len(rgba)):
+        img |= rgba[r].view(torch.int32)
+        if rec is not None:
+            rec |= aux[r]
+    return img.view(torch.float32), (par.merge_sharded_aux(rec) if rec is not None else None)
+
+
+@pytest.mark.parametrize("dims,world,bb,eye,image", CASES)
+def test_inband_rounds_without_any_read_back(pkg, par, dims, world, bb, eye, image):
+    """sdfv_raymarch_slab_round: the rounds sdfv_slab_march enqueues, here CAPTURED INTO A HIP GRAPH -- a capture fails on any
+    synchronisation or read-back, so a captured march proves there is none between rounds -- and replayed: merged image and
+    aux record equal the single-GPU march bit for bit, nothing overflowed, no ray is left in a buffer."""
+    W, H = image
+    prm = pkg.default_params()
+    full = pkg.make_grid(dims, bb[0], bb[1])
+    f0, f1 = pkg.alloc_textures(full)
+    pkg.fill_grid(prm, full, f0, f1)
+    rp = pkg.default_render_params(full)
+    cam = pkg.camera_look_at(eye=eye, aspect=W / H)
+    want_rgba, want_aux = pkg.raymarch(rp, f0, f1, cam, W, H, want_aux=True)
+    slabs, grids = build_slabs(pkg, par, prm, dims, world, bb)
+    enqueue, rgba, aux, out_down, out_up, overflow = run_lockstep_inband(pkg, rp, slabs, grids, cam, W, H, capacity=W * H)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        enqueue()  # eager once (allocations, lazy module loads) ...
+    s.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        enqueue()  # ... then captured: enqueue-only, or the capture raises
+    for t in rgba + [a for a in aux if a is not None]:
+        t.fill_(-1)
+    graph.replay()
+    torch.cuda.synchronize()
+    got_rgba, got_aux = merged(pkg, par, rgba, aux)
+    np.testing.assert_array_equal(got_rgba.cpu().numpy().view(np.uint32), want_rgba[0].cpu().numpy().view(np.uint32))
+    ga, wa = got_aux.cpu().numpy(), want_aux[0].cpu().numpy()
+    np.testing.assert_array_equal(ga[..., :14], wa[..., :14])
+    np.testing.assert_array_equal(ga[..., 17], wa[..., 17])
+    assert int(overflow.sum()) == 0
+    assert all(int(b[0]) == 0 for b in out_down + out_up)  # after `world` rounds nothing is in flight
+
+
+def test_ray_buffer_capacity_overflow_is_reported_not_fatal(pkg, par):
+    """A capacity the view does not fit in: the overflow word says so (the image is then incomplete), nothing is written
+    past the buffers, and the same march with room to spare is complete."""
+    dims, world, bb, eye, (W, H) = (32, 32, 32), 4, ((-1, -1, -1), (1, 1, 1)), (0.2, 0.1, -4.0), (64, 64)
+    prm = pkg.default_params()
+    full = pkg.make_grid(dims, bb[0], bb[1])
+    rp = pkg.default_render_params(full)
+    cam = pkg.camera_look_at(eye=eye, aspect=W / H)
+    slabs, grids = build_slabs(pkg, par, prm, dims, world, bb)
+    enqueue, rgba, aux, out_down, out_up, overflow = run_lockstep_inband(pkg, rp, slabs, grids, cam, W, H, capacity=8, want_aux=False)
+    guard = [torch.cat([b, torch.full((16,), 0x5a5a5a5a, dtype=torch.int32, device="cuda")]) for b in out_up]
+    enqueue()
+    torch.cuda.synchronize()
+    assert int(overflow.sum()) > 0
+    assert all(bool((g[-16:] == 0x5a5a5a5a).all()) for g in guard)
+    enqueue2, rgba2, _, _, _, overflow2 = run_lockstep_inband(pkg, rp, slabs, grids, cam, W, H, capacity=W * H, want_aux=False)
+    enqueue2()
+    torch.cuda.synchronize()
+    assert int(overflow2.sum()) == 0
+
+
+def test_library_march_over_a_world_of_one(pkg, par):
+    """sdfv_slab_march on a non-periodic communicator of one rank (what one GPU can run of it: one round, no exchange, the
+    merge all-reduce over a world of 1): the plain march's image; a periodic communicator is refused."""
+    dims, W, H = (32, 32, 32), 96, 64
+    prm = pkg.default_params()
+    full = pkg.make_grid(dims)
+    f0, f1 = pkg.alloc_textures(full)
+    pkg.fill_grid(prm, full, f0, f1)
+    rp = pkg.default_render_params(full)
+    cam = pkg.camera_look_at(aspect=W / H)
+    slab = par.alloc_slab(dims, 0, 1, "cuda")
+    slab.tex0.copy_(f0)
+    slab.tex1.copy_(f1)
+    comm = par.SlabComm(pkg, 0, 1)
+    try:
+        rgba, aux, status = comm.march(rp, full, slab, cam, W, H, want_aux=True)
+        got = par.raymarch_sharded(pkg, rp, full, slab, cam, W, H, 0, 1, comm=comm)
+        torch.cuda.synchronize()
+        want, want_aux = pkg.raymarch(rp, f0, f1, cam, W, H, want_aux=True)
+        assert status.tolist() == [0, 0]
+        assert torch.equal(rgba.view(torch.int32), want[0].view(torch.int32))
+        assert torch.equal(got.view(torch.int32), want[0].view(torch.int32))
+        np.testing.assert_array_equal(aux.cpu().numpy()[..., :14], want_aux[0].cpu().numpy()[..., :14])
+    finally:
+        comm.close()
+    loop = par.SlabComm(pkg, 0, 1, periodic=True)
+    try:
+        with pytest.raises(pkg.SdfvError):
+            loop.march(rp, full, slab, cam, W, H)
+    finally:
+        loop.close()
