@@ -346,6 +346,22 @@ int sdfv_raymarch_depth(const sdfv_render_params *rp, const float *tex0, const f
                         uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                         float *rgba, float *depth, sdfv_march_aux *aux, void *stream);
 
+/* A second acceleration structure for hosts that render MANY frames per load (an interactive viewer, a batch of cameras):
+ * the y-pair volume -- `pairs` (DEVICE, 8-byte aligned, 2 floats per voxel of the WHOLE grid): texel (x, y, z) holds
+ * (dist[z][y][x], dist[z][min(y + 1, H - 1)][x]).  The four corners of a trilinear cell's z-level are then 16 contiguous
+ * bytes, so the march's cell fetch is two 16-byte gathers over two cache lines instead of four 8-byte ones over four --
+ * and the gather count is what a fetch costs (profiles/EXPERIMENTS.md): single 1080p frame over 256^3 -15 %, 4K over 512^3
+ * -27 %, a 64-camera batch -23 %.  Built from the compact distance volume by sdfv_commit_pairs (12 B/voxel of traffic, once
+ * per load: 0.03 ms at 256^3); costs 8 B/voxel of memory.  NOT part of the fill: the fused fill stays at 36 B/voxel. */
+int sdfv_commit_pairs(const sdfv_grid *grid, const float *dist, float *pairs, void *stream);
+/* sdfv_raymarch_depth with the pair volume (`pairs` may be NULL = sdfv_raymarch_depth).  Bit-identical results: the march
+ * gathers the same values from another layout.  The pair volume serves the hand-written gfx950 loop (power-of-two grid and
+ * extents, symmetric box, <= 2^28 texels); any other launch reads `dist` / tex0.r as before. */
+int sdfv_raymarch_pairs(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
+                        const float *pairs, const sdfv_camera *cameras, uint32_t n_cameras,
+                        uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                        float *rgba, float *depth, sdfv_march_aux *aux, void *stream);
+
 /* ---- raymarch over a z-sharded grid (multi-GPU; the consumer of the slab halo) ----
  * The grid stays sharded: rank r holds [ghost_lo][owned z_begin..z_end)[ghost_hi] as laid out for sdfv_slab_*.
  * A ray is marched by the rank that owns the cell it is in (clamp(floor(w), 0, D-1) in [z_begin, z_end); the

@@ -331,6 +331,14 @@ def commit_distance(grid, tex0, dist=None, stream=None):
     return dist
 
 
+def commit_pairs(grid, dist, pairs=None, stream=None):
+    """The y-pair volume of the raymarch (sdfv_commit_pairs): [D, H, W, 2] floats from the compact distance volume."""
+    if pairs is None:
+        pairs = torch.empty(tuple(dist.shape) + (2,), dtype=torch.float32, device=dist.device)
+    check(lib.sdfv_commit_pairs(C.byref(grid), _dev_ptr(dist, "dist"), _dev_ptr(pairs, "pairs"), _stream_ptr(stream)))
+    return pairs
+
+
 def set_option(option, value):
     """sdfv_set_option: per-thread option of the library (A/B measurements, forcing kernel specialisations in tests)."""
     check(lib.sdfv_set_option(int(option), int(value)))
@@ -361,9 +369,10 @@ class options:
 
 
 def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=False, stream=None, out=None, dist=None,
-             want_depth=False, depth_out=None):
+             want_depth=False, depth_out=None, pairs=None):
     """material.frag main() over rows [y0,y1).  Returns rgba [n_cam, rows, W, 4] (+ aux [n_cam, rows, W, 18] words).
-    `dist` = optional compact distance volume from commit_distance().  want_depth / depth_out: also return the
+    `dist` = optional compact distance volume from commit_distance(); `pairs` = optional y-pair volume from commit_pairs()
+    (sdfv_raymarch_pairs).  want_depth / depth_out: also return the
     gl_FragDepth plane [n_cam, rows, W] (sdfv_raymarch_depth); return order: rgba[, depth][, aux]."""
     if isinstance(cameras, Camera):
         cameras = [cameras]
@@ -375,8 +384,9 @@ def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=Fal
     depth = depth_out
     if depth is None and want_depth:
         depth = torch.empty((n, y1 - y0, width), dtype=torch.float32, device=tex0.device)
-    check(lib.sdfv_raymarch_depth(C.byref(rp), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"),
-                                  None if dist is None else _dev_ptr(dist, "dist"), cam_arr, n, width, height,
+    check(lib.sdfv_raymarch_pairs(C.byref(rp), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"),
+                                  None if dist is None else _dev_ptr(dist, "dist"),
+                                  None if pairs is None else _dev_ptr(pairs, "pairs"), cam_arr, n, width, height,
                                   y0, y1, C.c_void_p(rgba.data_ptr()),
                                   None if depth is None else _dev_ptr(depth, "depth"),
                                   C.c_void_p(aux.data_ptr()) if want_aux else None, _stream_ptr(stream)))

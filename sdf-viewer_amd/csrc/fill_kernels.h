@@ -89,6 +89,8 @@ hipError_t launch_fill_slices(const FillArgs& a, hipStream_t stream);
 // dense_cfg: store policy / index form of the dense kernel, which an all-required step-1 pass is
 hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& p, const FillLaunch& dense_cfg, hipStream_t stream);
 hipError_t launch_commit_distance(const float* tex0, float* dist, uint64_t n_voxels, hipStream_t stream);
+// pairs[i] = (dist[i], dist[i + W] or, in the last row of a slice, dist[i]) over a whole grid of W x H x (n / (W * H)) voxels
+hipError_t launch_commit_pairs(const float* dist, float* pairs, uint32_t W, uint32_t H, uint64_t n_voxels, hipStream_t stream);
 hipError_t launch_grid_init(float* tex0, float* tex1, uint64_t n_voxels, float air, hipStream_t stream);
 
 }  // namespace sdfv

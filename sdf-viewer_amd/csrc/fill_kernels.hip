@@ -370,6 +370,20 @@ __global__ __launch_bounds__(kBlock) void commit_distance_kernel(const float4* _
         dist[i] = tex0[i].x;
 }
 
+// The y-pair volume the hand-written march loop gathers from (raymarch_kernels.hip SDFV_MARCH_ASM_INTERIOR_PAIRS): texel
+// (x, y, z) = (d[z][y][x], d[z][min(y + 1, H - 1)][x]).  Reads the compact distance volume twice (the second time one row
+// on: served by the caches), writes 8 B/voxel; once per load, pays for itself from the second frame on.
+__global__ __launch_bounds__(kBlock) void commit_pairs_kernel(const float* __restrict__ dist, float2* __restrict__ pairs,
+                                                              uint32_t W, uint32_t H, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t row = i / W;
+    const uint32_t y = (uint32_t)(row % H);
+    const float d0 = dist[i];
+    const float d1 = y + 1 < H ? dist[i + W] : d0;
+    pairs[i] = make_float2(d0, d1);
+}
+
 template <int TX, bool NT>
 hipError_t launch_dense_cfg(const FillArgs& args, hipStream_t stream) {
     constexpr int TY = kBlock / TX;
@@ -576,6 +590,15 @@ hipError_t launch_commit_distance(const float* tex0, float* dist, uint64_t n_vox
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(commit_distance_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, stream,
                        reinterpret_cast<const float4*>(tex0), dist, n_voxels);
+    return hipGetLastError();
+}
+
+hipError_t launch_commit_pairs(const float* dist, float* pairs, uint32_t W, uint32_t H, uint64_t n_voxels, hipStream_t stream) {
+    if (n_voxels == 0) return hipSuccess;
+    const uint64_t blocks = (n_voxels + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(commit_pairs_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, stream, dist, reinterpret_cast<float2*>(pairs),
+                       W, H, n_voxels);
     return hipGetLastError();
 }
 

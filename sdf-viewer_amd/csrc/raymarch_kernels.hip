@@ -304,6 +304,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "s_mov_b32 s72, 0xbf000000\n s_mov_b32 s73, 0xbf000000\n" /* (-0.5, -0.5) */                                     \
     "s_add_i32 s75, %[wm1], -1\n"                            /* W - 2 */                                             \
     "s_add_i32 s82, %[lgw], 2\n s_add_i32 s83, %[lgw], 4\n"  /* log2(W) + 2 / + 4: row -> byte offset shifts */      \
+    "s_add_i32 s85, %[lgw], 3\n"                            /* ... + 3: the y-pair volume (8 bytes per texel) */       \
     "s_movk_i32 s74, 254\n"                                  /* 255 iterations */                                    \
     /* interior cells (all eight corners inside the volume, no clamp): the four corner rows are one offset against four  \
      * bases -- b00 = base, b10 = base + a row, b01 = base + a slice, b11 = both (row shift: s82 for the distance volume, \
@@ -394,6 +395,31 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "global_load_dword v61, v39, s[68:69]\n global_load_dword v63, v39, s[68:69] offset:16\n"                     \
     "global_load_dword v65, v39, s[86:87]\n global_load_dword v67, v39, s[86:87] offset:16\n"                     \
     "s_waitcnt vmcnt(0)\n"
+// The y-pair volume (sdfv_commit_pairs): texel (x, y, z) holds (d[y], d[min(y + 1, H - 1)]), 8 bytes, so the four corners of a
+// cell's z-level -- (x0, y0), (x0, y1), (x1, y0), (x1, y1) -- are 16 CONTIGUOUS bytes: ONE dwordx4 per z-level, two gathers and
+// two cache lines per cell instead of four and four.  The gather count is what a fetch costs (tools: profiles/EXPERIMENTS.md).
+#define SDFV_MARCH_ASM_INTERIOR_PAIRS                                                                               \
+    "v_lshlrev_b32_e32 v39, 3, v39\n"                                                                               \
+    "global_load_dwordx4 v[24:27], v39, %[base]\n"           /* z0: t000, t010, t100, t110 */                       \
+    "global_load_dwordx4 v[28:31], v39, s[68:69]\n"          /* z1: t001, t011, t101, t111 */                       \
+    "s_waitcnt vmcnt(0)\n"                                                                                          \
+    "v_pk_mov_b32 v[60:61], v[24:25], v[28:29] op_sel:[0,0]\n" /* (t000, t001) */                                   \
+    "v_pk_mov_b32 v[64:65], v[24:25], v[28:29] op_sel:[1,1]\n" /* (t010, t011) */                                   \
+    "v_pk_mov_b32 v[62:63], v[26:27], v[30:31] op_sel:[0,0]\n" /* (t100, t101) */                                   \
+    "v_pk_mov_b32 v[66:67], v[26:27], v[30:31] op_sel:[1,1]\n" /* (t110, t111) */
+// Border cells of the pair volume: the first component of eight texels (clamped corners), one dword load each.
+#define SDFV_MARCH_ASM_FETCH_PAIRS                                                                                  \
+    "v_lshlrev_b32_e32 v35, 3, v35\n v_lshlrev_b32_e32 v32, 3, v32\n"   /* i0c, i1c as byte offsets */               \
+    "v_lshl_add_u32 v24, v28, s85, v35\n v_lshl_add_u32 v25, v28, s85, v32\n"                                        \
+    "global_load_dword v60, v24, %[base]\n global_load_dword v62, v25, %[base]\n"                                  \
+    "v_lshl_add_u32 v26, v29, s85, v35\n v_lshl_add_u32 v27, v29, s85, v32\n"                                        \
+    "global_load_dword v64, v26, %[base]\n global_load_dword v66, v27, %[base]\n"                                  \
+    "v_lshl_add_u32 v24, v30, s85, v35\n v_lshl_add_u32 v25, v30, s85, v32\n"                                        \
+    "global_load_dword v61, v24, %[base]\n global_load_dword v63, v25, %[base]\n"                                  \
+    "v_lshl_add_u32 v26, v31, s85, v35\n v_lshl_add_u32 v27, v31, s85, v32\n"                                        \
+    "global_load_dword v65, v26, %[base]\n global_load_dword v67, v27, %[base]\n"                                  \
+    "s_waitcnt vmcnt(0)\n"                                                                                          \
+    "s_branch .Lcached_%=\n"
 // STRIDE 1: x-neighbours are adjacent floats: one 8-byte load per (y, z) row at b = clamp(i0, 0, W - 2); where the clamp
 // folds the two x-corners together both come from the same half (lo_is_x / hi_is_y).
 #define SDFV_MARCH_ASM_FETCH_DIST                                                                                   \
@@ -528,7 +554,10 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
     if (T) {
         float tt = dist_from_origin;
         int n = 0;
-        if (STRIDE == 1) {
+        if (STRIDE == 2) {
+            if (cube) SDFV_MARCH_ASM_RUN_AUX("s85", SDFV_MARCH_ASM_INTERIOR_PAIRS, SDFV_MARCH_ASM_FETCH_PAIRS, SDFV_MARCH_ASM_OOB_CUBE);
+            else SDFV_MARCH_ASM_RUN_AUX("s85", SDFV_MARCH_ASM_INTERIOR_PAIRS, SDFV_MARCH_ASM_FETCH_PAIRS, SDFV_MARCH_ASM_OOB_BOX);
+        } else if (STRIDE == 1) {
             if (cube) SDFV_MARCH_ASM_RUN_AUX("s82", SDFV_MARCH_ASM_INTERIOR_DIST, SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_CUBE);
             else SDFV_MARCH_ASM_RUN_AUX("s82", SDFV_MARCH_ASM_INTERIOR_DIST, SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_BOX);
         } else {
@@ -537,6 +566,9 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
         }
         dist_from_origin = tt;
         steps = n;
+    } else if (STRIDE == 2) {
+        if (cube) SDFV_MARCH_ASM_RUN("s85", SDFV_MARCH_ASM_INTERIOR_PAIRS, SDFV_MARCH_ASM_FETCH_PAIRS, SDFV_MARCH_ASM_OOB_CUBE);
+        else SDFV_MARCH_ASM_RUN("s85", SDFV_MARCH_ASM_INTERIOR_PAIRS, SDFV_MARCH_ASM_FETCH_PAIRS, SDFV_MARCH_ASM_OOB_BOX);
     } else if (STRIDE == 1) {
         if (cube) SDFV_MARCH_ASM_RUN("s82", SDFV_MARCH_ASM_INTERIOR_DIST, SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_CUBE);
         else SDFV_MARCH_ASM_RUN("s82", SDFV_MARCH_ASM_INTERIOR_DIST, SDFV_MARCH_ASM_FETCH_DIST, SDFV_MARCH_ASM_OOB_BOX);
@@ -673,7 +705,8 @@ __device__ __forceinline__ bool box_fragment_ray(const RaymarchArgs& a, V3 eye, 
 }
 
 // MODE: 0 = general kernel (any filter, any extents: the shader's nested loop with full MirroredRepeat);
-//       1 = fast march over tex0.r; 2 = fast march over the compact distance volume (both LINEAR only).
+//       1 = fast march over tex0.r; 2 = fast march over the compact distance volume (both LINEAR only);
+//       3 = the hand-written loop over the y-pair volume (sdfv_commit_pairs; two 16-byte gathers per cell).
 // XF:   0 = IEEE divide, 1 = exact power-of-two reciprocal, 2 = power-of-two extents and texture sizes.
 // AUX:  the per-pixel march record is stored (and distanceFromOrigin accumulated).
 #ifndef SDFV_RM_MIN_WAVES
@@ -798,10 +831,12 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
                                 status, steps, iterations);
     } else if (ASM && MODE == 2) {
         march_asm<SYMM, 1, AUX>(a, a.dist, tex0, ray_dir, covered, ray_pos, dist_from_origin, status, steps, iterations);
+    } else if (ASM && MODE == 3) {
+        march_asm<SYMM, 2, AUX>(a, a.pairs, tex0, ray_dir, covered, ray_pos, dist_from_origin, status, steps, iterations);
     } else if (MODE == 1) {
         SDFV_MARCH<XF, SYMM, 4, AUX>(a, reinterpret_cast<const float*>(a.tex0), tex0, ray_dir, covered, ray_pos,
                                      dist_from_origin, status, steps, iterations);
-    } else if (MODE == 2) {
+    } else if (MODE >= 2) {  // (MODE 3 is only ever launched with the hand-written loop)
         SDFV_MARCH<XF, SYMM, 1, AUX>(a, a.dist, tex0, ray_dir, covered, ray_pos, dist_from_origin, status, steps,
                                      iterations);
     } else {
@@ -871,7 +906,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
             const V3 p3 = mk(ray_pos.x - h, ray_pos.y + h, ray_pos.z - h);  // k.yxy
             const V3 p4 = mk(ray_pos.x + h, ray_pos.y + h, ray_pos.z + h);  // k.xxx
             float d1, d2, d3, d4;
-            if (MODE == 2 && a.fast_normal) {  // the taps read the compact distance volume too
+            if (MODE >= 2 && a.dist && a.fast_normal) {  // the taps read the compact distance volume too
                 d1 = sample_r_linear<XF, true, 1>(a, a.dist, tex0, p1) - 1e-1f;
                 d2 = sample_r_linear<XF, true, 1>(a, a.dist, tex0, p2) - 1e-1f;
                 d3 = sample_r_linear<XF, true, 1>(a, a.dist, tex0, p3) - 1e-1f;
@@ -1236,7 +1271,7 @@ static uint32_t occupancy_rule(const RaymarchArgs& ag) {
     if (ag.waves_per_simd == 7) return 7;
     if (ag.n_cameras != 1 || ag.first_w == 0 || ag.group_shift == 0 || ag.wave_slots_per_simd_unit == 0) return 7;
     const uint64_t texels = (uint64_t)ag.rp.tex_size[0] * ag.rp.tex_size[1] * ag.rp.tex_size[2];
-    const uint64_t volume_bytes = texels * (ag.dist ? 4u : 16u);
+    const uint64_t volume_bytes = texels * (ag.pairs ? 8u : (ag.dist ? 4u : 16u));
     if (ag.last_level_cache_bytes == 0 || volume_bytes <= ag.last_level_cache_bytes) return 7;
     const uint64_t rect_waves = (uint64_t)ag.first_w * ag.first_h * (4ull << (2 * ag.group_shift));  // 4 waves per 16 x 16 tile
     const uint64_t slots7 = 7ull * ag.wave_slots_per_simd_unit;
@@ -1292,7 +1327,17 @@ hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream) {
 static hipError_t launch_raymarch_grid(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
     const bool linear = a.rp.lod_dist_between_samples == 1.0f;
     if (linear && a.fast_index) {
-        if (a.dist) launch_fast<2>(a, grid, stream);
+        // the pair volume is an acceleration structure of the hand-written loop only: wherever that loop's specialisation
+        // does not apply the march reads the distance volume / tex0.r as before -- the same bits either way
+        const uint64_t texels = (uint64_t)a.rp.tex_size[0] * a.rp.tex_size[1] * a.rp.tex_size[2];
+        const bool pairs_ok = a.pairs && a.pow2_extent && a.pow2_size && a.symmetric_box && a.asm_loop && a.rp.tex_size[0] >= 2 &&
+                              texels <= (1ull << 28);
+        if (pairs_ok) {
+            if (a.aux) hipLaunchKernelGGL((raymarch_kernel<3, true, 2, true, true, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
+            else if (a.compute_normal)
+                hipLaunchKernelGGL((raymarch_kernel<3, true, 2, true, false, true, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
+            else hipLaunchKernelGGL((raymarch_kernel<3, true, 2, true, false, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
+        } else if (a.dist) launch_fast<2>(a, grid, stream);
         else launch_fast<1>(a, grid, stream);
     } else if (linear) {
         if (a.pow2_extent) launch_aux<0, true, 1, false>(a, grid, stream);

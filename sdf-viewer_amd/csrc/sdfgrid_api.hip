@@ -879,6 +879,18 @@ int sdfv_commit_distance(const sdfv_grid* grid, const float* tex0, float* dist, 
     return SDFV_OK;
 }
 
+int sdfv_commit_pairs(const sdfv_grid* grid, const float* dist, float* pairs, void* stream) {
+    if (int rc = check_grid(grid)) return rc;
+    if (!dist || !pairs) return fail(SDFV_ERR_INVALID_ARGUMENT, "dist or pairs is NULL");
+    if (((uintptr_t)dist & 3) || ((uintptr_t)pairs & 7)) return fail(SDFV_ERR_INVALID_ARGUMENT, "dist: 4-byte, pairs: 8-byte aligned");
+    if (grid->z_begin != 0 || grid->z_end != grid->dims[2])
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "the pair volume is built over the whole grid (the march reads the whole grid)");
+    if (int rc = need_device()) return rc;
+    const uint64_t n = (uint64_t)grid->dims[0] * grid->dims[1] * grid->dims[2];
+    SDFV_HIP(sdfv::launch_commit_pairs(dist, pairs, grid->dims[0], grid->dims[1], n, (hipStream_t)stream));
+    return SDFV_OK;
+}
+
 int sdfv_raymarch(const sdfv_render_params* rp, const float* tex0, const float* tex1, const sdfv_camera* cameras,
                   uint32_t n_cameras, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, float* rgba,
                   sdfv_march_aux* aux, void* stream) {
@@ -894,11 +906,18 @@ int sdfv_raymarch_accel(const sdfv_render_params* rp, const float* tex0, const f
 int sdfv_raymarch_depth(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
                         const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width, uint32_t height, uint32_t y0,
                         uint32_t y1, float* rgba, float* depth, sdfv_march_aux* aux, void* stream) {
+    return sdfv_raymarch_pairs(rp, tex0, tex1, dist, nullptr, cameras, n_cameras, width, height, y0, y1, rgba, depth, aux, stream);
+}
+
+int sdfv_raymarch_pairs(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
+                        const float* pairs, const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width, uint32_t height,
+                        uint32_t y0, uint32_t y1, float* rgba, float* depth, sdfv_march_aux* aux, void* stream) {
     if (!rp || !tex0 || !tex1 || !rgba) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
     if (int rc = check_lights(rp)) return rc;
     if (int rc = check_texel_alignment(tex0, tex1, rgba)) return rc;
     if ((uintptr_t)dist & 3 || (uintptr_t)depth & 3 || (uintptr_t)aux & 3)
         return fail(SDFV_ERR_INVALID_ARGUMENT, "dist, depth and aux must be 4-byte aligned");
+    if ((uintptr_t)pairs & 7) return fail(SDFV_ERR_INVALID_ARGUMENT, "pairs must be 8-byte aligned");
     if (n_cameras && !cameras) return fail(SDFV_ERR_INVALID_ARGUMENT, "cameras is NULL");
     if (y0 > y1 || y1 > height) return fail(SDFV_ERR_INVALID_ARGUMENT, "rows [%u,%u) outside height %u", y0, y1, height);
     if (rp->tex_size[0] == 0 || rp->tex_size[1] == 0 || rp->tex_size[2] == 0)
@@ -910,6 +929,7 @@ int sdfv_raymarch_depth(const sdfv_render_params* rp, const float* tex0, const f
     sdfv::RaymarchArgs a;
     derive_raymarch_args(rp, a);
     a.dist = dist;
+    a.pairs = pairs;
     a.tex0 = reinterpret_cast<const float4*>(tex0);
     a.tex1 = reinterpret_cast<const float4*>(tex1);
     a.width = width;

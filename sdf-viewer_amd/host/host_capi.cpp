@@ -172,6 +172,7 @@ int sdfvh_viewer_render_device(void* v, uint32_t width, uint32_t height, const f
     cam.set_viewport(width, height);
     return V(v).material.render(cam, rgba_device, nullptr, V(v).stream);
 }
+int sdfvh_viewer_pairs_valid(void* v) { return V(v).material.pairs && V(v).material.pairs_valid ? 1 : 0; }
 int sdfvh_viewer_sync(void* v) { return hipStreamSynchronize((hipStream_t)V(v).stream) == hipSuccess ? 0 : -1; }
 
 // ---- SDFViewerAppScene (a manual clock, in milliseconds, makes the 500 ms commit spacing testable) ----

@@ -71,8 +71,10 @@ int SDFViewerMaterial::render(const Camera& camera, float* rgba_device, sdfv_mar
     const sdfv_camera cam = camera.to_device();
     // the distance volume is only meaningful for the fully loaded grid (LINEAR filter, lod == 1)
     const float* d = (dist && lod_dist_between_samples == 1.0f) ? dist->f32() : nullptr;
-    return sdfv_raymarch_accel(&rp, tex0->f32(), tex1->f32(), d, &cam, 1, camera.viewport_width,
-                               camera.viewport_height, 0, camera.viewport_height, rgba_device, aux_device, stream);
+    // a viewer renders many frames per load: the pair volume commit() built halves the march's gathers (same bits)
+    const float* p = (d && pairs && pairs_valid) ? pairs->f32() : nullptr;
+    return sdfv_raymarch_pairs(&rp, tex0->f32(), tex1->f32(), d, p, &cam, 1, camera.viewport_width, camera.viewport_height, 0,
+                               camera.viewport_height, rgba_device, nullptr, aux_device, stream);
 }
 
 // ---- SDFViewer ----
@@ -205,6 +207,7 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
             return 0;
         }
         fresh_ = false;
+        material.pairs_valid = false;
         while (loading_mgr.step_size() != 0) loading_mgr.finish_pass();
         publish_lod();
         return loading_mgr.total_iterations() - start_iter;
@@ -233,6 +236,7 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
             break;
         }
         fresh_ = false;
+        material.pairs_valid = false;
         loading_mgr.finish_pass();
         publish_lod();
     }
@@ -255,6 +259,16 @@ void SDFViewer::commit() {
     // Where the reference uploads both textures there is nothing to move, and nothing to derive either: the compact
     // distance volume the LINEAR march reads has been kept in sync by every fill.  Without one (allocation failed at
     // creation) the march reads tex0.r in place.
+    // What a commit of the fully loaded grid does derive is the pair volume: the frames that follow (the reference renders
+    // one per repaint) march over it.  12 B/voxel of traffic -- against the reference's re-upload of 32 B/voxel over PCIe.
+    if (dist_synced_ && loading_mgr.step_size() == 0 && !material.pairs_valid) {
+        if (!material.pairs) material.pairs = std::make_shared<DeviceBuffer>(material.dist->bytes() * 2);
+        const sdfv_grid g = grid();
+        if (material.pairs->ok() && sdfv_commit_pairs(&g, material.dist->f32(), material.pairs->f32(), stream) == 0)
+            material.pairs_valid = true;
+        else
+            material.pairs.reset();  // out of memory: the march keeps reading the distance volume
+    }
 }
 
 int SDFViewer::download(float* tex0_host, float* tex1_host) const {

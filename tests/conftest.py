@@ -22,7 +22,7 @@ def _ensure_built():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     if not os.path.exists(os.path.join(ROOT, "sdf-viewer_amd", "libsdfgrid.so")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "sdf-viewer_amd", "csrc")], stdout=subprocess.DEVNULL)
-    if not (os.path.exists(os.path.join(ROOT, "sdf-viewer_amd", "libsdfviewer_host.so")) and
+    if not (os.path.exists(os.path.join(ROOT, "sdf-viewer_amd", "libsdfviewer_host_test.so")) and
             os.path.exists(os.path.join(ROOT, "sdf-viewer_amd", "libsdfdemo_provider.so"))):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "sdf-viewer_amd", "host")], stdout=subprocess.DEVNULL)
 

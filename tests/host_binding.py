@@ -1,4 +1,4 @@
-"""ctypes binding of the C++ host mirror (libsdfviewer_host.so) and of the per-point provider library
+"""ctypes binding of the C++ host mirror (through the TEST-ONLY libsdfviewer_host_test.so = the mirror + host_capi.cpp's flat shims) and of the per-point provider library
 (libsdfdemo_provider.so, the reference's ffi.rs ABI)."""
 import ctypes as C
 import os
@@ -11,7 +11,7 @@ except ImportError:  # pragma: no cover
     pass
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-H = C.CDLL(os.path.join(ROOT, "sdf-viewer_amd", "libsdfviewer_host.so"))
+H = C.CDLL(os.path.join(ROOT, "sdf-viewer_amd", "libsdfviewer_host_test.so"))
 PROVIDER_PATH = os.path.join(ROOT, "sdf-viewer_amd", "libsdfdemo_provider.so")
 
 SZ = C.c_size_t
@@ -41,7 +41,7 @@ for name, res, args in [
     ("sdfvh_viewer_tex0", C.c_void_p, [C.c_void_p]), ("sdfvh_viewer_tex1", C.c_void_p, [C.c_void_p]),
     ("sdfvh_viewer_render", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("sdfvh_viewer_render_device", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
-    ("sdfvh_viewer_sync", C.c_int, [C.c_void_p]),
+    ("sdfvh_viewer_sync", C.c_int, [C.c_void_p]), ("sdfvh_viewer_pairs_valid", C.c_int, [C.c_void_p]),
     ("sdfvh_format_f32", SZ, [C.c_float, C.c_char_p, SZ]), ("sdfvh_ply_color_u8", C.c_uint32, [C.c_float]),
     ("sdfvh_mesh_sdf", C.c_void_p, [C.c_void_p, C.c_char_p, SZ, C.c_int, C.c_char_p, SZ]),
     ("sdfvh_mesh_from_arrays", C.c_void_p, [C.c_void_p, SZ, C.c_void_p, SZ]), ("sdfvh_mesh_free", None, [C.c_void_p]),
@@ -215,6 +215,9 @@ class Viewer:
 
     def sync(self):
         assert H.sdfvh_viewer_sync(self.h) == 0
+
+    def pairs_valid(self):
+        return bool(H.sdfvh_viewer_pairs_valid(self.h))
 
     def render(self, width, height, eye=None):
         out = np.empty((height, width, 4), np.float32)

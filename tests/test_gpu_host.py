@@ -121,6 +121,34 @@ def test_material_render_matches_oracle(host, oracle):
     assert np.abs(img2 - want2).max() <= 1e-4
 
 
+def test_commit_of_a_loaded_grid_builds_the_pair_volume_and_edits_retire_it(host, oracle):
+    """SDFViewer::commit on the fully loaded grid derives the y-pair volume the following frames march over (same bits as
+    the frame before it existed); any fill retires it until the next commit of a loaded grid."""
+    sdf = host.SDF.demo()
+    dims = (64, 64, 64)  # a power-of-two grid: the hand-written loop, hence the pair volume, applies
+    v = host.Viewer.new_voxels(dims, [-1, -1, -1, 1, 1, 1], 2)
+    while v.update(sdf, 1.0):
+        pass
+    assert not v.pairs_valid()
+    before = v.render(160, 120)          # over the distance volume
+    v.commit()
+    assert v.pairs_valid()
+    after = v.render(160, 120)           # over the pair volume
+    np.testing.assert_array_equal(before.view(np.uint32), after.view(np.uint32))
+    assert sdf.children()[1].set_parameter(1, 0.8) is None  # sphere radius
+    v.update(sdf, 1.0)
+    assert not v.pairs_valid()           # stale: the march must not read it
+    while v.update(sdf, 1.0) or v.has_changed_box():
+        pass
+    edited = v.render(160, 120)
+    v.commit()
+    assert v.pairs_valid()
+    np.testing.assert_array_equal(edited.view(np.uint32), v.render(160, 120).view(np.uint32))
+    t0, t1 = v.download()
+    want, _ = oracle.raymarch(oracle.default_render_params(dims), t0, t1, oracle.camera_look_at(aspect=160 / 120), 160, 120, want_aux=False)
+    assert np.abs(edited - want).max() <= 1e-4 and not np.array_equal(before, edited)
+
+
 def test_sdf_surface_per_point_calls(host, oracle):
     rng = np.random.default_rng(3)
     pts = rng.uniform(-1.1, 1.1, size=(40, 3)).astype(np.float32)

@@ -37,6 +37,9 @@ def compare(pkg, oracle, g, t0, t1, h0, h1, cam_kw, width, height, rp_edit=None,
     want_rgba, want_aux = oracle.raymarch(orp, h0, h1, ocam, width, height, y0=y0, y1=y1)
     dist = pkg.commit_distance(g, t0)
     assert torch.equal(dist, t0[..., 0])
+    whole = pkg.make_grid(tuple(int(d) for d in g.dims), tuple(g.bb_min), tuple(g.bb_max))
+    pairs = pkg.commit_pairs(whole, dist)  # (d[y], d[min(y + 1, H - 1)]) per texel
+    assert torch.equal(pairs[..., 0], dist) and torch.equal(pairs[:, :-1, :, 1], dist[:, 1:]) and torch.equal(pairs[:, -1, :, 1], dist[:, -1])
     # every march kernel family must reproduce the oracle: the fast march (symmetric-box / fused-scale /
     # reciprocal / divide variants) over tex0.r, the same over the compact distance volume, and the general
     # kernel (full MirroredRepeat, the shader's nested loop)
@@ -46,15 +49,20 @@ def compare(pkg, oracle, g, t0, t1, h0, h1, cam_kw, width, height, rp_edit=None,
     # "*_b": the hand-written loop with its interior fetch path switched off (every cell through the clamping fetch)
     disabled = {"fast": 0, "dist": 0, "fast_c": K.RM_NO_ASM_LOOP, "dist_c": K.RM_NO_ASM_LOOP, "general": K.RM_NO_FAST_INDEX,
                 "fast_b": K.RM_NO_INTERIOR_FETCH, "dist_b": K.RM_NO_INTERIOR_FETCH,
+                # "pairs*": the y-pair volume (two 16-byte gathers per cell), its border fetch for every cell, and a launch
+                # whose specialisation does not apply (falls back to the distance volume)
+                "pairs": 0, "pairs_b": K.RM_NO_INTERIOR_FETCH, "pairs_c": K.RM_NO_ASM_LOOP,
                 "fast_plain": K.RM_NO_SYMMETRIC | K.RM_NO_POW2_SIZE,
                 "fast_div": K.RM_NO_SYMMETRIC | K.RM_NO_POW2_EXTENT}
     for variant, mask in disabled.items():
         with pkg.options({K.OPT_RAYMARCH_DISABLE: mask}):
+            use_dist = dist if variant.startswith(("dist", "pairs")) else None
+            use_pairs = pairs if variant.startswith("pairs") else None
             rgba, depth, aux = pkg.raymarch(rp, t0, t1, cam, width, height, y0=y0, y1=y1, want_aux=True,
-                                            want_depth=True, dist=dist if variant.startswith("dist") else None)
+                                            want_depth=True, dist=use_dist, pairs=use_pairs)
             # the depth plane without the 72-byte record must be the same plane
             rgba_plain, depth_only = pkg.raymarch(rp, t0, t1, cam, width, height, y0=y0, y1=y1, want_depth=True,
-                                                  dist=dist if variant.startswith("dist") else None)
+                                                  dist=use_dist, pairs=use_pairs)
             torch.cuda.synchronize()
         assert torch.equal(depth.view(torch.int32), depth_only.view(torch.int32)), variant
         # the kernel WITHOUT the aux record (the one bench.py times) writes the same RGBA as the one with it

@@ -35,8 +35,9 @@ def run(side):
     rp = pkg.default_render_params(g)
     cams = pkg.orbit_cameras(64, aspect=W / H)
     out = torch.empty((64, H, W, 4), dtype=torch.float32, device="cuda")
+    pairs = pkg.commit_pairs(g, dist)  # what bench.py's batch marches over
     for _ in range(REPS):
-        pkg.raymarch(rp, t0, t1, cams, W, H, out=out, dist=dist)
+        pkg.raymarch(rp, t0, t1, cams, W, H, out=out, dist=dist, pairs=pairs)
     torch.cuda.synchronize()
 
 
@@ -60,7 +61,7 @@ def reduce(root, side):
                       "salu_wave_instructions_per_batch": int(per.get("SQ_INSTS_SALU", 0)),
                       "vmem_read_wave_instructions_per_batch": int(per.get("SQ_INSTS_VMEM_RD", 0)),
                       "launches_per_batch": n // REPS, "cameras": 64, "image": list(IMAGES[side]), "clock_GHz": 2.4,
-                      "source": f"rocprofv3 --pmc SQ_INSTS_VALU ... -- python tools/batch_valu.py run {side} ({REPS} batches averaged)",
+                      "source": f"rocprofv3 --pmc SQ_INSTS_VALU ... -- python tools/batch_valu.py run {side} ({REPS} batches over the y-pair volume averaged)",
                       "note": "SQ_INSTS_VALU counts wave-level instructions; clock = MI355X peak engine clock (MI355X_MICROARCH.md)"}
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out[str(side)]))

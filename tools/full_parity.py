@@ -81,6 +81,12 @@ def check(side, threads=None, log=print, eye=(2.5, 3.0, 5.0), pipeline="plain", 
     # the kernel bench.py times: no aux record, default options (hand-written loop, interior fetch, box-first order)
     rgba = pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist)
     rgba_aux, aux = pkg.raymarch(rp, t0, t1, cam, W, H, want_aux=True, dist=dist)
+    pairs_diff = None
+    if dist is not None:  # the y-pair volume (what a host that renders many frames per load marches over): same bits
+        pairs = pkg.commit_pairs(g, dist)
+        rgba_pairs = pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist, pairs=pairs)
+        pairs_diff = int((rgba_pairs.view(torch.int32) != rgba.view(torch.int32)).sum().item())
+        del pairs, rgba_pairs
     torch.cuda.synchronize()
     t = time.time()
     want_rgba, want_aux = oracle.raymarch(oracle.copy_struct(oracle.RenderParams, rp), h0, h1,
@@ -88,6 +94,8 @@ def check(side, threads=None, log=print, eye=(2.5, 3.0, 5.0), pipeline="plain", 
     got_aux = aux[0].cpu().numpy().view(oracle.AUX_DTYPE).reshape(H, W)
     diff = {f: int((got_aux[f].view(np.uint32) != want_aux[f].view(np.uint32)).sum()) for f in AUX_FIELDS}
     diff["rgba_noaux_vs_aux"] = int((rgba.view(torch.int32) != rgba_aux.view(torch.int32)).sum().item())
+    if pairs_diff is not None:
+        diff["rgba_pairs_vs_dist"] = pairs_diff
     err = float(np.abs(rgba[0].cpu().numpy() - want_rgba).max())
     hits = int((want_aux["status"] == 1).sum())
     log(f"[{pipeline}] {W}x{H} no-aux march over {'the distance volume' if dist is not None else 'tex0.r'} of {side}^3: "

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""The y-pair volume against the compact distance volume: single frames (1080p/256^3, 4K/512^3, eleven views each) and the
+64-camera batch, alternating rounds in one process, bits compared.  python tools/pairs_bench.py"""
+import importlib, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+pkg = importlib.import_module("sdf-viewer_amd")
+def run(fn, n=40, warm=0.05):
+    t_end = time.perf_counter() + warm
+    while time.perf_counter() < t_end: fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+res = {}
+prm = pkg.default_params()
+for side, W, H in ((256, 1920, 1080), (512, 3840, 2160)):
+    g = pkg.make_grid((side,) * 3)
+    t0, t1 = pkg.alloc_textures(g); dist = torch.empty((side,) * 3, dtype=torch.float32, device="cuda")
+    pkg.fill_grid(prm, g, t0, t1, dist=dist)
+    pairs = pkg.commit_pairs(g, dist)
+    res[f"{side}_commit_pairs_ms"] = round(run(lambda: pkg.commit_pairs(g, dist, pairs=pairs), n=20), 4)
+    rp = pkg.default_render_params(g)
+    out = torch.empty((1, H, W, 4), dtype=torch.float32, device="cuda")
+    ref = torch.empty_like(out)
+    views = {"default": pkg.camera_look_at(aspect=W / H)}
+    for k, c in enumerate(pkg.orbit_cameras(8, aspect=W / H)[1:]): views[f"orbit{k + 1}"] = c
+    views["close"] = pkg.camera_look_at(eye=(1.2, 1.5, 2.4), aspect=W / H)
+    views["far"] = pkg.camera_look_at(eye=(5.0, 6.0, 10.0), aspect=W / H)
+    views["axis"] = pkg.camera_look_at(eye=(0.0, 0.0, 5.0), aspect=W / H)
+    views["inside"] = pkg.camera_look_at(eye=(0.2, 0.1, 0.3), target=(1.0, 0.5, -1.0), aspect=W / H)
+    for name, cam in views.items():
+        ms = {"dist": [], "pairs": []}
+        for rnd in range(3):
+            ms["dist"].append(run(lambda: pkg.raymarch(rp, t0, t1, cam, W, H, out=ref, dist=dist)))
+            ms["pairs"].append(run(lambda: pkg.raymarch(rp, t0, t1, cam, W, H, out=out, dist=dist, pairs=pairs)))
+        same = bool(torch.equal(out.view(torch.int32), ref.view(torch.int32)))
+        res[f"{side}_{W}x{H}_{name}"] = {"dist_ms": round(min(ms["dist"]), 4), "pairs_ms": round(min(ms["pairs"]), 4), "same_bits": same}
+        print(f"{side} {W}x{H} {name:8s} dist {min(ms['dist']):.4f}  pairs {min(ms['pairs']):.4f}  ratio {min(ms['pairs']) / min(ms['dist']):.3f}  same bits {same}", file=sys.stderr, flush=True)
+    if side == 256:
+        cams = pkg.orbit_cameras(64, aspect=W / H)
+        big = torch.empty((64, H, W, 4), dtype=torch.float32, device="cuda"); big2 = torch.empty_like(big)
+        d = min(run(lambda: pkg.raymarch(rp, t0, t1, cams, W, H, out=big, dist=dist), n=5) for _ in range(2))
+        p = min(run(lambda: pkg.raymarch(rp, t0, t1, cams, W, H, out=big2, dist=dist, pairs=pairs), n=5) for _ in range(2))
+        res["256_batch64"] = {"dist_ms": round(d, 4), "pairs_ms": round(p, 4), "same_bits": bool(torch.equal(big.view(torch.int32), big2.view(torch.int32))),
+                              "Mrays_s_dist": round(64 * W * H / d / 1e3, 1), "Mrays_s_pairs": round(64 * W * H / p / 1e3, 1)}
+        print("batch64", res["256_batch64"], file=sys.stderr, flush=True)
+        del big, big2
+    del t0, t1, dist, pairs
+print(json.dumps(res))
