@@ -69,7 +69,7 @@ def main():
 
     out = {"steps": steps, "wait_value_capable": comm.wait_value_capable}
     if "--graph" in sys.argv and "--graph-child" not in sys.argv:
-        # the capture crashes the process on this image (hipStreamEndCapture, DESIGN.md 9.1): run it in a child and report
+        # the capture crashes the process on this image (hipStreamEndCapture, DESIGN.md 6): run it in a child and report
         import subprocess
         comm.close()
         r = subprocess.run([sys.executable, "-X", "faulthandler", os.path.abspath(__file__)] + sys.argv[1:] + ["--graph-child"],
@@ -82,7 +82,7 @@ def main():
         print(json.dumps(out), flush=True)
         return
     if "--graph" in sys.argv:
-        # DESIGN.md 9.1: the event form of the step (fork / join by events: capturable) recorded into a HIP graph and
+        # DESIGN.md 6: the event form of the step (fork / join by events: capturable) recorded into a HIP graph and
         # replayed, against the same form enqueued call by call
         form = K.STEP_SIDE_BOUNDARY | K.STEP_START_EVENT
         s = torch.cuda.Stream()

@@ -29,7 +29,10 @@ rp = pkg.default_render_params(g)
 cam = pkg.camera_look_at(aspect=W / H)
 n_waves = ((W + 15) // 16) * ((H + 15) // 16) * 4
 buf = torch.zeros((n_waves, 4), dtype=torch.int64, device="cuda")
-dist = pkg.commit_distance(g, t0) if "--dist" in sys.argv else None
+dist = pkg.commit_distance(g, t0) if ("--dist" in sys.argv or "--pairs" in sys.argv) else None
+pairs = pkg.commit_pairs(g, dist) if "--pairs" in sys.argv else None  # the y-pair volume (round 3)
+_march = pkg.raymarch
+pkg.raymarch = lambda *a_, **k_: _march(*a_, pairs=pairs, **k_)
 for _ in range(200):  # clock ramp
     pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist)
 if "--launch-order" in sys.argv:  # default: the product's order (the stamps are indexed by tile, not by workgroup)
