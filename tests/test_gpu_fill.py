@@ -233,6 +233,20 @@ def test_randomised_parameters_and_grids(pkg, oracle):
             pkg.fill_grid_pass(prm, g, step, p0, p1, sdf_id=sdf_id, dist=dvol)
         torch.cuda.synchronize()
         assert torch.equal(p0, t0) and torch.equal(p1, t1) and torch.equal(dvol, t0[..., 0]), (trial, kw, dims)
+        # the same load as its LoadingManager would flag it (first pass: fresh grid; later ones: same load), random steps
+        K = pkg._capi
+        steps = [int(s_) for s_ in sorted({int(2 ** rng.integers(0, 4)) for _ in range(3)} | {1}, reverse=True)]
+        pkg.grid_init(g, p0, p1)
+        pkg.commit_distance(g, p0, dist=dvol)
+        for k, step in enumerate(steps):
+            pkg.fill_grid_pass(prm, g, step, p0, p1, sdf_id=sdf_id, dist=dvol if trial % 2 else None,
+                               flags=(K.PASS_FRESH_GRID if k == 0 else 0) | K.PASS_SAME_LOAD)
+        torch.cuda.synchronize()
+        assert torch.equal(p0, t0) and torch.equal(p1, t1), (trial, kw, dims, steps)
+        if trial % 2:
+            assert torch.equal(dvol, t0[..., 0]), (trial, kw, dims, steps)
+        else:
+            pkg.commit_distance(g, p0, dist=dvol)
         other = pkg.default_params(**dict(kw, cube_half_side=min(1.0, kw["cube_half_side"] + 0.07)))
         box = tuple(float(v) for v in np.concatenate([lo + (hi - lo) * rng.uniform(0.0, 0.5, 3), lo + (hi - lo) * rng.uniform(0.5, 1.0, 3)]))
         q0, q1 = t0.clone(), t1.clone()
@@ -240,6 +254,14 @@ def test_randomised_parameters_and_grids(pkg, oracle):
         pkg.fill_grid_pass(other, g, 1, p0, p1, changed_box=box, sdf_id=sdf_id, dist=dvol)
         torch.cuda.synchronize()
         assert torch.equal(p0, q0) and torch.equal(p1, q1) and torch.equal(dvol, p0[..., 0]), (trial, kw, dims, box)
+        # an edit whose box holds every voxel (the store-only path the library picks itself), strided then step 1, against
+        # the dense fill with the new parameters
+        whole = tuple(float(v) for v in np.concatenate([np.minimum(lo, hi) - 0.5, np.maximum(lo, hi) + 0.5]))
+        for step in (2, 1):
+            pkg.fill_grid_pass(other, g, step, p0, p1, changed_box=whole, sdf_id=sdf_id, dist=dvol)
+        torch.cuda.synchronize()
+        o0, o1 = gpu_fill(pkg, other, dims, lo, hi, sdf_id=sdf_id)
+        assert torch.equal(p0, o0) and torch.equal(p1, o1) and torch.equal(dvol, o0[..., 0]), (trial, kw, dims, "whole box")
 
 
 @pytest.mark.parametrize("dims", [(64, 64, 64), (33, 5, 70), (130, 3, 9), (1, 5, 7), (256, 8, 4)])

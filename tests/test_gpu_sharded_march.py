@@ -168,6 +168,15 @@ def test_randomised_slabs_and_cameras(pkg, par):
         ga, wa = got_aux.cpu().numpy(), want_aux[0].cpu().numpy()
         np.testing.assert_array_equal(ga[..., :14], wa[..., :14])
         np.testing.assert_array_equal(ga[..., 17], wa[..., 17])
+        # the same march with in-band counts (what sdfv_slab_march enqueues), capacity drawn between "tight" and W * H
+        cap = int(rng.integers(max(64, W * H // 4), W * H + 1))
+        enqueue, rgba_i, aux_i, _, _, overflow = run_lockstep_inband(pkg, rp, slabs, grids, cam, W, H, capacity=cap)
+        enqueue()
+        torch.cuda.synchronize()
+        if int(overflow.sum()) == 0:  # a capacity below the busiest list only reports; the image is then incomplete
+            got_i, aux_m = merged(pkg, par, rgba_i, aux_i)
+            np.testing.assert_array_equal(got_i.cpu().numpy().view(np.uint32), want_rgba[0].cpu().numpy().view(np.uint32))
+            np.testing.assert_array_equal(aux_m.cpu().numpy()[..., :14], wa[..., :14])
 
 
 @pytest.mark.parametrize("dims,world,eye", [((32, 32, 32), 4, (2.5, 3.0, 5.0)), ((24, 20, 37), 3, (-3.0, 1.0, -2.0)),
