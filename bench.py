@@ -800,6 +800,20 @@ def run(redirect):
         march_ms, march_ev = region(lambda: pkg.raymarch(rp, r0, r1, my_cams, W, H, out=rgba, dist=dist_vol), K, Wm,
                                     torch, dist, world, device)
         march_mrays = W * H * world / march_ms / 1e3
+        # the distribution behind the two means, like the N = 1 line: every rank times its launches one by one (the step
+        # contains the exchange, so all ranks make the same calls), MAX over ranks of median and p95
+        STAGE("per-step statistics of the fill step and the march")
+        st_fill = per_step_stats(filler.step, min(args.per_step_samples, 20), torch, warm=2)
+        st_march = per_step_stats(lambda: pkg.raymarch(rp, r0, r1, my_cams, W, H, out=rgba, dist=dist_vol), min(args.per_step_samples, 20), torch, warm=2)
+        if st_fill and st_march:
+            t = torch.tensor([st_fill["median"], st_fill["p95"], st_march["median"], st_march["p95"]], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fm, fp, mm, mp = (float(v) for v in t.tolist())
+            out["ms_per_step_median"] = round(fm + mm, 4)
+            out["ms_per_step_p95"] = round(fp + mp, 4)
+            out["per_step"] = {"fill": {"median": round(fm, 5), "p95": round(fp, 5), "samples": st_fill["samples"]},
+                               "raymarch": {"median": round(mm, 5), "p95": round(mp, 5), "samples": st_march["samples"]},
+                               "note": "MAX over ranks of each rank's median / p95; one HIP-event pair per step"}
         out["pipeline"] = "fused"
         out["pipeline_note"] = ("N > 1: value = z-slab fill step = the fused fill per rank (textures + distance volume, "
                                 "36 B/voxel) incl. the RCCL halo exchange: N x the work of pipeline_fused at N = 1; value_rays "

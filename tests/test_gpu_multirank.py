@@ -38,7 +38,8 @@ def test_bench_weak_scaling_path_two_ranks_one_gpu(world, geometry):
     assert (gx, gy, gz) == ((64, 64, 64 * world) if geometry == "slab" else cube)
     assert d["value"] > 0 and d["value_rays"] > 0
     # the N > 1 line = the N = 1 contract + config4 + what RCCL saw (None here: gloo carries the halo, not the library's RCCL)
-    for key in CONTRACT_KEYS + ("config4", "rccl_ranks", "torch_world_size", "roofline_raymarch", "batch_raymarch"):
+    for key in CONTRACT_KEYS + ("config4", "rccl_ranks", "torch_world_size", "roofline_raymarch", "batch_raymarch",
+                                "ms_per_step_median", "ms_per_step_p95"):
         assert key in d, key
     assert d["rccl_ranks"] is None and d["torch_world_size"] == world
     assert d["roofline"]["frac_8d"] > 0 and d["roofline"]["algorithmic_bytes_per_voxel"] == 32
