@@ -171,8 +171,6 @@ typedef enum sdfv_option {
 #define SDFV_RM_NO_SYMMETRIC   8u /* max(min - p, p - max) instead of |p| - max */
 #define SDFV_RM_NO_ASM_LOOP   16u /* the compiler's march loop instead of the hand-written gfx950 one */
 #define SDFV_RM_NO_INTERIOR_FETCH 32u /* hand-written loop: always the clamping cell fetch, never the interior fast path */
-#define SDFV_RM_NO_REPACK     64u /* batches of cameras: one leg per wave (raymarch_kernel) instead of two legs with the surviving
-                                   * rays repacked in between */
 #define SDFV_STEP_SIDE_BOUNDARY 3u /* the one step form (values 1 and 2, round 2's two-launch / one-launch forms, lost every
                                     * measurement and are gone): the caller's stream runs the plain dense fill of the whole
                                     * slab; the communicator's stream computes the boundary slices once more, into the packed

@@ -40,7 +40,6 @@ struct RaymarchArgs {
     uint32_t waves_per_simd;     // option: 0 = the launcher's occupancy rule, 7 = never cap, 2..6 = that cap
     uint32_t wave_slots_per_simd_unit;  // SIMDs of the device (CUs x 4): resident waves at w per SIMD = w x this; 0 = unknown
     uint64_t last_level_cache_bytes;    // Infinity Cache (MI355X: 256 MB); 0 = unknown
-    uint32_t no_repack;          // batches: the one-leg kernel instead of raymarch_repack_kernel (tests, A/B)
     uint32_t cube_box;           // symmetric box with bounds_max[0] == [1] == [2]: two-instruction out-of-bounds test
     float4* rgba;                // n_cameras x (y1-y0) x width
     sdfv_march_aux* aux;         // same layout or nullptr

@@ -305,7 +305,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "s_add_i32 s75, %[wm1], -1\n"                            /* W - 2 */                                             \
     "s_add_i32 s82, %[lgw], 2\n s_add_i32 s83, %[lgw], 4\n"  /* log2(W) + 2 / + 4: row -> byte offset shifts */      \
     "s_add_i32 s85, %[lgw], 3\n"                            /* ... + 3: the y-pair volume (8 bytes per texel) */       \
-    "s_add_i32 s74, %[cap], -1\n"                            /* `cap` iterations (255: material.frag:97) */          \
+    "s_movk_i32 s74, 254\n"                                  /* 255 iterations */                                    \
     /* interior cells (all eight corners inside the volume, no clamp): the four corner rows are one offset against four  \
      * bases -- b00 = base, b10 = base + a row, b01 = base + a slice, b11 = both (row shift: s82 for the distance volume, \
      * s83 for tex0) */                                                                                              \
@@ -499,7 +499,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     [dx] "v"(dirx), [dy] "v"(diry), [dz] "v"(dirz), [cov] "s"(cov), [mx] "s"(a.rp.bounds_max[0]),    \
         [my] "s"(a.rp.bounds_max[1]), [mz] "s"(a.rp.bounds_max[2]), [minx] "s"(a.rp.bounds_min[0]),                 \
         [miny] "s"(a.rp.bounds_min[1]), [minz] "s"(a.rp.bounds_min[2]), [kx] "s"(kx), [ky] "s"(ky), [kz] "s"(kz),   \
-        [wm1] "s"(wm1), [hm1] "s"(hm1), [dm1] "s"(dm1), [lgw] "s"(lgw), [lgh] "s"(lgh), [base] "s"(vol), [base_lo] "s"(base_lo), [base_hi] "s"(base_hi), [thresh] "s"(thresh), [cap] "s"(cap)
+        [wm1] "s"(wm1), [hm1] "s"(hm1), [dm1] "s"(dm1), [lgw] "s"(lgw), [lgh] "s"(lgh), [base] "s"(vol), [base_lo] "s"(base_lo), [base_hi] "s"(base_hi), [thresh] "s"(thresh)
 #define SDFV_MARCH_ASM_CLOBBERS                                                                                     \
     "vcc", "scc", "memory", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",    \
         "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "v24", "v25", "v26", "v27", "v28",  \
@@ -510,10 +510,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 template <bool SYMM_UNUSED, int STRIDE, bool T>
 __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __restrict__ vol, const Tex& t,
                                           V3 ray_dir, bool covered, V3& ray_pos, float& dist_from_origin,
-                                          int& status, int& steps, int& iterations, int cap_in = 255) {
-    // iterations this call may run (wave-uniform): 255 = the shader's loop; the repacking kernel runs it in two legs.
-    // status -1 then means "still marching after `cap` iterations"
-    const int cap = __builtin_amdgcn_readfirstlane(cap_in);
+                                          int& status, int& steps, int& iterations) {
     // float multiplies are VALU work on gfx950: the (uniform) products are moved to scalar registers explicitly
     auto uniform = [](float f) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f))); };
     const float kx = uniform(a.inv_bsize[0] * (float)t.w), ky = uniform(a.inv_bsize[1] * (float)t.h),
@@ -580,7 +577,7 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
         else SDFV_MARCH_ASM_RUN("s83", SDFV_MARCH_ASM_INTERIOR_TEX0, SDFV_MARCH_ASM_FETCH_TEX0, SDFV_MARCH_ASM_OOB_BOX);
     }
 #ifdef SDFV_TUNING  // left = (iterations that ran the fetch block) << 16 | the down-counter at exit
-    iterations = cov ? (min(cap, cap - (int)(short)(left & 0xffff)) | (left & 0xffff0000)) : 0;
+    iterations = cov ? (min(255, 255 - (int)(short)(left & 0xffff)) | (left & 0xffff0000)) : 0;
 #else
     (void)iterations;
     (void)left;
@@ -953,110 +950,6 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
         if (a.depth) a.depth[out_index] = frag_depth;
         if (AUX) a.aux[out_index] = aux;
     }
-}
-
-// ---- batches of cameras: the march in two legs with the surviving rays repacked in between -------------------------------
-// A batch fills the machine and is bound by VALU issue, and a wave issues every iteration of its LONGEST ray for all 64
-// lanes: the rays of the 64-camera batch take 14.6 steps on average, their waves ~35 iterations.  So the workgroup (a 16 x 16
-// tile, four waves) marches kRepackLeg iterations, then the rays still marching -- a minority -- are compacted through LDS
-// into as few waves as hold them (state = position and direction, 24 bytes + the pixel's place in the tile; the one-cell
-// cache is simply refetched) and only those waves run the remaining iterations.  A ray's arithmetic does not know which lane
-// runs it: same operations, same order, same bits as raymarch_kernel (tests compare the two on every batch).
-// No aux record, no normal: the hand-written loop over the distance (MODE 2) or y-pair (MODE 3) volume only.
-constexpr int kRepackLeg = 32;
-
-__device__ __forceinline__ void repack_finish(const RaymarchArgs& a, const sdfv_camera& cam, const Tex& tex0, const Tex& tex1,
-                                              bool write, int status, V3 ray_pos, uint64_t out_index) {
-    float4 rgba = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float frag_depth = 1.0f;
-    if (status == 1) {
-        const float4 raw0 = sample_rgba<true, 2, true>(a, tex0, ray_pos);
-        V3 pos1 = ray_pos;
-        asm volatile("" : "+v"(pos1.x) : "v"(raw0.x), "v"(raw0.y), "v"(raw0.z), "v"(raw0.w));  // one texture's gathers at a time
-        const float4 raw1 = sample_rgba<true, 2, true>(a, tex1, pos1);
-        rgba = shade(a, raw0, raw1);
-        if (a.depth) {
-            const float* m = cam.bvp;
-            const float hz = m[2] * ray_pos.x + m[6] * ray_pos.y + m[10] * ray_pos.z + m[14];
-            const float hw = m[3] * ray_pos.x + m[7] * ray_pos.y + m[11] * ray_pos.z + m[15];
-            frag_depth = hz / hw;
-        }
-    }
-    if (write) {
-        store_rgba(a.rgba + out_index, rgba);
-        if (a.depth) a.depth[out_index] = frag_depth;
-    }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_repack_kernel(RaymarchArgs a) {
-    __shared__ float4 s_pos[256];  // xyz + the pixel's place in the tile (bits)
-    __shared__ float4 s_dir[256];
-    __shared__ uint32_t s_count;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t bx = blockIdx.x, by = blockIdx.y, cam_idx = blockIdx.z;  // launch order (what batches use)
-    const uint32_t tx = (wave & 1) * 8 + (lane & 7), ty = (wave >> 1) * 8 + (lane >> 3);
-    const uint32_t px = bx * 16 + tx, row = by * 16 + ty, py = a.y0 + row;
-    const bool in_image = px < a.width && py < a.y1;
-    const sdfv_camera& cam = a.cameras[cam_idx];
-    const uint64_t plane = (uint64_t)cam_idx * (a.y1 - a.y0);
-    const uint64_t out_index = (plane + row) * a.width + px;
-    if (threadIdx.x == 0) s_count = 0;
-    __syncthreads();
-
-    const Tex tex0{a.tex0, (int)a.rp.tex_size[0], (int)a.rp.tex_size[1], (int)a.rp.tex_size[2]};
-    const Tex tex1{a.tex1, tex0.w, tex0.h, tex0.d};
-    const float* vol = MODE == 3 ? a.pairs : a.dist;
-    constexpr int STRIDE = MODE == 3 ? 2 : 1;
-    const V3 eye = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
-    const V3 d_raw = pixel_ray_raw(a, cam, px, py);
-    bool maybe;  // the conservative tile cull of raymarch_kernel: waves that miss the box skip the exact test's divisions
-    {
-        const V3 m = sub(eye, mk(a.cull_center[0], a.cull_center[1], a.cull_center[2]));
-        const float dd = d_raw.x * d_raw.x + d_raw.y * d_raw.y + d_raw.z * d_raw.z;
-        const float mm = m.x * m.x + m.y * m.y + m.z * m.z;
-        const float md = m.x * d_raw.x + m.y * d_raw.y + m.z * d_raw.z;
-        const float r2 = a.cull_radius2;
-        const bool miss = mm > r2 && (md >= 0.0f || mm * dd - md * md > r2 * dd);
-        maybe = __ballot(in_image && !miss) != 0ull;
-    }
-    V3 ray_pos = mk(0.0f, 0.0f, 0.0f), ray_dir = mk(0.0f, 0.0f, 1.0f);
-    bool covered = false;
-    int status = 0, steps = 0, iterations = 0;
-    float t_unused = 0.0f;
-    if (maybe) {  // wave-uniform
-        V3 ray_origin;
-        covered = box_fragment_ray(a, eye, d_raw, in_image, ray_origin, ray_dir);
-        ray_pos = ray_origin;
-        status = covered ? -1 : 0;
-        march_asm<true, STRIDE, false>(a, vol, tex0, ray_dir, covered, ray_pos, t_unused, status, steps, iterations, kRepackLeg);
-    }
-    // first leg done: a covered lane either knows how its ray ended (hit 1 / left the box -2) or is still marching (-1)
-    const bool survivor = covered && status == -1;
-    const unsigned long long sm = __ballot(survivor);
-    if (sm != 0ull) {  // wave-uniform
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&s_count, (uint32_t)__popcll(sm));
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (survivor) {
-            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
-            s_pos[slot] = make_float4(ray_pos.x, ray_pos.y, ray_pos.z, __uint_as_float(tx | (ty << 4)));
-            s_dir[slot] = make_float4(ray_dir.x, ray_dir.y, ray_dir.z, 0.0f);
-        }
-    }
-    // the pixels whose rays have ended (and those off the box) are this lane's to write; a survivor's pixel is written by
-    // whoever finishes its ray
-    repack_finish(a, cam, tex0, tex1, in_image && !survivor, covered ? status : 0, ray_pos, out_index);
-    __syncthreads();
-    const uint32_t total = s_count;
-    if (threadIdx.x >= total) return;  // whole waves beyond the survivors leave; no barrier follows
-    const float4 sp = s_pos[threadIdx.x], sd = s_dir[threadIdx.x];
-    const uint32_t place = __float_as_uint(sp.w);
-    V3 pos2 = mk(sp.x, sp.y, sp.z);
-    int status2 = -1;
-    march_asm<true, STRIDE, false>(a, vol, tex0, mk(sd.x, sd.y, sd.z), true, pos2, t_unused, status2, steps, iterations, 255 - kRepackLeg);
-    const uint64_t out2 = (plane + by * 16 + (place >> 4)) * a.width + bx * 16 + (place & 15u);
-    repack_finish(a, cam, tex0, tex1, true, status2, pos2, out2);
 }
 
 // ---- march over a z-slab: the grid stays sharded across GPUs and rays are handed between ranks ----------------
@@ -1439,14 +1332,7 @@ static hipError_t launch_raymarch_grid(const RaymarchArgs& a, dim3 grid, hipStre
         const uint64_t texels = (uint64_t)a.rp.tex_size[0] * a.rp.tex_size[1] * a.rp.tex_size[2];
         const bool pairs_ok = a.pairs && a.pow2_extent && a.pow2_size && a.symmetric_box && a.asm_loop && a.rp.tex_size[0] >= 2 &&
                               texels <= (1ull << 28);
-        const bool asm_ok = a.pow2_extent && a.pow2_size && a.symmetric_box && a.asm_loop && a.rp.tex_size[0] >= 2;
-        const bool repack = a.n_cameras > 1 && !a.no_repack && !a.aux && !a.compute_normal && a.group_shift == 0 && asm_ok &&
-                            (pairs_ok || (a.dist && texels <= (1ull << 30)));
-        if (repack) {
-            // batches of cameras: two legs with the surviving rays repacked in between (raymarch_repack_kernel)
-            if (pairs_ok) hipLaunchKernelGGL(raymarch_repack_kernel<3>, grid, dim3(256), SDFV_RM_LDS(a), stream, a);
-            else hipLaunchKernelGGL(raymarch_repack_kernel<2>, grid, dim3(256), SDFV_RM_LDS(a), stream, a);
-        } else if (pairs_ok) {
+        if (pairs_ok) {
             if (a.aux) hipLaunchKernelGGL((raymarch_kernel<3, true, 2, true, true, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
             else if (a.compute_normal)
                 hipLaunchKernelGGL((raymarch_kernel<3, true, 2, true, false, true, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);

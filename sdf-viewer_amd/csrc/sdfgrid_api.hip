@@ -259,7 +259,6 @@ void derive_raymarch_args(const sdfv_render_params* rp, sdfv::RaymarchArgs& a) {
     if (!(a.cull_radius2 > 0.0f) || !std::isfinite(a.cull_radius2)) a.cull_radius2 = INFINITY;  // never cull
     a.asm_loop = (off & SDFV_RM_NO_ASM_LOOP) ? 0u : 1u;
     a.no_interior_fetch = (off & SDFV_RM_NO_INTERIOR_FETCH) ? 1u : 0u;
-    a.no_repack = (off & SDFV_RM_NO_REPACK) ? 1u : 0u;
     a.cube_box = (a.symmetric_box && rp->bounds_max[0] == rp->bounds_max[1] && rp->bounds_max[1] == rp->bounds_max[2]) ? 1u : 0u;
     if (off & SDFV_RM_NO_SYMMETRIC) a.symmetric_box = 0;
     if (off & SDFV_RM_NO_POW2_SIZE) a.pow2_size = 0;
@@ -410,7 +409,7 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             return SDFV_OK;
         case SDFV_OPT_RAYMARCH_DISABLE:
             if (value & ~(uint64_t)(SDFV_RM_NO_FAST_INDEX | SDFV_RM_NO_POW2_EXTENT | SDFV_RM_NO_POW2_SIZE | SDFV_RM_NO_SYMMETRIC |
-                                     SDFV_RM_NO_ASM_LOOP | SDFV_RM_NO_INTERIOR_FETCH | SDFV_RM_NO_REPACK)) break;
+                                     SDFV_RM_NO_ASM_LOOP | SDFV_RM_NO_INTERIOR_FETCH)) break;
             g_options.raymarch_disable = (uint32_t)value;
             return SDFV_OK;
         case SDFV_OPT_RAYMARCH_KEEP_NORMAL:

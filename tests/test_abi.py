@@ -53,7 +53,7 @@ def test_options_are_explicit_and_the_library_reads_no_environment(pkg):
     assert pkg.get_option(K.OPT_RAYMARCH_WAVES_PER_SIMD) == 0
     assert pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_WAVES_PER_SIMD, 1) == -1 and pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_WAVES_PER_SIMD, 8) == -1
     assert pkg.lib.sdfv_set_option(K.OPT_FILL_FORM, 3) == -1
-    assert pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_DISABLE, 128) == -1
+    assert pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_DISABLE, 64) == -1
     assert pkg.lib.sdfv_set_option(77, 0) == -1 and b"unknown option" in pkg.lib.sdfv_last_error()
     # the wave-timing stamps exist only in the tuning build
     assert pkg.lib.sdfv_set_option(K.OPT_TUNING_WAVE_TIMING, 4096) == -1

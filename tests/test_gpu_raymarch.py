@@ -181,42 +181,6 @@ def test_multi_camera_batch_equals_single(pkg, oracle):
     assert np.abs(batch[18].cpu().numpy() - want).max() <= RGBA_TOL
 
 
-@pytest.mark.parametrize("dims,size", [((64, 64, 64), (400, 300)), ((32, 32, 32), (333, 217)), ((128, 64, 32), (160, 120))])
-def test_batches_march_in_two_legs_with_the_survivors_repacked(pkg, oracle, dims, size):
-    """raymarch_repack_kernel (what a batch of cameras runs over the distance / y-pair volume): the rays still marching after
-    the first leg are compacted through LDS into fewer waves.  Same bits as the one-leg kernel (SDFV_RM_NO_REPACK) and as
-    per-camera single frames, RGBA and depth, cameras outside / inside / face-on, row bands, more than one launch's worth."""
-    K = pkg._capi
-    W, H = size
-    bb = ((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)) if dims[0] == dims[1] == dims[2] else ((-2.0, -1.0, -0.5), (2.0, 1.0, 0.5))
-    g = pkg.make_grid(dims, *bb)
-    t0, t1 = pkg.alloc_textures(g)
-    dist = torch.empty(tuple(t0.shape[:-1]), dtype=torch.float32, device="cuda")
-    pkg.fill_grid(pkg.default_params(), g, t0, t1, dist=dist)
-    pairs = pkg.commit_pairs(g, dist)
-    rp = pkg.default_render_params(g)
-    cams = pkg.orbit_cameras(17, aspect=W / H) + [pkg.camera_look_at(eye=(0.2, 0.1, 0.3), target=(1.0, 0.5, -1.0), aspect=W / H),
-                                                  pkg.camera_look_at(eye=(0.0, 0.0, 5.0), aspect=W / H),
-                                                  pkg.camera_look_at(eye=(1.2, 1.5, 2.4), aspect=W / H)]
-    for use_pairs in (None, pairs):
-        for y0, y1 in ((0, H), (16, H - 7)):
-            with pkg.options({K.OPT_RAYMARCH_DISABLE: K.RM_NO_REPACK}):
-                want, want_d = pkg.raymarch(rp, t0, t1, cams, W, H, y0=y0, y1=y1, dist=dist, pairs=use_pairs, want_depth=True)
-            got, got_d = pkg.raymarch(rp, t0, t1, cams, W, H, y0=y0, y1=y1, dist=dist, pairs=use_pairs, want_depth=True)
-            plain = pkg.raymarch(rp, t0, t1, cams, W, H, y0=y0, y1=y1, dist=dist, pairs=use_pairs)
-            torch.cuda.synchronize()
-            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (use_pairs is not None, y0, y1)
-            assert torch.equal(got_d.view(torch.int32), want_d.view(torch.int32))
-            assert torch.equal(plain.view(torch.int32), want.view(torch.int32))
-    single = pkg.raymarch(rp, t0, t1, cams[3], W, H, dist=dist)
-    assert torch.equal(single[0].view(torch.int32), got[3].view(torch.int32)) if (y0, y1) == (0, H) else True
-    full = pkg.raymarch(rp, t0, t1, cams, W, H, dist=dist)
-    for k in (0, 9, 17, 19):
-        one = pkg.raymarch(rp, t0, t1, cams[k], W, H, dist=dist)
-        assert torch.equal(one[0].view(torch.int32), full[k].view(torch.int32)), k
-    assert bool((full[..., 3] > 0).any())
-
-
 def test_1080p_properties_on_256_grid(pkg, oracle):
     """configs[1] at full size: rows split across launches are seamless, the image is deterministic,
     and a band of rows matches the oracle."""
