@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the batched raymarch (BASELINE.json config 5 shape on ONE GPU): n cameras x 1080p per call."""
 import importlib, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 pkg = importlib.import_module("sdf-viewer_amd")
 side, W, H = 256, 1920, 1080

@@ -2,7 +2,7 @@
 """What the part of the image that misses the box costs: the default frame, a frame with nothing covered (camera looking
 away), a plain memset of the image, and the rows that hold the box alone.  python tools/cull_cost.py"""
 import importlib, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 pkg = importlib.import_module("sdf-viewer_amd")
 side, W, H = 256, 1920, 1080

@@ -4,7 +4,7 @@ textures placed by alloc_textures(tuned=True), how does its rate depend on where
 python tools/dist_skew_sweep.py [side=512]"""
 import importlib, json, os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 pkg = importlib.import_module("sdf-viewer_amd")
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 prm = pkg.default_params(); g = pkg.make_grid((side,) * 3)

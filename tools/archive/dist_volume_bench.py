@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Raymarch with and without the compact distance volume (sdfv_commit_distance) at both bench workloads."""
 import importlib, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 pkg = importlib.import_module("sdf-viewer_amd")
 def timed(fn, reps=10):

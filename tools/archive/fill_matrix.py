@@ -3,7 +3,7 @@
 python tools/fill_matrix.py [side=512]"""
 import importlib, json, os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 pkg = importlib.import_module("sdf-viewer_amd"); K = pkg._capi
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 prm = pkg.default_params(); g = pkg.make_grid((side,) * 3)

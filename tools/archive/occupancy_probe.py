@@ -3,7 +3,7 @@
 frames and batches, one binary.  160 KB of LDS per CU, workgroups of 4 waves (one per SIMD): a w-th of it per workgroup
 allows w workgroups = w waves per SIMD (the register file allows 7).  python tools/occupancy_probe.py [side=256]"""
 import importlib, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 pkg = importlib.import_module("sdf-viewer_amd"); K = pkg._capi

@@ -2,7 +2,7 @@
 """Timing of the progressive path (sdfv_fill_grid_pass) on a 256^3 / 512^3 grid: every LoadingManager pass
 on a fresh grid, a no-op pass over a finished grid, and a changed_box refill."""
 import importlib, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 pkg = importlib.import_module("sdf-viewer_amd")
 

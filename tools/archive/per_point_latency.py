@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 pkg = importlib.import_module("sdf-viewer_amd")
 prm = pkg.default_params()
 for n in (1, 64, 1024, 4096):

@@ -4,7 +4,7 @@ frame yields every tile's longest ray (aux step counts); tiles at or above a thr
 following frames (SDFV_OPT_TUNING_PRIORITY_MAP).  An oracle for the decision, not a product feature.
 python tools/priority_map_probe.py [side=256]"""
 import importlib, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["SDFGRID_LIBRARY"] = os.path.join(ROOT, "sdf-viewer_amd", "libsdfgrid_tuning.so")
 import torch

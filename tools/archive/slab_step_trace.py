@@ -10,7 +10,7 @@ import sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("sdf-viewer_amd")
 par = importlib.import_module("sdf-viewer_amd.parallel")

@@ -4,7 +4,7 @@ counts); following frames render the tiles in orders built from them (SDFV_OPT_T
 first with the XCDs dealt round-robin (position L -> XCD L % 8 anyway), and the reverse as a control.
 python tools/tile_order_probe.py [side=256]   (256: 1080p, 512: 4K)"""
 import importlib, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["SDFGRID_LIBRARY"] = os.path.join(ROOT, "sdf-viewer_amd", "libsdfgrid_tuning.so")
 import torch
