@@ -44,7 +44,7 @@ __device__ __forceinline__ void store_texel(float4* dst, const float4& v) {
 
 // TX = lanes along x per row segment (64, 128 or 256); a workgroup owns TY = 256 / TX consecutive rows x TX
 // voxels and does ONE voxel per thread, so the grid walks memory front to back in dispatch order exactly
-// like a memset.  Measured on MI355X (profiles/r01_v1_fill_sweep.json, r01_v2_fill_sweep.json): persistent
+// like a memset.  Measured on MI355X (profiles/r01/v1_fill_sweep.json, r01/v2_fill_sweep.json): persistent
 // strided workgroups lose 25-40 % of the store rate and 2/4/8 rows per thread lose 7/11/14 %.
 // Boundary-first order: logical workgroup `b` of a launch -> the workgroup of the memory-order grid whose voxels it
 // fills.  The first order_lead * bps workgroups are the slab's leading slices, the next bps its LAST slice, then the

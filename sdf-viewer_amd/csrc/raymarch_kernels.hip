@@ -273,7 +273,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 // a lone wave issues one instruction every ~6-11 cycles whatever the instruction is.  So the loop is priced per
 // INSTRUCTION, and hipcc's lowering of either C++ form (the predicated march_fast above: 78 per iteration; the same loop
 // written as a plain divergent loop with breaks: ~83, the structurizer's mask bookkeeping -- tried and removed) leaves
-// half of the cost on the table.  This is the same loop written by hand (profiles/r02_raymarch_loop_isa.md):
+// half of the cost on the table.  This is the same loop written by hand (profiles/r02/raymarch_loop_isa.md):
 //   * the set of marching lanes IS the EXEC mask: v_cmpx removes the lanes that stop (out-of-bounds test, hit test), so
 //     nothing is predicated and no mask register is maintained; s_cbranch_execz is the wave-level early exit;
 //   * the one-cell cache is tested on the interpolation weights themselves: a = u - floor_cached(u) is the weight if the

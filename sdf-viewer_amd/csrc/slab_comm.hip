@@ -273,7 +273,7 @@ int sdfv_slab_comm_create(const unsigned char id[SDFV_COMM_ID_BYTES], int rank, 
     }
     // Highest priority: the exchange is short and the neighbours wait for it; HIP also keeps streams of different
     // priorities on different hardware queues, without which the exchange and the interior fill (both enqueued
-    // back to back) land on one queue and run one after the other (profiles/r01_slab_step_timeline.txt).
+    // back to back) land on one queue and run one after the other (profiles/r01/slab_step_timeline.txt).
     int prio_low = 0, prio_high = 0;
     e = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, prio_high);

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Regenerates the listings and per-iteration instruction counts of profiles/r02_raymarch_loop_isa.md from the current
+"""Regenerates the listings and per-iteration instruction counts of profiles/r02/raymarch_loop_isa.md from the current
 sources: compiles raymarch_kernels.hip to gfx950 assembly (hipcc -S, no GPU needed) and extracts (a) the hand-written
 march loop = the ;;#ASMSTART..ASMEND block of raymarch_kernel<2, true, 2, true, false, ASM=true> (cubic-box variant) and
 (b) hipcc's loop of the same kernel with ASM=false (the C++ march_fast).  Prints a JSON summary; --listing writes
-the two listings to profiles/r02_raymarch_loop_{hand,hipcc}.s"""
+the two listings to profiles/r02/raymarch_loop_{hand,hipcc}.s"""
 import json
 import os
 import re
@@ -93,8 +93,8 @@ def main():
             [int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1)), int(re.search(r"\.sgpr_count:\s+(\d+)", meta).group(1))]
     print(json.dumps(res, indent=1))
     if "--listing" in sys.argv:
-        open(os.path.join(ROOT, "profiles", "r02_raymarch_loop_hand.s"), "w").write("\n".join(hand) + "\n")
-        open(os.path.join(ROOT, "profiles", "r02_raymarch_loop_hipcc.s"), "w").write("\n".join(l.rstrip() for l in comp) + "\n")
+        open(os.path.join(ROOT, "profiles", "r02/raymarch_loop_hand.s"), "w").write("\n".join(hand) + "\n")
+        open(os.path.join(ROOT, "profiles", "r02/raymarch_loop_hipcc.s"), "w").write("\n".join(l.rstrip() for l in comp) + "\n")
 
 
 if __name__ == "__main__":

@@ -2,7 +2,7 @@
 """Tuning: per-wave start/end cycle stamps of the raymarch kernel (option SDFV_OPT_TUNING_WAVE_TIMING of the TUNING
 build, `make -C sdf-viewer_amd/csrc tuning`; the product library has no such code).  Prints a summary and, with
 --json PATH, writes the histogram of wave durations / iterations of the default 1080p frame over the 256^3 grid.
-Usage: python tools/wave_timing.py [--dist] [--json profiles/r02_wave_timing_1080p.json]"""
+Usage: python tools/wave_timing.py [--dist] [--json profiles/r02/wave_timing_1080p.json]"""
 import importlib
 import json
 import os
