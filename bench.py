@@ -478,31 +478,55 @@ class NativeStdoutToStderr:
         return False
 
 
+# The line as far as it is known: set once the two timed regions of the contract are in (value, value_rays, ms_per_step,
+# roofline), then completed extra by extra.  Should an EXTRA (self-check, config 4 block, batch, ...) hang on first contact with
+# real xGMI, the watchdog prints what is here instead of losing the measurement with it.
+PARTIAL = {"line": None, "since": None, "redirect": None}
+
+
 def main():
-    # A collective that never completes (a rank lost, P2P unavailable) must not hang the job for ever: after
-    # SDFV_BENCH_WATCHDOG_S seconds (default 900) a watchdog thread dumps every thread's stack to stderr and exits.
+    # A collective that never completes (a rank lost, P2P unavailable) must not hang the job for ever.  A watchdog thread
+    # fires after SDFV_BENCH_WATCHDOG_S seconds in total (default 900), or SDFV_BENCH_EXTRAS_S (default 420) after the
+    # contract's measurement was complete: it names the collective stage this rank is stuck in (parallel.enter_stage: every
+    # blocking stage of the multi-GPU path registers itself first), dumps every thread's stack, and -- when the measurement
+    # is already in -- rank 0 prints the line with what it has ("watchdog": the stage) and every rank exits 0; otherwise 3.
     import faulthandler
     import threading
     watchdog = float(os.environ.get("SDFV_BENCH_WATCHDOG_S", "900"))
+    extras = float(os.environ.get("SDFV_BENCH_EXTRAS_S", "420"))
     done = threading.Event()
+    t_start = time.monotonic()
 
     def bark():
-        # names the collective stage this rank is stuck in (parallel.enter_stage: every blocking stage of the multi-GPU
-        # path registers itself first), then every thread's stack, then exits: a hang on real xGMI is attributable in one run
-        if done.wait(watchdog):
-            return
-        try:
-            par = sys.modules.get("sdf-viewer_amd.parallel")
-            name, age, count = par.current_stage() if par else ("(parallel not imported)", 0.0, 0)
-            print(f"[bench rank {os.environ.get('RANK', '0')}/{os.environ.get('WORLD_SIZE', '1')}] WATCHDOG after {watchdog:.0f} s: "
-                  f"stuck in stage #{count} '{name}' for {age:.1f} s", file=sys.stderr, flush=True)
-            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
-        finally:
-            os._exit(3)
+        while not done.wait(1.0):
+            now = time.monotonic()
+            late = now - t_start > watchdog
+            stuck_in_extras = PARTIAL["since"] is not None and now - PARTIAL["since"] > extras
+            if not (late or stuck_in_extras):
+                continue
+            code = 3
+            try:
+                par = sys.modules.get("sdf-viewer_amd.parallel")
+                name, age, count = par.current_stage() if par else ("(parallel not imported)", 0.0, 0)
+                rank = os.environ.get("RANK", "0")
+                print(f"[bench rank {rank}/{os.environ.get('WORLD_SIZE', '1')}] WATCHDOG after {now - t_start:.0f} s: "
+                      f"stuck in stage #{count} '{name}' for {age:.1f} s", file=sys.stderr, flush=True)
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                if PARTIAL["line"] is not None:
+                    code = 0
+                    if rank == "0":
+                        line = dict(PARTIAL["line"])
+                        line["watchdog"] = f"an extra did not finish: stuck in stage '{name}' for {age:.0f} s; the line carries what was measured before it"
+                        if PARTIAL["redirect"] is not None:
+                            PARTIAL["redirect"].restore()
+                        print(json.dumps(line), flush=True)
+            finally:
+                os._exit(code)
 
     if watchdog > 0:
         threading.Thread(target=bark, daemon=True).start()
     with NativeStdoutToStderr() as redirect:
+        PARTIAL["redirect"] = redirect
         run(redirect)
     done.set()
 
@@ -825,6 +849,45 @@ def run(redirect):
         out["rccl_rank_of_rank0"] = None if comm is None else comm.rccl_ranks[0]
         out["torch_world_size"] = dist.get_world_size()
 
+    # ---------------- the contract's measurement is complete: the line exists from here on ----------------
+    line = {
+        "metric": "Mvoxels/s grid fill + Mrays/s sphere-trace @1080p, demo SDF",
+        "metric_note": "the metric is a pair: value = Mvoxels/s of the grid fill, value_rays = Mrays/s of the sphere-trace",
+        "value": round(fill_mvox, 1),
+        "unit": "Mvoxels/s",
+        "value_rays": round(march_mrays, 1),
+        "unit_rays": "Mrays/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": Wm,
+        "prewarm_ms": args.prewarm_ms,
+        "texture_placement": placement_note(args, slab),
+        "ms_per_step": round(fill_ms + march_ms, 4),
+        "ms_per_step_fill": round(fill_ms, 4),
+        "ms_per_step_raymarch": round(march_ms, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (demo SDF defaults on the integer lattice, fixed cameras; no RNG)",
+        "sharded_fill_verified": None,
+        "sharded_march": None,
+        "loopback": True if loopback else None,
+        "backend": None if not multi else ("rccl" if backend == "nccl" else backend + " (test only)"),
+        "halo_transport": None if not multi else {"rccl": "sdfv_slab_fill_step (library RCCL communicator)",
+                                                   "torch": "torch.distributed batch_isend_irecv"}[transport],
+        "config": {"workload": wl["name"], "grid_global": list(gdims), "voxels_per_gpu": voxels_per_rank,
+                   "image": [W, H], "cameras_per_gpu": len(my_cams),
+                   "weak_geometry": None if not multi else args.weak_geometry,
+                   "parallelism": "single GPU" if world == 1 else f"z-slab x{world} + 1-voxel RCCL halo; 1 camera/GPU"},
+        "keys_note": "N = 1 and N > 1 lines carry the same contract keys; N > 1 adds rccl_ranks, torch_world_size, config4",
+    }
+    line.update(out)
+    line["raymarch_kernel_ms"] = round(march_ev, 4)
+    for key in ("batch_raymarch", "target_512", "progressive", "halo_loopback", "config4"):
+        line[key] = None
+    PARTIAL["line"], PARTIAL["since"] = line, time.monotonic()
+
     # ---------------- N = 1 extras ----------------
     target_512 = None
     halo_loopback = None
@@ -882,6 +945,7 @@ def run(redirect):
         except Exception as e:  # noqa: BLE001 -- an extra, never fatal
             halo_loopback = {"error": f"{type(e).__name__}: {e}"}
 
+    line["target_512"], line["halo_loopback"] = target_512, halo_loopback  # (the watchdog prints the line as it stands)
     progressive = None
     if not multi and not args.no_batch and not args.no_progressive:
         try:
@@ -889,6 +953,7 @@ def run(redirect):
         except Exception as e:  # noqa: BLE001 -- an extra, never fatal
             progressive = {"error": f"{type(e).__name__}: {e}"}
 
+    line["progressive"] = progressive
     # ---------------- config 5 shape: a batch of 64 cameras, split over the ranks (extra, not `value`) ----------------
     n_batch = 64
     batch_report = None
@@ -945,6 +1010,7 @@ def run(redirect):
         # VALU instruction) -- the roofline that actually bounds it (counts: profiles/raymarch_batch_valu.json)
         batch_report["roofline_raymarch_batch"] = batch_valu_roofline(args.workload, world, batch_report["ms_per_batch"])
 
+    line["batch_raymarch"] = batch_report
     # ---------------- N > 1 extras: BASELINE config 4's geometry, and the self-checks ----------------
     config4 = None
     verified = None
@@ -977,6 +1043,7 @@ def run(redirect):
                 del cslab, cdist
             except Exception as e:  # noqa: BLE001 -- an extra, never fatal
                 config4 = {"error": f"{type(e).__name__}: {e}"}
+        line["config4"] = config4
         # outside the timed regions: the gathered slabs must equal a dense local fill of the global grid, and the
         # ghost slices must equal what the neighbour computed (= a local recompute: the SDF is analytic)
         if gdims[0] * gdims[1] * gdims[2] * 32 <= 8 << 30:
@@ -1036,46 +1103,10 @@ def run(redirect):
         else:
             verified = "skipped (global grid > 8 GiB)"
 
+    line.update({"sharded_fill_verified": verified, "sharded_march": sharded_march, "batch_raymarch": batch_report,
+                 "target_512": target_512, "progressive": progressive, "halo_loopback": halo_loopback, "config4": config4})
+    PARTIAL["since"] = None  # the extras are done (the CPU baseline below only uses this process's host cores)
     if rank == 0:
-        line = {
-            "metric": "Mvoxels/s grid fill + Mrays/s sphere-trace @1080p, demo SDF",
-            "metric_note": "the metric is a pair: value = Mvoxels/s of the grid fill, value_rays = Mrays/s of the sphere-trace",
-            "value": round(fill_mvox, 1),
-            "unit": "Mvoxels/s",
-            "value_rays": round(march_mrays, 1),
-            "unit_rays": "Mrays/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": Wm,
-            "prewarm_ms": args.prewarm_ms,
-            "texture_placement": placement_note(args, slab),
-            "ms_per_step": round(fill_ms + march_ms, 4),
-            "ms_per_step_fill": round(fill_ms, 4),
-            "ms_per_step_raymarch": round(march_ms, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic (demo SDF defaults on the integer lattice, fixed cameras; no RNG)",
-            "sharded_fill_verified": verified,
-            "sharded_march": sharded_march,
-            "loopback": True if loopback else None,
-            "backend": None if not multi else ("rccl" if backend == "nccl" else backend + " (test only)"),
-            "halo_transport": None if not multi else {"rccl": "sdfv_slab_fill_step (library RCCL communicator)",
-                                                       "torch": "torch.distributed batch_isend_irecv"}[transport],
-            "config": {"workload": wl["name"], "grid_global": list(gdims), "voxels_per_gpu": voxels_per_rank,
-                       "image": [W, H], "cameras_per_gpu": len(my_cams),
-                       "weak_geometry": None if not multi else args.weak_geometry,
-                       "parallelism": "single GPU" if world == 1 else f"z-slab x{world} + 1-voxel RCCL halo; 1 camera/GPU"},
-            "keys_note": "N = 1 and N > 1 lines carry the same contract keys; N > 1 adds rccl_ranks, torch_world_size, config4",
-        }
-        line.update(out)
-        line["raymarch_kernel_ms"] = round(march_ev, 4)
-        line["batch_raymarch"] = batch_report
-        line["target_512"] = target_512
-        line["progressive"] = progressive
-        line["halo_loopback"] = halo_loopback
-        line["config4"] = config4
         if not args.no_cpu_baseline and not multi:  # rank 0, N = 1 only
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_seconds)
         redirect.restore()

@@ -173,3 +173,20 @@ def test_slab_filler_auto_transport_with_distance_volume_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in results), results
+
+
+def test_watchdog_prints_the_measured_line_when_an_extra_hangs():
+    """First-contact insurance: once the contract's two timed regions are in, a hang in any EXTRA (self-check, config-4 block,
+    batch ...) must not lose them.  SDFV_BENCH_EXTRAS_S = 0.01 makes the watchdog fire inside the first extra: the process
+    exits 0 and its one JSON line carries value / value_rays / ms_per_step / roofline plus a "watchdog" note naming the stage."""
+    env = dict(os.environ, SDFV_BENCH_EXTRAS_S="0.01")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--workload", "64",
+           "--no-cpu-baseline", "--prewarm-ms", "5", "--per-step-samples", "2"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in CONTRACT_KEYS:
+        assert key in d, key
+    assert d["value"] > 0 and d["value_rays"] > 0 and "watchdog" in d and "WATCHDOG" in out.stderr
