@@ -40,6 +40,9 @@ sys.path.insert(0, ROOT)
 # one queue and the step runs 2.5x slower (265 us instead of 106 at 256^3, depending on creation order); with 8 every
 # order measured is fast.  Read by the HIP runtime at start-up, hence set before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's peer mapping fails (hipIpcGetMemHandle: invalid
+# argument).  Already exported on the GPU boxes; kept here for any environment the driver builds itself.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 FILL_BYTES_PER_VOXEL = 32  # tex0 16 B + tex1 16 B, store-only
