@@ -51,3 +51,10 @@ int extract_distance(const float* tex0, float* dist, size_t n, void* stream);
 int fill_boundary_slices(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* slab, float* o0, float* o1,
                          void* stream);
 }  // namespace sdfv
+
+// sdfv_raymarch_slab_round with a counter of the rays the round hands on (`leftover`, DEVICE or NULL): sdfv_slab_march passes
+// it in its last round, after which no ray may be in flight.  Not part of the ABI (hidden).
+extern "C" __attribute__((visibility("hidden"))) int sdfv_internal_raymarch_slab_round(
+    const sdfv_render_params* rp, const sdfv_grid* slab, uint32_t ghost_lo, uint32_t ghost_hi, const float* tex0, const float* tex1,
+    const sdfv_camera* camera, uint32_t width, uint32_t height, const void* in_lo, const void* in_hi, int first_round, float* rgba,
+    sdfv_march_aux* aux, void* out_down, void* out_up, uint32_t capacity, uint32_t* overflow, uint32_t* leftover, void* stream);

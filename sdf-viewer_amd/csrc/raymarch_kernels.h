@@ -71,6 +71,7 @@ struct SlabMarchArgs {
     uint32_t* count_down;          // rays in out_down / out_up (atomically appended)
     uint32_t* count_up;
     uint32_t* overflow;            // optional: set to 1 when a ray did not fit into `capacity`
+    uint32_t* leftover;            // optional: counts every ray this round hands on (the LAST round of a march: must stay 0)
     uint32_t capacity;             // entries each out list can hold
 };
 hipError_t launch_raymarch_slab(const RaymarchArgs& a, const SlabMarchArgs& s, hipStream_t stream);

@@ -1075,6 +1075,7 @@ __global__ __launch_bounds__(256) void raymarch_slab_kernel(RaymarchArgs a, Slab
             const int dir = k0c < (int)s.own_begin ? 0 : 1;
             const uint32_t at = atomicAdd(dir == 0 ? s.count_down : s.count_up, 1u);
             if (at >= s.capacity && s.overflow) *s.overflow = 1u;  // the caller's capacity was too small: the image is incomplete
+            if (s.leftover) atomicAdd(s.leftover, 1u);
             if (at < s.capacity) {
                 sdfv_ray_state st;
                 st.pixel = pixel;

@@ -1049,6 +1049,14 @@ int sdfv_raymarch_slab_round(const sdfv_render_params* rp, const sdfv_grid* slab
                              const float* tex0, const float* tex1, const sdfv_camera* camera, uint32_t width, uint32_t height,
                              const void* in_lo, const void* in_hi, int first_round, float* rgba, sdfv_march_aux* aux,
                              void* out_down, void* out_up, uint32_t capacity, uint32_t* overflow, void* stream) {
+    return sdfv_internal_raymarch_slab_round(rp, slab, ghost_lo, ghost_hi, tex0, tex1, camera, width, height, in_lo, in_hi,
+                                             first_round, rgba, aux, out_down, out_up, capacity, overflow, nullptr, stream);
+}
+
+__attribute__((visibility("hidden"))) int sdfv_internal_raymarch_slab_round(
+    const sdfv_render_params* rp, const sdfv_grid* slab, uint32_t ghost_lo, uint32_t ghost_hi, const float* tex0, const float* tex1,
+    const sdfv_camera* camera, uint32_t width, uint32_t height, const void* in_lo, const void* in_hi, int first_round, float* rgba,
+    sdfv_march_aux* aux, void* out_down, void* out_up, uint32_t capacity, uint32_t* overflow, uint32_t* leftover, void* stream) {
     if (!out_down || !out_up) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL ray buffer");
     if (((uintptr_t)in_lo | (uintptr_t)in_hi | (uintptr_t)out_down | (uintptr_t)out_up | (uintptr_t)overflow) & 3)
         return fail(SDFV_ERR_INVALID_ARGUMENT, "ray buffers must be 4-byte aligned");
@@ -1080,6 +1088,7 @@ int sdfv_raymarch_slab_round(const sdfv_render_params* rp, const sdfv_grid* slab
     s.count_down = reinterpret_cast<uint32_t*>(out_down);
     s.count_up = reinterpret_cast<uint32_t*>(out_up);
     s.overflow = overflow;
+    s.leftover = leftover;
     s.capacity = capacity;
     SDFV_HIP(sdfv::launch_raymarch_slab(a, s, (hipStream_t)stream));
     return SDFV_OK;

@@ -481,9 +481,10 @@ int sdfv_slab_march(sdfv_slab_comm* c, const sdfv_render_params* rp, const sdfv_
     const bool lo = c->rank > 0, hi = c->rank < c->world - 1;
     SDFV_HIPC(hipMemsetAsync(status, 0, 2 * sizeof(uint32_t), st));
     for (int round = 0; round < c->world; ++round) {
-        if (int rc = sdfv_raymarch_slab_round(rp, slab, c->ghost_lo(), c->ghost_hi(), tex0, tex1, camera, width, height,
-                                              round == 0 ? nullptr : (lo ? in_lo : nullptr), round == 0 ? nullptr : (hi ? in_hi : nullptr),
-                                              round == 0, rgba, aux, out_down, out_up, capacity, status, st))
+        const bool last = round == c->world - 1;
+        if (int rc = sdfv_internal_raymarch_slab_round(rp, slab, c->ghost_lo(), c->ghost_hi(), tex0, tex1, camera, width, height,
+                                               round == 0 ? nullptr : (lo ? in_lo : nullptr), round == 0 ? nullptr : (hi ? in_hi : nullptr),
+                                               round == 0, rgba, aux, out_down, out_up, capacity, status, last ? status + 1 : nullptr, st))
             return rc;
         if (round == c->world - 1 || (!lo && !hi)) break;  // z is monotonic along a ray: after `world` rounds every ray has ended
         SDFV_RCCL(lib, GroupStart());
@@ -500,8 +501,7 @@ int sdfv_slab_march(sdfv_slab_comm* c, const sdfv_render_params* rp, const sdfv_
         if (first_error != kNcclSuccess)
             return sdfv::set_error(SDFV_ERR_COMM, "RCCL ray exchange: %s", lib->GetErrorString(first_error));
     }
-    // status[1]: rays still waiting in this rank's outgoing lists after the last round (0 unless a list overflowed earlier)
-    SDFV_HIPC(hipMemcpyAsync(status + 1, out_down, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    // status[1] (counted by the last round's kernel): rays handed on after `world` rounds -- none, unless a list overflowed
     if (flags & SDFV_MARCH_MERGE) {
         // every pixel was written by exactly one rank and is all-zero bits elsewhere: the integer sum of the bit patterns IS
         // the image (a float sum would turn -0.0 into +0.0; RCCL has no bitwise OR)
