@@ -548,8 +548,10 @@ hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& pass, const FillL
     const uint64_t n = (uint64_t)p.nx * p.ny * p.nz;
     if (n == 0) return hipSuccess;
     const bool dflt = is_default_config(a);
-    if (p.all_required && p.step == 1) {
-        // every voxel of the slab is rewritten and nothing needs reading: that IS the dense fill (+ its distance volume)
+    if (p.all_required && p.step == 1 && (p.dist || p.fresh)) {
+        // every voxel of the slab is rewritten and nothing needs reading: that IS the dense fill (+ its distance volume).
+        // (The dense kernel writes tex1.a = AIR_DIST: what a fresh grid holds and what the volume's contract guarantees;
+        // without either the general kernel below carries the stored alpha through, as update() leaves it alone.)
         FillArgs d = a;
         d.dist = p.dist;
         return launch_fill_dense(d, dense_cfg, stream);

@@ -487,3 +487,24 @@ def test_full_size_progressive_load_states(pkg, oracle):
         pkg.fill_grid_pass(prm, g, step, t0, t1, dist=dist)
     torch.cuda.synchronize()
     assert torch.equal(t0, d0) and torch.equal(t1, d1) and torch.equal(dist, d0[..., 0])
+
+
+def test_store_only_passes_leave_a_foreign_tex1_alpha_alone(pkg, oracle):
+    """update() never writes tex1.a (scene/sdf/mod.rs:205-208).  Grids of this library hold AIR_DIST there, but a pass WITHOUT
+    the distance volume makes no such assumption: also on the store-only paths (changed box containing the grid, same-load
+    flag) a value the caller put into tex1.a survives, at every step."""
+    K = pkg._capi
+    dims = (32, 16, 12)
+    g = pkg.make_grid(dims)
+    prm, edited = pkg.default_params(), pkg.default_params(sphere_radius=0.7)
+    whole = (-1.0, -1.0, -1.0, 1.0, 1.0, 1.0)
+    for kwargs in (dict(changed_box=whole), dict(flags=K.PASS_SAME_LOAD)):
+        t0, t1 = gpu_fill(pkg, prm, dims)
+        t1[..., 3] = 42.0
+        for step in (4, 2, 1):
+            pkg.fill_grid_pass(edited, g, step, t0, t1, **kwargs)
+        torch.cuda.synchronize()
+        r0, r1 = oracle.fill_dense(oracle.params_from(edited), dims)
+        assert_bits_equal(t0, r0)
+        assert bool((t1[..., 3] == 42.0).all())
+        np.testing.assert_array_equal(t1.cpu().numpy()[..., :3].view(np.uint32), r1[..., :3].view(np.uint32))
