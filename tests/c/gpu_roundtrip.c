@@ -1,6 +1,9 @@
 /* gpu_roundtrip.c -- the hot path driven from plain C with nothing but the HIP runtime API for memory: what a host in
  * any language with a C FFI does.  hipMalloc -> sdfv_fill_grid_commit -> sdfv_raymarch_accel -> hipMemcpy back; the raw
- * results go to <prefix>.tex0.f32 / .tex1.f32 / .rgba.f32 for tests/test_gpu_host.py to compare with the oracle. */
+ * results go to <prefix>.tex0.f32 / .tex1.f32 / .rgba.f32 for tests/test_gpu_host.py to compare with the oracle.
+ * Then the reference's default 2-pass progressive load as its LoadingManager would drive it (sdfv_grid_init, two
+ * sdfv_fill_grid_pass_ex with the flags a host knows) into a second pair of textures, the y-pair volume of a viewer
+ * (sdfv_commit_pairs) and a frame over it (sdfv_raymarch_pairs): <prefix>.p_tex0.f32 / .p_tex1.f32 / .p_rgba.f32. */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
@@ -55,6 +58,28 @@ int main(int argc, char **argv) {
     if (dump(prefix, "tex0.f32", tex0, tex_bytes) || dump(prefix, "tex1.f32", tex1, tex_bytes) ||
         dump(prefix, "rgba.f32", rgba, (size_t)W * H * 16))
         return 1;
+    {
+        float *p0 = NULL, *p1 = NULL, *pd = NULL, *pairs = NULL;
+        if (hipMalloc((void **)&p0, tex_bytes) != hipSuccess || hipMalloc((void **)&p1, tex_bytes) != hipSuccess ||
+            hipMalloc((void **)&pd, voxels * 4) != hipSuccess || hipMalloc((void **)&pairs, voxels * 8) != hipSuccess)
+            return 1;
+        if (sdfv_grid_init(&grid, p0, p1, NULL) != SDFV_OK) DIE("grid_init");
+        if (sdfv_commit_distance(&grid, p0, pd, NULL) != SDFV_OK) DIE("commit_distance");
+        if (sdfv_fill_grid_pass_ex(&prm, SDFV_SDF_DEMO, &grid, 2, NULL, p0, p1, pd, SDFV_PASS_FRESH_GRID | SDFV_PASS_SAME_LOAD, NULL) != SDFV_OK)
+            DIE("pass step 2");
+        if (sdfv_fill_grid_pass_ex(&prm, SDFV_SDF_DEMO, &grid, 1, NULL, p0, p1, pd, SDFV_PASS_SAME_LOAD, NULL) != SDFV_OK)
+            DIE("pass step 1");
+        if (sdfv_commit_pairs(&grid, pd, pairs, NULL) != SDFV_OK) DIE("commit_pairs");
+        if (sdfv_raymarch_pairs(&rp, p0, p1, pd, pairs, &cam, 1, W, H, 0, H, rgba, NULL, NULL, NULL) != SDFV_OK) DIE("raymarch_pairs");
+        if (hipDeviceSynchronize() != hipSuccess) return 1;
+        if (dump(prefix, "p_tex0.f32", p0, tex_bytes) || dump(prefix, "p_tex1.f32", p1, tex_bytes) ||
+            dump(prefix, "p_rgba.f32", rgba, (size_t)W * H * 16))
+            return 1;
+        hipFree(p0);
+        hipFree(p1);
+        hipFree(pd);
+        hipFree(pairs);
+    }
     hipFree(tex0);
     hipFree(tex1);
     hipFree(dist);

@@ -361,3 +361,7 @@ def test_plain_c_host_drives_the_hot_path(oracle, tmp_path):
                               want_aux=False)
     got = np.fromfile(prefix + ".rgba.f32", np.float32).reshape(H, W, 4)
     assert np.abs(got - want).max() <= 1e-4 and (got[..., 3] > 0).any()
+    # the flagged 2-pass progressive load ends in the same textures; the frame over the y-pair volume has the same bits
+    for name, ref in (("p_tex0", t0), ("p_tex1", t1), ("p_rgba", got)):
+        arr = np.fromfile(prefix + f".{name}.f32", np.float32).reshape(ref.shape)
+        np.testing.assert_array_equal(arr.view(np.uint32), ref.view(np.uint32), err_msg=name)
