@@ -362,6 +362,27 @@ int sdfv_raymarch_pairs(const sdfv_render_params *rp, const float *tex0, const f
                         uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                         float *rgba, float *depth, sdfv_march_aux *aux, void *stream);
 
+/* A third layout of the same distances, WITHOUT duplication: the y-interleaved volume -- `ilv` (DEVICE, 8-byte aligned, one
+ * float per voxel of the WHOLE grid, H even): rows 2p and 2p + 1 of a slice stored as ONE row of (d[2p][x], d[2p+1][x])
+ * pairs, i.e. ilv[((z * H/2 + (y >> 1)) * W + x) * 2 + (y & 1)] = dist[z][y][x].  A trilinear cell then touches 2 cache
+ * lines (even y) or 4 (odd y) instead of always 4, at the distance volume's 4 B/voxel: the march gathers fewer lines without
+ * the doubled footprint the pair volume pays at large grids.  sdfv_commit_interleaved builds it from the compact distance
+ * volume (8 B/voxel of traffic). */
+int sdfv_commit_interleaved(const sdfv_grid *grid, const float *dist, float *ilv, void *stream);
+/* Which of the two a host that renders many frames per load should build for this grid on the current device:
+ * the pair volume while its 8 B/voxel fit the last-level cache (MI355X: 256 MB -- up to 256^3 x 2), the interleaved volume
+ * beyond (4K over 512^3: -10 % against either of the others; 1080p over 256^3: pairs -6 %, interleaved +-1 %).  Speed only. */
+#define SDFV_MARCH_VOLUME_PAIRS 1u
+#define SDFV_MARCH_VOLUME_INTERLEAVED 2u
+int sdfv_march_volume_advice(const sdfv_grid *grid, uint32_t *kind);
+/* The most general form of the march: any of the three acceleration volumes may be NULL (given both pairs and
+ * ilv the launcher applies the rule of sdfv_march_volume_advice; where the hand-written loop does not apply: dist, else
+ * tex0.r).  Bit-identical results in every combination. */
+int sdfv_raymarch_volumes(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
+                          const float *pairs, const float *ilv, const sdfv_camera *cameras, uint32_t n_cameras,
+                          uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
+                          float *rgba, float *depth, sdfv_march_aux *aux, void *stream);
+
 /* ---- raymarch over a z-sharded grid (multi-GPU; the consumer of the slab halo) ----
  * The grid stays sharded: rank r holds [ghost_lo][owned z_begin..z_end)[ghost_hi] as laid out for sdfv_slab_*.
  * A ray is marched by the rank that owns the cell it is in (clamp(floor(w), 0, D-1) in [z_begin, z_end); the

@@ -339,6 +339,21 @@ def commit_pairs(grid, dist, pairs=None, stream=None):
     return pairs
 
 
+def march_volume_advice(grid):
+    """"pairs" or "interleaved": the acceleration volume a many-frames host should build for this grid (speed only)."""
+    kind = C.c_uint32(0)
+    check(lib.sdfv_march_volume_advice(C.byref(grid), C.byref(kind)))
+    return {1: "pairs", 2: "interleaved"}[kind.value]
+
+
+def commit_interleaved(grid, dist, ilv=None, stream=None):
+    """The y-interleaved volume of the raymarch (sdfv_commit_interleaved): same floats as `dist`, rows paired."""
+    if ilv is None:
+        ilv = torch.empty_like(dist)
+    check(lib.sdfv_commit_interleaved(C.byref(grid), _dev_ptr(dist, "dist"), _dev_ptr(ilv, "ilv"), _stream_ptr(stream)))
+    return ilv
+
+
 def set_option(option, value):
     """sdfv_set_option: per-thread option of the library (A/B measurements, forcing kernel specialisations in tests)."""
     check(lib.sdfv_set_option(int(option), int(value)))
@@ -369,7 +384,7 @@ class options:
 
 
 def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=False, stream=None, out=None, dist=None,
-             want_depth=False, depth_out=None, pairs=None):
+             want_depth=False, depth_out=None, pairs=None, ilv=None):
     """material.frag main() over rows [y0,y1).  Returns rgba [n_cam, rows, W, 4] (+ aux [n_cam, rows, W, 18] words).
     `dist` = optional compact distance volume from commit_distance(); `pairs` = optional y-pair volume from commit_pairs()
     (sdfv_raymarch_pairs).  want_depth / depth_out: also return the
@@ -384,9 +399,10 @@ def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=Fal
     depth = depth_out
     if depth is None and want_depth:
         depth = torch.empty((n, y1 - y0, width), dtype=torch.float32, device=tex0.device)
-    check(lib.sdfv_raymarch_pairs(C.byref(rp), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"),
-                                  None if dist is None else _dev_ptr(dist, "dist"),
-                                  None if pairs is None else _dev_ptr(pairs, "pairs"), cam_arr, n, width, height,
+    check(lib.sdfv_raymarch_volumes(C.byref(rp), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"),
+                                    None if dist is None else _dev_ptr(dist, "dist"),
+                                    None if pairs is None else _dev_ptr(pairs, "pairs"),
+                                    None if ilv is None else _dev_ptr(ilv, "ilv"), cam_arr, n, width, height,
                                   y0, y1, C.c_void_p(rgba.data_ptr()),
                                   None if depth is None else _dev_ptr(depth, "depth"),
                                   C.c_void_p(aux.data_ptr()) if want_aux else None, _stream_ptr(stream)))

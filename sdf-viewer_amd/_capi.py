@@ -114,6 +114,11 @@ PROTOTYPES = {
                                       C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_commit_pairs": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdfv_march_volume_advice": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_uint32)]),
+    "sdfv_commit_interleaved": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdfv_raymarch_volumes": (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_fill_grid_host": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p, C.c_void_p]),
     "sdfv_sample_points_host": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_int,
                                           C.c_void_p]),

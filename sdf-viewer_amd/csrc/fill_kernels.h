@@ -91,6 +91,8 @@ hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& p, const FillLaun
 hipError_t launch_commit_distance(const float* tex0, float* dist, uint64_t n_voxels, hipStream_t stream);
 // pairs[i] = (dist[i], dist[i + W] or, in the last row of a slice, dist[i]) over a whole grid of W x H x (n / (W * H)) voxels
 hipError_t launch_commit_pairs(const float* dist, float* pairs, uint32_t W, uint32_t H, uint64_t n_voxels, hipStream_t stream);
+// ilv[(z * H/2 + p) * W + x] = (dist[z][2p][x], dist[z][2p+1][x]) over a whole grid with an even H
+hipError_t launch_commit_interleaved(const float* dist, float* ilv, uint32_t W, uint64_t n_voxels, hipStream_t stream);
 hipError_t launch_grid_init(float* tex0, float* tex1, uint64_t n_voxels, float air, hipStream_t stream);
 
 }  // namespace sdfv

@@ -384,6 +384,18 @@ __global__ __launch_bounds__(kBlock) void commit_pairs_kernel(const float* __res
     pairs[i] = make_float2(d0, d1);
 }
 
+// The y-interleaved volume (raymarch_kernels.hip SDFV_MARCH_ASM_INTERIOR_ILV): rows 2p and 2p + 1 of a slice stored as one
+// row of (d[2p][x], d[2p+1][x]) pairs; 4 B/voxel, H even.  One thread per PAIR: two coalesced 4-byte reads, one 8-byte store.
+__global__ __launch_bounds__(kBlock) void commit_interleaved_kernel(const float* __restrict__ dist, float2* __restrict__ ilv,
+                                                                    uint32_t W, uint64_t n_pairs) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;  // pair (x, p, z): i = (z * H/2 + p) * W + x
+    if (i >= n_pairs) return;
+    const uint64_t prow = i / W;
+    const uint32_t x = (uint32_t)(i - prow * W);
+    const uint64_t src = prow * 2 * W + x;  // row 2p of that slice: (z * H + 2p) * W + x
+    ilv[i] = make_float2(dist[src], dist[src + W]);
+}
+
 template <int TX, bool NT>
 hipError_t launch_dense_cfg(const FillArgs& args, hipStream_t stream) {
     constexpr int TY = kBlock / TX;
@@ -601,6 +613,16 @@ hipError_t launch_commit_pairs(const float* dist, float* pairs, uint32_t W, uint
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(commit_pairs_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, stream, dist, reinterpret_cast<float2*>(pairs),
                        W, H, n_voxels);
+    return hipGetLastError();
+}
+
+hipError_t launch_commit_interleaved(const float* dist, float* ilv, uint32_t W, uint64_t n_voxels, hipStream_t stream) {
+    const uint64_t n_pairs = n_voxels / 2;
+    if (n_pairs == 0) return hipSuccess;
+    const uint64_t blocks = (n_pairs + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(commit_interleaved_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, stream, dist, reinterpret_cast<float2*>(ilv),
+                       W, n_pairs);
     return hipGetLastError();
 }
 

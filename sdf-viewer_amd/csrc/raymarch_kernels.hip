@@ -420,6 +420,54 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "global_load_dword v65, v26, %[base]\n global_load_dword v67, v27, %[base]\n"                                  \
     "s_waitcnt vmcnt(0)\n"                                                                                          \
     "s_branch .Lcached_%=\n"
+// The y-INTERLEAVED volume (sdfv_commit_interleaved): rows 2p and 2p + 1 of a slice share one row of (d[2p][x], d[2p+1][x])
+// pairs -- 4 B/voxel like the distance volume, no duplication.  A cell whose j0 is even finds the four corners of a z-level
+// in 16 contiguous bytes of pair-row j0/2; an odd j0 takes (x0, x1) of row j0 from pair-row (j0-1)/2 and of row j0+1 from
+// pair-row (j0+1)/2.  Branch-free: every lane loads pair-rows j0 >> 1 and (j0 + 1) >> 1 (the same address, hence the same
+// line, when j0 is even) and picks by parity -- four dwordx4 gathers over 2 (even) or 4 (odd) lines instead of four dwordx2
+// over 4 lines: the line count is what a fetch costs (EXPERIMENTS R3.1, R3.10).
+#define SDFV_MARCH_ASM_INTERIOR_ILV                                                                                 \
+    "s_add_i32 s80, %[lgh], -1\n"                                                                                   \
+    "v_and_b32_e32 v48, 1, v33\n"                            /* parity of j0 */                                      \
+    "v_lshrrev_b32_e32 v35, 1, v33\n"                        /* p0 = j0 >> 1 */                                      \
+    "v_add_u32_e32 v36, 1, v33\n"                                                                                   \
+    "v_lshrrev_b32_e32 v36, 1, v36\n"                        /* p1 = (j0 + 1) >> 1 */                                \
+    "v_lshl_add_u32 v35, v34, s80, v35\n v_lshl_add_u32 v36, v34, s80, v36\n"   /* pair rows k0 * H/2 + p */         \
+    "v_lshl_add_u32 v35, v35, %[lgw], v32\n v_lshl_add_u32 v37, v36, %[lgw], v32\n"                                  \
+    "v_lshlrev_b32_e32 v36, 3, v35\n v_lshlrev_b32_e32 v37, 3, v37\n"                                               \
+    "v_cmp_eq_u32_e32 vcc, 1, v48\n"                                                                                \
+    "global_load_dwordx4 v[24:27], v36, %[base]\n"           /* z0, pair-row p0: (y_lo, y_hi) at x0, x1 */           \
+    "global_load_dwordx4 v[32:35], v36, s[68:69]\n"          /* z1, p0 */                                            \
+    "s_and_saveexec_b64 s[80:81], vcc\n"                     /* odd j0 only: row j0 + 1 lives in the next pair-row */ \
+    "global_load_dwordx3 v[28:30], v37, %[base]\n"           /* z0, p1: its y_lo at x0, x1 */                        \
+    "global_load_dwordx3 v[36:38], v37, s[68:69]\n"          /* z1, p1 */                                            \
+    "s_mov_b64 exec, s[80:81]\n"                                                                                    \
+    "s_waitcnt vmcnt(2)\n"                                                                                          \
+    "v_cndmask_b32_e32 v60, v24, v25, vcc\n v_cndmask_b32_e32 v62, v26, v27, vcc\n"   /* t000, t100: row j0 */       \
+    "v_cndmask_b32_e32 v61, v32, v33, vcc\n v_cndmask_b32_e32 v63, v34, v35, vcc\n"   /* t001, t101 */               \
+    "s_waitcnt vmcnt(0)\n"                                                                                          \
+    "v_cndmask_b32_e32 v64, v25, v28, vcc\n v_cndmask_b32_e32 v66, v27, v30, vcc\n"   /* t010, t110: row j0 + 1 */   \
+    "v_cndmask_b32_e32 v65, v33, v36, vcc\n v_cndmask_b32_e32 v67, v35, v38, vcc\n"   /* t011, t111 */
+// Border cells of the interleaved volume: eight dword loads at ((pair-row << lgw) + x) * 8 + (y & 1) * 4.  The clamped row
+// numbers of FETCH_PREP are k * H + j; j = row & (H - 1), k = row >> lgh (sizes are powers of two).
+#define SDFV_MARCH_ASM_ILV_ROW(R)                            /* v R: row number k * H + j  ->  byte offset of (x = 0) */ \
+    "v_and_b32_e32 v36, 1, v" #R "\n"                        /* y & 1 */                                             \
+    "v_lshrrev_b32_e32 v" #R ", 1, v" #R "\n"                /* k * H/2 + (j >> 1): H is even */                     \
+    "v_lshlrev_b32_e32 v" #R ", s85, v" #R "\n"              /* * W * 8 */                                           \
+    "v_lshl_add_u32 v" #R ", v36, 2, v" #R "\n"              /* + (y & 1) * 4 */
+#define SDFV_MARCH_ASM_FETCH_ILV                                                                                    \
+    "v_lshlrev_b32_e32 v35, 3, v35\n v_lshlrev_b32_e32 v32, 3, v32\n"   /* i0c, i1c as byte offsets (8 per x) */      \
+    SDFV_MARCH_ASM_ILV_ROW(28) SDFV_MARCH_ASM_ILV_ROW(29) SDFV_MARCH_ASM_ILV_ROW(30) SDFV_MARCH_ASM_ILV_ROW(31)       \
+    "v_add_u32_e32 v24, v28, v35\n v_add_u32_e32 v25, v28, v32\n"                                                    \
+    "global_load_dword v60, v24, %[base]\n global_load_dword v62, v25, %[base]\n"                                  \
+    "v_add_u32_e32 v26, v29, v35\n v_add_u32_e32 v27, v29, v32\n"                                                    \
+    "global_load_dword v64, v26, %[base]\n global_load_dword v66, v27, %[base]\n"                                  \
+    "v_add_u32_e32 v24, v30, v35\n v_add_u32_e32 v25, v30, v32\n"                                                    \
+    "global_load_dword v61, v24, %[base]\n global_load_dword v63, v25, %[base]\n"                                  \
+    "v_add_u32_e32 v26, v31, v35\n v_add_u32_e32 v27, v31, v32\n"                                                    \
+    "global_load_dword v65, v26, %[base]\n global_load_dword v67, v27, %[base]\n"                                  \
+    "s_waitcnt vmcnt(0)\n"                                                                                          \
+    "s_branch .Lcached_%=\n"
 // STRIDE 1: x-neighbours are adjacent floats: one 8-byte load per (y, z) row at b = clamp(i0, 0, W - 2); where the clamp
 // folds the two x-corners together both come from the same half (lo_is_x / hi_is_y).
 #define SDFV_MARCH_ASM_FETCH_DIST                                                                                   \
@@ -554,7 +602,10 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
     if (T) {
         float tt = dist_from_origin;
         int n = 0;
-        if (STRIDE == 2) {
+        if (STRIDE == 3) {
+            if (cube) SDFV_MARCH_ASM_RUN_AUX("s82", SDFV_MARCH_ASM_INTERIOR_ILV, SDFV_MARCH_ASM_FETCH_ILV, SDFV_MARCH_ASM_OOB_CUBE);
+            else SDFV_MARCH_ASM_RUN_AUX("s82", SDFV_MARCH_ASM_INTERIOR_ILV, SDFV_MARCH_ASM_FETCH_ILV, SDFV_MARCH_ASM_OOB_BOX);
+        } else if (STRIDE == 2) {
             if (cube) SDFV_MARCH_ASM_RUN_AUX("s85", SDFV_MARCH_ASM_INTERIOR_PAIRS, SDFV_MARCH_ASM_FETCH_PAIRS, SDFV_MARCH_ASM_OOB_CUBE);
             else SDFV_MARCH_ASM_RUN_AUX("s85", SDFV_MARCH_ASM_INTERIOR_PAIRS, SDFV_MARCH_ASM_FETCH_PAIRS, SDFV_MARCH_ASM_OOB_BOX);
         } else if (STRIDE == 1) {
@@ -566,6 +617,9 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
         }
         dist_from_origin = tt;
         steps = n;
+    } else if (STRIDE == 3) {
+        if (cube) SDFV_MARCH_ASM_RUN("s82", SDFV_MARCH_ASM_INTERIOR_ILV, SDFV_MARCH_ASM_FETCH_ILV, SDFV_MARCH_ASM_OOB_CUBE);
+        else SDFV_MARCH_ASM_RUN("s82", SDFV_MARCH_ASM_INTERIOR_ILV, SDFV_MARCH_ASM_FETCH_ILV, SDFV_MARCH_ASM_OOB_BOX);
     } else if (STRIDE == 2) {
         if (cube) SDFV_MARCH_ASM_RUN("s85", SDFV_MARCH_ASM_INTERIOR_PAIRS, SDFV_MARCH_ASM_FETCH_PAIRS, SDFV_MARCH_ASM_OOB_CUBE);
         else SDFV_MARCH_ASM_RUN("s85", SDFV_MARCH_ASM_INTERIOR_PAIRS, SDFV_MARCH_ASM_FETCH_PAIRS, SDFV_MARCH_ASM_OOB_BOX);
@@ -706,7 +760,8 @@ __device__ __forceinline__ bool box_fragment_ray(const RaymarchArgs& a, V3 eye, 
 
 // MODE: 0 = general kernel (any filter, any extents: the shader's nested loop with full MirroredRepeat);
 //       1 = fast march over tex0.r; 2 = fast march over the compact distance volume (both LINEAR only);
-//       3 = the hand-written loop over the y-pair volume (sdfv_commit_pairs; two 16-byte gathers per cell).
+//       3 = the hand-written loop over the y-pair volume (sdfv_commit_pairs; two 16-byte gathers per cell);
+//       4 = ... over the y-interleaved volume (sdfv_commit_interleaved; 4 B/voxel, 2 or 4 lines per cell).
 // XF:   0 = IEEE divide, 1 = exact power-of-two reciprocal, 2 = power-of-two extents and texture sizes.
 // AUX:  the per-pixel march record is stored (and distanceFromOrigin accumulated).
 #ifndef SDFV_RM_MIN_WAVES
@@ -833,6 +888,8 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
         march_asm<SYMM, 1, AUX>(a, a.dist, tex0, ray_dir, covered, ray_pos, dist_from_origin, status, steps, iterations);
     } else if (ASM && MODE == 3) {
         march_asm<SYMM, 2, AUX>(a, a.pairs, tex0, ray_dir, covered, ray_pos, dist_from_origin, status, steps, iterations);
+    } else if (ASM && MODE == 4) {
+        march_asm<SYMM, 3, AUX>(a, a.ilv, tex0, ray_dir, covered, ray_pos, dist_from_origin, status, steps, iterations);
     } else if (MODE == 1) {
         SDFV_MARCH<XF, SYMM, 4, AUX>(a, reinterpret_cast<const float*>(a.tex0), tex0, ray_dir, covered, ray_pos,
                                      dist_from_origin, status, steps, iterations);
@@ -1267,12 +1324,27 @@ static void box_first_rectangle(RaymarchArgs& ag, uint32_t groups_y) {
 // box (box-first order) in waves, the machine's wave slots, the volume's bytes.  Rule: cap at 4 when the rectangle holds
 // between 1x and 3.5x the slots at 7 per SIMD and the volume exceeds the last-level cache; no cap otherwise (camera
 // inside, box filling the image, batches of cameras, small volumes, a box of a few tiles).  Speed only.
+// Which volume the hand-written loop marches over, of those the caller handed in: 4 the y-interleaved volume, 3 the pair
+// volume, 0 neither (the loop's specialisation does not apply, or neither was given).  With both: the pair volume while its
+// 8 B/voxel fit the last-level cache (fewest gathers), the interleaved one beyond (half the footprint) --
+// tools/pairs_bench.py, profiles/r03_pairs_bench.json.
+static int march_volume_mode(const RaymarchArgs& a) {
+    const uint64_t texels = (uint64_t)a.rp.tex_size[0] * a.rp.tex_size[1] * a.rp.tex_size[2];
+    const bool loop_ok = a.rp.lod_dist_between_samples == 1.0f && a.fast_index && a.pow2_extent && a.pow2_size && a.symmetric_box &&
+                         a.asm_loop && a.rp.tex_size[0] >= 2 && texels <= (1ull << 28);
+    const bool pairs_ok = loop_ok && a.pairs;
+    const bool ilv_ok = loop_ok && a.ilv && a.rp.tex_size[1] >= 2;
+    if (pairs_ok && ilv_ok) return (a.last_level_cache_bytes && texels * 8u > a.last_level_cache_bytes) ? 4 : 3;
+    return ilv_ok ? 4 : (pairs_ok ? 3 : 0);
+}
+
 static uint32_t occupancy_rule(const RaymarchArgs& ag) {
     if (ag.waves_per_simd >= 2 && ag.waves_per_simd <= 6) return ag.waves_per_simd;  // the caller's cap
     if (ag.waves_per_simd == 7) return 7;
     if (ag.n_cameras != 1 || ag.first_w == 0 || ag.group_shift == 0 || ag.wave_slots_per_simd_unit == 0) return 7;
     const uint64_t texels = (uint64_t)ag.rp.tex_size[0] * ag.rp.tex_size[1] * ag.rp.tex_size[2];
-    const uint64_t volume_bytes = texels * (ag.pairs ? 8u : (ag.dist ? 4u : 16u));
+    const int mode = march_volume_mode(ag);
+    const uint64_t volume_bytes = texels * (mode == 3 ? 8u : ((mode == 4 || ag.dist) ? 4u : 16u));
     if (ag.last_level_cache_bytes == 0 || volume_bytes <= ag.last_level_cache_bytes) return 7;
     const uint64_t rect_waves = (uint64_t)ag.first_w * ag.first_h * (4ull << (2 * ag.group_shift));  // 4 waves per 16 x 16 tile
     const uint64_t slots7 = 7ull * ag.wave_slots_per_simd_unit;
@@ -1328,12 +1400,16 @@ hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream) {
 static hipError_t launch_raymarch_grid(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
     const bool linear = a.rp.lod_dist_between_samples == 1.0f;
     if (linear && a.fast_index) {
-        // the pair volume is an acceleration structure of the hand-written loop only: wherever that loop's specialisation
-        // does not apply the march reads the distance volume / tex0.r as before -- the same bits either way
-        const uint64_t texels = (uint64_t)a.rp.tex_size[0] * a.rp.tex_size[1] * a.rp.tex_size[2];
-        const bool pairs_ok = a.pairs && a.pow2_extent && a.pow2_size && a.symmetric_box && a.asm_loop && a.rp.tex_size[0] >= 2 &&
-                              texels <= (1ull << 28);
-        if (pairs_ok) {
+        // the pair / interleaved volumes are acceleration structures of the hand-written loop only: wherever that loop's
+        // specialisation does not apply the march reads the distance volume / tex0.r as before -- the same bits either way
+        const int mode = march_volume_mode(a);
+        const bool ilv_ok = mode == 4, pairs_ok = mode == 3;
+        if (ilv_ok) {
+            if (a.aux) hipLaunchKernelGGL((raymarch_kernel<4, true, 2, true, true, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
+            else if (a.compute_normal)
+                hipLaunchKernelGGL((raymarch_kernel<4, true, 2, true, false, true, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
+            else hipLaunchKernelGGL((raymarch_kernel<4, true, 2, true, false, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
+        } else if (pairs_ok) {
             if (a.aux) hipLaunchKernelGGL((raymarch_kernel<3, true, 2, true, true, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
             else if (a.compute_normal)
                 hipLaunchKernelGGL((raymarch_kernel<3, true, 2, true, false, true, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);

@@ -891,6 +891,29 @@ int sdfv_commit_pairs(const sdfv_grid* grid, const float* dist, float* pairs, vo
     return SDFV_OK;
 }
 
+int sdfv_commit_interleaved(const sdfv_grid* grid, const float* dist, float* ilv, void* stream) {
+    if (int rc = check_grid(grid)) return rc;
+    if (!dist || !ilv) return fail(SDFV_ERR_INVALID_ARGUMENT, "dist or ilv is NULL");
+    if (((uintptr_t)dist & 3) || ((uintptr_t)ilv & 7)) return fail(SDFV_ERR_INVALID_ARGUMENT, "dist: 4-byte, ilv: 8-byte aligned");
+    if (grid->z_begin != 0 || grid->z_end != grid->dims[2])
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "the interleaved volume is built over the whole grid");
+    if (grid->dims[1] & 1) return fail(SDFV_ERR_INVALID_ARGUMENT, "the interleaved volume pairs rows: H = %u is odd", grid->dims[1]);
+    if (int rc = need_device()) return rc;
+    const uint64_t n = (uint64_t)grid->dims[0] * grid->dims[1] * grid->dims[2];
+    SDFV_HIP(sdfv::launch_commit_interleaved(dist, ilv, grid->dims[0], n, (hipStream_t)stream));
+    return SDFV_OK;
+}
+
+int sdfv_march_volume_advice(const sdfv_grid* grid, uint32_t* kind) {
+    if (int rc = check_grid(grid)) return rc;
+    if (!kind) return fail(SDFV_ERR_INVALID_ARGUMENT, "kind is NULL");
+    if (int rc = need_device()) return rc;
+    const uint64_t n = (uint64_t)grid->dims[0] * grid->dims[1] * grid->dims[2];
+    const uint64_t llc = device_facts().last_level_cache_bytes;
+    *kind = (llc && n * 8u > llc && (grid->dims[1] & 1u) == 0) ? SDFV_MARCH_VOLUME_INTERLEAVED : SDFV_MARCH_VOLUME_PAIRS;
+    return SDFV_OK;
+}
+
 int sdfv_raymarch(const sdfv_render_params* rp, const float* tex0, const float* tex1, const sdfv_camera* cameras,
                   uint32_t n_cameras, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, float* rgba,
                   sdfv_march_aux* aux, void* stream) {
@@ -906,18 +929,24 @@ int sdfv_raymarch_accel(const sdfv_render_params* rp, const float* tex0, const f
 int sdfv_raymarch_depth(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
                         const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width, uint32_t height, uint32_t y0,
                         uint32_t y1, float* rgba, float* depth, sdfv_march_aux* aux, void* stream) {
-    return sdfv_raymarch_pairs(rp, tex0, tex1, dist, nullptr, cameras, n_cameras, width, height, y0, y1, rgba, depth, aux, stream);
+    return sdfv_raymarch_volumes(rp, tex0, tex1, dist, nullptr, nullptr, cameras, n_cameras, width, height, y0, y1, rgba, depth, aux, stream);
 }
 
 int sdfv_raymarch_pairs(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
                         const float* pairs, const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width, uint32_t height,
                         uint32_t y0, uint32_t y1, float* rgba, float* depth, sdfv_march_aux* aux, void* stream) {
+    return sdfv_raymarch_volumes(rp, tex0, tex1, dist, pairs, nullptr, cameras, n_cameras, width, height, y0, y1, rgba, depth, aux, stream);
+}
+
+int sdfv_raymarch_volumes(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
+                          const float* pairs, const float* ilv, const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width,
+                          uint32_t height, uint32_t y0, uint32_t y1, float* rgba, float* depth, sdfv_march_aux* aux, void* stream) {
     if (!rp || !tex0 || !tex1 || !rgba) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
     if (int rc = check_lights(rp)) return rc;
     if (int rc = check_texel_alignment(tex0, tex1, rgba)) return rc;
     if ((uintptr_t)dist & 3 || (uintptr_t)depth & 3 || (uintptr_t)aux & 3)
         return fail(SDFV_ERR_INVALID_ARGUMENT, "dist, depth and aux must be 4-byte aligned");
-    if ((uintptr_t)pairs & 7) return fail(SDFV_ERR_INVALID_ARGUMENT, "pairs must be 8-byte aligned");
+    if (((uintptr_t)pairs | (uintptr_t)ilv) & 7) return fail(SDFV_ERR_INVALID_ARGUMENT, "pairs and ilv must be 8-byte aligned");
     if (n_cameras && !cameras) return fail(SDFV_ERR_INVALID_ARGUMENT, "cameras is NULL");
     if (y0 > y1 || y1 > height) return fail(SDFV_ERR_INVALID_ARGUMENT, "rows [%u,%u) outside height %u", y0, y1, height);
     if (rp->tex_size[0] == 0 || rp->tex_size[1] == 0 || rp->tex_size[2] == 0)
@@ -930,6 +959,7 @@ int sdfv_raymarch_pairs(const sdfv_render_params* rp, const float* tex0, const f
     derive_raymarch_args(rp, a);
     a.dist = dist;
     a.pairs = pairs;
+    a.ilv = ilv;
     a.tex0 = reinterpret_cast<const float4*>(tex0);
     a.tex1 = reinterpret_cast<const float4*>(tex1);
     a.width = width;

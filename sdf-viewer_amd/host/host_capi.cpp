@@ -172,7 +172,10 @@ int sdfvh_viewer_render_device(void* v, uint32_t width, uint32_t height, const f
     cam.set_viewport(width, height);
     return V(v).material.render(cam, rgba_device, nullptr, V(v).stream);
 }
-int sdfvh_viewer_pairs_valid(void* v) { return V(v).material.pairs && V(v).material.pairs_valid ? 1 : 0; }
+// 0: the frames march over the distance volume; 1: over the pair volume commit() built; 2: over the interleaved volume
+int sdfvh_viewer_pairs_valid(void* v) {
+    return V(v).material.pairs && V(v).material.pairs_valid ? (V(v).material.pairs_interleaved ? 2 : 1) : 0;
+}
 int sdfvh_viewer_sync(void* v) { return hipStreamSynchronize((hipStream_t)V(v).stream) == hipSuccess ? 0 : -1; }
 
 // ---- SDFViewerAppScene (a manual clock, in milliseconds, makes the 500 ms commit spacing testable) ----

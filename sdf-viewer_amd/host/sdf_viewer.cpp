@@ -73,8 +73,9 @@ int SDFViewerMaterial::render(const Camera& camera, float* rgba_device, sdfv_mar
     const float* d = (dist && lod_dist_between_samples == 1.0f) ? dist->f32() : nullptr;
     // a viewer renders many frames per load: the pair volume commit() built halves the march's gathers (same bits)
     const float* p = (d && pairs && pairs_valid) ? pairs->f32() : nullptr;
-    return sdfv_raymarch_pairs(&rp, tex0->f32(), tex1->f32(), d, p, &cam, 1, camera.viewport_width, camera.viewport_height, 0,
-                               camera.viewport_height, rgba_device, nullptr, aux_device, stream);
+    return sdfv_raymarch_volumes(&rp, tex0->f32(), tex1->f32(), d, pairs_interleaved ? nullptr : p, pairs_interleaved ? p : nullptr,
+                                 &cam, 1, camera.viewport_width, camera.viewport_height, 0, camera.viewport_height, rgba_device,
+                                 nullptr, aux_device, stream);
 }
 
 // ---- SDFViewer ----
@@ -262,9 +263,18 @@ void SDFViewer::commit() {
     // What a commit of the fully loaded grid does derive is the pair volume: the frames that follow (the reference renders
     // one per repaint) march over it.  12 B/voxel of traffic -- against the reference's re-upload of 32 B/voxel over PCIe.
     if (dist_synced_ && loading_mgr.step_size() == 0 && !material.pairs_valid) {
-        if (!material.pairs) material.pairs = std::make_shared<DeviceBuffer>(material.dist->bytes() * 2);
         const sdfv_grid g = grid();
-        if (material.pairs->ok() && sdfv_commit_pairs(&g, material.dist->f32(), material.pairs->f32(), stream) == 0)
+        if (!material.pairs) {
+            // beyond the last-level cache the interleaved volume (4 B/voxel) marches faster than the pair volume (8)
+            uint32_t kind = SDFV_MARCH_VOLUME_PAIRS;
+            (void)sdfv_march_volume_advice(&g, &kind);
+            material.pairs_interleaved = kind == SDFV_MARCH_VOLUME_INTERLEAVED;
+            material.pairs = std::make_shared<DeviceBuffer>(material.dist->bytes() * (material.pairs_interleaved ? 1 : 2));
+        }
+        const int rc = !material.pairs->ok() ? -1
+                       : material.pairs_interleaved ? sdfv_commit_interleaved(&g, material.dist->f32(), material.pairs->f32(), stream)
+                                                    : sdfv_commit_pairs(&g, material.dist->f32(), material.pairs->f32(), stream);
+        if (rc == 0)
             material.pairs_valid = true;
         else
             material.pairs.reset();  // out of memory: the march keeps reading the distance volume

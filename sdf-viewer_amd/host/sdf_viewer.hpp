@@ -67,6 +67,7 @@ struct SDFViewerMaterial {
     std::shared_ptr<DeviceBuffer> dist;  // compact copy of tex0.r built by SDFViewer::commit (may be null)
     std::shared_ptr<DeviceBuffer> pairs;  // y-pair volume (sdfv_commit_pairs) of the LOADED grid, or null / stale
     bool pairs_valid = false;             // pairs mirrors dist: set by SDFViewer::commit, cleared by every fill
+    bool pairs_interleaved = false;       // `pairs` holds the y-interleaved volume instead (sdfv_march_volume_advice)
     std::array<uint32_t, 3> tex_size{0, 0, 0};
     BoundingBox voxels_bounds;
     float lod_dist_between_samples = 1.0f;

@@ -219,6 +219,9 @@ class Viewer:
     def pairs_valid(self):
         return bool(H.sdfvh_viewer_pairs_valid(self.h))
 
+    def march_volume(self):
+        return {0: "distance", 1: "pairs", 2: "interleaved"}[H.sdfvh_viewer_pairs_valid(self.h)]
+
     def render(self, width, height, eye=None):
         out = np.empty((height, width, 4), np.float32)
         e = None if eye is None else np.asarray(eye, np.float32)

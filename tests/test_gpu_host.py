@@ -149,6 +149,25 @@ def test_commit_of_a_loaded_grid_builds_the_pair_volume_and_edits_retire_it(host
     assert np.abs(edited - want).max() <= 1e-4 and not np.array_equal(before, edited)
 
 
+def test_commit_of_a_grid_beyond_the_last_level_cache_builds_the_interleaved_volume(host):
+    """512^3: the pair volume (1 GB) would not fit the Infinity Cache, so commit() asks sdfv_march_volume_advice and builds the
+    y-interleaved volume instead; the frames over it are the frames over the distance volume, bit for bit."""
+    sdf = host.SDF.demo()
+    v = host.Viewer.new_voxels((512, 512, 512), [-1, -1, -1, 1, 1, 1], 1)
+    while v.update(sdf, 1.0):
+        pass
+    assert v.march_volume() == "distance"
+    before = v.render(1280, 720)
+    v.commit()
+    assert v.march_volume() == "interleaved"
+    np.testing.assert_array_equal(before.view(np.uint32), v.render(1280, 720).view(np.uint32))
+    small = host.Viewer.new_voxels((64, 64, 64), [-1, -1, -1, 1, 1, 1], 1)
+    while small.update(sdf, 1.0):
+        pass
+    small.commit()
+    assert small.march_volume() == "pairs"
+
+
 def test_sdf_surface_per_point_calls(host, oracle):
     rng = np.random.default_rng(3)
     pts = rng.uniform(-1.1, 1.1, size=(40, 3)).astype(np.float32)

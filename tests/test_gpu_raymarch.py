@@ -40,6 +40,11 @@ def compare(pkg, oracle, g, t0, t1, h0, h1, cam_kw, width, height, rp_edit=None,
     whole = pkg.make_grid(tuple(int(d) for d in g.dims), tuple(g.bb_min), tuple(g.bb_max))
     pairs = pkg.commit_pairs(whole, dist)  # (d[y], d[min(y + 1, H - 1)]) per texel
     assert torch.equal(pairs[..., 0], dist) and torch.equal(pairs[:, :-1, :, 1], dist[:, 1:]) and torch.equal(pairs[:, -1, :, 1], dist[:, -1])
+    ilv = None
+    if int(g.dims[1]) % 2 == 0:  # the y-interleaved volume pairs rows 2p, 2p + 1
+        ilv = pkg.commit_interleaved(whole, dist)
+        v = ilv.view(dist.shape[0], dist.shape[1] // 2, dist.shape[2], 2)
+        assert torch.equal(v[..., 0], dist[:, 0::2]) and torch.equal(v[..., 1], dist[:, 1::2])
     # every march kernel family must reproduce the oracle: the fast march (symmetric-box / fused-scale /
     # reciprocal / divide variants) over tex0.r, the same over the compact distance volume, and the general
     # kernel (full MirroredRepeat, the shader's nested loop)
@@ -52,17 +57,22 @@ def compare(pkg, oracle, g, t0, t1, h0, h1, cam_kw, width, height, rp_edit=None,
                 # "pairs*": the y-pair volume (two 16-byte gathers per cell), its border fetch for every cell, and a launch
                 # whose specialisation does not apply (falls back to the distance volume)
                 "pairs": 0, "pairs_b": K.RM_NO_INTERIOR_FETCH, "pairs_c": K.RM_NO_ASM_LOOP,
+                # "ilv*": the y-interleaved volume, likewise
+                "ilv": 0, "ilv_b": K.RM_NO_INTERIOR_FETCH, "ilv_c": K.RM_NO_ASM_LOOP,
                 "fast_plain": K.RM_NO_SYMMETRIC | K.RM_NO_POW2_SIZE,
                 "fast_div": K.RM_NO_SYMMETRIC | K.RM_NO_POW2_EXTENT}
     for variant, mask in disabled.items():
+        if variant.startswith("ilv") and ilv is None:
+            continue
         with pkg.options({K.OPT_RAYMARCH_DISABLE: mask}):
-            use_dist = dist if variant.startswith(("dist", "pairs")) else None
+            use_dist = dist if variant.startswith(("dist", "pairs", "ilv")) else None
             use_pairs = pairs if variant.startswith("pairs") else None
+            use_ilv = ilv if variant.startswith("ilv") else None
             rgba, depth, aux = pkg.raymarch(rp, t0, t1, cam, width, height, y0=y0, y1=y1, want_aux=True,
-                                            want_depth=True, dist=use_dist, pairs=use_pairs)
+                                            want_depth=True, dist=use_dist, pairs=use_pairs, ilv=use_ilv)
             # the depth plane without the 72-byte record must be the same plane
             rgba_plain, depth_only = pkg.raymarch(rp, t0, t1, cam, width, height, y0=y0, y1=y1, want_depth=True,
-                                                  dist=use_dist, pairs=use_pairs)
+                                                  dist=use_dist, pairs=use_pairs, ilv=use_ilv)
             torch.cuda.synchronize()
         assert torch.equal(depth.view(torch.int32), depth_only.view(torch.int32)), variant
         # the kernel WITHOUT the aux record (the one bench.py times) writes the same RGBA as the one with it
@@ -451,6 +461,33 @@ def test_launcher_occupancy_rule_at_the_sizes_it_fires(pkg):
             with pkg.options({K.OPT_RAYMARCH_WAVES_PER_SIMD: 7}):
                 free = pkg.raymarch(rp, t0, t1, cam, W, H, dist=use_dist)
             assert torch.equal(auto.view(torch.int32), free.view(torch.int32)), (W, H, eye)
+
+
+def test_march_volume_advice_and_the_launchers_choice_at_512(pkg):
+    """sdfv_march_volume_advice: the pair volume while its 8 B/voxel fit the last-level cache, the interleaved volume beyond
+    (and whenever H is odd: pairs).  Handed both, the launcher applies the same rule; whichever volume a frame marches over
+    -- distance, pairs, interleaved, both -- the image and the depth plane are the same bits, here at 4K over 512^3 where the
+    rule picks the interleaved volume, with the camera outside, close and inside."""
+    assert pkg.march_volume_advice(pkg.make_grid((256, 256, 256))) == "pairs"
+    assert pkg.march_volume_advice(pkg.make_grid((512, 512, 512))) == "interleaved"
+    assert pkg.march_volume_advice(pkg.make_grid((512, 511, 512))) == "pairs"
+    prm = pkg.default_params()
+    g = pkg.make_grid((512, 512, 512))
+    t0, t1 = pkg.alloc_textures(g)
+    dist = torch.empty((512, 512, 512), dtype=torch.float32, device="cuda")
+    pkg.fill_grid(prm, g, t0, t1, dist=dist)
+    pairs, ilv = pkg.commit_pairs(g, dist), pkg.commit_interleaved(g, dist)
+    v = ilv.view(512, 256, 512, 2)
+    assert torch.equal(v[..., 0], dist[:, 0::2]) and torch.equal(v[..., 1], dist[:, 1::2])
+    rp = pkg.default_render_params(g)
+    W, H = 3840, 2160
+    for kw in (dict(), dict(eye=(1.2, 1.5, 2.4)), dict(eye=(0.2, 0.1, 0.3), target=(1.0, 0.5, -1.0))):
+        cam = pkg.camera_look_at(aspect=W / H, **kw)
+        ref, ref_depth = pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist, want_depth=True)
+        for vols in (dict(pairs=pairs), dict(ilv=ilv), dict(pairs=pairs, ilv=ilv)):
+            got, depth = pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist, want_depth=True, **vols)
+            assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (kw, list(vols))
+            assert torch.equal(depth.view(torch.int32), ref_depth.view(torch.int32)), (kw, list(vols))
 
 
 def test_row_bands_of_the_image_tile_split_tile_the_frame(pkg):

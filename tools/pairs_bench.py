@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The y-pair volume against the compact distance volume: single frames (1080p/256^3, 4K/512^3, eleven views each) and the
+"""The y-pair volume and the y-interleaved volume against the compact distance volume: single frames (1080p/256^3, 4K/512^3, eleven views each) and the
 64-camera batch, alternating rounds in one process, bits compared.  python tools/pairs_bench.py"""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +23,10 @@ for side, W, H in ((256, 1920, 1080), (512, 3840, 2160)):
     pkg.fill_grid(prm, g, t0, t1, dist=dist)
     pairs = pkg.commit_pairs(g, dist)
     res[f"{side}_commit_pairs_ms"] = round(run(lambda: pkg.commit_pairs(g, dist, pairs=pairs), n=20), 4)
+    ilv = pkg.commit_interleaved(g, dist)
+    res[f"{side}_commit_interleaved_ms"] = round(run(lambda: pkg.commit_interleaved(g, dist, ilv=ilv), n=20), 4)
     rp = pkg.default_render_params(g)
+    out3 = torch.empty((1, H, W, 4), dtype=torch.float32, device="cuda")
     out = torch.empty((1, H, W, 4), dtype=torch.float32, device="cuda")
     ref = torch.empty_like(out)
     views = {"default": pkg.camera_look_at(aspect=W / H)}
@@ -33,21 +36,27 @@ for side, W, H in ((256, 1920, 1080), (512, 3840, 2160)):
     views["axis"] = pkg.camera_look_at(eye=(0.0, 0.0, 5.0), aspect=W / H)
     views["inside"] = pkg.camera_look_at(eye=(0.2, 0.1, 0.3), target=(1.0, 0.5, -1.0), aspect=W / H)
     for name, cam in views.items():
-        ms = {"dist": [], "pairs": []}
+        ms = {"dist": [], "pairs": [], "ilv": []}
         for rnd in range(3):
             ms["dist"].append(run(lambda: pkg.raymarch(rp, t0, t1, cam, W, H, out=ref, dist=dist)))
             ms["pairs"].append(run(lambda: pkg.raymarch(rp, t0, t1, cam, W, H, out=out, dist=dist, pairs=pairs)))
-        same = bool(torch.equal(out.view(torch.int32), ref.view(torch.int32)))
-        res[f"{side}_{W}x{H}_{name}"] = {"dist_ms": round(min(ms["dist"]), 4), "pairs_ms": round(min(ms["pairs"]), 4), "same_bits": same}
-        print(f"{side} {W}x{H} {name:8s} dist {min(ms['dist']):.4f}  pairs {min(ms['pairs']):.4f}  ratio {min(ms['pairs']) / min(ms['dist']):.3f}  same bits {same}", file=sys.stderr, flush=True)
+            ms["ilv"].append(run(lambda: pkg.raymarch(rp, t0, t1, cam, W, H, out=out3, dist=dist, ilv=ilv)))
+        same = bool(torch.equal(out.view(torch.int32), ref.view(torch.int32)) and torch.equal(out3.view(torch.int32), ref.view(torch.int32)))
+        res[f"{side}_{W}x{H}_{name}"] = {"dist_ms": round(min(ms["dist"]), 4), "pairs_ms": round(min(ms["pairs"]), 4),
+                                         "ilv_ms": round(min(ms["ilv"]), 4), "same_bits": same}
+        print(f"{side} {W}x{H} {name:8s} dist {min(ms['dist']):.4f}  pairs {min(ms['pairs']):.4f}  ilv {min(ms['ilv']):.4f}  ratios {min(ms['pairs']) / min(ms['dist']):.3f} {min(ms['ilv']) / min(ms['dist']):.3f}  same bits {same}", file=sys.stderr, flush=True)
     if side == 256:
         cams = pkg.orbit_cameras(64, aspect=W / H)
         big = torch.empty((64, H, W, 4), dtype=torch.float32, device="cuda"); big2 = torch.empty_like(big)
         d = min(run(lambda: pkg.raymarch(rp, t0, t1, cams, W, H, out=big, dist=dist), n=5) for _ in range(2))
         p = min(run(lambda: pkg.raymarch(rp, t0, t1, cams, W, H, out=big2, dist=dist, pairs=pairs), n=5) for _ in range(2))
-        res["256_batch64"] = {"dist_ms": round(d, 4), "pairs_ms": round(p, 4), "same_bits": bool(torch.equal(big.view(torch.int32), big2.view(torch.int32))),
-                              "Mrays_s_dist": round(64 * W * H / d / 1e3, 1), "Mrays_s_pairs": round(64 * W * H / p / 1e3, 1)}
+        same = bool(torch.equal(big.view(torch.int32), big2.view(torch.int32)))
+        il = min(run(lambda: pkg.raymarch(rp, t0, t1, cams, W, H, out=big2, dist=dist, ilv=ilv), n=5) for _ in range(2))
+        same = same and bool(torch.equal(big.view(torch.int32), big2.view(torch.int32)))
+        res["256_batch64"] = {"dist_ms": round(d, 4), "pairs_ms": round(p, 4), "ilv_ms": round(il, 4), "same_bits": same,
+                              "Mrays_s_dist": round(64 * W * H / d / 1e3, 1), "Mrays_s_pairs": round(64 * W * H / p / 1e3, 1),
+                              "Mrays_s_ilv": round(64 * W * H / il / 1e3, 1)}
         print("batch64", res["256_batch64"], file=sys.stderr, flush=True)
         del big, big2
-    del t0, t1, dist, pairs
+    del t0, t1, dist, pairs, ilv
 print(json.dumps(res))
