@@ -1331,9 +1331,10 @@ static void box_first_rectangle(RaymarchArgs& ag, uint32_t groups_y) {
 static int march_volume_mode(const RaymarchArgs& a) {
     const uint64_t texels = (uint64_t)a.rp.tex_size[0] * a.rp.tex_size[1] * a.rp.tex_size[2];
     const bool loop_ok = a.rp.lod_dist_between_samples == 1.0f && a.fast_index && a.pow2_extent && a.pow2_size && a.symmetric_box &&
-                         a.asm_loop && a.rp.tex_size[0] >= 2 && texels <= (1ull << 28);
-    const bool pairs_ok = loop_ok && a.pairs;
-    const bool ilv_ok = loop_ok && a.ilv && a.rp.tex_size[1] >= 2;
+                         a.asm_loop && a.rp.tex_size[0] >= 2;
+    // 32-bit byte offsets: 8 B/texel of pairs reach 2^28 texels with the loop's shifts, 4 B/voxel of ilv 2^30 (like dist)
+    const bool pairs_ok = loop_ok && a.pairs && texels <= (1ull << 28);
+    const bool ilv_ok = loop_ok && a.ilv && a.rp.tex_size[1] >= 2 && texels <= (1ull << 30);
     if (pairs_ok && ilv_ok) return (a.last_level_cache_bytes && texels * 8u > a.last_level_cache_bytes) ? 4 : 3;
     return ilv_ok ? 4 : (pairs_ok ? 3 : 0);
 }

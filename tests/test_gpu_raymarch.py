@@ -490,6 +490,33 @@ def test_march_volume_advice_and_the_launchers_choice_at_512(pkg):
             assert torch.equal(depth.view(torch.int32), ref_depth.view(torch.int32)), (kw, list(vols))
 
 
+def test_hand_written_loops_past_2_28_texels(pkg):
+    """1024 x 1024 x 512 = 2^29 voxels: the distance and interleaved volumes' byte offsets pass 2^31 (the loops' 32-bit
+    offsets are unsigned and reach 2^30 voxels; the pair volume's 8 B/texel stop at 2^28 and fall back to the distance
+    volume).  The compiler's loop over the same volume is the reference, bit for bit, image and depth."""
+    if torch.cuda.mem_get_info()[0] < 40 << 30:
+        pytest.skip("needs 40 GB of free HBM")
+    K = pkg._capi
+    dims = (1024, 1024, 512)
+    g = pkg.make_grid(dims)
+    t0, t1 = pkg.alloc_textures(g)
+    dist = torch.empty((512, 1024, 1024), dtype=torch.float32, device="cuda")
+    pkg.fill_grid(pkg.default_params(), g, t0, t1, dist=dist)
+    ilv = pkg.commit_interleaved(g, dist)
+    pairs = pkg.commit_pairs(g, dist)
+    rp = pkg.default_render_params(g)
+    W, H = 1920, 1080
+    for kw in (dict(), dict(eye=(-1.4, -1.1, -2.2)), dict(eye=(0.3, -0.2, 0.9), target=(-1.0, 0.4, -1.0))):
+        cam = pkg.camera_look_at(aspect=W / H, **kw)
+        with pkg.options({K.OPT_RAYMARCH_DISABLE: K.RM_NO_ASM_LOOP}):
+            ref, ref_depth = pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist, want_depth=True)
+        for vols in (dict(), dict(ilv=ilv), dict(pairs=pairs)):
+            got, depth = pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist, want_depth=True, **vols)
+            assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (kw, list(vols))
+            assert torch.equal(depth.view(torch.int32), ref_depth.view(torch.int32)), (kw, list(vols))
+    assert (ref_depth < 1.0).sum() > 1000  # the last camera looks at the far corner from inside: hits at high z
+
+
 def test_row_bands_of_the_image_tile_split_tile_the_frame(pkg):
     """parallel.split_rows (config 5's image-tile split): the bands rendered by the "ranks" concatenate to the frame."""
     import importlib
