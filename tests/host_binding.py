@@ -11,7 +11,8 @@ except ImportError:  # pragma: no cover
     pass
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-H = C.CDLL(os.path.join(ROOT, "sdf-viewer_amd", "libsdfviewer_host_test.so"))
+# SDFV_HOST_TEST_LIB: another build of the same library (a sanitizer build run under LD_PRELOAD=libasan.so, say)
+H = C.CDLL(os.environ.get("SDFV_HOST_TEST_LIB") or os.path.join(ROOT, "sdf-viewer_amd", "libsdfviewer_host_test.so"))
 PROVIDER_PATH = os.path.join(ROOT, "sdf-viewer_amd", "libsdfdemo_provider.so")
 
 SZ = C.c_size_t
