@@ -73,10 +73,11 @@ def parse_args():
                          "distance between them inside one block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the extra 64-camera batch (profiling runs)")
-    ap.add_argument("--batch-split", choices=["both", "cameras", "rows"], default="both",
-                    help="N>1, 64-camera batch: rows = every rank renders a band of rows of every camera (BASELINE.json "
-                         "config 5's image-tile split), cameras = whole cameras dealt to the ranks; default: both are timed, "
-                         "`batch_raymarch` is the image-tile split and carries the camera split beside it")
+    ap.add_argument("--batch-split", choices=["both", "all", "tiles", "cameras", "rows"], default="all",
+                    help="N>1, 64-camera batch: tiles = every rank renders the 16-row tile bands r, r + N, ... of every camera "
+                         "(BASELINE.json config 5's image-tile split, balanced), rows = one contiguous range of rows per rank "
+                         "(the same split unbalanced: the outer ranks see background only), cameras = whole cameras dealt to the "
+                         "ranks; default: all three are timed, `batch_raymarch` is the tile split and carries the others beside it")
     ap.add_argument("--per-step-samples", type=int, default=50,
                     help="launches timed one by one with HIP events for ms_per_step_median / p95 (outside the K-step regions)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
@@ -982,40 +983,49 @@ def run(redirect):
             accel_kw = {"pairs": accel_vol}
 
         def time_split(split, use_pairs=True):
-            """rows = BASELINE config 5 as named (image-tile split: a band of rows of EVERY camera per rank, cut on the
-            kernel's 16-row tiles); cameras = whole cameras dealt to the ranks.  At N = 1 both are the same call."""
-            if split == "rows":
+            """tiles = BASELINE config 5 as named (image-tile split), balanced: the 16-row tile bands r, r + N, ... of EVERY
+            camera per rank (sdfv_raymarch_bands); rows = one contiguous range of rows of every camera per rank; cameras =
+            whole cameras dealt to the ranks.  At N = 1 all three are the same call."""
+            where = {}
+            if split == "tiles" and world > 1:
+                mine = batch_cams
+                where = {"bands": par.split_bands(H, rank, world)}
+                n_rows = len(par.band_rows(H, *where["bands"]))
+            elif split == "cameras":
+                mine = [batch_cams[i] for i in par.split_cameras(n_batch, rank, world)]
+                n_rows = H
+            else:
                 mine = batch_cams
                 by0, by1 = par.split_rows(H, rank, world)
-            else:
-                mine = [batch_cams[i] for i in par.split_cameras(n_batch, rank, world)]
-                by0, by1 = 0, H
-            batch_out = torch.empty((len(mine), by1 - by0, W, 4), dtype=torch.float32, device=device)
+                where, n_rows = {"y0": by0, "y1": by1}, by1 - by0
+            batch_out = torch.empty((len(mine), n_rows, W, 4), dtype=torch.float32, device=device)
 
             def batch_step():
-                pkg.raymarch(rp, r0, r1, mine, W, H, y0=by0, y1=by1, out=batch_out, dist=dist_vol,
-                             **(accel_kw if use_pairs else {}))
+                pkg.raymarch(rp, r0, r1, mine, W, H, out=batch_out, dist=dist_vol, **where, **(accel_kw if use_pairs else {}))
 
             batch_step()
             batch_dt, _ = timed_region(batch_step, batch_steps, torch, dist, world, device)
             ms = batch_dt / batch_steps * 1e3
-            return {"split": split if world > 1 else None, "cameras_per_gpu": len(mine), "rows_per_gpu": by1 - by0,
+            return {"split": split if world > 1 else None, "cameras_per_gpu": len(mine), "rows_per_gpu": n_rows,
                     "value": round(n_batch * W * H / ms / 1e3, 1), "unit": "Mrays/s", "ms_per_batch": round(ms, 4),
                     "march_over": (f"y-{volume_kind} volume" if volume_kind == "interleaved" else "y-pair volume") if use_pairs
                                   else "distance volume"}
 
-        splits = ["rows"] if world == 1 else (["rows", "cameras"] if args.batch_split == "both" else [args.batch_split])
+        splits = ["tiles"] if world == 1 else (["tiles", "rows", "cameras"] if args.batch_split in ("all", "both") else [args.batch_split])
         reports = {sp: time_split(sp) for sp in splits}
         batch_report = {"cameras": n_batch, "image": [W, H]}
         batch_report.update(reports[splits[0]])
-        if len(splits) > 1:
+        if "cameras" in splits[1:]:
             batch_report["camera_split"] = reports["cameras"]
+        if "rows" in splits[1:]:
+            batch_report["contiguous_rows_split"] = reports["rows"]
         over_dist = time_split(splits[0], use_pairs=False)
         batch_report["over_distance_volume"] = {k: over_dist[k] for k in ("value", "ms_per_batch")}
         batch_report["commit_pairs_ms"] = round(commit_pairs_ms, 4)
         batch_report["value_incl_commit"] = round(n_batch * W * H / (batch_report["ms_per_batch"] + commit_pairs_ms) / 1e3, 1)
         batch_report["note"] = ("BASELINE.json configs[4] shape (64-camera orbit) over the same grid, distance-volume march; "
-                                "top level = the image-tile split config 5 names (rows), camera_split = whole cameras per rank; the march "
+                                "top level = the image-tile split config 5 names, balanced (tile bands r, r + N, ... per rank; "
+                                "contiguous_rows_split = one range of rows per rank, tools/split_balance.py), camera_split = whole cameras per rank; the march "
                                 "reads the volume sdfv_march_volume_advice names (march_over), built once per load (commit_pairs_ms; "
                                 "value_incl_commit folds it in), "
                                 "over_distance_volume = the same batch over the 4 B/voxel volume")

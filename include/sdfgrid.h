@@ -383,6 +383,19 @@ int sdfv_raymarch_volumes(const sdfv_render_params *rp, const float *tex0, const
                           uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
                           float *rgba, float *depth, sdfv_march_aux *aux, void *stream);
 
+/* The balanced image-tile split (BASELINE config 5): the 16-row tile bands band_first, band_first + band_step, ... of the
+ * image -- rank r of N renders (r, N) -- instead of one contiguous range of rows (the rows under the object cost ten times
+ * the rows of background: 8 contiguous ranges of a 1080p orbit view scale 2.4x on 8 GPUs, 8 interleaved sets 6-7x).  The
+ * bands are stored one after the other: rgba / depth / aux hold n_cameras x sdfv_band_rows(height, band_first, band_step)
+ * x width pixels; band k of the output is rows [16 * (band_first + k * band_step), ...+16) of the image (the last band of
+ * an image whose height is not a multiple of 16 is short; a band set that starts below the image renders nothing and
+ * succeeds).  Otherwise sdfv_raymarch_volumes; same bits per pixel. */
+uint32_t sdfv_band_rows(uint32_t height, uint32_t band_first, uint32_t band_step);
+int sdfv_raymarch_bands(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
+                        const float *pairs, const float *ilv, const sdfv_camera *cameras, uint32_t n_cameras,
+                        uint32_t width, uint32_t height, uint32_t band_first, uint32_t band_step,
+                        float *rgba, float *depth, sdfv_march_aux *aux, void *stream);
+
 /* ---- raymarch over a z-sharded grid (multi-GPU; the consumer of the slab halo) ----
  * The grid stays sharded: rank r holds [ghost_lo][owned z_begin..z_end)[ghost_hi] as laid out for sdfv_slab_*.
  * A ray is marched by the rank that owns the cell it is in (clamp(floor(w), 0, D-1) in [z_begin, z_end); the

@@ -114,6 +114,10 @@ PROTOTYPES = {
                                       C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_commit_pairs": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdfv_band_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    "sdfv_raymarch_bands": (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_march_volume_advice": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_uint32)]),
     "sdfv_commit_interleaved": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_raymarch_volumes": (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

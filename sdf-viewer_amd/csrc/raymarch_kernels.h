@@ -42,7 +42,10 @@ struct RaymarchArgs {
     uint32_t wave_slots_per_simd_unit;  // SIMDs of the device (CUs x 4): resident waves at w per SIMD = w x this; 0 = unknown
     uint64_t last_level_cache_bytes;    // Infinity Cache (MI355X: 256 MB); 0 = unknown
     uint32_t cube_box;           // symmetric box with bounds_max[0] == [1] == [2]: two-instruction out-of-bounds test
-    float4* rgba;                // n_cameras x (y1-y0) x width
+    uint32_t rows_out;           // rows per camera in the outputs: y1 - y0, or the rows of the rendered bands (band_skip != 0)
+    uint32_t band_skip;          // 0: rows [y0, y1).  16 * (step - 1): the 16-row tile bands y0/16, y0/16 + step, ... below y1,
+                                 // stored one after the other (sdfv_raymarch_bands: the balanced image-tile split)
+    float4* rgba;                // n_cameras x rows_out x width
     sdfv_march_aux* aux;         // same layout or nullptr
     float* depth;                // gl_FragDepth plane, same pixel layout, or nullptr
 #ifdef SDFV_TUNING

@@ -716,7 +716,7 @@ __device__ __forceinline__ void stamp_wave(const RaymarchArgs& a, uint32_t bx, u
                                            unsigned long long t_start, unsigned long long t_start_rt, int iterations,
                                            unsigned long long covered_mask) {
     // indexed by the TILE (whatever workgroup rendered it): stamps of any tile order land in the same slots
-    const uint32_t tiles_x = (a.width + 15) / 16, tiles_y = (a.y1 - a.y0 + 15) / 16;
+    const uint32_t tiles_x = (a.width + 15) / 16, tiles_y = (a.rows_out + 15) / 16;
     const uint64_t wave_id = ((uint64_t)(blockIdx.z * tiles_y + by) * tiles_x + bx) * 4 + wave;
     a.wave_timing[wave_id * 4 + 0] = t_start;
     a.wave_timing[wave_id * 4 + 1] = __builtin_readcyclecounter();
@@ -824,12 +824,12 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
         if (bx >= a.tiles_x || by >= a.tiles_y) return;  // padding of the last groups
     }
     const uint32_t px = bx * 16 + (wave & 1) * 8 + (lane & 7);
-    const uint32_t row = by * 16 + (wave >> 1) * 8 + (lane >> 3);  // row within [y0, y1)
-    const uint32_t py = a.y0 + row;
+    const uint32_t row = by * 16 + (wave >> 1) * 8 + (lane >> 3);  // row of the output: within [y0, y1), or of the bands
+    const uint32_t py = a.y0 + row + by * a.band_skip;
     const uint32_t cam_idx = blockIdx.z;
     const bool in_image = px < a.width && py < a.y1;
     const sdfv_camera& cam = a.cameras[cam_idx];
-    const uint64_t out_index = ((uint64_t)cam_idx * (a.y1 - a.y0) + row) * a.width + px;
+    const uint64_t out_index = ((uint64_t)cam_idx * a.rows_out + row) * a.width + px;
 #ifdef SDFV_TUNING
     if (a.priority_map && a.priority_map[by * ((a.width + 15) / 16) + bx]) __builtin_amdgcn_s_setprio(3);
     const unsigned long long t_start = a.wave_timing ? __builtin_readcyclecounter() : 0ull;
@@ -1361,7 +1361,7 @@ static uint32_t lds_cap_for(uint32_t w) {
 }
 
 hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream) {
-    const uint32_t rows = a.y1 - a.y0;
+    const uint32_t rows = a.rows_out;
     if (a.width == 0 || rows == 0 || a.n_cameras == 0) return hipSuccess;
     dim3 grid((a.width + 15) / 16, (rows + 15) / 16, a.n_cameras);
     RaymarchArgs ag = a;
@@ -1386,7 +1386,9 @@ hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream) {
         if (a.box_first && a.n_cameras == 1 && groups < 65536u) box_first_rectangle(ag, groups_y);  // 16-bit quotients
         grid = dim3(groups << (2 * shift), 1, a.n_cameras);
     };
-    if (a.group_shift == kGroupAuto) {
+    if (a.band_skip) {
+        ag.group_shift = 0;  // interleaved bands: launch order (the tile orders below assume a contiguous range of rows)
+    } else if (a.group_shift == kGroupAuto) {
         // one camera: groups of 2 x 2 tiles with the box-first order where the bounding box projects to a proper part of the
         // image, otherwise (camera inside the box, box filling the image, order switched off) groups of 4 x 4
         grouped(1);

@@ -380,6 +380,11 @@ int fill_boundary_slices(const sdfv_demo_params* params, uint32_t sdf_id, const 
 }  // namespace sdfv
 
 #pragma GCC visibility push(default)
+static int raymarch_rows(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
+                         const float* pairs, const float* ilv, const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width,
+                         uint32_t height, uint32_t y0, uint32_t y1, uint32_t band_step, float* rgba, float* depth,
+                         sdfv_march_aux* aux, void* stream);
+
 extern "C" {
 
 uint32_t sdfv_abi_version(void) { return SDFV_ABI_VERSION; }
@@ -941,6 +946,32 @@ int sdfv_raymarch_pairs(const sdfv_render_params* rp, const float* tex0, const f
 int sdfv_raymarch_volumes(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
                           const float* pairs, const float* ilv, const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width,
                           uint32_t height, uint32_t y0, uint32_t y1, float* rgba, float* depth, sdfv_march_aux* aux, void* stream) {
+    return raymarch_rows(rp, tex0, tex1, dist, pairs, ilv, cameras, n_cameras, width, height, y0, y1, 1, rgba, depth, aux, stream);
+}
+
+uint32_t sdfv_band_rows(uint32_t height, uint32_t band_first, uint32_t band_step) {
+    const uint32_t tiles_y = (height + 15) / 16;
+    if (band_step == 0 || band_first >= tiles_y) return 0;
+    const uint32_t n = (tiles_y - band_first + band_step - 1) / band_step, last = band_first + (n - 1) * band_step;
+    return (n - 1) * 16 + (height - last * 16 < 16 ? height - last * 16 : 16);
+}
+
+int sdfv_raymarch_bands(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
+                        const float* pairs, const float* ilv, const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width,
+                        uint32_t height, uint32_t band_first, uint32_t band_step, float* rgba, float* depth, sdfv_march_aux* aux,
+                        void* stream) {
+    if (band_step == 0) return fail(SDFV_ERR_INVALID_ARGUMENT, "band_step is 0");
+    if (sdfv_band_rows(height, band_first, band_step) == 0) return SDFV_OK;  // a band set below the image: nothing to render
+    const uint32_t y0 = band_first * 16;
+    return raymarch_rows(rp, tex0, tex1, dist, pairs, ilv, cameras, n_cameras, width, height, y0, height, band_step, rgba, depth, aux, stream);
+}
+
+}  // extern "C"
+// Rows [y0, y1) of the image (band_step 1), or the 16-row bands y0 / 16, y0 / 16 + band_step, ... below y1 == height.
+static int raymarch_rows(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
+                         const float* pairs, const float* ilv, const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width,
+                         uint32_t height, uint32_t y0, uint32_t y1, uint32_t band_step, float* rgba, float* depth,
+                         sdfv_march_aux* aux, void* stream) {
     if (!rp || !tex0 || !tex1 || !rgba) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
     if (int rc = check_lights(rp)) return rc;
     if (int rc = check_texel_alignment(tex0, tex1, rgba)) return rc;
@@ -966,6 +997,8 @@ int sdfv_raymarch_volumes(const sdfv_render_params* rp, const float* tex0, const
     a.height = height;
     a.y0 = y0;
     a.y1 = y1;
+    a.band_skip = 16u * (band_step - 1u);
+    a.rows_out = band_step > 1 ? sdfv_band_rows(height, y0 / 16, band_step) : y1 - y0;
     // sdfNormal's result only feeds calculate_lighting (material.frag:155,163), and the one AmbientLight the scene
     // configures (scene/mod.rs:106-112) does not read it: dead code a GLSL compiler removes.  It is evaluated when the
     // aux record asks for it; SDFV_OPT_RAYMARCH_KEEP_NORMAL evaluates it per hit regardless (what it would cost once a
@@ -993,7 +1026,7 @@ int sdfv_raymarch_volumes(const sdfv_render_params* rp, const float* tex0, const
     a.priority_map = reinterpret_cast<const unsigned char*>(g_options.priority_map);
     a.tile_order = n_cameras == 1 ? reinterpret_cast<const uint32_t*>(g_options.tile_order) : nullptr;
 #endif
-    const uint64_t pixels_per_cam = (uint64_t)(y1 - y0) * width;
+    const uint64_t pixels_per_cam = (uint64_t)a.rows_out * width;
     for (uint32_t c0 = 0; c0 < n_cameras; c0 += sdfv::kMaxCamerasPerLaunch) {
         const uint32_t nc = n_cameras - c0 < sdfv::kMaxCamerasPerLaunch ? n_cameras - c0 : sdfv::kMaxCamerasPerLaunch;
         a.n_cameras = nc;
@@ -1005,6 +1038,7 @@ int sdfv_raymarch_volumes(const sdfv_render_params* rp, const float* tex0, const
     }
     return SDFV_OK;
 }
+extern "C" {
 
 // Argument checks and RaymarchArgs / SlabMarchArgs shared by the two forms of a round of the sharded march.
 static int slab_round_args(const sdfv_render_params* rp, const sdfv_grid* slab, uint32_t ghost_lo, uint32_t ghost_hi,
@@ -1039,6 +1073,8 @@ static int slab_round_args(const sdfv_render_params* rp, const sdfv_grid* slab, 
     a.height = height;
     a.y0 = 0;
     a.y1 = height;
+    a.rows_out = height;
+    a.band_skip = 0;
     a.n_cameras = 1;
     a.cameras[0] = *camera;
     a.rgba = reinterpret_cast<float4*>(rgba);

@@ -504,6 +504,47 @@ def split_rows(height, rank, world, tile=16):
     return min(height, tiles * rank // world * tile), min(height, tiles * (rank + 1) // world * tile)
 
 
+def split_bands(height, rank, world):
+    """The BALANCED image-tile split of config 5: rank r renders the 16-row tile bands r, r + world, r + 2 world, ... of every
+    image (sdfv_raymarch_bands) -- the rows under the object cost ten times the background's, so contiguous ranges leave the
+    outer ranks idle; -> (band_first, band_step) for raymarch(bands=...)."""
+    return rank, world
+
+
+def band_rows(height, first, step, tile=16):
+    """Image rows of the bands (first, step), in the order raymarch(bands=...) stores them."""
+    rows = []
+    for t in range(first, (height + tile - 1) // tile, step):
+        rows.extend(range(t * tile, min(height, (t + 1) * tile)))
+    return rows
+
+
+def assemble_bands(parts, height):
+    """The image [n_cam, height, W, ...] from the `world` band sets of split_bands, parts[r] = what rank r rendered."""
+    world = len(parts)
+    out = torch.empty((parts[0].shape[0], height) + tuple(parts[0].shape[2:]), dtype=parts[0].dtype, device=parts[0].device)
+    for r, part in enumerate(parts):
+        out[:, torch.as_tensor(band_rows(height, r, world), dtype=torch.long, device=out.device)] = part
+    return out
+
+
+def gather_bands(part, height, rank, world, dst=0, group=None):
+    """Collect the band sets of split_bands on rank `dst` -> [n_cam, height, W, 4] (None elsewhere)."""
+    if world == 1:
+        return part
+    deepest = max(len(band_rows(height, r, world)) for r in range(world))
+    staged = _needs_host_staging(part, group)
+    dev = torch.device("cpu") if staged else part.device
+    padded = torch.zeros((part.shape[0], deepest) + tuple(part.shape[2:]), dtype=part.dtype, device=dev)
+    padded[:, :part.shape[1]] = part
+    got = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    enter_stage("gather_bands: gather of the tile bands")
+    c10d.gather(padded, got, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return assemble_bands([g[:, :len(band_rows(height, r, world))] for r, g in enumerate(got)], height).to(part.device)
+
+
 def gather_rows(band, height, rank, world, dst=0, group=None, tile=16):
     """Collect the row bands of split_rows ([n_cam, rows, W, 4] each) on rank `dst` -> [n_cam, height, W, 4]."""
     if world == 1:

@@ -43,10 +43,12 @@ def test_bench_weak_scaling_path_two_ranks_one_gpu(world, geometry):
         assert key in d, key
     assert d["rccl_ranks"] is None and d["torch_world_size"] == world
     assert d["roofline"]["frac_8d"] > 0 and d["roofline"]["algorithmic_bytes_per_voxel"] == 32
-    # config 5 as BASELINE names it (image-tile split) is the batch's top level, the camera split rides beside it
+    # config 5 as BASELINE names it (image-tile split, balanced: interleaved tile bands) is the batch's top level; the
+    # contiguous-rows form of the same split and the camera split ride beside it
     b = d["batch_raymarch"]
-    assert b["value"] > 0 and b["split"] == "rows" and b["rows_per_gpu"] == 512 // world and b["cameras_per_gpu"] == 64
+    assert b["value"] > 0 and b["split"] == "tiles" and b["rows_per_gpu"] == 512 // world and b["cameras_per_gpu"] == 64
     assert b["camera_split"]["value"] > 0 and b["camera_split"]["cameras_per_gpu"] == 64 // world
+    assert b["contiguous_rows_split"]["value"] > 0 and b["contiguous_rows_split"]["rows_per_gpu"] == 512 // world
     assert d["sharded_fill_verified"] is True  # gathered slabs == dense fill, ghost slices == neighbour's slices
     c4 = d["config4"]  # the cube geometry next to the default one, in the same line
     assert c4["value"] > 0 and c4["voxels_per_gpu"] == 32 ** 3 and len(c4["grid_global"]) == 3, c4

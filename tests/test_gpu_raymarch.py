@@ -532,3 +532,44 @@ def test_row_bands_of_the_image_tile_split_tile_the_frame(pkg):
         bands = [pkg.raymarch(rp, t0, t1, cams, W, H, *par.split_rows(H, r, world)) for r in range(world)
                  if par.split_rows(H, r, world)[1] > par.split_rows(H, r, world)[0]]
         assert torch.equal(torch.cat(bands, dim=1).view(torch.int32), whole.view(torch.int32))
+
+
+def test_interleaved_tile_bands_assemble_to_the_frame(pkg):
+    """sdfv_raymarch_bands (config 5's balanced image-tile split): rank r of N renders the 16-row bands r, r + N, ... of every
+    camera's image into a compact buffer; the N buffers assemble to the frame bit for bit -- RGBA, depth plane and aux
+    record, over tex0.r / the distance volume / the pair volume, with the general (NEAREST, lod 2) kernel too, for image
+    heights that are and are not multiples of 16 -- and nothing is written past sdfv_band_rows rows."""
+    import importlib
+    par = importlib.import_module("sdf-viewer_amd.parallel")
+    dims = (32, 32, 32)
+    g = pkg.make_grid(dims)
+    t0, t1 = pkg.alloc_textures(g)
+    pkg.fill_grid(pkg.default_params(), g, t0, t1)
+    dist = pkg.commit_distance(g, t0)
+    pairs = pkg.commit_pairs(g, dist)
+    for (W, H), lod in (((120, 100), 1.0), ((96, 64), 1.0), ((70, 33), 2.0), ((50, 7), 1.0)):
+        rp = pkg.default_render_params(g)
+        rp.lod_dist_between_samples = lod
+        cams = pkg.orbit_cameras(3, aspect=W / H)
+        for vols in (dict(), dict(dist=dist), dict(dist=dist, pairs=pairs)):
+            whole, whole_depth, whole_aux = pkg.raymarch(rp, t0, t1, cams, W, H, want_depth=True, want_aux=True, **vols)
+            for world in (1, 2, 3, 8):
+                parts = [pkg.raymarch(rp, t0, t1, cams, W, H, bands=par.split_bands(H, r, world), want_depth=True, want_aux=True, **vols)
+                         for r in range(world)]
+                for r, (rgba, depth, aux) in enumerate(parts):
+                    assert rgba.shape[1] == len(par.band_rows(H, r, world)) == int(pkg.lib.sdfv_band_rows(H, r, world))
+                for k, ref in enumerate((whole, whole_depth, whole_aux)):
+                    got = par.assemble_bands([p[k] for p in parts], H)
+                    assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (W, H, lod, list(vols), world, k)
+    # a compact buffer with a canary behind it; a band set beyond the image renders nothing
+    rp = pkg.default_render_params(g)
+    W, H = 64, 40
+    cam = pkg.camera_look_at(aspect=W / H)
+    rows = len(par.band_rows(H, 1, 2))  # band 1 only: 16 rows
+    buf = torch.full((1, rows + 3, W, 4), -7.0, device="cuda")
+    pkg.raymarch(rp, t0, t1, cam, W, H, bands=(1, 2), out=buf)
+    torch.cuda.synchronize()
+    assert rows == 16 and bool((buf[:, rows:] == -7.0).all()) and not bool((buf[:, :rows] == -7.0).any())
+    assert pkg.raymarch(rp, t0, t1, cam, W, H, bands=(3, 4)).shape[1] == 0
+    with pytest.raises(pkg.SdfvError):
+        pkg.raymarch(rp, t0, t1, cam, W, H, bands=(0, 0))

@@ -72,6 +72,17 @@ def _worker(rank, world, port, dims, q, halo_hi=1):
                 ok &= bool((whole[:, a:b] == float(r + 1)).all())
         else:
             ok &= whole is None
+        # the balanced image-tile split: rank r's 16-row tile bands r, r + world, ...; every pixel carries its image row
+        for Himg in (50, 64, 7):
+            first, step = par.split_bands(Himg, rank, world)
+            rows = par.band_rows(Himg, first, step)
+            part = torch.tensor(rows, dtype=torch.float32).reshape(1, -1, 1, 1).expand(2, -1, 6, 4).contiguous()
+            whole = par.gather_bands(part, Himg, rank, world, dst=0)
+            if rank == 0:
+                ok &= whole.shape == (2, Himg, 6, 4)
+                ok &= bool((whole == torch.arange(Himg, dtype=torch.float32).reshape(1, -1, 1, 1)).all())
+            else:
+                ok &= whole is None
         # ray hand-over of the sharded march: lists of data-dependent length to both neighbours, some empty.
         # Rank r sends r + 1 rays down and 2 * r rays up (rank 0 none up); every word carries (sender, direction, k).
         def rays(n, direction):
@@ -129,6 +140,12 @@ def test_partition_helpers():
             assert bands[0][0] == 0 and bands[-1][1] == h and all(a[1] == b[0] for a, b in zip(bands[:-1], bands[1:]))
             assert all(y0 % 16 == 0 for y0, _ in bands)
     assert par.split_rows(1080, 3, 8) == (400, 544)
+    for h in (1, 15, 16, 17, 100, 1080, 2160):
+        for world in (1, 2, 3, 8, 80):
+            rows = [par.band_rows(h, *par.split_bands(h, r, world)) for r in range(world)]
+            assert sorted(sum(rows, [])) == list(range(h))              # a partition of the image's rows
+            assert all(r == sorted(r) for r in rows)                     # each set in image order
+    assert par.band_rows(1080, 3, 8)[:17] == list(range(48, 64)) + [176] and len(par.band_rows(1080, 3, 8)) == 8 * 16 + 8
     cams = [list(par.split_cameras(64, r, 8)) for r in range(8)]
     assert sum(cams, []) == list(range(64)) and all(len(c) == 8 for c in cams)
 

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Config 5 on ONE GPU, rank by rank: what each of `world` ranks would do under the three splits of the 64-camera batch --
+contiguous row bands, whole cameras, interleaved 16-row tile bands -- timed one share after the other.  The slowest share
+is what a barrier-to-barrier measurement over `world` GPUs sees; mean / max = the split's balance.
+python tools/split_balance.py [world]"""
+import importlib, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+pkg = importlib.import_module("sdf-viewer_amd")
+par = importlib.import_module("sdf-viewer_amd.parallel")
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+side, W, H, n = 256, 1920, 1080, 64
+g = pkg.make_grid((side,) * 3)
+t0, t1 = pkg.alloc_textures(g); dist = torch.empty((side,) * 3, dtype=torch.float32, device="cuda")
+pkg.fill_grid(pkg.default_params(), g, t0, t1, dist=dist); pairs = pkg.commit_pairs(g, dist)
+rp = pkg.default_render_params(g)
+cams = pkg.orbit_cameras(n, aspect=W / H)
+def run(fn, reps=5):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+res = {"world": world, "whole_batch_ms": round(run(lambda: pkg.raymarch(rp, t0, t1, cams, W, H, dist=dist, pairs=pairs)), 4)}
+shares = {"rows": [], "cameras": [], "tiles": []}
+for r in range(world):
+    y0, y1 = par.split_rows(H, r, world)
+    shares["rows"].append(run(lambda: pkg.raymarch(rp, t0, t1, cams, W, H, y0=y0, y1=y1, dist=dist, pairs=pairs)))
+    mine = [cams[i] for i in par.split_cameras(n, r, world)]
+    shares["cameras"].append(run(lambda: pkg.raymarch(rp, t0, t1, mine, W, H, dist=dist, pairs=pairs)))
+    if hasattr(par, "split_bands"):
+        first, step = par.split_bands(H, r, world)
+        shares["tiles"].append(run(lambda: pkg.raymarch(rp, t0, t1, cams, W, H, bands=(first, step), dist=dist, pairs=pairs)))
+for k, v in shares.items():
+    if v:
+        res[k] = {"ms_per_rank": [round(x, 4) for x in v], "max_ms": round(max(v), 4), "mean_ms": round(sum(v) / len(v), 4),
+                  "balance": round(sum(v) / len(v) / max(v), 3), "speedup_over_one_gpu": round(res["whole_batch_ms"] / max(v), 2)}
+print(json.dumps(res))
