@@ -51,6 +51,7 @@ def test_options_are_explicit_and_the_library_reads_no_environment(pkg):
     assert pkg.get_option(K.OPT_RAYMARCH_TILE_GROUP) == 0 and pkg.get_option(K.OPT_RAYMARCH_BOX_FIRST) == 1
     assert pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_BOX_FIRST, 2) == -1 and pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_TILE_GROUP, 6) == -1
     assert pkg.get_option(K.OPT_RAYMARCH_WAVES_PER_SIMD) == 0
+    assert pkg.get_option(K.OPT_RAYMARCH_BATCH_STREAMS) == 1 and pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_BATCH_STREAMS, 2) == -1
     assert pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_WAVES_PER_SIMD, 1) == -1 and pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_WAVES_PER_SIMD, 8) == -1
     assert pkg.lib.sdfv_set_option(K.OPT_FILL_FORM, 3) == -1
     assert pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_DISABLE, 64) == -1

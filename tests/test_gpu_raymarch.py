@@ -573,3 +573,43 @@ def test_interleaved_tile_bands_assemble_to_the_frame(pkg):
     assert pkg.raymarch(rp, t0, t1, cam, W, H, bands=(3, 4)).shape[1] == 0
     with pytest.raises(pkg.SdfvError):
         pkg.raymarch(rp, t0, t1, cam, W, H, bands=(0, 0))
+
+
+def test_small_launches_of_a_batch_overlap_on_side_streams_and_change_nothing(pkg):
+    """A batch of more than 16 cameras is several launches; small ones (low-resolution views, band shares) are forked onto the
+    library's side streams and joined back into the caller's stream.  Same images as one launch after the other; ordered
+    with the caller's stream on both sides (a fill before, a read after, no synchronisation in between); capturable."""
+    K = pkg._capi
+    dims = (64, 64, 64)
+    g = pkg.make_grid(dims)
+    t0, t1 = pkg.alloc_textures(g)
+    prm = pkg.default_params()
+    rp = pkg.default_render_params(g)
+    W, H = 200, 120
+    cams = pkg.orbit_cameras(50, aspect=W / H)  # 4 launches: 16 + 16 + 16 + 2
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for radius in (1.05, 0.8):  # the second fill overwrites what the first batch read: the batch must wait for it, and it for the batch
+            prm.sphere_radius = radius
+            pkg.fill_grid(prm, g, t0, t1, stream=side)
+            got, got_depth = pkg.raymarch(rp, t0, t1, cams, W, H, want_depth=True, stream=side)
+            summed = got.sum(dim=(1, 2, 3))  # a consumer on the caller's stream
+        side.synchronize()
+        with pkg.options({K.OPT_RAYMARCH_BATCH_STREAMS: 0}):
+            ref, ref_depth = pkg.raymarch(rp, t0, t1, cams, W, H, want_depth=True, stream=side)
+        side.synchronize()
+        assert torch.equal(got.view(torch.int32), ref.view(torch.int32)) and torch.equal(got_depth.view(torch.int32), ref_depth.view(torch.int32))
+        assert torch.equal(summed, ref.sum(dim=(1, 2, 3)))
+        # captured into a graph: the fork and the joins are events, the side streams join the capture
+        out = torch.zeros_like(ref)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            pkg.raymarch(rp, t0, t1, cams, W, H, out=out, stream=side)
+        out.zero_()
+        graph.replay()
+        side.synchronize()
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    assert pkg.lib.sdfv_mesh_trim() == 0  # releases the side streams; the next batch makes new ones
+    again = pkg.raymarch(rp, t0, t1, cams, W, H)
+    torch.cuda.synchronize()
+    assert torch.equal(again.view(torch.int32), ref.view(torch.int32))
