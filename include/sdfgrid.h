@@ -158,7 +158,7 @@ typedef enum sdfv_option {
                                         * whose projected bounding box holds 1x .. 3.5x the machine's wave slots (latency-bound on
                                         * its long waves: 1440p over 512^3 -17 %, 4K -6 %), otherwise no cap | 2..6: that cap |
                                         * 7: never cap (what the register file allows).  Speed only */
-    SDFV_OPT_RAYMARCH_BATCH_STREAMS = 9, /* 1 (default) | 0: a batch of more than 16 cameras is several launches (the cameras ride
+    SDFV_OPT_RAYMARCH_BATCH_STREAMS = 9, /* 1 (default) | 0: a batch of more than 64 cameras is several launches (the cameras ride
                                         * in the kernel arguments); when each is small (at most 40 000 workgroups: low-resolution
                                         * views, a rank's share of a split batch) they run on side streams forked from and joined
                                         * back into the caller's stream, where they overlap -- a small launch is as long as its

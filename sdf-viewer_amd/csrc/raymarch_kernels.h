@@ -53,10 +53,12 @@ struct RaymarchArgs {
     const unsigned char* priority_map;  // tuning build only: one byte per tile, non-zero = raise the waves' priority
     unsigned long long* wave_timing;  // tuning build only: per wave {start, end, iterations, covered mask} or nullptr
 #endif
-    sdfv_camera cameras[16];
+    sdfv_camera cameras[64];
 };
 
-constexpr uint32_t kMaxCamerasPerLaunch = 16;
+// 64 x 120 B: an 8 KB kernel-argument block (beyond HIP's documented 4 KB, accepted by ROCm 7 on gfx950 -- the 64-camera tests
+// render through it).  One launch for BASELINE config 5's batch: 1.59 -> 1.48 ms, and a rank's share of it is one launch too.
+constexpr uint32_t kMaxCamerasPerLaunch = 64;
 constexpr uint32_t kGroupAuto = 255;  // RaymarchArgs::group_shift as handed to launch_raymarch: let the launcher choose
 
 // One round of the march over a z-slab of the grid (multi-GPU: the grid stays sharded, rays move between ranks).

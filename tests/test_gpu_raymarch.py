@@ -576,7 +576,7 @@ def test_interleaved_tile_bands_assemble_to_the_frame(pkg):
 
 
 def test_small_launches_of_a_batch_overlap_on_side_streams_and_change_nothing(pkg):
-    """A batch of more than 16 cameras is several launches; small ones (low-resolution views, band shares) are forked onto the
+    """A batch of more than 64 cameras is several launches; small ones (low-resolution views, band shares) are forked onto the
     library's side streams and joined back into the caller's stream.  Same images as one launch after the other; ordered
     with the caller's stream on both sides (a fill before, a read after, no synchronisation in between); capturable."""
     K = pkg._capi
@@ -586,7 +586,7 @@ def test_small_launches_of_a_batch_overlap_on_side_streams_and_change_nothing(pk
     prm = pkg.default_params()
     rp = pkg.default_render_params(g)
     W, H = 200, 120
-    cams = pkg.orbit_cameras(50, aspect=W / H)  # 4 launches: 16 + 16 + 16 + 2
+    cams = pkg.orbit_cameras(150, aspect=W / H)  # 3 launches: 64 + 64 + 22
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         for radius in (1.05, 0.8):  # the second fill overwrites what the first batch read: the batch must wait for it, and it for the batch
