@@ -973,7 +973,9 @@ def run(redirect):
         # exactly that case: 64 frames over one grid.  Its one-off cost is reported and folded into value_incl_commit.
         # Beyond the last-level cache (512^3) the library advises the y-interleaved volume instead (4 B/voxel, rows paired).
         volume_kind = pkg.march_volume_advice(rgrid_whole)
-        if volume_kind == "interleaved":
+        if volume_kind is None:  # (a grid that is not cubic: the distance volume is what marches fastest)
+            accel_kw, commit_pairs_ms = {}, 0.0
+        elif volume_kind == "interleaved":
             accel_vol = pkg.commit_interleaved(rgrid_whole, dist_vol)
             commit_pairs_ms = region(lambda: pkg.commit_interleaved(rgrid_whole, dist_vol, ilv=accel_vol), 3, 1, torch, dist, world, device)[0]
             accel_kw = {"ilv": accel_vol}

@@ -377,6 +377,7 @@ int sdfv_commit_interleaved(const sdfv_grid *grid, const float *dist, float *ilv
 /* Which of the two a host that renders many frames per load should build for this grid on the current device:
  * the pair volume while its 8 B/voxel fit the last-level cache (MI355X: 256 MB -- up to 256^3 x 2), the interleaved volume
  * beyond (4K over 512^3: -10 % against either of the others; 1080p over 256^3: pairs -6 %, interleaved +-1 %).  Speed only. */
+#define SDFV_MARCH_VOLUME_NONE 0u /* a grid that is not cubic: neither pays over the distance volume */
 #define SDFV_MARCH_VOLUME_PAIRS 1u
 #define SDFV_MARCH_VOLUME_INTERLEAVED 2u
 int sdfv_march_volume_advice(const sdfv_grid *grid, uint32_t *kind);

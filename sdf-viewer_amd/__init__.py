@@ -340,10 +340,10 @@ def commit_pairs(grid, dist, pairs=None, stream=None):
 
 
 def march_volume_advice(grid):
-    """"pairs" or "interleaved": the acceleration volume a many-frames host should build for this grid (speed only)."""
+    """"pairs", "interleaved" or None: the acceleration volume a many-frames host should build for this grid (speed only)."""
     kind = C.c_uint32(0)
     check(lib.sdfv_march_volume_advice(C.byref(grid), C.byref(kind)))
-    return {1: "pairs", 2: "interleaved"}[kind.value]
+    return {0: None, 1: "pairs", 2: "interleaved"}[kind.value]
 
 
 def commit_interleaved(grid, dist, ilv=None, stream=None):

@@ -17,7 +17,8 @@ struct RaymarchArgs {
     const float* dist;           // compact copy of tex0.r (sdfv_commit_distance) or nullptr
     const float* pairs;          // y-pair volume (sdfv_commit_pairs: 2 floats per texel) or nullptr
     const float* ilv;            // y-interleaved volume (sdfv_commit_interleaved: 1 float per texel, rows paired) or nullptr
-    uint32_t pow2_size;          // every tex_size[i] is a power of two (with pow2_extent: one fused scale per axis)
+    uint32_t pow2_size;          // with pow2_extent: one fused scale (1/size) * N per axis -- exact for ANY N below 2^24, since
+                                 // 1/size is a power of two (the name dates from when only power-of-two N took it)
     uint32_t symmetric_box;      // bounds_min == -bounds_max on every axis
     uint32_t fast_normal;        // the normal's 4 taps also keep floor(u) in [-1, N-1]
     float cull_center[3];        // bounding sphere of the box, radius inflated by 1 % (conservative tile cull)

@@ -294,7 +294,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 #else
 #define SDFV_MARCH_ASM_TUNE(x) ""
 #endif
-#define SDFV_MARCH_ASM_HEAD(ROW_SHIFT)                                                                                         \
+#define SDFV_MARCH_ASM_HEAD(ROW_BYTES)                                                                                         \
     "s_mov_b64 s[76:77], exec\n"                                                                                    \
     "s_and_b64 exec, exec, %[cov]\n"                                                                                \
     "s_cbranch_execz .Ldone_%=\n"                                                                                   \
@@ -303,15 +303,14 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "s_mov_b32 s70, %[ky]\n s_mov_b32 s71, %[kz]\n"          /* (ky, kz) */                                          \
     "s_mov_b32 s72, 0xbf000000\n s_mov_b32 s73, 0xbf000000\n" /* (-0.5, -0.5) */                                     \
     "s_add_i32 s75, %[wm1], -1\n"                            /* W - 2 */                                             \
-    "s_add_i32 s82, %[lgw], 2\n s_add_i32 s83, %[lgw], 4\n"  /* log2(W) + 2 / + 4: row -> byte offset shifts */      \
-    "s_add_i32 s85, %[lgw], 3\n"                            /* ... + 3: the y-pair volume (8 bytes per texel) */       \
+    "s_lshl_b32 s82, %[w], 2\n s_lshl_b32 s83, %[w], 4\n"    /* bytes per row: W * 4 (distance volume), W * 16 (tex0) */     \
+    "s_lshl_b32 s85, %[w], 3\n"                              /* ... W * 8: the y-pair / y-interleaved volumes */        \
     "s_movk_i32 s74, 254\n"                                  /* 255 iterations */                                    \
     /* interior cells (all eight corners inside the volume, no clamp): the four corner rows are one offset against four  \
-     * bases -- b00 = base, b10 = base + a row, b01 = base + a slice, b11 = both (row shift: s82 for the distance volume, \
-     * s83 for tex0) */                                                                                              \
-    "s_lshl_b32 s64, 1, " ROW_SHIFT "\n"                                                                              \
-    "s_add_i32 s86, %[lgh], " ROW_SHIFT "\n"                                                                          \
-    "s_lshl_b32 s86, 1, s86\n"                                                                                      \
+     * bases -- b00 = base, b10 = base + a row, b01 = base + a slice, b11 = both (row bytes: s82 for the distance volume, \
+     * s83 for tex0, s85 for the pair volume).  Sizes need not be powers of two: rows and slices go by multiplication */ \
+    "s_mov_b32 s64, " ROW_BYTES "\n"                                                                                 \
+    "s_mul_i32 s86, %[h], " ROW_BYTES "\n"                                                                           \
     "s_add_u32 s68, %[base_lo], s86\n s_addc_u32 s69, %[base_hi], 0\n"   /* b01 */                                   \
     "s_add_u32 s64, %[base_lo], s64\n s_addc_u32 s65, %[base_hi], 0\n"   /* b10 */                                   \
     "s_add_u32 s86, s64, s86\n s_addc_u32 s87, s65, 0\n"                 /* b11 */                                   \
@@ -364,17 +363,17 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "v_cmp_gt_u32_e32 vcc, %[thresh], v35\n"                                                                        \
     "s_xor_b64 vcc, vcc, exec\n"                                                                                    \
     "s_cbranch_scc1 .Lborder_%=\n"                                                                                  \
-    "v_lshl_add_u32 v39, v34, %[lgh], v33\n"                                                                        \
-    "v_lshl_add_u32 v39, v39, %[lgw], v32\n" INTERIOR                                                               \
+    "v_mad_u32_u24 v39, v34, %[h], v33\n"                    /* (k0 * H + j0) * W + i0: 24-bit factors (the launcher checks) */ \
+    "v_mad_u32_u24 v39, v39, %[w], v32\n" INTERIOR                                                               \
     "s_branch .Lcached_%=\n"                                                                                        \
     ".Lborder_%=:\n"                                                                                                \
     "v_max_i32_e32 v35, 0, v32\n v_max_i32_e32 v37, 0, v33\n v_max_i32_e32 v38, 0, v34\n"  /* i0c, j0c, k0c */       \
     "v_add_u32_e32 v32, 1, v32\n v_add_u32_e32 v33, 1, v33\n v_add_u32_e32 v34, 1, v34\n"                            \
     "v_min_i32_e32 v32, %[wm1], v32\n v_min_i32_e32 v33, %[hm1], v33\n v_min_i32_e32 v34, %[dm1], v34\n" /* i1c.. */  \
-    "v_lshl_add_u32 v28, v38, %[lgh], v37\n"                 /* rows: (k0c, j0c) */                                  \
-    "v_lshl_add_u32 v29, v38, %[lgh], v33\n"                 /*       (k0c, j1c) */                                  \
-    "v_lshl_add_u32 v30, v34, %[lgh], v37\n"                 /*       (k1c, j0c) */                                  \
-    "v_lshl_add_u32 v31, v34, %[lgh], v33\n"                 /*       (k1c, j1c) */
+    "v_mad_u32_u24 v28, v38, %[h], v37\n"                    /* rows: (k0c, j0c) */                                  \
+    "v_mad_u32_u24 v29, v38, %[h], v33\n"                    /*       (k0c, j1c) */                                  \
+    "v_mad_u32_u24 v30, v34, %[h], v37\n"                    /*       (k1c, j0c) */                                  \
+    "v_mad_u32_u24 v31, v34, %[h], v33\n"                    /*       (k1c, j1c) */
 // Interior fetch (v39 = texel index of corner (i0, j0, k0)): no clamps, no selects.
 #define SDFV_MARCH_ASM_INTERIOR_DIST                                                                                \
     "v_lshlrev_b32_e32 v39, 2, v39\n"                                                                               \
@@ -410,13 +409,13 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 // Border cells of the pair volume: the first component of eight texels (clamped corners), one dword load each.
 #define SDFV_MARCH_ASM_FETCH_PAIRS                                                                                  \
     "v_lshlrev_b32_e32 v35, 3, v35\n v_lshlrev_b32_e32 v32, 3, v32\n"   /* i0c, i1c as byte offsets */               \
-    "v_lshl_add_u32 v24, v28, s85, v35\n v_lshl_add_u32 v25, v28, s85, v32\n"                                        \
+    "v_mad_u32_u24 v24, v28, s85, v35\n v_mad_u32_u24 v25, v28, s85, v32\n"                                          \
     "global_load_dword v60, v24, %[base]\n global_load_dword v62, v25, %[base]\n"                                  \
-    "v_lshl_add_u32 v26, v29, s85, v35\n v_lshl_add_u32 v27, v29, s85, v32\n"                                        \
+    "v_mad_u32_u24 v26, v29, s85, v35\n v_mad_u32_u24 v27, v29, s85, v32\n"                                          \
     "global_load_dword v64, v26, %[base]\n global_load_dword v66, v27, %[base]\n"                                  \
-    "v_lshl_add_u32 v24, v30, s85, v35\n v_lshl_add_u32 v25, v30, s85, v32\n"                                        \
+    "v_mad_u32_u24 v24, v30, s85, v35\n v_mad_u32_u24 v25, v30, s85, v32\n"                                          \
     "global_load_dword v61, v24, %[base]\n global_load_dword v63, v25, %[base]\n"                                  \
-    "v_lshl_add_u32 v26, v31, s85, v35\n v_lshl_add_u32 v27, v31, s85, v32\n"                                        \
+    "v_mad_u32_u24 v26, v31, s85, v35\n v_mad_u32_u24 v27, v31, s85, v32\n"                                          \
     "global_load_dword v65, v26, %[base]\n global_load_dword v67, v27, %[base]\n"                                  \
     "s_waitcnt vmcnt(0)\n"                                                                                          \
     "s_branch .Lcached_%=\n"
@@ -427,13 +426,13 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 // line, when j0 is even) and picks by parity -- four dwordx4 gathers over 2 (even) or 4 (odd) lines instead of four dwordx2
 // over 4 lines: the line count is what a fetch costs (EXPERIMENTS R3.1, R3.10).
 #define SDFV_MARCH_ASM_INTERIOR_ILV                                                                                 \
-    "s_add_i32 s80, %[lgh], -1\n"                                                                                   \
+    "s_lshr_b32 s80, %[h], 1\n"                                                                                     \
     "v_and_b32_e32 v48, 1, v33\n"                            /* parity of j0 */                                      \
     "v_lshrrev_b32_e32 v35, 1, v33\n"                        /* p0 = j0 >> 1 */                                      \
     "v_add_u32_e32 v36, 1, v33\n"                                                                                   \
     "v_lshrrev_b32_e32 v36, 1, v36\n"                        /* p1 = (j0 + 1) >> 1 */                                \
-    "v_lshl_add_u32 v35, v34, s80, v35\n v_lshl_add_u32 v36, v34, s80, v36\n"   /* pair rows k0 * H/2 + p */         \
-    "v_lshl_add_u32 v35, v35, %[lgw], v32\n v_lshl_add_u32 v37, v36, %[lgw], v32\n"                                  \
+    "v_mad_u32_u24 v35, v34, s80, v35\n v_mad_u32_u24 v36, v34, s80, v36\n"     /* pair rows k0 * H/2 + p */         \
+    "v_mad_u32_u24 v35, v35, %[w], v32\n v_mad_u32_u24 v37, v36, %[w], v32\n"                                        \
     "v_lshlrev_b32_e32 v36, 3, v35\n v_lshlrev_b32_e32 v37, 3, v37\n"                                               \
     "v_cmp_eq_u32_e32 vcc, 1, v48\n"                                                                                \
     "global_load_dwordx4 v[24:27], v36, %[base]\n"           /* z0, pair-row p0: (y_lo, y_hi) at x0, x1 */           \
@@ -448,12 +447,12 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     "s_waitcnt vmcnt(0)\n"                                                                                          \
     "v_cndmask_b32_e32 v64, v25, v28, vcc\n v_cndmask_b32_e32 v66, v27, v30, vcc\n"   /* t010, t110: row j0 + 1 */   \
     "v_cndmask_b32_e32 v65, v33, v36, vcc\n v_cndmask_b32_e32 v67, v35, v38, vcc\n"   /* t011, t111 */
-// Border cells of the interleaved volume: eight dword loads at ((pair-row << lgw) + x) * 8 + (y & 1) * 4.  The clamped row
-// numbers of FETCH_PREP are k * H + j; j = row & (H - 1), k = row >> lgh (sizes are powers of two).
+// Border cells of the interleaved volume: eight dword loads at (pair-row * W + x) * 8 + (y & 1) * 4.  The clamped row
+// numbers of FETCH_PREP are k * H + j with H even: the pair-row is row >> 1, the half row & 1.
 #define SDFV_MARCH_ASM_ILV_ROW(R)                            /* v R: row number k * H + j  ->  byte offset of (x = 0) */ \
     "v_and_b32_e32 v36, 1, v" #R "\n"                        /* y & 1 */                                             \
     "v_lshrrev_b32_e32 v" #R ", 1, v" #R "\n"                /* k * H/2 + (j >> 1): H is even */                     \
-    "v_lshlrev_b32_e32 v" #R ", s85, v" #R "\n"              /* * W * 8 */                                           \
+    "v_mul_u32_u24_e32 v" #R ", s85, v" #R "\n"              /* * W * 8 */                                           \
     "v_lshl_add_u32 v" #R ", v36, 2, v" #R "\n"              /* + (y & 1) * 4 */
 #define SDFV_MARCH_ASM_FETCH_ILV                                                                                    \
     "v_lshlrev_b32_e32 v35, 3, v35\n v_lshlrev_b32_e32 v32, 3, v32\n"   /* i0c, i1c as byte offsets (8 per x) */      \
@@ -473,8 +472,8 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 #define SDFV_MARCH_ASM_FETCH_DIST                                                                                   \
     "v_min_i32_e32 v36, s75, v35\n"                          /* b = min(i0c, W - 2) */                               \
     "v_lshlrev_b32_e32 v39, 2, v36\n"                                                                               \
-    "v_lshl_add_u32 v28, v28, s82, v39\n v_lshl_add_u32 v29, v29, s82, v39\n"                                        \
-    "v_lshl_add_u32 v30, v30, s82, v39\n v_lshl_add_u32 v31, v31, s82, v39\n"                                        \
+    "v_mad_u32_u24 v28, v28, s82, v39\n v_mad_u32_u24 v29, v29, s82, v39\n"                                          \
+    "v_mad_u32_u24 v30, v30, s82, v39\n v_mad_u32_u24 v31, v31, s82, v39\n"                                          \
     "global_load_dwordx2 v[24:25], v28, %[base]\n"           /* (z0, y0) */                                          \
     "global_load_dwordx2 v[26:27], v29, %[base]\n"           /* (z0, y1) */                                          \
     "global_load_dwordx2 v[28:29], v30, %[base]\n"           /* (z1, y0) */                                          \
@@ -494,13 +493,13 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
 // STRIDE 4: tex0.r out of 16-byte texels, one dword load per corner.
 #define SDFV_MARCH_ASM_FETCH_TEX0                                                                                   \
     "v_lshlrev_b32_e32 v35, 4, v35\n v_lshlrev_b32_e32 v32, 4, v32\n"   /* i0c, i1c as byte offsets */               \
-    "v_lshl_add_u32 v24, v28, s83, v35\n v_lshl_add_u32 v25, v28, s83, v32\n"                                        \
+    "v_mad_u32_u24 v24, v28, s83, v35\n v_mad_u32_u24 v25, v28, s83, v32\n"                                          \
     "global_load_dword v60, v24, %[base]\n global_load_dword v62, v25, %[base]\n"                                  \
-    "v_lshl_add_u32 v26, v29, s83, v35\n v_lshl_add_u32 v27, v29, s83, v32\n"                                        \
+    "v_mad_u32_u24 v26, v29, s83, v35\n v_mad_u32_u24 v27, v29, s83, v32\n"                                          \
     "global_load_dword v64, v26, %[base]\n global_load_dword v66, v27, %[base]\n"                                  \
-    "v_lshl_add_u32 v24, v30, s83, v35\n v_lshl_add_u32 v25, v30, s83, v32\n"                                        \
+    "v_mad_u32_u24 v24, v30, s83, v35\n v_mad_u32_u24 v25, v30, s83, v32\n"                                          \
     "global_load_dword v61, v24, %[base]\n global_load_dword v63, v25, %[base]\n"                                  \
-    "v_lshl_add_u32 v26, v31, s83, v35\n v_lshl_add_u32 v27, v31, s83, v32\n"                                        \
+    "v_mad_u32_u24 v26, v31, s83, v35\n v_mad_u32_u24 v27, v31, s83, v32\n"                                          \
     "global_load_dword v65, v26, %[base]\n global_load_dword v67, v27, %[base]\n"                                  \
     "s_waitcnt vmcnt(0)\n"                                                                                          \
     "s_branch .Lcached_%=\n"
@@ -547,7 +546,7 @@ __device__ __forceinline__ void march_fast(const RaymarchArgs& a, const float* _
     [dx] "v"(dirx), [dy] "v"(diry), [dz] "v"(dirz), [cov] "s"(cov), [mx] "s"(a.rp.bounds_max[0]),    \
         [my] "s"(a.rp.bounds_max[1]), [mz] "s"(a.rp.bounds_max[2]), [minx] "s"(a.rp.bounds_min[0]),                 \
         [miny] "s"(a.rp.bounds_min[1]), [minz] "s"(a.rp.bounds_min[2]), [kx] "s"(kx), [ky] "s"(ky), [kz] "s"(kz),   \
-        [wm1] "s"(wm1), [hm1] "s"(hm1), [dm1] "s"(dm1), [lgw] "s"(lgw), [lgh] "s"(lgh), [base] "s"(vol), [base_lo] "s"(base_lo), [base_hi] "s"(base_hi), [thresh] "s"(thresh)
+        [wm1] "s"(wm1), [hm1] "s"(hm1), [dm1] "s"(dm1), [w] "s"(t.w), [h] "s"(t.h), [base] "s"(vol), [base_lo] "s"(base_lo), [base_hi] "s"(base_hi), [thresh] "s"(thresh)
 #define SDFV_MARCH_ASM_CLOBBERS                                                                                     \
     "vcc", "scc", "memory", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",    \
         "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "v24", "v25", "v26", "v27", "v28",  \
@@ -562,9 +561,8 @@ __device__ __forceinline__ void march_asm(const RaymarchArgs& a, const float* __
     // float multiplies are VALU work on gfx950: the (uniform) products are moved to scalar registers explicitly
     auto uniform = [](float f) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f))); };
     const float kx = uniform(a.inv_bsize[0] * (float)t.w), ky = uniform(a.inv_bsize[1] * (float)t.h),
-                kz = uniform(a.inv_bsize[2] * (float)t.d);  // exact: powers of two times powers of two
+                kz = uniform(a.inv_bsize[2] * (float)t.d);  // exact: a power of two times an integer below 2^24
     const int wm1 = t.w - 1, hm1 = t.h - 1, dm1 = t.d - 1;
-    const int lgw = 31 - __builtin_clz((uint32_t)t.w), lgh = 31 - __builtin_clz((uint32_t)t.h);  // sizes are powers of two
     const unsigned long long cov = __ballot(covered);
     const uint32_t base_lo = (uint32_t)(uintptr_t)vol, base_hi = (uint32_t)((uintptr_t)vol >> 32);
     // the interior fetch path tests all three cell indices with ONE compare: cubic volumes only (0: never taken)
@@ -1238,13 +1236,19 @@ void launch_aux(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
         hipLaunchKernelGGL((raymarch_kernel<MODE, LINEAR, XF, SYMM, false>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
 }
 
+// The hand-written loop addresses rows and slices by 24-bit multiplies (v_mad_u32_u24: full rate, any size -- not only powers
+// of two): row numbers k * H + j and the bytes of a row (16 * W for tex0) must stay below 2^24.
+static bool asm_addressing_ok(const RaymarchArgs& a) {
+    return a.rp.tex_size[0] < (1u << 20) && (uint64_t)a.rp.tex_size[1] * a.rp.tex_size[2] < (1ull << 24);
+}
+
 template <int MODE>
 void launch_fast(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
     const int xf = a.pow2_extent ? (a.pow2_size ? 2 : 1) : 0;
     const bool symm = a.symmetric_box != 0;
     // the hand-written loop: its specialisation (power-of-two extents and sizes, symmetric box) and 32-bit byte offsets
     const uint64_t texels = (uint64_t)a.rp.tex_size[0] * a.rp.tex_size[1] * a.rp.tex_size[2];
-    if (xf == 2 && symm && a.asm_loop && a.rp.tex_size[0] >= 2 && texels <= (MODE == 2 ? (1ull << 30) : (1ull << 28))) {
+    if (xf == 2 && symm && a.asm_loop && a.rp.tex_size[0] >= 2 && asm_addressing_ok(a) && texels <= (MODE == 2 ? (1ull << 30) : (1ull << 28))) {
         if (a.aux) hipLaunchKernelGGL((raymarch_kernel<MODE, true, 2, true, true, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
         else if (a.compute_normal)
             hipLaunchKernelGGL((raymarch_kernel<MODE, true, 2, true, false, true, true>), grid, dim3(256), SDFV_RM_LDS(a), stream, a);
@@ -1331,10 +1335,14 @@ static void box_first_rectangle(RaymarchArgs& ag, uint32_t groups_y) {
 static int march_volume_mode(const RaymarchArgs& a) {
     const uint64_t texels = (uint64_t)a.rp.tex_size[0] * a.rp.tex_size[1] * a.rp.tex_size[2];
     const bool loop_ok = a.rp.lod_dist_between_samples == 1.0f && a.fast_index && a.pow2_extent && a.pow2_size && a.symmetric_box &&
-                         a.asm_loop && a.rp.tex_size[0] >= 2;
+                         a.asm_loop && a.rp.tex_size[0] >= 2 && asm_addressing_ok(a);
     // 32-bit byte offsets: 8 B/texel of pairs reach 2^28 texels with the loop's shifts, 4 B/voxel of ilv 2^30 (like dist)
+    // a non-cubic grid never takes the loop's interior fetch (one compare for all three cell indices), and the border fetch of
+    // these two volumes is eight single loads against the distance volume's four 8-byte ones: with `dist` at hand, use it
+    const bool cubic = a.rp.tex_size[0] == a.rp.tex_size[1] && a.rp.tex_size[1] == a.rp.tex_size[2];
+    if (!cubic && a.dist) return 0;
     const bool pairs_ok = loop_ok && a.pairs && texels <= (1ull << 28);
-    const bool ilv_ok = loop_ok && a.ilv && a.rp.tex_size[1] >= 2 && texels <= (1ull << 30);
+    const bool ilv_ok = loop_ok && a.ilv && a.rp.tex_size[1] >= 2 && (a.rp.tex_size[1] & 1u) == 0 && texels <= (1ull << 30);
     if (pairs_ok && ilv_ok) return (a.last_level_cache_bytes && texels * 8u > a.last_level_cache_bytes) ? 4 : 3;
     return ilv_ok ? 4 : (pairs_ok ? 3 : 0);
 }

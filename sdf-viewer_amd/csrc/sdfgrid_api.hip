@@ -281,7 +281,7 @@ void derive_raymarch_args(const sdfv_render_params* rp, sdfv::RaymarchArgs& a) {
         int e = 0;
         // x / 2^k == x * 2^-k exactly (both correctly rounded), provided 2^-k is itself normal
         if (!(a.bsize[i] > 0.0f) || frexpf(a.bsize[i], &e) != 0.5f || e < -100 || e > 100) a.pow2_extent = 0;
-        if (rp->tex_size[i] & (rp->tex_size[i] - 1)) a.pow2_size = 0;
+        if (rp->tex_size[i] >= (1u << 24)) a.pow2_size = 0;  // (N as a float is exact below 2^24)
         if (rp->bounds_min[i] != -rp->bounds_max[i]) a.symmetric_box = 0;
         a.cull_center[i] = 0.5f * (rp->bounds_min[i] + rp->bounds_max[i]);
         radius2 += 0.25f * a.bsize[i] * a.bsize[i];
@@ -952,7 +952,10 @@ int sdfv_march_volume_advice(const sdfv_grid* grid, uint32_t* kind) {
     if (int rc = need_device()) return rc;
     const uint64_t n = (uint64_t)grid->dims[0] * grid->dims[1] * grid->dims[2];
     const uint64_t llc = device_facts().last_level_cache_bytes;
-    *kind = (llc && n * 8u > llc && (grid->dims[1] & 1u) == 0) ? SDFV_MARCH_VOLUME_INTERLEAVED : SDFV_MARCH_VOLUME_PAIRS;
+    if (grid->dims[0] != grid->dims[1] || grid->dims[1] != grid->dims[2])
+        *kind = SDFV_MARCH_VOLUME_NONE;  // the two-gather cell fetch is the cubic grid's: the distance volume marches fastest here
+    else
+        *kind = (llc && n * 8u > llc && (grid->dims[1] & 1u) == 0) ? SDFV_MARCH_VOLUME_INTERLEAVED : SDFV_MARCH_VOLUME_PAIRS;
     return SDFV_OK;
 }
 

@@ -264,13 +264,16 @@ void SDFViewer::commit() {
     // one per repaint) march over it.  12 B/voxel of traffic -- against the reference's re-upload of 32 B/voxel over PCIe.
     if (dist_synced_ && loading_mgr.step_size() == 0 && !material.pairs_valid) {
         const sdfv_grid g = grid();
-        if (!material.pairs) {
+        if (!material.pairs && !material.no_march_volume) {
             // beyond the last-level cache the interleaved volume (4 B/voxel) marches faster than the pair volume (8)
             uint32_t kind = SDFV_MARCH_VOLUME_PAIRS;
             (void)sdfv_march_volume_advice(&g, &kind);
             material.pairs_interleaved = kind == SDFV_MARCH_VOLUME_INTERLEAVED;
-            material.pairs = std::make_shared<DeviceBuffer>(material.dist->bytes() * (material.pairs_interleaved ? 1 : 2));
+            material.no_march_volume = kind == SDFV_MARCH_VOLUME_NONE;  // (a grid that is not cubic: the distance volume it is)
+            if (!material.no_march_volume)
+                material.pairs = std::make_shared<DeviceBuffer>(material.dist->bytes() * (material.pairs_interleaved ? 1 : 2));
         }
+        if (!material.pairs) return;
         const int rc = !material.pairs->ok() ? -1
                        : material.pairs_interleaved ? sdfv_commit_interleaved(&g, material.dist->f32(), material.pairs->f32(), stream)
                                                     : sdfv_commit_pairs(&g, material.dist->f32(), material.pairs->f32(), stream);

@@ -67,6 +67,7 @@ struct SDFViewerMaterial {
     std::shared_ptr<DeviceBuffer> dist;  // compact copy of tex0.r built by SDFViewer::commit (may be null)
     std::shared_ptr<DeviceBuffer> pairs;  // y-pair volume (sdfv_commit_pairs) of the LOADED grid, or null / stale
     bool pairs_valid = false;             // pairs mirrors dist: set by SDFViewer::commit, cleared by every fill
+    bool no_march_volume = false;         // sdfv_march_volume_advice said neither pays for this grid: commit() builds none
     bool pairs_interleaved = false;       // `pairs` holds the y-interleaved volume instead (sdfv_march_volume_advice)
     std::array<uint32_t, 3> tex_size{0, 0, 0};
     BoundingBox voxels_bounds;

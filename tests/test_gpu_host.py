@@ -166,6 +166,13 @@ def test_commit_of_a_grid_beyond_the_last_level_cache_builds_the_interleaved_vol
         pass
     small.commit()
     assert small.march_volume() == "pairs"
+    flat = host.Viewer.new_voxels((64, 64, 32), [-1, -1, -0.5, 1, 1, 0.5], 1)  # not cubic: no volume beyond the distance volume
+    while flat.update(sdf, 1.0):
+        pass
+    before = flat.render(320, 200)
+    flat.commit()
+    assert flat.march_volume() == "distance"
+    np.testing.assert_array_equal(before.view(np.uint32), flat.render(320, 200).view(np.uint32))
 
 
 def test_sdf_surface_per_point_calls(host, oracle):

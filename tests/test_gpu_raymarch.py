@@ -59,13 +59,15 @@ def compare(pkg, oracle, g, t0, t1, h0, h1, cam_kw, width, height, rp_edit=None,
                 "pairs": 0, "pairs_b": K.RM_NO_INTERIOR_FETCH, "pairs_c": K.RM_NO_ASM_LOOP,
                 # "ilv*": the y-interleaved volume, likewise
                 "ilv": 0, "ilv_b": K.RM_NO_INTERIOR_FETCH, "ilv_c": K.RM_NO_ASM_LOOP,
+                # without the distance volume beside them (given it, a non-cubic grid marches over that instead)
+                "pairs_only": 0, "ilv_only": 0,
                 "fast_plain": K.RM_NO_SYMMETRIC | K.RM_NO_POW2_SIZE,
                 "fast_div": K.RM_NO_SYMMETRIC | K.RM_NO_POW2_EXTENT}
     for variant, mask in disabled.items():
         if variant.startswith("ilv") and ilv is None:
             continue
         with pkg.options({K.OPT_RAYMARCH_DISABLE: mask}):
-            use_dist = dist if variant.startswith(("dist", "pairs", "ilv")) else None
+            use_dist = dist if variant.startswith(("dist", "pairs", "ilv")) and not variant.endswith("_only") else None
             use_pairs = pairs if variant.startswith("pairs") else None
             use_ilv = ilv if variant.startswith("ilv") else None
             rgba, depth, aux = pkg.raymarch(rp, t0, t1, cam, width, height, y0=y0, y1=y1, want_aux=True,
@@ -278,19 +280,22 @@ def test_randomised_cameras_grids_and_boxes(pkg, oracle):
 
 
 def test_randomised_sweep_of_the_hand_written_march_loop(pkg, oracle):
-    """Seeded sweep aimed at the gfx950 assembly loop's specialisation: power-of-two grids (cubic or not, down to 2 texels
-    per axis; a 1-texel axis has NaN coordinates, 0/0 in scene/sdf/mod.rs:179), symmetric boxes with power-of-two extents (cubic or not), cameras outside /
+    """Seeded sweep aimed at the gfx950 assembly loop's specialisation: grids of ANY size (powers of two or not, cubic or not,
+    down to 2 texels per axis; a 1-texel axis has NaN coordinates, 0/0 in scene/sdf/mod.rs:179 -- the loop addresses rows by
+    24-bit multiplies), symmetric boxes with power-of-two extents (cubic or not), cameras outside /
     inside / on a face.  compare() runs the hand-written loop and the compiler's on the same inputs, over tex0.r and over
     the distance volume, with the aux record (distance and step counters ride along in the loop) -- all bit for bit."""
     import os
     rng = np.random.default_rng(int(os.environ.get("SDFV_SOAK_SEED", 99)) + 5000)
     sizes = [2, 4, 8, 16, 32, 64, 128]
-    for trial in range(int(os.environ.get("SDFV_SOAK_TRIALS", 12))):
-        dims = tuple(int(rng.choice(sizes)) for _ in range(3))
+    odd_sizes = [3, 5, 6, 7, 10, 12, 20, 24, 33, 36, 50, 63, 65, 100]
+    for trial in range(int(os.environ.get("SDFV_SOAK_TRIALS", 16))):
+        pool = sizes if trial % 4 < 2 else sizes + odd_sizes * 2  # half of the trials: sizes that are not powers of two
+        dims = tuple(int(rng.choice(pool)) for _ in range(3))
         if dims[0] * dims[1] * dims[2] > 2 ** 19:
             dims = (dims[0], dims[1], max(2, 2 ** 19 // (dims[0] * dims[1])))
         if trial % 2 == 0:  # cubic volumes: the loop's interior fetch path (one compare for all three cell indices)
-            dims = (int(rng.choice(sizes[:6])),) * 3
+            dims = (int(rng.choice(sizes[:6] if trial % 4 < 2 else odd_sizes[:-3] + [63, 65])),) * 3
         half = np.array([2.0 ** int(rng.integers(-2, 3)) for _ in range(3)]) if trial % 2 else np.full(3, 2.0 ** int(rng.integers(-2, 3)))
         bb_min, bb_max = tuple(-half), tuple(half)
         scale = float(half.min())
@@ -470,7 +475,8 @@ def test_march_volume_advice_and_the_launchers_choice_at_512(pkg):
     rule picks the interleaved volume, with the camera outside, close and inside."""
     assert pkg.march_volume_advice(pkg.make_grid((256, 256, 256))) == "pairs"
     assert pkg.march_volume_advice(pkg.make_grid((512, 512, 512))) == "interleaved"
-    assert pkg.march_volume_advice(pkg.make_grid((512, 511, 512))) == "pairs"
+    assert pkg.march_volume_advice(pkg.make_grid((511, 511, 511))) == "pairs"       # odd H: no interleaved volume
+    assert pkg.march_volume_advice(pkg.make_grid((512, 256, 512))) is None           # not cubic: the distance volume
     prm = pkg.default_params()
     g = pkg.make_grid((512, 512, 512))
     t0, t1 = pkg.alloc_textures(g)
