@@ -360,8 +360,9 @@ int sdfv_raymarch_depth(const sdfv_render_params *rp, const float *tex0, const f
  * per load: 0.03 ms at 256^3); costs 8 B/voxel of memory.  NOT part of the fill: the fused fill stays at 36 B/voxel. */
 int sdfv_commit_pairs(const sdfv_grid *grid, const float *dist, float *pairs, void *stream);
 /* sdfv_raymarch_depth with the pair volume (`pairs` may be NULL = sdfv_raymarch_depth).  Bit-identical results: the march
- * gathers the same values from another layout.  The pair volume serves the hand-written gfx950 loop (power-of-two grid and
- * extents, symmetric box, <= 2^28 texels); any other launch reads `dist` / tex0.r as before. */
+ * gathers the same values from another layout.  The pair volume serves the hand-written gfx950 loop (any grid size,
+ * power-of-two extents, symmetric box, <= 2^28 texels) on a CUBIC grid; any other launch -- and a grid that is not cubic
+ * whenever `dist` is given -- reads `dist` / tex0.r as before. */
 int sdfv_raymarch_pairs(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
                         const float *pairs, const sdfv_camera *cameras, uint32_t n_cameras,
                         uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
