@@ -87,6 +87,10 @@ def check(side, threads=None, log=print, eye=(2.5, 3.0, 5.0), pipeline="plain", 
         rgba_pairs = pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist, pairs=pairs)
         pairs_diff = int((rgba_pairs.view(torch.int32) != rgba.view(torch.int32)).sum().item())
         del pairs, rgba_pairs
+        ilv = pkg.commit_interleaved(g, dist)
+        rgba_ilv = pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist, ilv=ilv)
+        ilv_diff = int((rgba_ilv.view(torch.int32) != rgba.view(torch.int32)).sum().item())
+        del ilv, rgba_ilv
     torch.cuda.synchronize()
     t = time.time()
     want_rgba, want_aux = oracle.raymarch(oracle.copy_struct(oracle.RenderParams, rp), h0, h1,
@@ -96,6 +100,7 @@ def check(side, threads=None, log=print, eye=(2.5, 3.0, 5.0), pipeline="plain", 
     diff["rgba_noaux_vs_aux"] = int((rgba.view(torch.int32) != rgba_aux.view(torch.int32)).sum().item())
     if pairs_diff is not None:
         diff["rgba_pairs_vs_dist"] = pairs_diff
+        diff["rgba_ilv_vs_dist"] = ilv_diff
     err = float(np.abs(rgba[0].cpu().numpy() - want_rgba).max())
     hits = int((want_aux["status"] == 1).sum())
     log(f"[{pipeline}] {W}x{H} no-aux march over {'the distance volume' if dist is not None else 'tex0.r'} of {side}^3: "
