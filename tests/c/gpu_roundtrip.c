@@ -3,7 +3,10 @@
  * results go to <prefix>.tex0.f32 / .tex1.f32 / .rgba.f32 for tests/test_gpu_host.py to compare with the oracle.
  * Then the reference's default 2-pass progressive load as its LoadingManager would drive it (sdfv_grid_init, two
  * sdfv_fill_grid_pass_ex with the flags a host knows) into a second pair of textures, the y-pair volume of a viewer
- * (sdfv_commit_pairs) and a frame over it (sdfv_raymarch_pairs): <prefix>.p_tex0.f32 / .p_tex1.f32 / .p_rgba.f32. */
+ * (sdfv_commit_pairs) and a frame over it (sdfv_raymarch_pairs): <prefix>.p_tex0.f32 / .p_tex1.f32 / .p_rgba.f32.
+ * Last, what a multi-GPU host does per rank and a host of a large grid per load: the same frame as the two band sets of a
+ * world of 2 (sdfv_raymarch_bands over the volume sdfv_march_volume_advice names: <prefix>.b0_rgba.f32, .b1_rgba.f32) and
+ * over the y-interleaved volume (sdfv_commit_interleaved, sdfv_raymarch_volumes: <prefix>.i_rgba.f32). */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
@@ -75,6 +78,28 @@ int main(int argc, char **argv) {
         if (dump(prefix, "p_tex0.f32", p0, tex_bytes) || dump(prefix, "p_tex1.f32", p1, tex_bytes) ||
             dump(prefix, "p_rgba.f32", rgba, (size_t)W * H * 16))
             return 1;
+        {
+            uint32_t kind = 99, r;
+            float *ilv = NULL, *band = NULL;
+            if (sdfv_march_volume_advice(&grid, &kind) != SDFV_OK || kind != SDFV_MARCH_VOLUME_PAIRS) DIE("march_volume_advice");
+            for (r = 0; r < 2; ++r) {  /* rank r of 2: tile bands r, r + 2, ... into a compact buffer */
+                const uint32_t rows = sdfv_band_rows(H, r, 2);
+                char name[32];
+                if (rows != (r == 0 ? 32u : 16u)) DIE("band_rows");  /* H = 48: bands 0, 2 | band 1 */
+                if (hipMalloc((void **)&band, (size_t)rows * W * 16) != hipSuccess) return 1;
+                if (sdfv_raymarch_bands(&rp, p0, p1, pd, pairs, NULL, &cam, 1, W, H, r, 2, band, NULL, NULL, NULL) != SDFV_OK) DIE("raymarch_bands");
+                if (hipDeviceSynchronize() != hipSuccess) return 1;
+                snprintf(name, sizeof name, "b%u_rgba.f32", r);
+                if (dump(prefix, name, band, (size_t)rows * W * 16)) return 1;
+                hipFree(band);
+            }
+            if (hipMalloc((void **)&ilv, voxels * 4) != hipSuccess) return 1;
+            if (sdfv_commit_interleaved(&grid, pd, ilv, NULL) != SDFV_OK) DIE("commit_interleaved");
+            if (sdfv_raymarch_volumes(&rp, p0, p1, pd, NULL, ilv, &cam, 1, W, H, 0, H, rgba, NULL, NULL, NULL) != SDFV_OK) DIE("raymarch_volumes");
+            if (hipDeviceSynchronize() != hipSuccess) return 1;
+            if (dump(prefix, "i_rgba.f32", rgba, (size_t)W * H * 16)) return 1;
+            hipFree(ilv);
+        }
         hipFree(p0);
         hipFree(p1);
         hipFree(pd);

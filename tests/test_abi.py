@@ -169,6 +169,21 @@ def test_slab_communicator_argument_checks_and_no_device(pkg):
         assert b"no HIP device" in lib.sdfv_last_error()
 
 
+def test_band_rows_is_the_partition_the_harness_uses(pkg):
+    """sdfv_band_rows (pure host arithmetic: no device needed) == the rows parallel.band_rows enumerates, for every band set
+    of worlds 1..9 over heights around the 16-row tile; together the sets partition the image."""
+    import importlib
+    par = importlib.import_module("sdf-viewer_amd.parallel")
+    for h in (1, 7, 15, 16, 17, 31, 32, 33, 100, 1080, 2160):
+        for world in range(1, 10):
+            rows = [par.band_rows(h, r, world) for r in range(world)]
+            assert sorted(sum(rows, [])) == list(range(h))
+            for r in range(world):
+                assert pkg.lib.sdfv_band_rows(h, r, world) == len(rows[r]), (h, r, world)
+        assert pkg.lib.sdfv_band_rows(h, 0, 0) == 0 and pkg.lib.sdfv_band_rows(h, (h + 15) // 16, 1) == 0
+    assert pkg.lib.sdfv_band_rows(1080, 3, 8) == 8 * 16 + 8  # bands 3, 11, ..., 67: the last one holds rows 1072..1079
+
+
 def test_power_of_two_modulus_identity():
     """The kernels replace `x % 0.5` / `x % 0.25` (cube.rs:192) by a - trunc(a * (1/m)) * m and `v / 0.25`,
     `floor(r) / 4` by multiplications.  Every step is exact for a power-of-two modulus; checked here against

@@ -388,6 +388,10 @@ def test_plain_c_host_drives_the_hot_path(oracle, tmp_path):
     got = np.fromfile(prefix + ".rgba.f32", np.float32).reshape(H, W, 4)
     assert np.abs(got - want).max() <= 1e-4 and (got[..., 3] > 0).any()
     # the flagged 2-pass progressive load ends in the same textures; the frame over the y-pair volume has the same bits
-    for name, ref in (("p_tex0", t0), ("p_tex1", t1), ("p_rgba", got)):
+    for name, ref in (("p_tex0", t0), ("p_tex1", t1), ("p_rgba", got), ("i_rgba", got)):  # (i_: over the interleaved volume)
         arr = np.fromfile(prefix + f".{name}.f32", np.float32).reshape(ref.shape)
         np.testing.assert_array_equal(arr.view(np.uint32), ref.view(np.uint32), err_msg=name)
+    # the two band sets of a world of 2 (rank 0: tile bands 0 and 2, rank 1: band 1) assemble to the same frame
+    b0 = np.fromfile(prefix + ".b0_rgba.f32", np.float32).reshape(32, W, 4)
+    b1 = np.fromfile(prefix + ".b1_rgba.f32", np.float32).reshape(16, W, 4)
+    np.testing.assert_array_equal(np.concatenate([b0[:16], b1, b0[16:]]).view(np.uint32), got.view(np.uint32))
