@@ -27,7 +27,7 @@ class LoadingManager {
     using Index = std::array<size_t, 3>;
 
     // loading.rs:23-35
-    LoadingManager(Index limits, size_t passes) : limits(limits), passes(passes) { reset(passes); }
+    LoadingManager(Index limits_, size_t passes_) : limits(limits_), passes(passes_) { reset(passes_); }
 
     // loading.rs:38-44
     void reset(size_t passes_) {
