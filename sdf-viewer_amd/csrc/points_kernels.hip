@@ -36,7 +36,8 @@ __global__ __launch_bounds__(kBlock) void sample_points_staged_kernel(sdfv_demo_
     __shared__ __attribute__((aligned(16))) float s_out[kBlock * 7];
     const uint32_t t = threadIdx.x;
     const size_t in4 = (size_t)blockIdx.x * (kBlock * 3 / 4), out4 = (size_t)blockIdx.x * (kBlock * 7 / 4);
-    if (t < kBlock * 3 / 4) reinterpret_cast<float4*>(s_in)[t] = points[in4 + t];
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    if (t < kBlock * 3 / 4) reinterpret_cast<v4f*>(s_in)[t] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(points) + in4 + t);
     __syncthreads();
     const float px = s_in[t * 3 + 0], py = s_in[t * 3 + 1], pz = s_in[t * 3 + 2];
     Sample s = demo_sample(prm, sdf_id, px, py, pz, distance_only);
@@ -45,15 +46,17 @@ __global__ __launch_bounds__(kBlock) void sample_points_staged_kernel(sdfv_demo_
     o[1] = s.m.r; o[2] = s.m.g; o[3] = s.m.b;
     o[4] = s.m.metallic; o[5] = s.m.roughness; o[6] = s.m.occlusion;
     __syncthreads();
-    out[out4 + t] = reinterpret_cast<const float4*>(s_out)[t];
-    if (t < kBlock * 7 / 4 - kBlock) out[out4 + kBlock + t] = reinterpret_cast<const float4*>(s_out)[kBlock + t];
+    // streamed: the read stream and the store stream get along better when the stores pass L2 by (EXPERIMENTS R3.4)
+    __builtin_nontemporal_store(reinterpret_cast<const v4f*>(s_out)[t], reinterpret_cast<v4f*>(out) + out4 + t);
+    if (t < kBlock * 7 / 4 - kBlock)
+        __builtin_nontemporal_store(reinterpret_cast<const v4f*>(s_out)[kBlock + t], reinterpret_cast<v4f*>(out) + out4 + kBlock + t);
 }
 
 __global__ __launch_bounds__(kBlock) void normal_points_kernel(sdfv_demo_params prm, uint32_t sdf_id, SourceBox box,
-                                                               const float* __restrict__ points, size_t n,
+                                                               const float* __restrict__ points, size_t first, size_t n,
                                                                float eps, bool use_default,
                                                                float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t i = first + (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float px = points[i * 3 + 0], py = points[i * 3 + 1], pz = points[i * 3 + 2];
     box.to_world(px, py, pz);
@@ -62,15 +65,50 @@ __global__ __launch_bounds__(kBlock) void normal_points_kernel(sdfv_demo_params 
     out[i * 3 + 0] = nx; out[i * 3 + 1] = ny; out[i * 3 + 2] = nz;
 }
 
+// The same for whole workgroups of 256 points, staged like sample_points_staged_kernel: 3 KiB in and 3 KiB out cross global
+// memory as streamed dwordx4 and are re-sliced per point in LDS.
+__global__ __launch_bounds__(kBlock) void normal_points_staged_kernel(sdfv_demo_params prm, uint32_t sdf_id, SourceBox box,
+                                                                      const float4* __restrict__ points, float eps,
+                                                                      bool use_default, float4* __restrict__ out) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float s_io[kBlock * 3];
+    const uint32_t t = threadIdx.x;
+    const size_t at4 = (size_t)blockIdx.x * (kBlock * 3 / 4);
+    if (t < kBlock * 3 / 4) reinterpret_cast<v4f*>(s_io)[t] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(points) + at4 + t);
+    __syncthreads();
+    float px = s_io[t * 3 + 0], py = s_io[t * 3 + 1], pz = s_io[t * 3 + 2];
+    box.to_world(px, py, pz);
+    float nx, ny, nz;
+    demo_normal(prm, sdf_id, px, py, pz, eps, use_default, nx, ny, nz);
+    s_io[t * 3 + 0] = nx; s_io[t * 3 + 1] = ny; s_io[t * 3 + 2] = nz;  // a thread's own three words: no barrier in between
+    __syncthreads();
+    if (t < kBlock * 3 / 4) __builtin_nontemporal_store(reinterpret_cast<const v4f*>(s_io)[t], reinterpret_cast<v4f*>(out) + at4 + t);
+}
+
 // ScalarSource::sample_scalar, meshers/isosurface.rs:78-84: distance only, 12 B in, 4 B out per point.
 __global__ __launch_bounds__(kBlock) void source_scalar_kernel(sdfv_demo_params prm, uint32_t sdf_id, SourceBox box,
-                                                               const float* __restrict__ points, size_t n,
+                                                               const float* __restrict__ points, size_t first, size_t n,
                                                                float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t i = first + (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float px = points[i * 3 + 0], py = points[i * 3 + 1], pz = points[i * 3 + 2];
     box.to_world(px, py, pz);
     out[i] = demo_sample(prm, sdf_id, px, py, pz, true).distance;
+}
+
+// Whole workgroups: the 12-byte points through LDS as streamed dwordx4; the 4-byte results are coalesced as they are.
+__global__ __launch_bounds__(kBlock) void source_scalar_staged_kernel(sdfv_demo_params prm, uint32_t sdf_id, SourceBox box,
+                                                                      const float4* __restrict__ points,
+                                                                      float* __restrict__ out) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float s_in[kBlock * 3];
+    const uint32_t t = threadIdx.x;
+    if (t < kBlock * 3 / 4)
+        reinterpret_cast<v4f*>(s_in)[t] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(points) + (size_t)blockIdx.x * (kBlock * 3 / 4) + t);
+    __syncthreads();
+    float px = s_in[t * 3 + 0], py = s_in[t * 3 + 1], pz = s_in[t * 3 + 2];
+    box.to_world(px, py, pz);
+    __builtin_nontemporal_store(demo_sample(prm, sdf_id, px, py, pz, true).distance, out + (size_t)blockIdx.x * kBlock + t);
 }
 
 // Mesh::postproc, meshers/mesh.rs:22-33, in place over #[repr(Rust)]-free 48-byte vertices (sdfv_vertex):
@@ -104,14 +142,17 @@ __global__ __launch_bounds__(kBlock) void mesh_postproc_staged_kernel(sdfv_demo_
     __shared__ __attribute__((aligned(16))) float s_v[kBlock * 12];
     const uint32_t t = threadIdx.x;
     float4* base = vertices + (size_t)blockIdx.x * (kBlock * 3);
-    for (int k = 0; k < 3; ++k) reinterpret_cast<float4*>(s_v)[k * kBlock + t] = base[k * kBlock + t];
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    for (int k = 0; k < 3; ++k)
+        reinterpret_cast<v4f*>(s_v)[k * kBlock + t] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(base) + k * kBlock + t);
     __syncthreads();
     float v[12];
     for (int k = 0; k < 12; ++k) v[k] = s_v[t * 12 + k];
     postproc_vertex(prm, sdf_id, v);
     for (int k = 3; k < 12; ++k) s_v[t * 12 + k] = v[k];
     __syncthreads();
-    for (int k = 0; k < 3; ++k) base[k * kBlock + t] = reinterpret_cast<const float4*>(s_v)[k * kBlock + t];
+    for (int k = 0; k < 3; ++k)
+        __builtin_nontemporal_store(reinterpret_cast<const v4f*>(s_v)[k * kBlock + t], reinterpret_cast<v4f*>(base) + k * kBlock + t);
 }
 
 uint32_t blocks_for(size_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
@@ -155,8 +196,17 @@ hipError_t launch_normal_points(const sdfv_demo_params& prm, uint32_t sdf_id, co
                                 float* out, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     if ((n + kBlock - 1) / kBlock > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(normal_points_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, prm, sdf_id,
-                       make_box(bb_min, bb_max), points, n, eps, use_default, out);
+    const SourceBox box = make_box(bb_min, bb_max);
+    size_t done = 0;
+    const size_t whole = n / kBlock;
+    if (whole > 0 && (((uintptr_t)points | (uintptr_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(normal_points_staged_kernel, dim3((uint32_t)whole), dim3(kBlock), 0, stream, prm, sdf_id, box,
+                           reinterpret_cast<const float4*>(points), eps, use_default, reinterpret_cast<float4*>(out));
+        done = whole * kBlock;
+    }
+    if (done < n)
+        hipLaunchKernelGGL(normal_points_kernel, dim3(blocks_for(n - done)), dim3(kBlock), 0, stream, prm, sdf_id, box, points,
+                           done, n, eps, use_default, out);
     return hipGetLastError();
 }
 
@@ -164,8 +214,17 @@ hipError_t launch_source_scalar(const sdfv_demo_params& prm, uint32_t sdf_id, co
                                 const float* bb_max, const float* points, size_t n, float* out, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     if ((n + kBlock - 1) / kBlock > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(source_scalar_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, prm, sdf_id,
-                       make_box(bb_min, bb_max), points, n, out);
+    const SourceBox box = make_box(bb_min, bb_max);
+    size_t done = 0;
+    const size_t whole = n / kBlock;
+    if (whole > 0 && (((uintptr_t)points & 15) | ((uintptr_t)out & 3)) == 0) {
+        hipLaunchKernelGGL(source_scalar_staged_kernel, dim3((uint32_t)whole), dim3(kBlock), 0, stream, prm, sdf_id, box,
+                           reinterpret_cast<const float4*>(points), out);
+        done = whole * kBlock;
+    }
+    if (done < n)
+        hipLaunchKernelGGL(source_scalar_kernel, dim3(blocks_for(n - done)), dim3(kBlock), 0, stream, prm, sdf_id, box, points,
+                           done, n, out);
     return hipGetLastError();
 }
 
