@@ -31,7 +31,10 @@
 extern "C" {
 #endif
 
-#define SDFV_ABI_VERSION 2
+/* 3 (round 3): the step forms other than SDFV_STEP_SIDE_BOUNDARY are gone; added sdfv_fill_grid_pass_ex, the pair and
+ * interleaved volumes (sdfv_commit_pairs / _interleaved, sdfv_raymarch_pairs / _volumes, sdfv_march_volume_advice),
+ * sdfv_raymarch_bands, the ray buffers with their count in band (sdfv_raymarch_slab_round, sdfv_slab_march). */
+#define SDFV_ABI_VERSION 3
 
 typedef enum sdfv_status {
     SDFV_OK = 0,

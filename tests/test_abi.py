@@ -30,7 +30,7 @@ def test_struct_layouts(pkg):
     assert C.sizeof(pkg.Light) == 32
     assert C.sizeof(pkg.RenderParams) == 80 + 4 + 4 * 32
     assert C.sizeof(pkg.MarchAux) == 72
-    assert pkg.lib.sdfv_abi_version() == 2
+    assert pkg.lib.sdfv_abi_version() == 3
 
 
 def test_options_are_explicit_and_the_library_reads_no_environment(pkg):
