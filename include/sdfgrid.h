@@ -321,7 +321,7 @@ int sdfv_mesh_extract(const sdfv_demo_params *params, uint32_t sdf_id, const flo
                       uint32_t max_voxels_per_axis, uint32_t algorithm, sdfv_mesh *out, void *stream);
 int sdfv_mesh_free(sdfv_mesh *mesh);
 /* sdfv_mesh_extract keeps its scratch (about 13 bytes per lattice point) for the calling thread's next extraction;
- * this releases it. */
+ * this releases it -- and the three side streams a batch of more than 64 cameras makes (SDFV_OPT_RAYMARCH_BATCH_STREAMS). */
 int sdfv_mesh_trim(void);
 
 /* ---- raymarch ---- */
