@@ -166,6 +166,12 @@ typedef enum sdfv_option {
                                         * views, a rank's share of a split batch) they run on side streams forked from and joined
                                         * back into the caller's stream, where they overlap -- a small launch is as long as its
                                         * longest waves, not as its work.  Events only: capturable.  Order only */
+    SDFV_OPT_EXT_SRGB_QUANT = 10,      /* how the fill evaluates three-d-asset's Srgba::from(Vector3<f32>) (scene/sdf/mod.rs:201) -- a crate
+                                        * whose source is not under the reference tree, so the restatement is unpinned: 0 (default)
+                                        * (c * 255.0) as u8, truncating | 1 (c * 255.0 + 0.5) as u8, rounding.  The only restated
+                                        * piece whose alternative moves visible output (19 M tex0 words at 256^3, profiles/
+                                        * ext_sensitivity.json): both are compiled in, so whoever runs tools/ref_golden/ against the
+                                        * real crate flips a flag instead of patching kernels.  Affects every fill and pass call */
     SDFV_OPT_TUNING_WAVE_TIMING = 100, /* tuning build only (-DSDFV_TUNING): DEVICE address of 32 B per raymarch wave */
     SDFV_OPT_TUNING_TILE_ORDER = 102,  /* tuning build only: DEVICE address of tiles_x * tiles_y uint32 tile numbers (row-major
                                         * tile index by * tiles_x + bx): workgroup L of a single-camera launch renders tile

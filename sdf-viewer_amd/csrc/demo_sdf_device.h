@@ -155,22 +155,28 @@ __device__ __forceinline__ float clamp01_rust(float v) {
     return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
 }
 
-// three-d-asset Srgba::from(Vec3): (c * 255.0) as u8 -- truncating, saturating, NaN -> 0.
+// three-d-asset Srgba::from(Vec3) [EXT: that crate's source is not under the reference tree].  ROUND = false is the
+// restatement the product ships: (c * 255.0) as u8 -- truncating, saturating, NaN -> 0.  ROUND = true is the one plausible
+// alternative with visible consequences (profiles/ext_sensitivity.json): (c * 255.0 + 0.5) as u8, what the oracle evaluates
+// under OR_EXT_SRGB_QUANT_ROUND.  Chosen per call by SDFV_OPT_EXT_SRGB_QUANT, compiled in as a template policy.
+template <bool ROUND>
 __device__ __forceinline__ uint32_t srgb_quantize(float c) {
-    float v = fminf(fmaxf(c * 255.0f, 0.0f), 255.0f);  // fmaxf(NaN, 0) = 0
+    float v = c * 255.0f;
+    if (ROUND) v = v + 0.5f;
+    v = fminf(fmaxf(v, 0.0f), 255.0f);  // fmaxf(NaN, 0) = 0
     return (uint32_t)v;
 }
 
 // SDFViewer::update's packing, scene/sdf/mod.rs:196-208.  lut = to_linear_srgb per u8 (256 floats).
-template <typename Lut>
+template <bool ROUND, typename Lut>
 __device__ __forceinline__ void pack_sample(const Sample& s, const Lut& lut, float air_dist,
                                             float4& t0, float4& t1) {
     float r = s.m.r, g = s.m.g, b = s.m.b;
     if (r == 0.0f && g == 0.0f && b == 0.0f) { r = 0.5f; g = 0.5f; b = 0.5f; }
     t0.x = clamp01_rust(1e-1f + s.distance);
-    t0.y = lut[srgb_quantize(r)];
-    t0.z = lut[srgb_quantize(g)];
-    t0.w = lut[srgb_quantize(b)];
+    t0.y = lut[srgb_quantize<ROUND>(r)];
+    t0.z = lut[srgb_quantize<ROUND>(g)];
+    t0.w = lut[srgb_quantize<ROUND>(b)];
     t1.x = s.m.metallic;
     t1.y = s.m.roughness;
     t1.z = s.m.occlusion <= 0.0f ? 1.0f : s.m.occlusion;
@@ -192,38 +198,52 @@ constexpr float kSrgbToLinear[256] = {
 #include "srgb_lut.inc"
 };
 
-constexpr uint32_t quantize_constexpr(float c) {  // srgb_quantize() for compile-time constants
+template <bool ROUND>
+constexpr uint32_t quantize_constexpr(float c) {  // srgb_quantize<ROUND>() for compile-time constants
     float v = c * 255.0f;
+    if (ROUND) v = v + 0.5f;
     return !(v > 0.0f) ? 0u : (v >= 255.0f ? 255u : (uint32_t)v);
 }
-constexpr float linear_of(float c) { return kSrgbToLinear[quantize_constexpr(c)]; }
+template <bool ROUND>
+constexpr float linear_of(float c) { return kSrgbToLinear[quantize_constexpr<ROUND>(c)]; }
 
 struct Packed {  // what update() writes besides tex0.r: tex0.gba and tex1.rgb
     float lr, lg, lb, metallic, roughness, occlusion;
 };
 
-// occlusion <= 0 -> 1 (scene/sdf/mod.rs:208) is folded into the constants below.
-constexpr Packed kPackedCement = {linear_of(56.0f / 255.0f), linear_of(70.0f / 255.0f), linear_of(60.0f / 255.0f),
-                                  0.4f, 0.5f, 1.0f};
-constexpr Packed kPackedBrick = {linear_of(150.0f / 255.0f), linear_of(24.0f / 255.0f), linear_of(10.0f / 255.0f),
-                                 0.2f, 0.8f, 1.0f};
-constexpr Packed kPackedCustom = {linear_of(0.5f), linear_of(0.6f), linear_of(0.7f), 0.5f, 0.0f, 1.0f};
-constexpr Packed kPackedAir = {linear_of(0.5f), linear_of(0.5f), linear_of(0.5f), 0.0f, 0.0f, 1.0f};  // zero colour -> 0.5
+// Both sets of packed constants are compiled in (one per Srgba::from policy); occlusion <= 0 -> 1 (scene/sdf/mod.rs:208) is
+// folded into them.  (Truncation maps 0.5 / 0.6 / 0.7 to 127 / 153 / 178, rounding to 128 / 153 / 179; the brick and cement
+// colours are k / 255 and land on k either way unless k / 255 * 255 rounds below k.)
+template <bool ROUND>
+struct PackedSet {
+    static constexpr Packed kCement = {linear_of<ROUND>(56.0f / 255.0f), linear_of<ROUND>(70.0f / 255.0f),
+                                       linear_of<ROUND>(60.0f / 255.0f), 0.4f, 0.5f, 1.0f};
+    static constexpr Packed kBrick = {linear_of<ROUND>(150.0f / 255.0f), linear_of<ROUND>(24.0f / 255.0f),
+                                      linear_of<ROUND>(10.0f / 255.0f), 0.2f, 0.8f, 1.0f};
+    static constexpr Packed kCustom = {linear_of<ROUND>(0.5f), linear_of<ROUND>(0.6f), linear_of<ROUND>(0.7f), 0.5f, 0.0f, 1.0f};
+    static constexpr Packed kAir = {linear_of<ROUND>(0.5f), linear_of<ROUND>(0.5f), linear_of<ROUND>(0.5f), 0.0f, 0.0f, 1.0f};  // zero colour -> 0.5
+};
 
-struct DefaultCfg {  // SDFDemo::default(): brick cube minus normal-shaded sphere
+template <bool ROUND>
+struct DefaultCfgT {  // SDFDemo::default(): brick cube minus normal-shaded sphere
     static constexpr bool kStatic = true;
+    static constexpr bool kRound = ROUND;
     __device__ static __forceinline__ uint32_t sdf_id(uint32_t) { return SDFV_SDF_DEMO; }
     __device__ static __forceinline__ uint32_t cube_material(const sdfv_demo_params&) { return SDFV_MATERIAL_BRICK; }
     __device__ static __forceinline__ uint32_t sphere_material(const sdfv_demo_params&) { return SDFV_MATERIAL_NORMAL; }
     __device__ static __forceinline__ bool disable_sphere(const sdfv_demo_params&) { return false; }
 };
-struct RuntimeCfg {
+template <bool ROUND>
+struct RuntimeCfgT {
     static constexpr bool kStatic = false;
+    static constexpr bool kRound = ROUND;
     __device__ static __forceinline__ uint32_t sdf_id(uint32_t id) { return id; }
     __device__ static __forceinline__ uint32_t cube_material(const sdfv_demo_params& p) { return p.cube_material; }
     __device__ static __forceinline__ uint32_t sphere_material(const sdfv_demo_params& p) { return p.sphere_material; }
     __device__ static __forceinline__ bool disable_sphere(const sdfv_demo_params& p) { return p.disable_sphere != 0; }
 };
+using DefaultCfg = DefaultCfgT<false>;
+using RuntimeCfg = RuntimeCfgT<false>;
 
 __device__ __forceinline__ Packed select_packed(bool c, const Packed& a, const Packed& b) {
     Packed r;
@@ -234,7 +254,7 @@ __device__ __forceinline__ Packed select_packed(bool c, const Packed& a, const P
 }
 
 // Material::render + packing for a normal n.  `lut` is only read by the Normal material.
-template <typename Lut>
+template <bool ROUND, typename Lut>
 __device__ __forceinline__ Packed render_packed(uint32_t material, float px, float py, float pz,
                                                 float nx, float ny, float nz, const Lut& lut) {
     float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
@@ -250,14 +270,14 @@ __device__ __forceinline__ Packed render_packed(uint32_t material, float px, flo
         float bx = fmod_pow2(fabsf(u + brick_offset), BRICK_WIDTH, 2.0f);
         float by = fmod_pow2(fabsf(v), BRICK_HEIGHT, 4.0f);
         bool cement = bx < mcd || bx > BRICK_WIDTH - mcd || by < mcd || by > BRICK_HEIGHT - mcd;
-        return select_packed(cement, kPackedCement, kPackedBrick);
+        return select_packed(cement, PackedSet<ROUND>::kCement, PackedSet<ROUND>::kBrick);
     }
     Packed r;  // colour |n|, metallic = roughness = 0, occlusion 0 -> 1
     bool zero = ax == 0.0f && ay == 0.0f && az == 0.0f;
     float cr = zero ? 0.5f : ax, cg = zero ? 0.5f : ay, cb = zero ? 0.5f : az;
-    r.lr = lut[srgb_quantize(cr)];
-    r.lg = lut[srgb_quantize(cg)];
-    r.lb = lut[srgb_quantize(cb)];
+    r.lr = lut[srgb_quantize<ROUND>(cr)];
+    r.lg = lut[srgb_quantize<ROUND>(cg)];
+    r.lb = lut[srgb_quantize<ROUND>(cb)];
     r.metallic = 0.0f; r.roughness = 0.0f; r.occlusion = 1.0f;
     return r;
 }
@@ -265,20 +285,20 @@ __device__ __forceinline__ Packed render_packed(uint32_t material, float px, flo
 template <typename Cfg, typename Lut>
 __device__ __forceinline__ Packed cube_packed(const sdfv_demo_params& prm, float px, float py, float pz,
                                               float d_box, const Lut& lut) {
-    if (d_box > 0.1f) return kPackedAir;  // cube.rs:83-85
+    if (d_box > 0.1f) return PackedSet<Cfg::kRound>::kAir;  // cube.rs:83-85
     float side = prm.cube_half_side;
     float nx = fabsf(px) > side ? signum_f32(px) : 0.0f;
     float ny = fabsf(py) > side ? signum_f32(py) : 0.0f;
     float nz = fabsf(pz) > side ? signum_f32(pz) : 0.0f;
-    return render_packed(Cfg::cube_material(prm), px, py, pz, nx, ny, nz, lut);
+    return render_packed<Cfg::kRound>(Cfg::cube_material(prm), px, py, pz, nx, ny, nz, lut);
 }
 
 template <typename Cfg, typename Lut>
 __device__ __forceinline__ Packed sphere_packed(const sdfv_demo_params& prm, float px, float py, float pz,
                                                 float len, float d_sph, const Lut& lut) {
-    if (d_sph > 0.1f) return kPackedAir;  // sphere.rs:41-43
+    if (d_sph > 0.1f) return PackedSet<Cfg::kRound>::kAir;  // sphere.rs:41-43
     float inv = 1.0f / len;
-    return render_packed(Cfg::sphere_material(prm), px, py, pz, px * inv, py * inv, pz * inv, lut);
+    return render_packed<Cfg::kRound>(Cfg::sphere_material(prm), px, py, pz, px * inv, py * inv, pz * inv, lut);
 }
 
 // sample(p, false) + packing.  xx_yy = px*px + py*py may be hoisted by the caller.
@@ -302,7 +322,7 @@ __device__ __forceinline__ void fill_voxel(const sdfv_demo_params& prm, uint32_t
         distance = fmaxf(d_box, -d_sph);
         float inter = fabsf(d_box) - fabsf(d_sph);
         if (fabsf(inter) <= prm.max_distance_custom_material) {
-            m = kPackedCustom;
+            m = PackedSet<Cfg::kRound>::kCustom;
         } else if (inter < 0.0f) {
             m = cube_packed<Cfg>(prm, px, py, pz, d_box, lut);
         } else {

@@ -25,6 +25,7 @@ struct FillArgs {
     float4* tex0;
     float4* tex1;
     float* dist;             // optional compact copy of tex0.r written in the same pass (fused SDFViewer::commit)
+    uint32_t srgb_round;     // Srgba::from policy (SDFV_OPT_EXT_SRGB_QUANT): 0 truncate (default), 1 round
     // ---- boundary-first order (multi-GPU fill step, launch_fill_dense_ordered) ----
     // The slab's `order_lead` first slices and its last slice are the ones the z-neighbours wait for: the workgroups
     // that fill them come FIRST in dispatch order, the interior follows in memory order.

@@ -361,6 +361,25 @@ bool is_default_config(const FillArgs& a) {
            a.prm.sphere_material == SDFV_MATERIAL_NORMAL && a.prm.disable_sphere == 0;
 }
 
+// Calls launch(Cfg{}) with the kernels' configuration policy for these arguments: the static default configuration or the
+// one read from the parameter block, each with either Srgba::from policy (FillArgs::srgb_round, SDFV_OPT_EXT_SRGB_QUANT).
+template <typename Launch>
+void with_cfg(const FillArgs& a, Launch&& launch) {
+    const bool dflt = is_default_config(a);
+    if (a.srgb_round) {
+        if (dflt) launch(DefaultCfgT<true>{});
+        else launch(RuntimeCfgT<true>{});
+    } else {
+        if (dflt) launch(DefaultCfgT<false>{});
+        else launch(RuntimeCfgT<false>{});
+    }
+}
+#define SDFV_LAUNCH_CFG(a, KERNEL, ...) \
+    with_cfg(a, [&](auto cfg_) {        \
+        using Cfg = decltype(cfg_);     \
+        hipLaunchKernelGGL(KERNEL, __VA_ARGS__); \
+    })
+
 // SDFViewer::commit's device-side analogue: nothing to upload, but the raymarch likes a compact copy of
 // tex0.r (4 B/voxel instead of one dword in every 16 B).  Reads whole texels (coalesced dwordx4) and writes
 // one dword per voxel: 20 B/voxel of traffic, once per commit.
@@ -410,10 +429,7 @@ hipError_t launch_dense_cfg(const FillArgs& args, hipStream_t stream) {
     const uint64_t blocks = a.x_chunks * ((n_rows + TY - 1) / TY);
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     dim3 grid((uint32_t)blocks, 1, 1);
-    if (is_default_config(a))
-        hipLaunchKernelGGL((fill_dense_kernel<TX, NT, DefaultCfg>), grid, dim3(kBlock), 0, stream, a);
-    else
-        hipLaunchKernelGGL((fill_dense_kernel<TX, NT, RuntimeCfg>), grid, dim3(kBlock), 0, stream, a);
+    SDFV_LAUNCH_CFG(a, (fill_dense_kernel<TX, NT, Cfg>), grid, dim3(kBlock), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -431,10 +447,7 @@ hipError_t launch_dense_flat(const FillArgs& args, hipStream_t stream) {
     // floor((2^64 - 1) / W) + 1: floor(2^64 / W) + 1 when W does not divide 2^64, exactly 2^64 / W when it does
     a.w_magic = a.W > 1 ? (~0ull / a.W) + 1ull : 0ull;
     const uint32_t blocks = (uint32_t)((n_vox + kBlock - 1) / kBlock);
-    if (is_default_config(a))
-        hipLaunchKernelGGL((fill_dense_flat_kernel<NT, DefaultCfg>), dim3(blocks), dim3(kBlock), 0, stream, a);
-    else
-        hipLaunchKernelGGL((fill_dense_flat_kernel<NT, RuntimeCfg>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    SDFV_LAUNCH_CFG(a, (fill_dense_flat_kernel<NT, Cfg>), dim3(blocks), dim3(kBlock), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -469,10 +482,7 @@ template <int TX>
 void launch_ordered_rows(const FillArgs& args, uint32_t blocks, hipStream_t stream) {
     FillArgs a = args;
     a.x_chunks = (a.W + TX - 1) / TX;
-    if (is_default_config(a))
-        hipLaunchKernelGGL((fill_dense_kernel<TX, false, DefaultCfg, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
-    else
-        hipLaunchKernelGGL((fill_dense_kernel<TX, false, RuntimeCfg, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    SDFV_LAUNCH_CFG(a, (fill_dense_kernel<TX, false, Cfg, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
 }
 }  // namespace
 
@@ -496,10 +506,7 @@ hipError_t launch_fill_dense_ordered(const FillArgs& args, uint32_t block_begin,
     else if (p.tx == 256) launch_ordered_rows<256>(a, blocks, stream);
     else {
         a.w_magic = a.W > 1 ? (~0ull / a.W) + 1ull : 0ull;
-        if (is_default_config(a))
-            hipLaunchKernelGGL((fill_dense_flat_kernel<false, DefaultCfg, false, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
-        else
-            hipLaunchKernelGGL((fill_dense_flat_kernel<false, RuntimeCfg, false, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        SDFV_LAUNCH_CFG(a, (fill_dense_flat_kernel<false, Cfg, false, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
     }
     return hipGetLastError();
 }
@@ -524,10 +531,7 @@ hipError_t launch_fill_slices(const FillArgs& args, hipStream_t stream) {
     if (n_vox >= (1ull << 32) || a.z_step == 0) return hipErrorInvalidValue;
     a.w_magic = a.W > 1 ? (~0ull / a.W) + 1ull : 0ull;
     const uint32_t blocks = (uint32_t)((n_vox + kBlock - 1) / kBlock);
-    if (is_default_config(a))
-        hipLaunchKernelGGL((fill_dense_flat_kernel<false, DefaultCfg, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
-    else
-        hipLaunchKernelGGL((fill_dense_flat_kernel<false, RuntimeCfg, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    SDFV_LAUNCH_CFG(a, (fill_dense_flat_kernel<false, Cfg, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -564,7 +568,6 @@ hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& pass, const FillL
     }
     const uint64_t n = (uint64_t)p.nx * p.ny * p.nz;
     if (n == 0) return hipSuccess;
-    const bool dflt = is_default_config(a);
     if (p.all_required && p.step == 1 && (p.dist || p.fresh)) {
         // every voxel of the slab is rewritten and nothing needs reading: that IS the dense fill (+ its distance volume).
         // (The dense kernel writes tex1.a = AIR_DIST: what a fresh grid holds and what the volume's contract guarantees;
@@ -582,11 +585,9 @@ hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& pass, const FillL
         // whole visited rows: one of every `step` texels computed, the rest re-stored (a constant over a fresh grid)
         const uint32_t blocks = (uint32_t)(((uint64_t)a.W * p.ny * p.nz + kBlock - 1) / kBlock);
         if (p.fresh) {
-            if (dflt) hipLaunchKernelGGL((fill_pass_rows_kernel<DefaultCfg, true>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
-            else hipLaunchKernelGGL((fill_pass_rows_kernel<RuntimeCfg, true>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
+            SDFV_LAUNCH_CFG(a, (fill_pass_rows_kernel<Cfg, true>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
         } else {
-            if (dflt) hipLaunchKernelGGL((fill_pass_rows_kernel<DefaultCfg, false>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
-            else hipLaunchKernelGGL((fill_pass_rows_kernel<RuntimeCfg, false>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
+            SDFV_LAUNCH_CFG(a, (fill_pass_rows_kernel<Cfg, false>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
         }
         return hipGetLastError();
     }
@@ -594,11 +595,9 @@ hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& pass, const FillL
     const uint64_t threads = quad ? (n + 3) / 4 : n;
     const uint32_t blocks = (uint32_t)((threads + kBlock - 1) / kBlock);
     if (quad) {
-        if (dflt) hipLaunchKernelGGL(fill_pass_quad_kernel<DefaultCfg>, dim3(blocks), dim3(kBlock), 0, stream, a, p);
-        else hipLaunchKernelGGL(fill_pass_quad_kernel<RuntimeCfg>, dim3(blocks), dim3(kBlock), 0, stream, a, p);
+        SDFV_LAUNCH_CFG(a, (fill_pass_quad_kernel<Cfg>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
     } else {
-        if (dflt) hipLaunchKernelGGL(fill_pass_kernel<DefaultCfg>, dim3(blocks), dim3(kBlock), 0, stream, a, p);
-        else hipLaunchKernelGGL(fill_pass_kernel<RuntimeCfg>, dim3(blocks), dim3(kBlock), 0, stream, a, p);
+        SDFV_LAUNCH_CFG(a, (fill_pass_kernel<Cfg>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
     }
     return hipGetLastError();
 }

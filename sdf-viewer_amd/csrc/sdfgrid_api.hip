@@ -104,6 +104,7 @@ sdfv::FillArgs make_fill_args(const sdfv_demo_params& p, uint32_t sdf_id, const 
     }
     a.air_dist = air_dist();
     a.z_step = 1;
+    a.srgb_round = g_options.ext_srgb_quant;
     a.tex0 = reinterpret_cast<float4*>(tex0);
     a.tex1 = reinterpret_cast<float4*>(tex1);
     return a;
@@ -470,6 +471,10 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             g_options.slab_step_form = (uint32_t)value;
             return SDFV_OK;
         }
+        case SDFV_OPT_EXT_SRGB_QUANT:
+            if (value > 1) break;
+            g_options.ext_srgb_quant = (uint32_t)value;
+            return SDFV_OK;
         case SDFV_OPT_RAYMARCH_WAVES_PER_SIMD:
             if (value == 1 || value > 7) break;  // 0 auto (the launcher's rule) | 2..6 cap | 7 never cap
             g_options.raymarch_waves_per_simd = (uint32_t)value;
@@ -516,6 +521,7 @@ int sdfv_get_option(uint32_t option, uint64_t* value) {
         case SDFV_OPT_TUNING_PRIORITY_MAP: *value = g_options.priority_map; return SDFV_OK;
         case SDFV_OPT_TUNING_TILE_ORDER: *value = g_options.tile_order; return SDFV_OK;
         case SDFV_OPT_RAYMARCH_WAVES_PER_SIMD: *value = g_options.raymarch_waves_per_simd; return SDFV_OK;
+        case SDFV_OPT_EXT_SRGB_QUANT: *value = g_options.ext_srgb_quant; return SDFV_OK;
         default: return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown option %u", option);
     }
 }
