@@ -1,6 +1,7 @@
 """The ORACLE against the reference-side fixtures (tests/golden/ref_*.json, written by tools/ref_golden/golden_gen.rs run
 inside a checkout of the reference).  Absent files skip; the consumer code itself is exercised on files the emulator
 writes from the oracle into a temporary directory (plumbing only -- that proves nothing about parity and says so)."""
+import ctypes as C
 import importlib.util
 import os
 
@@ -56,7 +57,7 @@ def check_grid(data, oracle, configs):
         t0, t1 = oracle.grid_init(dims)
         lm = oracle.lm_new(dims, data["loading_passes"])
         assert oracle.viewer_update(prm, dims, lm, t0, t1) == entry["iterations"]
-        assert oracle.L.or_lm_passes_left(lm) == entry["passes_left"] == 0
+        assert oracle.L.or_lm_passes_left(C.byref(lm)) == entry["passes_left"] == 0
         rg.assert_same_words(t0, rg.f32(entry["tex0"]).reshape(shape), f"grid config {entry['config']} tex0")
         rg.assert_same_words(t1, rg.f32(entry["tex1"]).reshape(shape), f"grid config {entry['config']} tex1")
         if "edit" in entry:
