@@ -172,6 +172,10 @@ typedef enum sdfv_option {
                                         * piece whose alternative moves visible output (19 M tex0 words at 256^3, profiles/
                                         * ext_sensitivity.json): both are compiled in, so whoever runs tools/ref_golden/ against the
                                         * real crate flips a flag instead of patching kernels.  Affects every fill and pass call */
+    SDFV_OPT_PASS_INDEX_LIMIT = 11,    /* 0 (default) = 2^32 | v in [2, 2^32]: a LoadingManager pass over a slab of v voxels or more runs as
+                                        * several launches over pieces of whole slices, each below v (the pass kernels index with 32
+                                        * bits; slabs from ~1626^3 voxels up, which fit in 288 GB, need it).  A test hook: small
+                                        * values exercise the piecewise path on small grids.  Same texels */
     SDFV_OPT_TUNING_WAVE_TIMING = 100, /* tuning build only (-DSDFV_TUNING): DEVICE address of 32 B per raymarch wave */
     SDFV_OPT_TUNING_TILE_ORDER = 102,  /* tuning build only: DEVICE address of tiles_x * tiles_y uint32 tile numbers (row-major
                                         * tile index by * tiles_x + bx): workgroup L of a single-camera launch renders tile
@@ -215,6 +219,13 @@ int  sdfv_camera_look_at(sdfv_camera *cam, const float eye[3], const float targe
 
 /* SDFViewer::new_voxels initial state: both textures = [AIR_DIST; 4] (scene/sdf/mod.rs:76-77). */
 int sdfv_grid_init(const sdfv_grid *grid, float *tex0, float *tex1, void *stream);
+
+/* The lazy half of new_voxels for a grid loaded with SDFV_PASS_VIRGIN_GRID passes (below): [AIR_DIST; 4] into every row of the
+ * slab that a pass with `step` (a power of two; the SMALLEST step run so far) does not visit -- y or global z not a multiple of
+ * step -- and AIR_DIST into those rows of `dist` (DEVICE, one float per voxel, or NULL).  step 0: no pass has run, every row
+ * (= sdfv_grid_init + the volume); step 1: nothing to do.  A host calls it before anything READS the whole grid while a
+ * virgin load is unfinished (a frame at an intermediate LOD, a download, a pass with a changed box). */
+int sdfv_grid_init_unvisited(const sdfv_grid *grid, uint32_t step, float *tex0, float *tex1, float *dist, void *stream);
 
 /* Dense fill: the state SDFViewer::update (scene/sdf/mod.rs:128-217) converges to on a fresh grid once
  * the LoadingManager is exhausted.  Store-only (32 B/voxel), does not read the textures; writes tex1.a =
@@ -272,6 +283,16 @@ int sdfv_fill_grid_pass_dist(const sdfv_demo_params *params, uint32_t sdf_id, co
  * flag overwrites voxels the reference would have kept. */
 #define SDFV_PASS_FRESH_GRID 1u
 #define SDFV_PASS_SAME_LOAD  2u
+/*   SDFV_PASS_VIRGIN_GRID the slab is a fresh ALLOCATION: new_voxels' initial state has not been WRITTEN (sdfv_grid_init was
+ *                         skipped), its voxels are only LOGICALLY [AIR_DIST; 4] wherever no earlier pass of this load stored a
+ *                         sample.  The pass reads nothing and writes the rows it visits whole -- samples on its lattice,
+ *                         [AIR_DIST; 4] between them (and the distance volume's entries alike) -- so after it the rows with y
+ *                         and global z multiples of `step` hold exactly what the reference's textures hold there; the other
+ *                         rows stay UNDEFINED until a pass with a smaller step writes them or sdfv_grid_init_unvisited(step)
+ *                         does.  Implies FRESH_GRID's knowledge; on the later passes of the load combine it with SAME_LOAD.
+ *                         A step-1 pass is the dense fill and leaves nothing undefined: a load that runs all its passes
+ *                         never pays for the initial state (36 B/voxel) at all.  changed_box must be NULL. */
+#define SDFV_PASS_VIRGIN_GRID 4u
 int sdfv_fill_grid_pass_ex(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid, uint32_t step,
                            const float *changed_box, float *tex0, float *tex1, float *dist, uint32_t flags, void *stream);
 

@@ -84,6 +84,7 @@ PROTOTYPES = {
     "sdfv_camera_look_at": (C.c_int, [C.POINTER(Camera), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float]),
     "sdfv_grid_init": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdfv_grid_init_unvisited": (C.c_int, [C.POINTER(Grid), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_fill_grid": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
     "sdfv_tune_texture_placement": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
@@ -171,13 +172,14 @@ OPT_RAYMARCH_TILE_GROUP = 6
 OPT_RAYMARCH_BOX_FIRST = 7
 OPT_RAYMARCH_WAVES_PER_SIMD = 8
 OPT_RAYMARCH_BATCH_STREAMS = 9
+OPT_PASS_INDEX_LIMIT = 11
 OPT_EXT_SRGB_QUANT = 10  # Srgba::from(Vec3): 0 truncate (default) | 1 round
 OPT_TUNING_WAVE_TIMING = 100
 OPT_TUNING_PRIORITY_MAP = 101
 OPT_TUNING_TILE_ORDER = 102
 RM_NO_FAST_INDEX, RM_NO_POW2_EXTENT, RM_NO_POW2_SIZE, RM_NO_SYMMETRIC, RM_NO_ASM_LOOP, RM_NO_INTERIOR_FETCH = 1, 2, 4, 8, 16, 32
 STEP_SIDE_BOUNDARY, STEP_UNPACKED, STEP_START_EVENT, STEP_DEFER_JOIN = 3, 4, 8, 16
-PASS_FRESH_GRID, PASS_SAME_LOAD = 1, 2
+PASS_FRESH_GRID, PASS_SAME_LOAD, PASS_VIRGIN_GRID = 1, 2, 4
 FILL_FORM = {"auto": 0, "rows": 1, "flat": 2}
 PLACEMENT_SLACK = 64 << 10
 COMM_ID_BYTES = 128

@@ -58,6 +58,8 @@ struct PassArgs {
                              // instead of the 16-byte texel and rewritten with it (nullptr = read tex0 itself)
     uint32_t all_required;   // update_required is known to hold for every visited voxel: nothing is read
     uint32_t fresh;          // every voxel of the slab holds [AIR_DIST; 4] on entry (first pass of a fresh load)
+    uint32_t virgin;         // SDFV_PASS_VIRGIN_GRID: the slab's contents are undefined wherever no pass of this load has written
+    uint64_t index_limit;    // 0 = 2^32: slabs of this many voxels or more are passed over in pieces of whole slices
     // set by the launcher:
     uint32_t n_visited;      // nx * ny * nz
     DivU32 div_nx, div_ny, div_w;
@@ -95,5 +97,8 @@ hipError_t launch_commit_pairs(const float* dist, float* pairs, uint32_t W, uint
 // ilv[(z * H/2 + p) * W + x] = (dist[z][2p][x], dist[z][2p+1][x]) over a whole grid with an even H
 hipError_t launch_commit_interleaved(const float* dist, float* ilv, uint32_t W, uint64_t n_voxels, hipStream_t stream);
 hipError_t launch_grid_init(float* tex0, float* tex1, uint64_t n_voxels, float air, hipStream_t stream);
+// [air; 4] (+ dist = air) into every row of the slab whose y or global z is not a multiple of step (step 0: every row)
+hipError_t launch_grid_init_unvisited(float* tex0, float* tex1, float* dist, uint32_t W, uint32_t H, uint32_t z_begin,
+                                      uint32_t slab_d, uint32_t step, float air, hipStream_t stream);
 
 }  // namespace sdfv

@@ -356,6 +356,23 @@ __global__ __launch_bounds__(kBlock) void grid_init_kernel(float4* tex0, float4*
     }
 }
 
+// Lazy half of new_voxels' initial state for a grid whose first passes ran with SDFV_PASS_VIRGIN_GRID: [AIR_DIST; 4] into
+// every row those passes did NOT write (y or global z not a multiple of `step`; step 0 = every row), and AIR_DIST into the
+// distance volume's entries of those rows.  One workgroup per row chunk (x chunks, y, local z): no index division, the
+// workgroups of written rows leave at once.
+__global__ __launch_bounds__(kBlock) void grid_init_unvisited_kernel(float4* tex0, float4* tex1, float* dist, uint32_t W,
+                                                                     uint32_t H, uint32_t z_begin, uint32_t step, float air) {
+    const uint32_t y = blockIdx.y, zl = blockIdx.z;
+    if (step != 0 && (y & (step - 1)) == 0 && ((z_begin + zl) & (step - 1)) == 0) return;  // a row the passes wrote whole
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= W) return;
+    const uint64_t i = ((uint64_t)zl * H + y) * W + x;
+    const float4 v = make_float4(air, air, air, air);
+    store_texel<true>(tex0 + i, v);
+    store_texel<true>(tex1 + i, v);
+    if (dist) dist[i] = air;
+}
+
 bool is_default_config(const FillArgs& a) {
     return a.sdf_id == SDFV_SDF_DEMO && a.prm.cube_material == SDFV_MATERIAL_BRICK &&
            a.prm.sphere_material == SDFV_MATERIAL_NORMAL && a.prm.disable_sphere == 0;
@@ -559,6 +576,7 @@ static DivU32 make_div(uint32_t d) {
 
 hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& pass, const FillLaunch& dense_cfg, hipStream_t stream) {
     PassArgs p = pass;
+    if (p.virgin) p.fresh = p.all_required = 1;  // nothing is read: every voxel no pass of this load has written is LOGICALLY AIR
     for (int i = 0; i < 3; ++i) {
         // |idx * (size / dm1) + min  -  ((idx / dm1) * size + min)| is a few ulp of the largest intermediate
         // (<= |size| + |min|); 64 ulp of that is a safe bound, and tiny next to a voxel's extent.
@@ -576,12 +594,34 @@ hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& pass, const FillL
         d.dist = p.dist;
         return launch_fill_dense(d, dense_cfg, stream);
     }
-    if (n >= (1ull << 32) || (uint64_t)a.W * p.ny * p.nz >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit lattice indices
+    // The kernels below index the slab's voxels, the visited lattice and the visited rows with 32 bits.  A slab beyond that
+    // (>= ~1626^3 voxels: fits in 288 GB) is passed over in pieces of whole slices, each below the limit.
+    const uint64_t limit = p.index_limit ? p.index_limit : (1ull << 32);
+    const uint64_t slice = (uint64_t)a.W * a.H;
+    if (slice * a.slab_d >= limit) {
+        const uint64_t per_piece = (limit - 1) / slice;  // slices per piece
+        if (per_piece == 0) return hipErrorInvalidValue;  // one slice alone exceeds 32-bit indexing
+        for (uint64_t z0 = 0; z0 < a.slab_d; z0 += per_piece) {
+            FillArgs a2 = a;
+            PassArgs p2 = pass;
+            a2.z_begin = a.z_begin + (uint32_t)z0;
+            a2.slab_d = (uint32_t)(a.slab_d - z0 < per_piece ? a.slab_d - z0 : per_piece);
+            a2.tex0 = a.tex0 + z0 * slice;
+            a2.tex1 = a.tex1 + z0 * slice;
+            if (a.dist) a2.dist = a.dist + z0 * slice;
+            if (pass.dist) p2.dist = pass.dist + z0 * slice;
+            const uint32_t z_end = a2.z_begin + a2.slab_d;
+            p2.z_first = ((a2.z_begin + p.step - 1) / p.step) * p.step;
+            p2.nz = p2.z_first < z_end ? (z_end - p2.z_first + p.step - 1) / p.step : 0;
+            if (hipError_t e = launch_fill_pass(a2, p2, dense_cfg, stream)) return e;
+        }
+        return hipSuccess;
+    }
     p.n_visited = (uint32_t)n;
     p.div_nx = make_div(p.nx);
     p.div_ny = make_div(p.ny);
     p.div_w = make_div(a.W);
-    if (p.all_required && p.step <= 8) {
+    if (p.all_required && (p.step <= 8 || p.virgin)) {  // (a virgin grid has nothing to read back: whole rows at any step)
         // whole visited rows: one of every `step` texels computed, the rest re-stored (a constant over a fresh grid)
         const uint32_t blocks = (uint32_t)(((uint64_t)a.W * p.ny * p.nz + kBlock - 1) / kBlock);
         if (p.fresh) {
@@ -635,6 +675,16 @@ hipError_t launch_commit_interleaved(const float* dist, float* ilv, uint32_t W, 
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(commit_interleaved_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, stream, dist, reinterpret_cast<float2*>(ilv),
                        W, n_pairs);
+    return hipGetLastError();
+}
+
+hipError_t launch_grid_init_unvisited(float* tex0, float* tex1, float* dist, uint32_t W, uint32_t H, uint32_t z_begin,
+                                      uint32_t slab_d, uint32_t step, float air, hipStream_t stream) {
+    if ((uint64_t)W * H * slab_d == 0) return hipSuccess;
+    dim3 grid, block;
+    if (!commit_grid(W, H, slab_d, grid, block)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(grid_init_unvisited_kernel, grid, block, 0, stream, reinterpret_cast<float4*>(tex0),
+                       reinterpret_cast<float4*>(tex1), dist, W, H, z_begin, step, air);
     return hipGetLastError();
 }
 

@@ -471,6 +471,10 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             g_options.slab_step_form = (uint32_t)value;
             return SDFV_OK;
         }
+        case SDFV_OPT_PASS_INDEX_LIMIT:
+            if (value != 0 && (value < 2 || value > (1ull << 32))) break;
+            g_options.pass_index_limit = value;
+            return SDFV_OK;
         case SDFV_OPT_EXT_SRGB_QUANT:
             if (value > 1) break;
             g_options.ext_srgb_quant = (uint32_t)value;
@@ -522,6 +526,7 @@ int sdfv_get_option(uint32_t option, uint64_t* value) {
         case SDFV_OPT_TUNING_TILE_ORDER: *value = g_options.tile_order; return SDFV_OK;
         case SDFV_OPT_RAYMARCH_WAVES_PER_SIMD: *value = g_options.raymarch_waves_per_simd; return SDFV_OK;
         case SDFV_OPT_EXT_SRGB_QUANT: *value = g_options.ext_srgb_quant; return SDFV_OK;
+        case SDFV_OPT_PASS_INDEX_LIMIT: *value = g_options.pass_index_limit; return SDFV_OK;
         default: return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown option %u", option);
     }
 }
@@ -631,6 +636,19 @@ int sdfv_grid_init(const sdfv_grid* grid, float* tex0, float* tex1, void* stream
     return SDFV_OK;
 }
 
+int sdfv_grid_init_unvisited(const sdfv_grid* grid, uint32_t step, float* tex0, float* tex1, float* dist, void* stream) {
+    if (int rc = check_grid(grid)) return rc;
+    if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
+    if (step & (step - 1)) return fail(SDFV_ERR_INVALID_ARGUMENT, "step %u is neither 0 nor a power of two", step);
+    if (int rc = check_texel_alignment(tex0, tex1)) return rc;
+    if ((uintptr_t)dist & 3) return fail(SDFV_ERR_INVALID_ARGUMENT, "dist must be 4-byte aligned");
+    if (int rc = need_device()) return rc;
+    if (step == 1) return SDFV_OK;  // a step-1 pass wrote every row
+    SDFV_HIP(sdfv::launch_grid_init_unvisited(tex0, tex1, dist, grid->dims[0], grid->dims[1], grid->z_begin,
+                                              grid->z_end - grid->z_begin, step, air_dist(), (hipStream_t)stream));
+    return SDFV_OK;
+}
+
 int sdfv_fill_grid_commit(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, float* tex0,
                           float* tex1, float* dist, void* stream) {
     if (int rc = check_params(params, sdf_id)) return rc;
@@ -733,7 +751,10 @@ int sdfv_fill_grid_pass_ex(const sdfv_demo_params* params, uint32_t sdf_id, cons
     if (int rc = check_grid(grid)) return rc;
     if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
     if (step == 0 || (step & (step - 1))) return fail(SDFV_ERR_INVALID_ARGUMENT, "step %u is not a power of two", step);
-    if (flags & ~(SDFV_PASS_FRESH_GRID | SDFV_PASS_SAME_LOAD)) return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown pass flags 0x%x", flags);
+    if (flags & ~(SDFV_PASS_FRESH_GRID | SDFV_PASS_SAME_LOAD | SDFV_PASS_VIRGIN_GRID))
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown pass flags 0x%x", flags);
+    if ((flags & SDFV_PASS_VIRGIN_GRID) && changed_box)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "SDFV_PASS_VIRGIN_GRID with a changed box: a box test reads the grid (sdfv_grid_init_unvisited first)");
     if (int rc = check_texel_alignment(tex0, tex1)) return rc;
     if ((uintptr_t)dist & 3) return fail(SDFV_ERR_INVALID_ARGUMENT, "dist must be 4-byte aligned");
     if (int rc = need_device()) return rc;
@@ -767,6 +788,8 @@ int sdfv_fill_grid_pass_ex(const sdfv_demo_params* params, uint32_t sdf_id, cons
         covers = first >= changed_box[i] && first <= changed_box[3 + i] && last >= changed_box[i] && last <= changed_box[3 + i];
     }
     p.fresh = (flags & SDFV_PASS_FRESH_GRID) ? 1u : 0u;
+    p.virgin = (flags & SDFV_PASS_VIRGIN_GRID) ? 1u : 0u;
+    p.index_limit = g_options.pass_index_limit;
     p.all_required = (flags != 0 || covers) ? 1u : 0u;
     SDFV_HIP(sdfv::launch_fill_pass(a, p, fill_launch_config(dist != nullptr), (hipStream_t)stream));
     return SDFV_OK;

@@ -135,6 +135,7 @@ void* sdfvh_viewer_new_voxels(size_t w, size_t h, size_t d, const float bb[6], s
     BoundingBox b{Vec3{bb[0], bb[1], bb[2]}, Vec3{bb[3], bb[4], bb[5]}};
     return SDFViewer::new_voxels({w, h, d}, b, loading_passes).release();
 }
+int sdfvh_viewer_tune(size_t w, size_t h, size_t d) { return SDFViewer::tune({w, h, d}); }
 void sdfvh_viewer_free(void* v) { delete static_cast<SDFViewer*>(v); }
 static SDFViewer& V(void* v) { return *static_cast<SDFViewer*>(v); }
 void sdfvh_viewer_dims(void* v, uint32_t out[3]) {

@@ -1,0 +1,142 @@
+// host_load_bench.cpp -- what a host that drops libsdfviewer_host.so in actually pays for a load:
+//   SDFViewer::from_bb -> update(sdf, budget) [-> update ...] -> commit        (reference: src/app/scene/mod.rs:139-156 set_sdf,
+//   src/app/scene/sdf/mod.rs:46-101 from_bb / new_voxels, :128-217 update, :220-239 commit)
+// through the C++ mirror of the reference's classes, NOT through the kernels' own entry points.  bench.py runs this binary and
+// attaches its JSON as "host_load".  Timed per load, HIP events on the viewer's stream + the host's wall clock:
+//   create_ms      from_bb alone (hipMalloc of both textures + the distance volume; nothing is launched or waited for)
+//   load_ms        update() to completion + commit()'s march volume, GPU time between events    <- the number to compare with
+//                  the fused fill kernel (bench.py "ms_per_step_fill")
+//   update_ms      ... the update() share
+//   enqueue_us     host time spent inside update() + commit() (they only enqueue)
+// Forms: "dense" = one update() with the reference's 30 ms budget (every pass fits: the dense shortcut); "progressive" = one
+// pass per update() call (zero budget), the reference's order of passes.  A fresh viewer per repetition (a load starts from
+// new_voxels), created outside the timed region.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sdf_demo.hpp"
+#include "sdf_viewer.hpp"
+
+using namespace sdfviewer;
+using Clock = std::chrono::steady_clock;
+
+static double median(std::vector<double> v) {
+    if (v.empty()) return 0.0;
+    std::sort(v.begin(), v.end());
+    return v[v.size() / 2];
+}
+
+struct Result {
+    double create_ms, load_ms, update_ms, commit_ms, enqueue_us;
+    size_t iterations;
+    int passes_run;
+};
+
+static bool one_load(size_t side, size_t passes, bool progressive, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, Result& r) {
+    std::string err;
+    auto demo = SDFDemo::from_args({}, &err);
+    if (!demo) return false;
+    const BoundingBox bb = demo->bounding_box();
+    const auto t0 = Clock::now();
+    auto v = SDFViewer::from_bb(bb, side, passes);
+    const auto t1 = Clock::now();
+    if (!v) return false;
+    r.create_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    hipStream_t st = (hipStream_t)v->stream;
+    if (hipStreamSynchronize(st) != hipSuccess) return false;
+    r.iterations = 0;
+    r.passes_run = 0;
+    const auto h0 = Clock::now();
+    (void)hipEventRecord(e0, st);
+    for (;;) {
+        const size_t n = v->update(*demo, progressive ? std::chrono::nanoseconds(0) : std::chrono::milliseconds(30));
+        if (n == 0) break;
+        r.iterations += n;
+        ++r.passes_run;
+    }
+    (void)hipEventRecord(e1, st);
+    v->commit();
+    (void)hipEventRecord(e2, st);
+    const auto h1 = Clock::now();
+    if (hipEventSynchronize(e2) != hipSuccess) return false;
+    float a = 0.0f, b = 0.0f;
+    (void)hipEventElapsedTime(&a, e0, e1);
+    (void)hipEventElapsedTime(&b, e1, e2);
+    r.update_ms = a;
+    r.commit_ms = b;
+    r.load_ms = a + b;
+    r.enqueue_us = std::chrono::duration<double, std::micro>(h1 - h0).count();
+    return v->material.lod_dist_between_samples == 1.0f && !v->material.undefined_rows;
+}
+
+int main(int argc, char** argv) {
+    size_t side = 256, passes = 2;
+    int reps = 20;
+    bool tune = false;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--side") && i + 1 < argc) side = strtoul(argv[++i], nullptr, 10);
+        else if (!strcmp(argv[i], "--passes") && i + 1 < argc) passes = strtoul(argv[++i], nullptr, 10);
+        else if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--tune")) tune = true;
+        else {
+            fprintf(stderr, "usage: %s [--side N] [--passes P] [--reps R] [--tune]\n", argv[0]);
+            return 2;
+        }
+    }
+    if (sdfv_device_count() <= 0) {
+        fprintf(stderr, "no HIP device\n");
+        return 3;
+    }
+    double tune_ms = 0.0;
+    if (tune) {
+        const auto t0 = Clock::now();
+        if (SDFViewer::tune({side, side, side}) != 0) fprintf(stderr, "tune failed: %s\n", sdfv_last_error());
+        tune_ms = std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
+    }
+    hipEvent_t e0, e1, e2;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) return 3;
+    const double voxels = (double)side * side * side;
+    printf("{\"side\": %zu, \"loading_passes\": %zu, \"reps\": %d, \"tuned_placement\": %s, \"tune_ms\": %.1f", side, passes, reps,
+           tune ? "true" : "false", tune_ms);
+    for (int form = 0; form < 2; ++form) {
+        const bool progressive = form == 1;
+        std::vector<double> load, update, commit, create, enqueue;
+        Result r{};
+        bool ok = true;
+        // keep the device busy before the timed loads (it idles at a few hundred MHz; bench.py does the same)
+        for (int i = 0; i < 3 && ok; ++i) ok = one_load(side, passes, progressive, e0, e1, e2, r);
+        for (int i = 0; i < reps && ok; ++i) {
+            ok = one_load(side, passes, progressive, e0, e1, e2, r);
+            load.push_back(r.load_ms);
+            update.push_back(r.update_ms);
+            commit.push_back(r.commit_ms);
+            create.push_back(r.create_ms);
+            enqueue.push_back(r.enqueue_us);
+        }
+        if (!ok) {
+            fprintf(stderr, "load failed: %s\n", sdfv_last_error());
+            return 1;
+        }
+        // algorithmic bytes of the update() share: every voxel's two texels + its distance-volume entry once (36 B) for the
+        // dense form; the progressive form also writes the rows its coarser passes visit (36 B per voxel of those rows)
+        double bytes = 36.0 * voxels;
+        if (progressive)
+            for (size_t step = (size_t)1 << (passes - 1); step > 1; step >>= 1)
+                bytes += 36.0 * (double)side * (double)((side + step - 1) / step) * (double)((side + step - 1) / step);
+        const double up = median(update);
+        printf(", \"%s\": {\"load_ms\": %.4f, \"update_ms\": %.4f, \"commit_ms\": %.4f, \"create_ms\": %.3f, \"enqueue_us\": %.1f, "
+               "\"update_calls\": %d, \"iterations\": %zu, \"update_bytes\": %.0f, \"update_TBps\": %.3f, \"Mvoxels_per_s\": %.0f}",
+               progressive ? "progressive" : "dense", median(load), up, median(commit), median(create), median(enqueue),
+               r.passes_run, r.iterations, bytes, up > 0 ? bytes / (up * 1e-3) / 1e12 : 0.0,
+               median(load) > 0 ? voxels / (median(load) * 1e-3) / 1e6 : 0.0);
+    }
+    printf("}\n");
+    return 0;
+}

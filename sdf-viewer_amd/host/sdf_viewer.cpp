@@ -6,6 +6,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 namespace sdfviewer {
 
@@ -66,7 +68,20 @@ sdfv_render_params SDFViewerMaterial::uniforms() const {
     return rp;
 }
 
+int SDFViewerMaterial::materialize(void* stream) const {
+    if (!undefined_rows) return 0;
+    sdfv_grid g{};
+    for (int i = 0; i < 3; ++i) g.dims[i] = tex_size[i];
+    g.z_end = g.dims[2];  // (the bounding box plays no part in an initialisation)
+    const int rc = sdfv_grid_init_unvisited(&g, defined_step, tex0->f32(), tex1->f32(), dist ? dist->f32() : nullptr, stream);
+    if (rc == 0) undefined_rows = false;
+    return rc;
+}
+
 int SDFViewerMaterial::render(const Camera& camera, float* rgba_device, sdfv_march_aux* aux_device, void* stream) const {
+    // a frame in the middle of a virgin load reads voxels no pass has written (NEAREST snaps onto the lattice, but
+    // MirroredRepeat folds coordinate 1.0 onto voxel N - 1): they must hold the AIR the reference's textures hold
+    if (int rc = materialize(stream)) return rc;
     const sdfv_render_params rp = uniforms();
     const sdfv_camera cam = camera.to_device();
     // the distance volume is only meaningful for the fully loaded grid (LINEAR filter, lod == 1)
@@ -79,23 +94,56 @@ int SDFViewerMaterial::render(const Camera& camera, float* rgba_device, sdfv_mar
 }
 
 // ---- SDFViewer ----
+namespace {
+// tune()'s verdicts: (device, bytes per texture) -> distance of tex1 from tex0's end
+std::mutex g_placement_mutex;
+std::map<std::pair<int, size_t>, size_t> g_placement_skew;
+
+int current_device() {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return d;
+}
+}  // namespace
+
+int SDFViewer::tune(std::array<size_t, 3> voxels, void* stream) {
+    const size_t bytes = voxels[0] * voxels[1] * voxels[2] * 16;
+    if (bytes == 0) return 0;
+    DeviceBuffer block(2 * bytes + SDFV_PLACEMENT_SLACK);
+    if (!block.ok()) return SDFV_ERR_HIP;
+    sdfv_grid g{};
+    for (int i = 0; i < 3; ++i) {
+        g.dims[i] = (uint32_t)voxels[i];
+        g.bb_min[i] = -1.0f;  // the probe times the demo's default fill; the box it samples plays no part in the store rate
+        g.bb_max[i] = 1.0f;
+    }
+    g.z_end = g.dims[2];
+    size_t o0 = 0, o1 = bytes;
+    const int rc = sdfv_tune_texture_placement(&g, block.get(), block.bytes(), &o0, &o1, stream);
+    if (rc != 0) return rc;
+    std::lock_guard<std::mutex> lock(g_placement_mutex);
+    g_placement_skew[{current_device(), bytes}] = o1 - o0 - bytes;
+    return 0;
+}
+
 SDFViewer::SDFViewer(std::array<size_t, 3> voxels, const BoundingBox& bb, size_t passes)
     : loading_mgr(voxels, passes), bounding_box(bb) {
     const size_t bytes = voxels[0] * voxels[1] * voxels[2] * 16;
-    // Both textures in one block, tex1 where sdfv_tune_texture_placement finds the dense fill's two store streams
-    // run fastest (they differ by up to 9-12 % with the distance between the bases).  If the block cannot be had,
-    // two plain allocations do.
+    // Both textures in one block, tex1 at the distance tune() measured for this size on this device (0 when nobody asked:
+    // allocation only, nothing is launched or waited for here).  If the block cannot be had, two plain allocations do.
+    size_t skew = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_placement_mutex);
+        const auto it = g_placement_skew.find({current_device(), bytes});
+        if (it != g_placement_skew.end()) skew = it->second;
+    }
     block_ = std::make_shared<DeviceBuffer>(2 * bytes + SDFV_PLACEMENT_SLACK);
-    size_t o0 = 0, o1 = bytes;
     if (bytes > 0 && block_->ok()) {
-        sdfv_grid g{};
-        for (int i = 0; i < 3; ++i) g.dims[i] = (uint32_t)voxels[i];
-        g.bb_min[0] = g.bb_min[1] = g.bb_min[2] = -1.0f;
-        g.bb_max[0] = g.bb_max[1] = g.bb_max[2] = 1.0f;
-        g.z_end = g.dims[2];
-        (void)sdfv_tune_texture_placement(&g, block_->get(), block_->bytes(), &o0, &o1, stream);  // failure keeps 0 / bytes
-        material.tex0 = std::make_shared<DeviceBuffer>(static_cast<char*>(block_->get()) + o0, bytes);
-        material.tex1 = std::make_shared<DeviceBuffer>(static_cast<char*>(block_->get()) + o1, bytes);
+        material.tex0 = std::make_shared<DeviceBuffer>(static_cast<char*>(block_->get()), bytes);
+        material.tex1 = std::make_shared<DeviceBuffer>(static_cast<char*>(block_->get()) + bytes + skew, bytes);
     } else {
         block_.reset();
         material.tex0 = std::make_shared<DeviceBuffer>(bytes);
@@ -117,13 +165,14 @@ std::unique_ptr<SDFViewer> SDFViewer::new_voxels(std::array<size_t, 3> voxels, c
                                                  size_t loading_passes) {
     std::unique_ptr<SDFViewer> v(new SDFViewer(voxels, bb, loading_passes));
     if (!v->material.tex0->ok() || !v->material.tex1->ok()) return nullptr;
-    const sdfv_grid g = v->grid();
-    if (sdfv_grid_init(&g, v->tex0_device(), v->tex1_device(), v->stream) != 0) return nullptr;  // [AIR_DIST; 4]
+    // The reference fills both textures with [AIR_DIST; 4] here (:76-77).  This grid is VIRGIN instead: that state is
+    // recorded, not written -- the first update() overwrites every byte of it anyway (36 B/voxel the load never pays for).
+    v->material.undefined_rows = true;
+    v->material.defined_step = 0;
     // The compact distance volume (tex0.r, 4 B/voxel) lives next to the textures from the start and every fill keeps
     // it in sync: passes read it for update_required instead of tex0's 16-byte texels, commit() has nothing to derive.
     v->material.dist = std::make_shared<DeviceBuffer>(v->material.tex0->bytes() / 4);
-    v->dist_synced_ = v->material.dist->ok() &&
-                      sdfv_commit_distance(&g, v->tex0_device(), v->material.dist->f32(), v->stream) == 0;
+    v->dist_synced_ = v->material.dist->ok();
     if (!v->dist_synced_) v->material.dist.reset();  // out of memory: march tex0.r in place, passes read tex0
     return v;
 }
@@ -208,6 +257,7 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
             return 0;
         }
         fresh_ = false;
+        material.undefined_rows = false;  // the dense fill wrote every voxel
         material.pairs_valid = false;
         while (loading_mgr.step_size() != 0) loading_mgr.finish_pass();
         publish_lod();
@@ -229,14 +279,27 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
         // What this LoadingManager knows about the grid (sdfv_fill_grid_pass_ex): the first pass of a load over the grid
         // new_voxels initialised sees AIR_DIST everywhere; the later passes of that load revisit only what ITS earlier
         // passes wrote (same SDF, same parameters -- a changed box or another SDF ends the load, see set below).
+        // A virgin grid (nothing written by new_voxels): the same passes, told so -- they write the rows they visit whole
+        // and read nothing.  A pass that must READ the grid (a changed box, another SDF mid-load) first gets the initial
+        // state written into the rows no pass has reached.
         uint32_t flags = 0;
-        if (same_load_ && !changed_box) flags = (fresh_ ? SDFV_PASS_FRESH_GRID : 0u) | SDFV_PASS_SAME_LOAD;
+        if (same_load_ && !changed_box)
+            flags = material.undefined_rows ? (SDFV_PASS_VIRGIN_GRID | SDFV_PASS_SAME_LOAD)
+                                            : ((fresh_ ? SDFV_PASS_FRESH_GRID : 0u) | SDFV_PASS_SAME_LOAD);
+        else if (material.materialize(stream) != 0) {
+            error_ = sdfv_last_error();
+            break;
+        }
         if (sdfv_fill_grid_pass_ex(&dev->params, dev->sdf_id, &g, (uint32_t)step, box_ptr, tex0_device(), tex1_device(),
                                    dist_synced_ ? material.dist->f32() : nullptr, flags, stream) != 0) {
             error_ = sdfv_last_error();
             break;
         }
         fresh_ = false;
+        if (material.undefined_rows) {  // (only virgin passes get here with the flag still set)
+            material.defined_step = (uint32_t)step;
+            if (step == 1) material.undefined_rows = false;
+        }
         material.pairs_valid = false;
         loading_mgr.finish_pass();
         publish_lod();
@@ -285,6 +348,7 @@ void SDFViewer::commit() {
 }
 
 int SDFViewer::download(float* tex0_host, float* tex1_host) const {
+    if (material.materialize(stream) != 0) return -1;  // a virgin grid shows new_voxels' [AIR_DIST; 4] like any other
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
     if (hipMemcpy(tex0_host, tex0_device(), material.tex0->bytes(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     if (hipMemcpy(tex1_host, tex1_device(), material.tex1->bytes(), hipMemcpyDeviceToHost) != hipSuccess) return -1;

@@ -9,7 +9,11 @@
 //     lod_dist_between_samples = 2^passes_left (the uniform that tells the shader how to read them) with the data;
 //     commit() has nothing to upload (the reference re-uploads both whole textures and sets the uniform there,
 //     :220-239) and nothing to derive: the compact distance volume is kept in sync by every fill and pass;
-//   - SDFViewerMaterial::render() is the fragment shader over every pixel (sdfv_raymarch).
+//   - SDFViewerMaterial::render() is the fragment shader over every pixel (sdfv_raymarch);
+//   - new_voxels() allocates and writes NOTHING ("virgin" grid): the reference's initial state [AIR_DIST; 4] is only recorded.
+//     A load that runs all its passes never pays for it (the dense fill, or the step-1 pass, writes every byte); the passes
+//     before it write the rows they visit whole (SDFV_PASS_VIRGIN_GRID) and whatever READS the whole grid in between -- a
+//     frame at an intermediate LOD, download(), a pass with a changed box -- first writes AIR into the rows no pass reached.
 #pragma once
 
 #include <chrono>
@@ -69,6 +73,11 @@ struct SDFViewerMaterial {
     bool pairs_valid = false;             // pairs mirrors dist: set by SDFViewer::commit, cleared by every fill
     bool no_march_volume = false;         // sdfv_march_volume_advice said neither pays for this grid: commit() builds none
     bool pairs_interleaved = false;       // `pairs` holds the y-interleaved volume instead (sdfv_march_volume_advice)
+    // Virgin load: the rows of the textures (and of dist) no pass has written yet hold undefined bytes, logically [AIR_DIST; 4].
+    mutable bool undefined_rows = false;
+    mutable uint32_t defined_step = 0;    // smallest step of the passes run so far: rows with y and z multiples of it are defined (0: none)
+    // Writes new_voxels' initial state into the rows still undefined (sdfv_grid_init_unvisited); a no-op otherwise.
+    int materialize(void* stream) const;
     std::array<uint32_t, 3> tex_size{0, 0, 0};
     BoundingBox voxels_bounds;
     float lod_dist_between_samples = 1.0f;
@@ -87,6 +96,13 @@ class SDFViewer {
     // scene/sdf/mod.rs:75-101 (allocates both textures on the device and fills them with AIR_DIST)
     static std::unique_ptr<SDFViewer> new_voxels(std::array<size_t, 3> voxels, const BoundingBox& bb,
                                                  size_t loading_passes);
+
+    // Texture placement.  The dense fill's two store streams run up to 12 % apart with the distance between the texture
+    // bases (include/sdfgrid.h, sdfv_tune_texture_placement).  tune() MEASURES it for grids of this size on the current
+    // device -- tens of milliseconds, blocking -- and remembers the verdict process-wide; viewers created afterwards for a
+    // grid of the same byte size on that device are placed accordingly.  Never called implicitly: from_bb / new_voxels
+    // allocate and return (untuned placement: tex1 right after tex0).  Returns 0, or the library's error code.
+    static int tune(std::array<size_t, 3> voxels, void* stream = nullptr);
 
     // scene/sdf/mod.rs:128-217.  Returns the number of LoadingManager iterations consumed, like the reference.
     // The time budget is checked between passes (the GPU does a whole pass per launch).

@@ -34,7 +34,7 @@ for name, res, args in [
     ("sdfvh_sdf_changed", C.c_int, [C.c_void_p, C.c_void_p]), ("sdfvh_sdf_parameters", SZ, [C.c_void_p, C.c_char_p, SZ]),
     ("sdfvh_viewer_from_bb", C.c_void_p, [C.c_void_p, SZ, SZ]),
     ("sdfvh_viewer_new_voxels", C.c_void_p, [SZ, SZ, SZ, C.c_void_p, SZ]), ("sdfvh_viewer_free", None, [C.c_void_p]),
-    ("sdfvh_viewer_dims", None, [C.c_void_p, C.c_void_p]),
+    ("sdfvh_viewer_dims", None, [C.c_void_p, C.c_void_p]), ("sdfvh_viewer_tune", C.c_int, [SZ, SZ, SZ]),
     ("sdfvh_viewer_update", SZ, [C.c_void_p, C.c_void_p, C.c_double]), ("sdfvh_viewer_commit", None, [C.c_void_p]),
     ("sdfvh_viewer_lod", C.c_float, [C.c_void_p]), ("sdfvh_viewer_remaining", SZ, [C.c_void_p]),
     ("sdfvh_viewer_passes_left", SZ, [C.c_void_p]), ("sdfvh_viewer_has_changed_box", C.c_int, [C.c_void_p]),
@@ -182,6 +182,16 @@ class Viewer:
         bb = np.asarray(bb, np.float32).reshape(6)
         return Viewer(H.sdfvh_viewer_new_voxels(dims[0], dims[1], dims[2], bb.ctypes.data, passes))
 
+    @staticmethod
+    def tune(dims):
+        """SDFViewer::tune: measure the texture placement for grids of this size (blocking), remember it process-wide."""
+        return H.sdfvh_viewer_tune(dims[0], dims[1], dims[2])
+
+    def texture_gap(self):
+        """Bytes between the end of tex0 and the start of tex1 (the placement the constructor used)."""
+        w, h, d = self.dims()
+        return H.sdfvh_viewer_tex1(self.h) - H.sdfvh_viewer_tex0(self.h) - w * h * d * 16
+
     def dims(self):
         out = (C.c_uint32 * 3)()
         H.sdfvh_viewer_dims(self.h, out)
@@ -260,6 +270,16 @@ class Scene:
 
     def lod(self):
         return H.sdfvh_scene_lod(self.h)
+
+    @staticmethod
+    def tune(dims):
+        """SDFViewer::tune: measure the texture placement for grids of this size (blocking), remember it process-wide."""
+        return H.sdfvh_viewer_tune(dims[0], dims[1], dims[2])
+
+    def texture_gap(self):
+        """Bytes between the end of tex0 and the start of tex1 (the placement the constructor used)."""
+        w, h, d = self.dims()
+        return H.sdfvh_viewer_tex1(self.h) - H.sdfvh_viewer_tex0(self.h) - w * h * d * 16
 
     def dims(self):
         out = (C.c_uint32 * 3)()

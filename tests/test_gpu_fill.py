@@ -508,3 +508,89 @@ def test_store_only_passes_leave_a_foreign_tex1_alpha_alone(pkg, oracle):
         assert_bits_equal(t0, r0)
         assert bool((t1[..., 3] == 42.0).all())
         np.testing.assert_array_equal(t1.cpu().numpy()[..., :3].view(np.uint32), r1[..., :3].view(np.uint32))
+
+
+@pytest.mark.parametrize("dims,z_range,steps", [((21, 18, 13), (0, 13), (4, 2, 1)), ((64, 64, 64), (0, 64), (2, 1)),
+                                                ((40, 12, 29), (7, 22), (16, 4, 2, 1)), ((130, 9, 6), (1, 6), (2, 1)),
+                                                ((256, 16, 8), (0, 8), (8, 1))])
+@pytest.mark.parametrize("use_dist", [False, True])
+def test_virgin_grid_passes(pkg, oracle, dims, z_range, steps, use_dist):
+    """SDFV_PASS_VIRGIN_GRID: a load over a fresh ALLOCATION (new_voxels' [AIR_DIST; 4] never written; the buffers hold
+    garbage).  After every pass the rows it visited are the reference's, sdfv_grid_init_unvisited(step) completes a copy to
+    the oracle's whole state at that pass boundary, and the step-1 pass leaves the dense grid with nothing undefined."""
+    K = pkg._capi
+    bb = ((-1.0, -0.75, -1.0), (1.0, 1.0, 0.5))
+    g = pkg.make_grid(dims, *bb, *z_range)
+    prm = pkg.default_params()
+    t0, t1 = pkg.alloc_textures(g)
+    t0.fill_(-7.0)
+    t1.fill_(float("nan"))
+    dist = torch.full(tuple(t0.shape[:-1]), 123.0, dtype=torch.float32, device="cuda") if use_dist else None
+    # the oracle: the LoadingManager loop over the WHOLE grid, cut to the slab afterwards
+    r0, r1 = oracle.grid_init(dims)
+    z0, z1 = z_range
+    # before any pass: step 0 = plain new_voxels
+    c0, c1 = t0.clone(), t1.clone()
+    cd = dist.clone() if use_dist else None
+    pkg.grid_init_unvisited(g, 0, c0, c1, dist=cd)
+    assert bool((c0 == pkg.AIR_DIST).all()) and bool((c1 == pkg.AIR_DIST).all()) and (cd is None or bool((cd == pkg.AIR_DIST).all()))
+    for step in steps:
+        pkg.fill_grid_pass(prm, g, step, t0, t1, dist=dist, flags=K.PASS_VIRGIN_GRID | K.PASS_SAME_LOAD)
+        lm = oracle.lm_new(dims, 1)
+        lm.step_size = step  # one pass with this step over the oracle's grid
+        oracle.viewer_update(oracle.params_from(prm), dims, lm, r0, r1, bb_min=bb[0], bb_max=bb[1],
+                             max_iterations=-(-dims[0] // step) * -(-dims[1] // step) * -(-dims[2] // step))
+        torch.cuda.synchronize()
+        ys = torch.arange(0, dims[1], step, device="cuda")
+        zs = [z - z0 for z in range(z0, z1) if z % step == 0]
+        if zs:
+            rows0 = t0[zs][:, ys].cpu().numpy()
+            rows1 = t1[zs][:, ys].cpu().numpy()
+            np.testing.assert_array_equal(rows0.view(np.uint32), r0[z0:z1][zs][:, ys.cpu().numpy()].view(np.uint32))
+            np.testing.assert_array_equal(rows1.view(np.uint32), r1[z0:z1][zs][:, ys.cpu().numpy()].view(np.uint32))
+        c0, c1 = t0.clone(), t1.clone()
+        cd = dist.clone() if use_dist else None
+        pkg.grid_init_unvisited(g, step, c0, c1, dist=cd)
+        torch.cuda.synchronize()
+        assert_bits_equal(c0, r0[z0:z1])
+        assert_bits_equal(c1, r1[z0:z1])
+        assert cd is None or torch.equal(cd, c0[..., 0])
+    d0, d1 = gpu_fill(pkg, prm, dims, *bb, *z_range)
+    assert torch.equal(t0, d0) and torch.equal(t1, d1) and (dist is None or torch.equal(dist, t0[..., 0]))
+    with pytest.raises(pkg.SdfvError):  # a box test reads the grid
+        pkg.fill_grid_pass(prm, g, 2, t0, t1, changed_box=(-1, -1, -1, 1, 1, 1), flags=K.PASS_VIRGIN_GRID)
+
+
+def test_passes_over_slabs_beyond_32_bit_indices_run_in_pieces(pkg, oracle):
+    """a pass over a slab of >= 2^32 voxels used to fail.  It now runs as several launches over pieces of whole
+    slices; SDFV_OPT_PASS_INDEX_LIMIT lowers the threshold so that a small grid takes that path: unflagged, flagged, with a
+    changed box, with and without the distance volume, whole grids and slabs -- same texels as in one piece."""
+    K = pkg._capi
+    dims = (24, 20, 23)
+    prm, edited = pkg.default_params(), pkg.default_params(sphere_radius=0.8, cube_material=1)
+    box = (-0.5, -1.0, -0.25, 0.5, 0.1, 1.0)
+    for z_range in ((0, 23), (5, 20)):
+        g = pkg.make_grid(dims, z_begin=z_range[0], z_end=z_range[1])
+        for use_dist in (False, True):
+            for flagged in (False, True):
+                results = []
+                for limit in (0, 24 * 20 * 3 + 1, 24 * 20 + 1):  # one piece, pieces of 3 slices, pieces of 1 slice
+                    with pkg.options({K.OPT_PASS_INDEX_LIMIT: limit}):
+                        t0, t1 = pkg.alloc_textures(g)
+                        pkg.grid_init(g, t0, t1)
+                        dist = pkg.commit_distance(g, t0) if use_dist else None
+                        for k, step in enumerate((4, 2, 1)):
+                            flags = ((K.PASS_FRESH_GRID if k == 0 else 0) | K.PASS_SAME_LOAD) if flagged else 0
+                            pkg.fill_grid_pass(prm, g, step, t0, t1, dist=dist, flags=flags)
+                        a0, a1 = t0.clone(), t1.clone()
+                        for step in (4, 2, 1):
+                            pkg.fill_grid_pass(edited, g, step, t0, t1, changed_box=box, dist=dist)
+                        torch.cuda.synchronize()
+                        assert dist is None or torch.equal(dist, t0[..., 0])
+                        results.append((a0, a1, t0, t1))
+                for r in results[1:]:
+                    assert all(torch.equal(x, y) for x, y in zip(results[0], r)), (z_range, use_dist, flagged)
+        r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, z0=z_range[0], z1=z_range[1])
+        assert_bits_equal(results[0][0], r0)
+    with pytest.raises(pkg.SdfvError):
+        pkg.set_option(K.OPT_PASS_INDEX_LIMIT, 1)

@@ -76,6 +76,72 @@ def test_viewer_progressive_states_and_lod(host, oracle):
     assert v.update(sdf, 0.0) == 0
 
 
+def test_viewer_virgin_load_never_writes_the_initial_state_it_does_not_need(host, oracle):
+    """new_voxels records [AIR_DIST; 4] instead of writing it.  Three passes with nothing reading the grid in between (the
+    virgin chain: SDFV_PASS_VIRGIN_GRID each), then one download: the dense oracle.  And the other order of events: a frame
+    rendered after the FIRST pass only (the blocky LOD preview) equals the oracle's frame over the oracle's state at that
+    pass boundary -- the rows no pass reached were materialised as AIR on demand -- and so does everything after it; an edit
+    before the first update() (a pass that must read the grid) materialises first too."""
+    sdf = host.SDF.demo()
+    dims = (24, 20, 16)
+    v = host.Viewer.new_voxels(dims, [-1, -1, -1, 1, 1, 1], 3)
+    for _ in range(3):
+        assert v.update(sdf, 0.0) > 0
+    assert v.update(sdf, 0.0) == 0 and v.lod() == 1.0
+    r0, r1 = oracle.fill_dense(oracle.default_params(), dims)
+    t0, t1 = v.download()
+    np.testing.assert_array_equal(t0.view(np.uint32), r0.view(np.uint32))
+    np.testing.assert_array_equal(t1.view(np.uint32), r1.view(np.uint32))
+
+    v = host.Viewer.new_voxels(dims, [-1, -1, -1, 1, 1, 1], 3)
+    v.update(sdf, 0.0)
+    img = v.render(80, 60)  # no download before it: render() itself must see defined voxels
+    o0, o1 = oracle.grid_init(dims)
+    lm = oracle.lm_new(dims, 3)
+    oracle.viewer_update(oracle.default_params(), dims, lm, o0, o1, max_iterations=6 * 5 * 4)
+    rp = oracle.default_render_params(dims)
+    rp.lod_dist_between_samples = 4.0
+    want, _ = oracle.raymarch(rp, o0, o1, oracle.camera_look_at(aspect=80 / 60), 80, 60, want_aux=False)
+    assert np.abs(img - want).max() <= 1e-4 and (img[..., 3] == want[..., 3]).all()
+    t0, t1 = v.download()
+    np.testing.assert_array_equal(t0.view(np.uint32), o0.view(np.uint32))
+    np.testing.assert_array_equal(t1.view(np.uint32), o1.view(np.uint32))
+    while v.update(sdf, 0.0):
+        pass
+    t0, t1 = v.download()
+    np.testing.assert_array_equal(t0.view(np.uint32), r0.view(np.uint32))
+
+    edited = host.SDF.demo()
+    v = host.Viewer.new_voxels(dims, [-1, -1, -1, 1, 1, 1], 2)
+    assert edited.children()[1].set_parameter(1, 0.7) is None  # changed() reports a box before anything was loaded
+    for _ in range(12):
+        if v.update(edited, 0.0) == 0 and not v.has_changed_box():
+            break
+    t0, t1 = v.download()
+    e0, e1 = oracle.fill_dense(oracle.default_params(sphere_radius=0.7), dims)
+    np.testing.assert_array_equal(t0.view(np.uint32), e0.view(np.uint32))
+    np.testing.assert_array_equal(t1.view(np.uint32), e1.view(np.uint32))
+
+
+def test_texture_placement_is_measured_only_on_request(host, oracle):
+    """from_bb / new_voxels allocate and return (the constructor used to run a blocking 16-candidate probe on
+    every set_sdf).  SDFViewer::tune() is the explicit form: it measures once, and viewers made afterwards for that size on
+    that device are placed where it said; a viewer of another size keeps the plain placement; the load is the same bits."""
+    dims = (64, 64, 48)
+    plain = host.Viewer.new_voxels(dims, [-1, -1, -1, 1, 1, 1], 2)
+    assert plain.texture_gap() == 0
+    assert host.Viewer.tune(dims) == 0
+    tuned = host.Viewer.new_voxels(dims, [-1, -1, -1, 1, 1, 1], 2)
+    assert tuned.texture_gap() in (0, 4096, 8192, 12288, 20480, 28672, 36864, 53248)
+    assert host.Viewer.new_voxels((32, 32, 32), [-1, -1, -1, 1, 1, 1], 2).texture_gap() == 0
+    sdf = host.SDF.demo()
+    for v in (plain, tuned):
+        while v.update(sdf, 1.0):
+            pass
+    for a, b in zip(plain.download(), tuned.download()):
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_viewer_parameter_edit_refills_changed_box(host, oracle):
     """set_parameter -> changed() -> a fresh 3-pass manager re-samples the reported box (mod.rs:131-156)."""
     sdf = host.SDF.demo()
