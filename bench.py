@@ -21,6 +21,10 @@ N = 1 workload: BASELINE.json configs[1] (256^3 grid + 1920x1080).  --workload 5
 each fill step includes the one-voxel RCCL halo exchange (overlapped with the interior fill); the raymarch renders one camera per rank
 (orbit) over a replica of the N = 1 grid.
 
+This file is the CONTRACT: arguments, the two timed regions, the JSON line, the CPU baseline, the watchdog.  Everything the
+line carries beside that (target_512, progressive, host_load, batch_raymarch, halo_loopback, config4, self-checks) is
+bench_extras.py; the timing helpers both share are bench_common.py.
+
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
@@ -44,8 +48,11 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # argument).  Already exported on the GPU boxes; kept here for any environment the driver builds itself.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-FILL_BYTES_PER_VOXEL = 32  # tex0 16 B + tex1 16 B, store-only
+from types import SimpleNamespace
+
+import bench_common
+from bench_common import (FILL_8D_PEAK_MVOX, FILL_BYTES_PER_VOXEL, HBM_PEAK_GBS, STAGE, fill_roofline, load_traffic,  # noqa: F401
+                          per_step_stats, placement_note, region)
 
 WORKLOADS = {
     "256": dict(side=256, width=1920, height=1080, name="demo_sdf 256^3 grid + 1920x1080 sphere-trace (configs[1])"),
@@ -88,6 +95,7 @@ def parse_args():
                          "per-kernel rocprof averages then belong to one kernel variant)")
     ap.add_argument("--no-progressive", action="store_true",
                     help="N=1: skip the progressive / changed_box block (LoadingManager passes, SURVEY 8(f)1)")
+    ap.add_argument("--no-host-load", action="store_true", help="N=1: skip the SDFViewer load through libsdfviewer_host.so")
     ap.add_argument("--no-target-512", action="store_true", help="N=1: skip the 512^3 fill block (north-star target config)")
     ap.add_argument("--no-config4", action="store_true", help="N>1: skip the cube-geometry block (BASELINE config 4)")
     ap.add_argument("--config4-side", type=int, default=512,
@@ -95,79 +103,29 @@ def parse_args():
     return ap.parse_args()
 
 
-PREWARM_S = 0.25  # --prewarm-ms
 
-
-def STAGE(name):
-    """Registers the collective stage about to block (parallel.enter_stage) for the watchdog's report."""
-    par = sys.modules.get("sdf-viewer_amd.parallel")
-    if par is not None:
-        par.enter_stage("bench.py " + name)
-
-
-def prewarm(fn, torch, dist=None, world=1, device=None, seconds=None):
-    """Untimed: keep the device busy with `fn` for ~0.25 s so that the timed steps run at the clocks a busy GPU runs at.
-    The MI355X idles at a few hundred MHz and needs ~10 ms of load to ramp (tools/clock_ramp.py: the first 8 ms of
-    256^3 fills after an idle period are 9 % slower than the steady state, and on some boxes the rate keeps drifting
-    for about a second: tools/tex_skew_sweep.py); a few warm-up steps of 0.1 ms each do not get it there.  At N > 1 the steps contain exchanges, so every rank must make the SAME number of calls: the
-    count is agreed on (MAX over ranks) before the loop."""
-    seconds = PREWARM_S if seconds is None else seconds
-    if seconds <= 0:
-        return
-    fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    fn()
-    torch.cuda.synchronize()
-    one = max(time.perf_counter() - t0, 1e-5)
-    n = min(2000, int(seconds / one) + 1)
-    if world > 1:
-        STAGE("prewarm: all_reduce(MAX) of the call count")
-        t = torch.tensor([n], dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        n = int(t.item())
-    STAGE("prewarm: running")
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-
-
-def timed_region(fn, steps, torch, dist, world, device):
-    """EXACTLY `steps` calls of fn bracketed by barrier + synchronize on both sides; MAX over ranks.
-    Also returns the HIP-event time of the region on the launch stream (kernel time incl. launch gaps)."""
-    if world > 1:
-        STAGE("timed_region: barrier before")
-        dist.barrier()
-    torch.cuda.synchronize()
-    STAGE("timed_region: K steps + synchronize")
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(steps):
-        fn()
-    ev1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        STAGE("timed_region: barrier after")
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        STAGE("timed_region: all_reduce(MAX) of the times")
-        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, ev_ms = float(t[0]), float(t[1])
-    return dt, ev_ms
-
-
-def placement_note(args, slab):
-    """How tex0 and tex1 were placed (the dense fill's two store streams run up to ~10 % faster or slower with it)."""
-    if args.no_tuned_placement:
-        return "two separate allocations, not probed"
-    gap = slab.tex1.data_ptr() - slab.tex0.data_ptr() - slab.tex0.numel() * 4
-    if 0 <= gap <= (64 << 10):
-        return f"placement probe kept: one block, tex1 {gap} B after tex0's end (sdfv_tune_texture_placement)"
-    return "placement probe kept: two separate allocations (faster here than the block candidates)"
+def box_stamp(torch, device):
+    """Which box, at which clocks: the same binary differs by +-8 % from box to box, so every line says where
+    it was measured.  Best effort (sysfs / rocm-smi may be unavailable); never fatal."""
+    import socket
+    import subprocess
+    st = {"host": socket.gethostname()}
+    try:
+        p = torch.cuda.get_device_properties(device)
+        st.update({"name": p.name, "arch": getattr(p, "gcnArchName", None), "cus": p.multi_processor_count,
+                   "hbm_GiB": round(p.total_memory / 2 ** 30, 1)})
+        st["uuid"] = str(getattr(p, "uuid", "")) or None
+    except Exception as e:  # noqa: BLE001
+        st["props_error"] = f"{type(e).__name__}: {e}"
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showuniqueid", "--showperflevel", "--json"], capture_output=True,
+                           text=True, timeout=20)
+        card = next(iter(json.loads(r.stdout[r.stdout.index("{"):]).values()))
+        st["rocm_smi"] = {k: v for k, v in card.items() if any(w in k.lower() for w in ("sclk", "mclk", "fclk", "unique", "performance"))}
+    except Exception as e:  # noqa: BLE001
+        st["rocm_smi"] = f"unavailable: {type(e).__name__}"
+    st["note"] = "clocks as rocm-smi reports them right after the timed regions (the device is still warm)"
+    return st
 
 
 def effective_cores():
@@ -269,192 +227,6 @@ def cpu_baseline(workload, budget_s):
                                "sample": f"{frames} whole {W}x{H} frame(s), OpenMP over rows ({all_rays_dt:.1f} s)"}}
 
 
-def load_traffic(workload_key, name="fill_pmc_traffic.json"):
-    """HBM bytes per launch from the committed PMC pass (profiles/*_pmc_traffic.json), or None."""
-    path = os.path.join(ROOT, "profiles", name)
-    try:
-        d = json.load(open(path))
-        return d.get(workload_key, {}).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
-
-
-def raymarch_traffic_report(workload_key, launch_ms, path_key="product_path", traffic_key=None):
-    """SURVEY.md 8(d)'s raymarch byte model next to the measured figures.  compulsory / nominal bytes come from the
-    oracle's deterministic counts (tools/raymarch_bytes.py -> profiles/raymarch_model_bytes.json, committed); `traffic`
-    is the HBM bytes of one launch from the committed PMC pass.  The kernel is bound by dependent-gather latency /
-    instruction issue, not by HBM: `frac` says how far from the HBM roofline the COMPULSORY bytes are."""
-    rep = {"kernel": "raymarch_kernel", "bound": "latency (<=255 dependent gathers per ray), not hbm",
-           "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": round(launch_ms, 5)}
-    traffic = load_traffic(traffic_key or workload_key, "raymarch_pmc_traffic.json") if workload_key else None
-    model = None
-    try:
-        model = json.load(open(os.path.join(ROOT, "profiles", "raymarch_model_bytes.json"))).get(workload_key)
-    except Exception:
-        pass
-    sec = launch_ms * 1e-3
-    rep["traffic"] = traffic
-    rep["traffic_GBs"] = None if traffic is None else round(traffic / sec / 1e9, 1)
-    if model:
-        comp, nominal = model["compulsory_bytes"], model["nominal_gather_bytes"]
-        pp = model[path_key]
-        rep.update({
-            "compulsory_bytes": comp, "nominal_gather_bytes": nominal,
-            "achieved": round(comp / sec / 1e9, 1), "frac": round(comp / sec / 1e9 / HBM_PEAK_GBS, 4),
-            "nominal_gather_GBs": round(nominal / sec / 1e9, 1),
-            "traffic_over_compulsory": None if traffic is None else round(traffic / comp, 3),
-            "path_run": {"which": path_key, "compulsory_bytes": pp["compulsory_bytes"],
-                         "compulsory_line_bytes": pp["compulsory_line_bytes"],
-                         "nominal_gather_bytes": pp["nominal_gather_bytes"],
-                         "nominal_gather_GBs": round(pp["nominal_gather_bytes"] / sec / 1e9, 1),
-                         "traffic_over_compulsory_lines": None if traffic is None else round(traffic / pp["compulsory_line_bytes"], 3)},
-            "counts": model["counts"], "unique_texels": model["unique_texels"],
-            "note": "SURVEY 8(d): compulsory = 16 B x (unique tex0 + tex1 texels touched) + 16 B x W*H (achieved/frac "
-                    "are computed from it); nominal = 128 B x (sum steps + 5 x hits) + 16 B x W*H (cache-level gather "
-                    "rate); path_run = the same two figures for the kernel variant timed here; traffic = PMC HBM bytes "
-                    "per launch of this configuration (committed pass)"})
-    else:
-        rep.update({"achieved": rep["traffic_GBs"], "frac": None if traffic is None else round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4),
-                    "note": "no byte model committed for this configuration (tools/raymarch_bytes.py)"})
-    return rep
-
-
-def progressive_block(pkg, torch, prm, sides, reps=7):
-    """SURVEY 8(f)1 under the bench's measurement discipline: the LoadingManager passes (loading.rs:50-76) with
-    update_required (scene/sdf/mod.rs:184-190) on the device, over textures that travel with their distance volume
-    (sdfv_fill_grid_pass_dist).  Per case: median ms over `reps` runs (HIP events; the state is re-created, untimed, before
-    every run), visited voxels, updated voxels, and the fraction of the HBM roofline on SURVEY 8(d)'s incremental figure,
-    36 B per UPDATED voxel (4 B read + 32 B written) + 4 B per voxel that is visited only."""
-    import ctypes as C
-    AIR = pkg.AIR_DIST
-    out = {}
-    for side in sides:
-        g = pkg.make_grid((side,) * 3)
-        t0, t1 = pkg.alloc_textures(g)
-        dist = torch.empty((side,) * 3, dtype=torch.float32, device=t0.device)
-        n = side ** 3
-
-        def fresh():
-            pkg.grid_init(g, t0, t1)
-            dist.fill_(AIR)
-
-        def loaded():
-            pkg.fill_grid(prm, g, t0, t1, dist=dist)
-
-        def timed(fn, setup):
-            ts = []
-            for _ in range(reps):
-                setup()
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                fn()
-                b.record()
-                torch.cuda.synchronize()
-                ts.append(a.elapsed_time(b))
-            return sorted(ts)[len(ts) // 2]
-
-        FRESH, SAME = pkg._capi.PASS_FRESH_GRID, pkg._capi.PASS_SAME_LOAD
-
-        def passes(steps, box=None, flagged=False):
-            # flagged: what host/sdf_viewer.cpp's LoadingManager tells the library (sdfv_fill_grid_pass_ex): the first pass
-            # of a load sees a fresh grid, the later ones revisit what the same load wrote -- nothing is read
-            return lambda: [pkg.fill_grid_pass(prm, g, st, t0, t1, changed_box=box, dist=dist,
-                                               flags=((FRESH | SAME) if k == 0 else SAME) if flagged else 0)
-                            for k, st in enumerate(steps)]
-
-        def visited(steps):
-            return sum((-(-side // st)) ** 3 for st in steps)
-
-        def case(ms, vis, upd, what):
-            bytes_ = 36 * upd + 4 * (vis - upd)
-            return {"ms": round(ms, 4), "visited_voxels": vis, "updated_voxels": upd,
-                    "Mvoxels_s_updated": round(upd / ms / 1e3, 1) if upd else 0.0,
-                    "algorithmic_bytes": bytes_, "frac": round(bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "what": what}
-
-        whole = (-1.0, -1.0, -1.0, 1.0, 1.0, 1.0)
-        eighth = (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5)
-        # voxels of the 1/8 box: coordinates idx/(N-1)*2-1 in [-0.5, 0.5] per axis
-        in_box_axis = sum(1 for i in range(side) if -0.5 <= (i / (side - 1)) * 2.0 - 1.0 <= 0.5)
-        res = {}
-        res["fresh_load_2_passes"] = case(timed(passes((2, 1), flagged=True), fresh), visited((2, 1)), n,
-                                          "the reference's DEFAULT load (cli/mod.rs:13-18): step 2 then step 1 over a fresh grid, as "
-                                          "SDFViewer::update enqueues it (sdfv_fill_grid_pass_ex with the LoadingManager's knowledge: "
-                                          "store-only; the intermediate LOD-2 state is produced)")
-        res["fresh_load_2_passes"]["algorithmic_bytes"] = 36 * (n + visited((2,)))  # no reads; the step-2 lattice is written twice
-        res["fresh_load_2_passes"]["frac"] = round(36 * (n + visited((2,))) / (res["fresh_load_2_passes"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        res["fresh_pass_step_2_flagged"] = case(timed(passes((2,), flagged=True), fresh), visited((2,)), visited((2,)),
-                                                "first pass of that load alone (whole visited rows written: 1/4 of the textures)")
-        res["fresh_load_2_passes_unflagged"] = case(timed(passes((2, 1)), fresh), visited((2, 1)), n,
-                                                    "the same load through sdfv_fill_grid_pass_dist (update_required read from the volume)")
-        res["fresh_pass_step_2"] = case(timed(passes((2,)), fresh), visited((2,)), visited((2,)), "first pass, unflagged")
-
-        def after_step2():
-            fresh()
-            pkg.fill_grid_pass(prm, g, 2, t0, t1, dist=dist)
-        res["fresh_pass_step_1_after_step_2"] = case(timed(passes((1,)), after_step2), n, n - visited((2,)), "second pass of that load alone")
-        res["fresh_pass_step_1"] = case(timed(passes((1,)), fresh), n, n, "a single step-1 pass over a fresh grid")
-        res["edit_full_box_3_passes"] = case(timed(passes((4, 2, 1), whole), loaded), visited((4, 2, 1)), visited((4, 2, 1)),
-                                             "parameter edit whose changed_box is the whole bounding box (what the demo reports): "
-                                             "steps 4, 2, 1 rewrite everything they visit")
-        res["edit_eighth_box_3_passes"] = case(timed(passes((4, 2, 1), eighth), loaded), visited((4, 2, 1)),
-                                               sum((-(-in_box_axis // st)) ** 3 for st in (4, 2, 1)),
-                                               "changed_box = [-0.5, 0.5]^3 (1/8 of the volume); updated count approximate for step > 1")
-        res["noop_pass_step_1"] = case(timed(passes((1,)), loaded), n, 0, "step-1 pass over a loaded grid, no box: reads the volume, writes nothing")
-        res["dense_fused_fill_ms"] = round(timed(lambda: pkg.fill_grid(prm, g, t0, t1, dist=dist), lambda: None), 4)
-        out[str(side)] = res
-        del t0, t1, dist
-    out["note"] = ("sdfv_fill_grid_pass_dist; frac = (36 B x updated + 4 B x visited-only voxels) / ms / 8 TB/s; every intermediate "
-                   "state is bit-identical to the oracle's LoadingManager loop (tests/test_gpu_fill.py)")
-    return out
-
-
-def batch_valu_roofline(workload_key, world, ms_per_batch):
-    """The 64-camera batch fills the machine with short waves and is bound by VALU ISSUE, not by HBM: one wave64 VALU
-    instruction occupies its SIMD's issue port for 4 cycles (16 lanes per cycle), so a SIMD retires at most clock / 4 wave
-    instructions per second.  frac = (VALU wave-instructions of one batch, PMC SQ_INSTS_VALU, committed pass) /
-    (1024 SIMDs x clock / 4 x batch time)."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "raymarch_batch_valu.json")))[workload_key]
-    except Exception:  # noqa: BLE001
-        return None
-    simds, clock = 1024 * world, float(d.get("clock_GHz", 2.4))
-    peak = simds * clock * 1e9 / 4.0
-    rate = d["valu_wave_instructions_per_batch"] / (ms_per_batch * 1e-3)
-    return {"bound": "valu issue", "valu_wave_instructions_per_batch": d["valu_wave_instructions_per_batch"],
-            "achieved": round(rate / 1e12, 3), "peak": round(peak / 1e12, 3), "unit": "T wave-instructions/s",
-            "frac": round(rate / peak, 4), "simds": simds, "clock_GHz": clock, "source": d.get("source"),
-            "note": "wave64 VALU instruction = 4 issue cycles on its SIMD; peak = SIMDs x clock / 4"}
-
-
-def raymarch_rank_cameras_report(workload_key, world, launch_ms):
-    """N > 1: every rank marches ONE camera of the `world`-camera orbit (camera r = camera r * 64 / world of the 64-camera
-    orbit when world divides 64) over its replica.  SURVEY 8(d)'s compulsory / nominal bytes of exactly those cameras come
-    from the per-camera entries of profiles/raymarch_model_bytes.json's batch model; achieved = their sum / the (max over
-    ranks) launch time, against `world` x 8 TB/s."""
-    rep = {"kernel": "raymarch_kernel", "bound": "latency (<=255 dependent gathers per ray), not hbm",
-           "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "avg_launch_ms": round(launch_ms, 5), "traffic": None}
-    try:
-        model = json.load(open(os.path.join(ROOT, "profiles", "raymarch_model_bytes.json")))
-        per_cam = model[f"{workload_key}_batch64"]["per_camera"]
-        if 64 % world:
-            raise KeyError(f"{world} does not divide the 64-camera orbit the model was made for")
-        mine = [per_cam[r * 64 // world] for r in range(world)]
-    except Exception as e:  # noqa: BLE001
-        rep.update({"achieved": None, "frac": None, "note": f"no per-camera byte model for this configuration: {type(e).__name__}: {e}"})
-        return rep
-    sec = launch_ms * 1e-3
-    comp = sum(c["compulsory_bytes"] for c in mine)
-    nominal = sum(c["nominal_gather_bytes"] for c in mine)
-    rep.update({"compulsory_bytes": comp, "nominal_gather_bytes": nominal,
-                "product_path_compulsory_bytes": sum(c["product_path_compulsory_bytes"] for c in mine),
-                "achieved": round(comp / sec / 1e9, 1), "frac": round(comp / sec / 1e9 / (HBM_PEAK_GBS * world), 4),
-                "nominal_gather_GBs": round(nominal / sec / 1e9, 1),
-                "cameras": [{"orbit_index": r * 64 // world, "hits": c["hits"], "sum_steps": c["sum_steps"]} for r, c in enumerate(mine)],
-                "note": "SURVEY 8(d) over the ranks' cameras (one each): compulsory = 16 B x (unique tex0 + tex1 texels of that "
-                        "camera's frame) + 16 B x W*H, summed over ranks; peak = n_gpus x 8 TB/s; no PMC pass exists for N > 1"})
-    return rep
-
-
 class NativeStdoutToStderr:
     """RCCL prints a version banner to the C-level stdout when its first communicator comes up (buffered, so it lands
     after anything Python has printed).  The contract is ONE JSON line on stdout: while the benchmark runs, file
@@ -520,6 +292,7 @@ def main():
                     code = 0
                     if rank == "0":
                         line = dict(PARTIAL["line"])
+                        line["incomplete"] = True  # a hang in an extra must not look like a clean run
                         line["watchdog"] = f"an extra did not finish: stuck in stage '{name}' for {age:.0f} s; the line carries what was measured before it"
                         if PARTIAL["redirect"] is not None:
                             PARTIAL["redirect"].restore()
@@ -535,66 +308,14 @@ def main():
     done.set()
 
 
-def region(fn, steps, warmup, torch, dist, world, device):
-    """prewarm + `warmup` untimed calls + EXACTLY `steps` timed calls of fn -> (wall ms per call, HIP-event ms per call)."""
-    prewarm(fn, torch, dist, world, device)
-    for _ in range(warmup):
-        fn()
-    dt, ev_ms = timed_region(fn, steps, torch, dist, world, device)
-    return dt / steps * 1e3, ev_ms / steps
-
-
-def per_step_stats(fn, n, torch, warm=5):
-    """"hipEvent around the kernel, >= 20 iterations after warm-up, median".  n calls of fn, each bracketed
-    by its own pair of HIP events on the launch stream (n + 1 events, one between consecutive calls) -> the distribution
-    the K-step mean hides (box / placement / clock spread).  Outside the timed regions; never `value`."""
-    if n <= 0:
-        return None
-    for _ in range(warm):
-        fn()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
-    evs[0].record()
-    for i in range(n):
-        fn()
-        evs[i + 1].record()
-    torch.cuda.synchronize()
-    ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n))
-    q = lambda f: ms[min(n - 1, int(f * n))]  # noqa: E731
-    return {"samples": n, "median": round(ms[n // 2] if n % 2 else 0.5 * (ms[n // 2 - 1] + ms[n // 2]), 5),
-            "p95": round(q(0.95), 5), "min": round(ms[0], 5), "max": round(ms[-1], 5),
-            "note": "one HIP-event pair per launch (includes the event's own packet: ~1-2 us more than back-to-back launches)"}
-
-
-FILL_8D_PEAK_MVOX = HBM_PEAK_GBS * 1e9 / FILL_BYTES_PER_VOXEL / 1e6  # 250 000 Mvoxels/s = 8 TB/s at SURVEY 8(d)'s 32 B/voxel
-
-
-def fill_roofline(kern_ms, voxels, bytes_per_voxel, traffic):
-    """the fill's algorithmic bytes are 32 B/voxel (tex0 + tex1), whatever else the launch stores.  achieved /
-    frac are on that figure (frac = Mvoxels/s / 250 000, the scale the north-star target is worded on); the fused launch
-    also stores the compact distance volume (36 B/voxel on the bus): achieved_bus / frac_bus say how busy the bus is."""
-    gbs = FILL_BYTES_PER_VOXEL * voxels / (kern_ms * 1e-3) / 1e9
-    bus = bytes_per_voxel * voxels / (kern_ms * 1e-3) / 1e9
-    return {"kernel": "fill_dense_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_8d": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": traffic,
-            "algorithmic_bytes_per_voxel": FILL_BYTES_PER_VOXEL,
-            "algorithmic_bytes_per_launch": FILL_BYTES_PER_VOXEL * voxels,
-            "bus_bytes_per_voxel": bytes_per_voxel, "achieved_bus": round(bus, 1), "frac_bus": round(bus / HBM_PEAK_GBS, 4),
-            "frac_note": "frac = frac_8d = 32 B/voxel x voxels / launch time / 8 TB/s (SURVEY 8d; = Mvoxels/s / 250 000); "
-                         "frac_bus counts every byte the launch stores (36 B/voxel when it also writes the distance volume)",
-            "avg_launch_ms": round(kern_ms, 5),
-            "avg_launch_note": "HIP events around K back-to-back launches / K: includes the ~6 us gap between "
-                               "launches, which rocprofv3's kernel-only average leaves out (8 % at 256^3, under 1 % at 512^3)"}
-
-
 def run(redirect):
-    global PREWARM_S
     args = parse_args()
-    PREWARM_S = args.prewarm_ms / 1e3
+    bench_common.PREWARM_S = args.prewarm_ms / 1e3
     import torch
     import torch.distributed as dist
     pkg = importlib.import_module("sdf-viewer_amd")
     par = importlib.import_module("sdf-viewer_amd.parallel")
+    from bench_extras import raymarch_rank_cameras_report, raymarch_traffic_report  # the march's byte model beside `roofline`
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -888,258 +609,19 @@ def run(redirect):
     }
     line.update(out)
     line["raymarch_kernel_ms"] = round(march_ev, 4)
-    for key in ("batch_raymarch", "target_512", "progressive", "halo_loopback", "config4"):
+    line["incomplete"] = None  # True only when the watchdog had to print the line for an extra that hung
+    line["box"] = box_stamp(torch, device)
+    for key in ("batch_raymarch", "target_512", "progressive", "host_load", "halo_loopback", "config4"):
         line[key] = None
     PARTIAL["line"], PARTIAL["since"] = line, time.monotonic()
 
-    # ---------------- N = 1 extras ----------------
-    target_512 = None
-    halo_loopback = None
-    if not multi and not args.no_batch:
-        # the north-star target configuration (>= 70 % of the HBM roofline on the 512^3 fill), whatever --workload is
-        if not args.no_target_512:
-            try:
-                if side == 512:
-                    t_slab, t_grid = slab, grid
-                else:
-                    t_slab = par.alloc_slab((512, 512, 512), 0, 1, device, pkg=None if args.no_tuned_placement else pkg)
-                    t_grid = pkg.make_grid((512, 512, 512))
-                t_dist = torch.empty((512, 512, 512), dtype=torch.float32, device=device)
-                ts = max(5, min(K, 20))
-                t_ms, t_ev = region(lambda: pkg.fill_grid(prm, t_grid, t_slab.owned0, t_slab.owned1), ts, 2, torch, dist, 1, device)
-                f_ms, f_ev = region(lambda: pkg.fill_grid(prm, t_grid, t_slab.owned0, t_slab.owned1, dist=t_dist), ts, 2,
-                                    torch, dist, 1, device)
-                n512 = 512 ** 3
-                target_512 = {"grid": [512, 512, 512], "steps": ts, "ms_fill": round(t_ms, 4),
-                              "Mvoxels_s": round(n512 / t_ms / 1e3, 1), "avg_launch_ms": round(t_ev, 5),
-                              "achieved_GBs": round(32 * n512 / (t_ev * 1e-3) / 1e9, 1),
-                              "frac": round(32 * n512 / (t_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                              "frac_8d": round(32 * n512 / (t_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                              "per_launch": per_step_stats(lambda: pkg.fill_grid(prm, t_grid, t_slab.owned0, t_slab.owned1),
-                                                           min(args.per_step_samples, 30), torch, warm=2),
-                              "fused_commit": {"ms_fill": round(f_ms, 4), "Mvoxels_s": round(n512 / f_ms / 1e3, 1),
-                                               "achieved_GBs": round(36 * n512 / (f_ev * 1e-3) / 1e9, 1),
-                                               "frac": round(36 * n512 / (f_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                               "frac_8d": round(32 * n512 / (f_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                               "frac_note": "frac: 36 B/voxel on the bus; frac_8d: SURVEY 8(d)'s 32 B/voxel"},
-                              "texture_placement": placement_note(args, t_slab), "target_frac": 0.70,
-                              "note": "north_star: >= 70 % HBM-roofline Mvoxels/s on the demo SDF 512^3 grid fill at 1 GPU; "
-                                      "32 B/voxel algorithmic, HIP events over the timed launches"}
-                del t_dist
-                if side != 512:
-                    del t_slab
-            except Exception as e:  # noqa: BLE001 -- an extra, never fatal
-                target_512 = {"error": f"{type(e).__name__}: {e}"}
-        # the multi-GPU fill step in loopback, measured by tools/slab_step_probe.py in a process of its own (so that
-        # this process never brings up an RCCL communicator at N = 1)
-        try:
-            import subprocess
-            torch.cuda.synchronize()
-            loop = {}
-            for s_side in sorted({side, 512}):
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "slab_step_probe.py"), str(s_side), str(K)],
-                                   capture_output=True, text=True, timeout=300)
-                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                loop[str(s_side)] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else \
-                    {"error": (r.stderr or r.stdout)[-300:]}
-            halo_loopback = loop[str(side)]
-            halo_loopback["by_side"] = {k: {kk: v.get(kk) for kk in ("ms_per_step", "plain_fill_ms", "fraction_of_plain_fill_rate",
-                                                                     "ghosts_verified", "deferred_join", "error") if kk in v}
-                                        for k, v in loop.items()}
-        except Exception as e:  # noqa: BLE001 -- an extra, never fatal
-            halo_loopback = {"error": f"{type(e).__name__}: {e}"}
-
-    line["target_512"], line["halo_loopback"] = target_512, halo_loopback  # (the watchdog prints the line as it stands)
-    progressive = None
-    if not multi and not args.no_batch and not args.no_progressive:
-        try:
-            progressive = progressive_block(pkg, torch, prm, sorted({side, 512}))
-        except Exception as e:  # noqa: BLE001 -- an extra, never fatal
-            progressive = {"error": f"{type(e).__name__}: {e}"}
-
-    line["progressive"] = progressive
-    # ---------------- config 5 shape: a batch of 64 cameras, split over the ranks (extra, not `value`) ----------------
-    n_batch = 64
-    batch_report = None
-    if not args.no_batch:
-        if not multi:
-            pkg.fill_grid(prm, grid, owned0, owned1, dist=dist_vol)  # the volume of the grid being marched
-        rgrid_whole = pkg.make_grid((side, side, side))  # the grid the batch marches (N > 1: every rank's replica)
-        batch_cams = pkg.orbit_cameras(n_batch, aspect=W / H)
-        batch_steps = max(2, min(K, 5))
-
-        # A host that renders MANY frames per load marches over the y-pair volume (sdfv_commit_pairs: 8 B/voxel, built once
-        # from the distance volume; two 16-byte gathers per cell instead of four 8-byte ones, bit-identical).  The batch is
-        # exactly that case: 64 frames over one grid.  Its one-off cost is reported and folded into value_incl_commit.
-        # Beyond the last-level cache (512^3) the library advises the y-interleaved volume instead (4 B/voxel, rows paired).
-        volume_kind = pkg.march_volume_advice(rgrid_whole)
-        if volume_kind is None:  # (a grid that is not cubic: the distance volume is what marches fastest)
-            accel_kw, commit_pairs_ms = {}, 0.0
-        elif volume_kind == "interleaved":
-            accel_vol = pkg.commit_interleaved(rgrid_whole, dist_vol)
-            commit_pairs_ms = region(lambda: pkg.commit_interleaved(rgrid_whole, dist_vol, ilv=accel_vol), 3, 1, torch, dist, world, device)[0]
-            accel_kw = {"ilv": accel_vol}
-        else:
-            accel_vol = pkg.commit_pairs(rgrid_whole, dist_vol)
-            commit_pairs_ms = region(lambda: pkg.commit_pairs(rgrid_whole, dist_vol, pairs=accel_vol), 3, 1, torch, dist, world, device)[0]
-            accel_kw = {"pairs": accel_vol}
-
-        def time_split(split, use_pairs=True):
-            """tiles = BASELINE config 5 as named (image-tile split), balanced: the 16-row tile bands r, r + N, ... of EVERY
-            camera per rank (sdfv_raymarch_bands); rows = one contiguous range of rows of every camera per rank; cameras =
-            whole cameras dealt to the ranks.  At N = 1 all three are the same call."""
-            where = {}
-            if split == "tiles" and world > 1:
-                mine = batch_cams
-                where = {"bands": par.split_bands(H, rank, world)}
-                n_rows = len(par.band_rows(H, *where["bands"]))
-            elif split == "cameras":
-                mine = [batch_cams[i] for i in par.split_cameras(n_batch, rank, world)]
-                n_rows = H
-            else:
-                mine = batch_cams
-                by0, by1 = par.split_rows(H, rank, world)
-                where, n_rows = {"y0": by0, "y1": by1}, by1 - by0
-            batch_out = torch.empty((len(mine), n_rows, W, 4), dtype=torch.float32, device=device)
-
-            def batch_step():
-                pkg.raymarch(rp, r0, r1, mine, W, H, out=batch_out, dist=dist_vol, **where, **(accel_kw if use_pairs else {}))
-
-            batch_step()
-            batch_dt, _ = timed_region(batch_step, batch_steps, torch, dist, world, device)
-            ms = batch_dt / batch_steps * 1e3
-            return {"split": split if world > 1 else None, "cameras_per_gpu": len(mine), "rows_per_gpu": n_rows,
-                    "value": round(n_batch * W * H / ms / 1e3, 1), "unit": "Mrays/s", "ms_per_batch": round(ms, 4),
-                    "march_over": (f"y-{volume_kind} volume" if volume_kind == "interleaved" else "y-pair volume") if use_pairs
-                                  else "distance volume"}
-
-        splits = ["tiles"] if world == 1 else (["tiles", "rows", "cameras"] if args.batch_split in ("all", "both") else [args.batch_split])
-        reports = {sp: time_split(sp) for sp in splits}
-        batch_report = {"cameras": n_batch, "image": [W, H]}
-        batch_report.update(reports[splits[0]])
-        if "cameras" in splits[1:]:
-            batch_report["camera_split"] = reports["cameras"]
-        if "rows" in splits[1:]:
-            batch_report["contiguous_rows_split"] = reports["rows"]
-        over_dist = time_split(splits[0], use_pairs=False)
-        batch_report["over_distance_volume"] = {k: over_dist[k] for k in ("value", "ms_per_batch")}
-        batch_report["commit_pairs_ms"] = round(commit_pairs_ms, 4)
-        batch_report["value_incl_commit"] = round(n_batch * W * H / (batch_report["ms_per_batch"] + commit_pairs_ms) / 1e3, 1)
-        batch_report["note"] = ("BASELINE.json configs[4] shape (64-camera orbit) over the same grid, distance-volume march; "
-                                "top level = the image-tile split config 5 names, balanced (tile bands r, r + N, ... per rank; "
-                                "contiguous_rows_split = one range of rows per rank, tools/split_balance.py), camera_split = whole cameras per rank; the march "
-                                "reads the volume sdfv_march_volume_advice names (march_over), built once per load (commit_pairs_ms; "
-                                "value_incl_commit folds it in), "
-                                "over_distance_volume = the same batch over the 4 B/voxel volume")
-        # the viewer's steady state: ONE camera, frame after frame over the loaded grid (the reference repaints per event) --
-        # the same frame as `value_rays`, over the advised volume instead of the distance volume the fill wrote
-        if world == 1:
-            frame_out = torch.empty((1, H, W, 4), dtype=torch.float32, device=device)
-            cam0 = pkg.camera_look_at(aspect=W / H)
-            f_acc = region(lambda: pkg.raymarch(rp, r0, r1, cam0, W, H, out=frame_out, dist=dist_vol, **accel_kw), 20, 3, torch, dist, world, device)[0]
-            f_dist = region(lambda: pkg.raymarch(rp, r0, r1, cam0, W, H, out=frame_out, dist=dist_vol), 20, 3, torch, dist, world, device)[0]
-            batch_report["steady_state_frame"] = {"march_over": batch_report["march_over"], "ms_per_frame": round(f_acc, 4),
-                                                  "value": round(W * H / f_acc / 1e3, 1), "unit": "Mrays/s",
-                                                  "over_distance_volume_ms": round(f_dist, 4)}
-        # the batch is issue-bound, not HBM-bound: VALU wave-instructions per batch / (SIMDs x clock / 4 cycles per wave64
-        # VALU instruction) -- the roofline that actually bounds it (counts: profiles/raymarch_batch_valu.json)
-        batch_report["roofline_raymarch_batch"] = batch_valu_roofline(args.workload, world, batch_report["ms_per_batch"])
-
-    line["batch_raymarch"] = batch_report
-    # ---------------- N > 1 extras: BASELINE config 4's geometry, and the self-checks ----------------
-    config4 = None
-    verified = None
-    sharded_march = None
-    if multi:
-        if not args.no_config4:
-            # cube geometry at --config4-side^3 voxels per rank: 8 ranks x 512^3 = config 4's 1024^3 (1024 x 1024 slices,
-            # 33.5 MB per halo message pair and direction against a 128-slice slab)
-            try:
-                cside = args.config4_side
-                cdims = par.weak_scaling_dims(cside, world, "cube")
-                cslab = par.alloc_slab(cdims, rank, world, device, pkg=None if args.no_tuned_placement else pkg, periodic=loopback)
-                cgrid = pkg.make_grid(cdims, z_begin=cslab.z_begin, z_end=cslab.z_end)
-                cdist = torch.empty(tuple(cslab.tex0.shape[:3]), dtype=torch.float32, device=device)
-                c_own = cdist[cslab.ghost_lo:cslab.ghost_lo + (cslab.z_end - cslab.z_begin)]
-                cfiller = par.SlabFiller(pkg, prm, cdims, cslab, rank, world, transport=transport,
-                                         comm=filler.comm, dist=cdist, periodic=loopback)  # the same communicator serves this slab too
-                cs = max(3, min(K, 10))
-                c_ms, _ = region(cfiller.step, cs, 2, torch, dist, world, device)
-                _, c_kern = region(lambda: pkg.fill_grid(prm, cgrid, cslab.owned0, cslab.owned1, dist=c_own), cs, 1, torch,
-                                   dist, world, device)
-                cvox = pkg.slab_voxels(cgrid)
-                config4 = {"grid_global": list(cdims), "voxels_per_gpu": cvox, "steps": cs,
-                           "value": round(cvox * world / c_ms / 1e3, 1), "unit": "Mvoxels/s",
-                           "ms_per_step_fill": round(c_ms, 4), "plain_fill_ms": round(c_kern, 4),
-                           "fill_step_fraction_of_plain_fill": round(c_kern / c_ms, 3),
-                           "frac_of_hbm_peak_per_gpu": round(36 * cvox / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           "bytes_per_voxel": 36, "halo_bytes_per_direction": int(cdims[0]) * int(cdims[1]) * 32,
-                           "note": "BASELINE.json configs[3] geometry (cube; 8 x 512^3 = 1024^3), weak scaling like `value`"}
-                del cslab, cdist
-            except Exception as e:  # noqa: BLE001 -- an extra, never fatal
-                config4 = {"error": f"{type(e).__name__}: {e}"}
-        line["config4"] = config4
-        # outside the timed regions: the gathered slabs must equal a dense local fill of the global grid, and the
-        # ghost slices must equal what the neighbour computed (= a local recompute: the SDF is analytic)
-        if gdims[0] * gdims[1] * gdims[2] * 32 <= 8 << 30:
-            try:
-                filler.step()
-                torch.cuda.synchronize()
-                full0, full1 = par.gather_replica(slab, gdims, world)
-                chk0, chk1 = pkg.alloc_textures(pkg.make_grid(gdims), device=device)
-                pkg.fill_grid(prm, pkg.make_grid(gdims), chk0, chk1)
-                torch.cuda.synchronize()
-                ok = torch.equal(full0, chk0) and torch.equal(full1, chk1)
-                if loopback:  # periodic world of 1: the ghosts hold the grid's last and first slice
-                    want0, want1 = torch.cat([chk0[-1:], chk0, chk0[:1]]), torch.cat([chk1[-1:], chk1, chk1[:1]])
-                else:
-                    lo, hi = slab.z_begin - slab.ghost_lo, slab.z_end + slab.ghost_hi
-                    want0, want1 = chk0[lo:hi], chk1[lo:hi]
-                ok = ok and torch.equal(slab.tex0, want0) and torch.equal(slab.tex1, want1)
-                ok = ok and torch.equal(slab_dist, want0[..., 0])  # the distance volume the step wrote, ghosts included
-                del want0, want1
-                flag = torch.tensor([1.0 if ok else 0.0], device=cdev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                verified = bool(flag.item() == 1.0)
-                del full0, full1
-                # the consumer of the halo: raymarch the grid where it lies (sharded, rays handed between ranks)
-                # and compare with a march over the whole grid, bit for bit
-                try:
-                    if loopback:
-                        raise RuntimeError("skipped: the loopback slab is periodic, the sharded march is not")
-                    ggrid = pkg.make_grid(gdims)
-                    grp = pkg.default_render_params(ggrid)
-                    sw, sh = 320, 180
-                    scam = pkg.camera_look_at(eye=(1.5, 2.0, 3.5), aspect=sw / sh)
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    # under RCCL the whole march runs inside the library (sdfv_slab_march: `world` rounds + the ray exchange
-                    # enqueued in one call, no host round trip); over gloo (tests) torch.distributed carries the rays
-                    lib_comm = getattr(filler, "comm", None) if transport == "rccl" else None
-                    STAGE("sharded march self-check (" + ("sdfv_slab_march over the library communicator" if lib_comm else "torch.distributed rounds") + ")")
-                    got = par.raymarch_sharded(pkg, grp, grid, slab, scam, sw, sh, rank, world, comm=lib_comm)
-                    torch.cuda.synchronize()
-                    sharded_march_ms = (time.perf_counter() - t0) * 1e3
-                    want = pkg.raymarch(grp, chk0, chk1, scam, sw, sh)[0]
-                    same = torch.equal(got.view(torch.int32), want.view(torch.int32)) and bool((want[..., 3] > 0).any())
-                    flag = torch.tensor([1.0 if same else 0.0], device=cdev)
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                    sharded_march = {"verified": bool(flag.item() == 1.0), "image": [sw, sh], "rounds": world,
-                                     "ms": round(sharded_march_ms, 3),
-                                     "transport": "sdfv_slab_march (library RCCL communicator, no host round trip per round)" if lib_comm
-                                                  else "torch.distributed (counter read-back + count exchange per round)",
-                                     "note": "sdfv_raymarch_slab over the sharded grid vs sdfv_raymarch over the whole "
-                                             "grid, bit for bit; not part of the timed regions"}
-                except Exception as e:  # noqa: BLE001
-                    sharded_march = {"verified": f"error: {type(e).__name__}: {e}"}
-                del chk0, chk1
-            except Exception as e:  # never lose the measurement over the self-check
-                verified = f"error: {type(e).__name__}: {e}"
-        else:
-            verified = "skipped (global grid > 8 GiB)"
-
-    line.update({"sharded_fill_verified": verified, "sharded_march": sharded_march, "batch_raymarch": batch_report,
-                 "target_512": target_512, "progressive": progressive, "halo_loopback": halo_loopback, "config4": config4})
+    # ---------------- everything beside the contract (bench_extras.py): never `value`, never fatal ----------------
+    import bench_extras
+    ctx = SimpleNamespace(args=args, pkg=pkg, par=par, torch=torch, dist=dist, world=world, rank=rank, device=device, cdev=cdev,
+                          multi=multi, loopback=loopback, backend=backend, transport=transport, filler=filler, slab=slab,
+                          grid=grid, gdims=gdims, side=side, W=W, H=H, K=K, prm=prm, rp=rp, r0=r0, r1=r1, owned0=owned0,
+                          owned1=owned1, dist_vol=dist_vol, slab_dist=slab_dist if multi else None, line=line)
+    bench_extras.run_extras(ctx)
     PARTIAL["since"] = None  # the extras are done (the CPU baseline below only uses this process's host cores)
     if rank == 0:
         if not args.no_cpu_baseline and not multi:  # rank 0, N = 1 only
@@ -1156,3 +638,4 @@ def run(redirect):
 
 if __name__ == "__main__":
     main()
+
