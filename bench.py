@@ -571,6 +571,7 @@ def run(redirect):
         # what RCCL itself says about the library communicator the step ran on (None under the torch transport)
         comm = getattr(filler, "comm", None)
         out["rccl_ranks"] = None if comm is None else comm.rccl_ranks[1]
+        out["roofline"]["rccl_ranks"] = out["rccl_ranks"]  # (the driver's record keeps nested objects whole)
         out["rccl_rank_of_rank0"] = None if comm is None else comm.rccl_ranks[0]
         out["torch_world_size"] = dist.get_world_size()
 

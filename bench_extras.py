@@ -358,10 +358,36 @@ def run_extras(c):
             batch_step()
             batch_dt, _ = timed_region(batch_step, batch_steps, torch, dist, world, device)
             ms = batch_dt / batch_steps * 1e3
-            return {"split": split if world > 1 else None, "cameras_per_gpu": len(mine), "rows_per_gpu": n_rows,
-                    "value": round(n_batch * W * H / ms / 1e3, 1), "unit": "Mrays/s", "ms_per_batch": round(ms, 4),
-                    "march_over": (f"y-{volume_kind} volume" if volume_kind == "interleaved" else "y-pair volume") if use_pairs
-                                  else "distance volume"}
+            rep = {"split": split if world > 1 else None, "cameras_per_gpu": len(mine), "rows_per_gpu": n_rows,
+                   "value": round(n_batch * W * H / ms / 1e3, 1), "unit": "Mrays/s", "ms_per_batch": round(ms, 4),
+                   "march_over": (f"y-{volume_kind} volume" if volume_kind == "interleaved" else "y-pair volume") if use_pairs
+                                 else "distance volume"}
+            if multi and use_pairs:
+                # SURVEY 8(e)'s collective of config 5: the images assembled on rank 0.  Over the library communicator when the
+                # step runs on it (sdfv_comm_gather_bands / _gather_cameras: one message per peer, all links into one rank),
+                # torch.distributed otherwise (gloo tests).  n_batch x W x H x 16 B into ONE rank dwarfs a rank's share of the
+                # march: said here with its own number rather than left out of the line.
+                lib_comm = getattr(filler, "comm", None) if transport == "rccl" else None
+
+                def gather_step():
+                    if split == "tiles" and world > 1:
+                        return par.gather_bands(batch_out, H, rank, world, comm=lib_comm)
+                    if split == "cameras":
+                        return par.gather_images(batch_out, n_batch, rank, world, comm=lib_comm)
+                    return par.gather_rows(batch_out, H, rank, world) if world > 1 else batch_out
+
+                try:
+                    STAGE(f"batch gather ({split}) to rank 0")
+                    gather_step()
+                    g_dt, _ = timed_region(gather_step, 2, torch, dist, world, device)
+                    g_ms = g_dt / 2 * 1e3
+                    rep.update({"gather_ms": round(g_ms, 4), "gather_bytes_to_rank0": n_batch * W * H * 16 * (world - 1) // max(world, 1),
+                                "gather_transport": "library RCCL communicator (sdfv_comm_gather_*)" if lib_comm is not None
+                                                    else "torch.distributed gather",
+                                "value_incl_gather": round(n_batch * W * H / (ms + g_ms) / 1e3, 1)})
+                except Exception as e:  # noqa: BLE001 -- an extra, never fatal
+                    rep["gather_ms"] = f"error: {type(e).__name__}: {e}"
+            return rep
 
         splits = ["tiles"] if world == 1 else (["tiles", "rows", "cameras"] if args.batch_split in ("all", "both") else [args.batch_split])
         reports = {sp: time_split(sp) for sp in splits}
@@ -438,7 +464,7 @@ def run_extras(c):
             try:
                 filler.step()
                 torch.cuda.synchronize()
-                full0, full1 = par.gather_replica(slab, gdims, world)
+                full0, full1 = par.gather_replica(slab, gdims, world, comm=getattr(filler, "comm", None) if transport == "rccl" else None)
                 chk0, chk1 = pkg.alloc_textures(pkg.make_grid(gdims), device=device)
                 pkg.fill_grid(prm, pkg.make_grid(gdims), chk0, chk1)
                 torch.cuda.synchronize()

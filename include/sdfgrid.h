@@ -566,6 +566,38 @@ int sdfv_slab_march(sdfv_slab_comm *comm, const sdfv_render_params *rp, const sd
                     sdfv_march_aux *aux, void *scratch, size_t scratch_bytes, uint32_t capacity, uint32_t flags,
                     uint32_t *status, void *stream);
 
+/* ---- config 5's collectives on the library communicator ("gather of RGBA tiles to rank 0", replicas by
+ * all-gather of slabs).  Every rank of the communicator calls; everything is enqueued on `stream`, nothing synchronises. ---- */
+
+/* The inverse of sdfv_raymarch_bands' output layout, on one device (no communicator): moves the band set `part` (DEVICE,
+ * n_cameras x sdfv_band_rows(height, band_first, band_step) x width x channels floats) to its rows of the images `out` (DEVICE,
+ * n_cameras x height x width x channels).  channels: 4 for rgba, 1 for the depth plane, 18 for the aux record.  What
+ * sdfv_comm_gather_bands runs per received set; a host with another transport (MPI, torch.distributed) calls it itself. */
+int sdfv_bands_scatter(const float *part, uint32_t band_first, uint32_t band_step, uint32_t n_cameras, uint32_t width,
+                       uint32_t height, uint32_t channels, float *out, void *stream);
+/* The image-tile split's gather: rank r passes the band set it rendered with sdfv_raymarch_bands(band_first = r, band_step =
+ * world); rank `dst` receives every other rank's set whole (one message per peer, all xGMI links at once) into `scratch` and
+ * assembles the n_cameras images in `out` (DEVICE, n_cameras x height x width x channels floats; ignored elsewhere, may be
+ * NULL).  scratch: DEVICE, 16-byte aligned, sdfv_comm_gather_bands_scratch_bytes() bytes on dst (0 elsewhere).  64 cameras x
+ * 1080p are 2.1 GB into ONE rank: tens of milliseconds over seven links against the 0.3 ms a rank spends rendering its share --
+ * a host that can consume the bands where they were rendered should. */
+size_t sdfv_comm_gather_bands_scratch_bytes(const sdfv_slab_comm *comm, int dst, uint32_t n_cameras, uint32_t width,
+                                            uint32_t height, uint32_t channels);
+int sdfv_comm_gather_bands(sdfv_slab_comm *comm, const float *part, uint32_t n_cameras, uint32_t width, uint32_t height,
+                           uint32_t channels, int dst, float *out, void *scratch, size_t scratch_bytes, void *stream);
+/* The camera split's gather: rank r rendered cameras [n_cameras * r / world, n_cameras * (r + 1) / world) whole (`part`); dst
+ * receives them in place, in camera order (`out`: n_cameras x height x width x channels floats).  No scratch. */
+int sdfv_comm_gather_cameras(sdfv_slab_comm *comm, const float *part, uint32_t n_cameras, uint32_t width, uint32_t height,
+                             uint32_t channels, int dst, float *out, void *stream);
+/* Replicas from a z-sharded grid: every rank ends up with the whole dims[0] x dims[1] x dims[2] grid.  z_bounds: HOST, world + 1
+ * entries, rank r owns slices [z_bounds[r], z_bounds[r + 1]) (depths may differ); tex0_owned / tex1_owned / dist_owned: DEVICE,
+ * this rank's FIRST OWNED slice (past any ghost slice; dist_owned and out_dist may both be NULL); out0 / out1 / out_dist:
+ * DEVICE, the whole grid.  (For the demo SDF a redundant local fill of the replica is cheaper than moving it -- 34 GB at 8 TB/s
+ * against 30 GB per rank over xGMI, SURVEY 8(e) -- this is for grids whose samples are not free to recompute.) */
+int sdfv_comm_allgather_slabs(sdfv_slab_comm *comm, const uint32_t dims[3], const uint32_t *z_bounds, const float *tex0_owned,
+                              const float *tex1_owned, const float *dist_owned, float *out0, float *out1, float *out_dist,
+                              void *stream);
+
 /* Makes `stream` wait for the most recent exchange the communicator has enqueued (a no-op when there is none).  Needed
  * only after steps taken with SDFV_STEP_DEFER_JOIN: before anything put on `stream` reads the ghost slices of the
  * textures (or the ghost slices' share of the distance volume).  The owned slices never need it: the flag is honoured

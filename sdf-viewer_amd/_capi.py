@@ -164,6 +164,15 @@ PROTOTYPES = {
     "sdfv_slab_fill_step_commit": (C.c_int, [C.c_void_p, C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_slab_comm_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sdfv_bands_scatter": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                     C.c_void_p, C.c_void_p]),
+    "sdfv_comm_gather_bands_scratch_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "sdfv_comm_gather_bands": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sdfv_comm_gather_cameras": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                           C.c_void_p, C.c_void_p]),
+    "sdfv_comm_allgather_slabs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 LIGHT_AMBIENT, LIGHT_DIRECTIONAL, MAX_LIGHTS = 0, 1, 4
 # sdfv_option / values (include/sdfgrid.h)

@@ -698,7 +698,8 @@ int sdfv_tune_texture_placement(const sdfv_grid* grid, void* block, size_t block
         return hip_fail(err, "hipEventCreate");
     }
     constexpr int kCandidates = 8;
-    const size_t skews[kCandidates] = {0, 4096, 8192, 12288, 20480, 28672, 36864, 53248};
+    // the rate is periodic in the distance with a period of 16 or 32 KiB (EXPERIMENTS R4.1): the eight residues cover it
+    const size_t skews[kCandidates] = {0, 4096, 8192, 12288, 16384, 20480, 24576, 28672};
     float total_ms[kCandidates] = {0, 0, 0, 0, 0, 0, 0, 0};
     int rc = SDFV_OK;
     int timed = 8;  // launches per measurement; raised below so that one measurement lasts about 3 ms

@@ -39,6 +39,7 @@ struct Rccl {
     int (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     const char* load_error = nullptr;
 };
@@ -69,6 +70,7 @@ const Rccl* rccl() {
         ok = bind(r.handle, "ncclSend", r.Send) && ok;
         ok = bind(r.handle, "ncclRecv", r.Recv) && ok;
         ok = bind(r.handle, "ncclAllReduce", r.AllReduce) && ok;
+        ok = bind(r.handle, "ncclBroadcast", r.Broadcast) && ok;
         ok = bind(r.handle, "ncclGetErrorString", r.GetErrorString) && ok;
         if (!ok) r.load_error = "librccl.so.1 lacks an ncclSend/ncclRecv entry point";
         return r;
@@ -230,10 +232,182 @@ int enqueue_exchange_packed(const Rccl* lib, const sdfv_slab_comm* c, const sdfv
     return sdfv::copy_texel_segments(src, dst, n, r_out, stream);
 }
 
+// sdfv_raymarch_bands stores a band set as [camera][band k][<= 16 rows][width]: pixel row j of the set is row
+// 16 * (band_first + (j / 16) * band_step) + j % 16 of the image.  One thread per 16-byte group of a pixel row.
+__global__ __launch_bounds__(256) void bands_scatter_kernel(const float4* __restrict__ part, float4* __restrict__ out,
+                                                            uint32_t row_vec4, uint32_t rows_part, uint32_t height,
+                                                            uint32_t band_first, uint32_t band_step) {
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, cam = blockIdx.z;
+    if (x >= row_vec4) return;
+    const uint32_t y = 16u * (band_first + (j >> 4) * band_step) + (j & 15u);
+    out[((size_t)cam * height + y) * row_vec4 + x] = part[((size_t)cam * rows_part + j) * row_vec4 + x];
+}
+__global__ __launch_bounds__(256) void bands_scatter_scalar_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                   uint32_t row_floats, uint32_t rows_part, uint32_t height,
+                                                                   uint32_t band_first, uint32_t band_step) {
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, cam = blockIdx.z;
+    if (x >= row_floats) return;
+    const uint32_t y = 16u * (band_first + (j >> 4) * band_step) + (j & 15u);
+    out[((size_t)cam * height + y) * row_floats + x] = part[((size_t)cam * rows_part + j) * row_floats + x];
+}
+
+int scatter_bands(const float* part, uint32_t band_first, uint32_t band_step, uint32_t n_cameras, uint32_t width, uint32_t height,
+                  uint32_t channels, float* out, hipStream_t st) {
+    const uint32_t rows = sdfv_band_rows(height, band_first, band_step);
+    if (rows == 0 || n_cameras == 0 || width == 0) return SDFV_OK;
+    const uint64_t row_floats = (uint64_t)width * channels;
+    if (rows > 65535u || n_cameras > 65535u || row_floats >= (1ull << 32))
+        return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "band set of %u rows x %u cameras is too large for one launch", rows, n_cameras);
+    if (row_floats % 4 == 0 && !(((uintptr_t)part | (uintptr_t)out) & 15)) {
+        const uint32_t v = (uint32_t)(row_floats / 4);
+        hipLaunchKernelGGL(bands_scatter_kernel, dim3((v + 255) / 256, rows, n_cameras), dim3(256), 0, st,
+                           reinterpret_cast<const float4*>(part), reinterpret_cast<float4*>(out), v, rows, height, band_first, band_step);
+    } else {
+        hipLaunchKernelGGL(bands_scatter_scalar_kernel, dim3(((uint32_t)row_floats + 255) / 256, rows, n_cameras), dim3(256), 0, st,
+                           part, out, (uint32_t)row_floats, rows, height, band_first, band_step);
+    }
+    SDFV_HIPC(hipGetLastError());
+    return SDFV_OK;
+}
+
+// floats of rank r's band set (band_first = r, band_step = world) of n_cameras images
+size_t band_set_floats(uint32_t height, int r, int world, uint32_t n_cameras, uint32_t width, uint32_t channels) {
+    return (size_t)n_cameras * sdfv_band_rows(height, (uint32_t)r, (uint32_t)world) * width * channels;
+}
+
 }  // namespace
 
 #pragma GCC visibility push(default)
 extern "C" {
+
+// ---- config 5's collectives ("gather of RGBA tiles to rank 0", replicas "by ncclAllGather of slabs") ----
+
+int sdfv_bands_scatter(const float* part, uint32_t band_first, uint32_t band_step, uint32_t n_cameras, uint32_t width,
+                       uint32_t height, uint32_t channels, float* out, void* stream) {
+    if (!part || !out) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (band_step == 0 || channels == 0) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "band_step or channels is 0");
+    if (((uintptr_t)part | (uintptr_t)out) & 3) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "buffers must be 4-byte aligned");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+        (void)hipGetLastError();
+        return sdfv::set_error(SDFV_ERR_NO_DEVICE, "no HIP device visible: libsdfgrid has no CPU path");
+    }
+    return scatter_bands(part, band_first, band_step, n_cameras, width, height, channels, out, (hipStream_t)stream);
+}
+
+size_t sdfv_comm_gather_bands_scratch_bytes(const sdfv_slab_comm* c, int dst, uint32_t n_cameras, uint32_t width, uint32_t height,
+                                            uint32_t channels) {
+    if (!c || c->rank != dst) return 0;
+    size_t floats = 0;
+    for (int r = 0; r < c->world; ++r)
+        if (r != dst) floats += (band_set_floats(height, r, c->world, n_cameras, width, channels) + 3) & ~(size_t)3;  // 16-byte aligned parts
+    return floats * sizeof(float);
+}
+
+int sdfv_comm_gather_bands(sdfv_slab_comm* c, const float* part, uint32_t n_cameras, uint32_t width, uint32_t height,
+                           uint32_t channels, int dst, float* out, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!c) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "communicator is NULL");
+    if (dst < 0 || dst >= c->world) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "dst %d is not a rank of a world of %d", dst, c->world);
+    if (channels == 0) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "channels is 0");
+    const size_t mine = band_set_floats(height, c->rank, c->world, n_cameras, width, channels);
+    if (mine && !part) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "part is NULL");
+    const Rccl* lib;
+    if (int rc = need_rccl(lib)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (c->rank != dst) {  // one message: the whole band set
+        if (mine) SDFV_RCCL(lib, Send(part, mine, kNcclFloat, dst, c->comm, st));
+        return SDFV_OK;
+    }
+    if (!out) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "out is NULL on the gathering rank");
+    const size_t need = sdfv_comm_gather_bands_scratch_bytes(c, dst, n_cameras, width, height, channels);
+    if (need && (!scratch || scratch_bytes < need || ((uintptr_t)scratch & 15)))
+        return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "scratch: 16-byte aligned, at least sdfv_comm_gather_bands_scratch_bytes() = %zu bytes", need);
+    // every peer's set arrives whole, side by side in the scratch block (all links at once), then one launch per set moves
+    // its bands to their rows; this rank's own set goes straight from `part`
+    SDFV_RCCL(lib, GroupStart());
+    int first_error = kNcclSuccess;
+    size_t at = 0;
+    for (int r = 0; r < c->world; ++r) {
+        if (r == dst) continue;
+        const size_t n = band_set_floats(height, r, c->world, n_cameras, width, channels);
+        if (n && first_error == kNcclSuccess) first_error = lib->Recv(static_cast<float*>(scratch) + at, n, kNcclFloat, r, c->comm, st);
+        at += (n + 3) & ~(size_t)3;
+    }
+    const int end = lib->GroupEnd();
+    if (first_error == kNcclSuccess) first_error = end;
+    if (first_error != kNcclSuccess) return sdfv::set_error(SDFV_ERR_COMM, "RCCL gather of the tile bands: %s", lib->GetErrorString(first_error));
+    at = 0;
+    for (int r = 0; r < c->world; ++r) {
+        const float* src = r == dst ? part : static_cast<const float*>(scratch) + at;
+        if (int rc = scatter_bands(src, (uint32_t)r, (uint32_t)c->world, n_cameras, width, height, channels, out, st)) return rc;
+        if (r != dst) at += (band_set_floats(height, r, c->world, n_cameras, width, channels) + 3) & ~(size_t)3;
+    }
+    return SDFV_OK;
+}
+
+int sdfv_comm_gather_cameras(sdfv_slab_comm* c, const float* part, uint32_t n_cameras, uint32_t width, uint32_t height,
+                             uint32_t channels, int dst, float* out, void* stream) {
+    if (!c) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "communicator is NULL");
+    if (dst < 0 || dst >= c->world) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "dst %d is not a rank of a world of %d", dst, c->world);
+    const Rccl* lib;
+    if (int rc = need_rccl(lib)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t image = (size_t)width * height * channels;
+    auto first_of = [&](int r) { return (size_t)n_cameras * r / c->world; };  // rank r renders cameras [first_of(r), first_of(r + 1))
+    const size_t mine = (first_of(c->rank + 1) - first_of(c->rank)) * image;
+    if (mine && !part) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "part is NULL");
+    if (c->rank != dst) {
+        if (mine) SDFV_RCCL(lib, Send(part, mine, kNcclFloat, dst, c->comm, st));
+        return SDFV_OK;
+    }
+    if (!out) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "out is NULL on the gathering rank");
+    SDFV_RCCL(lib, GroupStart());
+    int first_error = kNcclSuccess;
+    for (int r = 0; r < c->world; ++r) {  // whole cameras are contiguous in camera order: received in place
+        const size_t n = (first_of(r + 1) - first_of(r)) * image;
+        if (r == dst || n == 0 || first_error != kNcclSuccess) continue;
+        first_error = lib->Recv(out + first_of(r) * image, n, kNcclFloat, r, c->comm, st);
+    }
+    const int end = lib->GroupEnd();
+    if (first_error == kNcclSuccess) first_error = end;
+    if (first_error != kNcclSuccess) return sdfv::set_error(SDFV_ERR_COMM, "RCCL gather of the cameras: %s", lib->GetErrorString(first_error));
+    if (mine && out + first_of(dst) * image != part)
+        SDFV_HIPC(hipMemcpyAsync(out + first_of(dst) * image, part, mine * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return SDFV_OK;
+}
+
+int sdfv_comm_allgather_slabs(sdfv_slab_comm* c, const uint32_t dims[3], const uint32_t* z_bounds, const float* tex0_owned,
+                              const float* tex1_owned, const float* dist_owned, float* out0, float* out1, float* out_dist,
+                              void* stream) {
+    if (!c || !dims || !z_bounds) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!tex0_owned || !tex1_owned || !out0 || !out1) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
+    if ((dist_owned == nullptr) != (out_dist == nullptr))
+        return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "dist_owned and out_dist go together (both or neither)");
+    if (z_bounds[0] != 0 || z_bounds[c->world] != dims[2]) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "z_bounds must run from 0 to the grid's depth");
+    for (int r = 0; r < c->world; ++r)
+        if (z_bounds[r] > z_bounds[r + 1]) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "z_bounds must not decrease");
+    const Rccl* lib;
+    if (int rc = need_rccl(lib)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t slice = (size_t)dims[0] * dims[1];
+    // one broadcast per slab and buffer, all in one group: slabs may differ in depth (ncclAllGather wants equal shares)
+    SDFV_RCCL(lib, GroupStart());
+    int first_error = kNcclSuccess;
+    auto post = [&](int r) {
+        if (first_error == kNcclSuccess) first_error = r;
+    };
+    for (int r = 0; r < c->world; ++r) {
+        const size_t z0 = z_bounds[r], n = (size_t)(z_bounds[r + 1] - z_bounds[r]) * slice;
+        if (n == 0) continue;
+        const bool me = r == c->rank;
+        post(lib->Broadcast(me ? tex0_owned : out0 + z0 * slice * 4, out0 + z0 * slice * 4, n * 4, kNcclFloat, r, c->comm, st));
+        post(lib->Broadcast(me ? tex1_owned : out1 + z0 * slice * 4, out1 + z0 * slice * 4, n * 4, kNcclFloat, r, c->comm, st));
+        if (out_dist) post(lib->Broadcast(me ? dist_owned : out_dist + z0 * slice, out_dist + z0 * slice, n, kNcclFloat, r, c->comm, st));
+    }
+    post(lib->GroupEnd());
+    if (first_error != kNcclSuccess) return sdfv::set_error(SDFV_ERR_COMM, "RCCL all-gather of the slabs: %s", lib->GetErrorString(first_error));
+    return SDFV_OK;
+}
 
 int sdfv_slab_comm_unique_id(unsigned char id_out[SDFV_COMM_ID_BYTES]) {
     if (!id_out) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "id_out is NULL");

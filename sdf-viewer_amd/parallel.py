@@ -255,20 +255,81 @@ class SlabComm:
         [overflow flag, rays left over]); the caller checks status when it synchronises anyway."""
         pkg = self.pkg
         dev = slab.tex0.device
-        capacity = width * height if capacity is None else int(capacity)
+        # A message is 16 + 24 * capacity bytes per neighbour and round WHATEVER it carries (ADVICE r03: width * height made it
+        # 49.8 MB at 1080p).  Default: an eighth of the pixels -- no view measured hands more than a few per cent of its rays
+        # across one slab boundary in one round; raymarch_sharded() retries with width * height should status[0] report overflow.
+        capacity = max(4096, width * height // 8) if capacity is None else int(capacity)
         n = pkg.lib.sdfv_slab_march_scratch_bytes(capacity)
-        scratch = torch.empty(n // 4, dtype=torch.int32, device=dev)
-        rgba = torch.empty((height, width, 4), dtype=torch.float32, device=dev)
-        aux = torch.empty((height, width, pkg.AUX_FLOATS), dtype=torch.int32, device=dev) if want_aux else None
-        status = torch.zeros(2, dtype=torch.int32, device=dev)
         stream = torch.cuda.current_stream() if stream is None else stream
-        pkg.check(pkg.lib.sdfv_slab_march(self.handle, C.byref(rp), C.byref(grid), C.c_void_p(slab.tex0.data_ptr()),
-                                          C.c_void_p(slab.tex1.data_ptr()), C.byref(camera), width, height,
-                                          C.c_void_p(rgba.data_ptr()), None if aux is None else C.c_void_p(aux.data_ptr()),
-                                          C.c_void_p(scratch.data_ptr()), n, capacity, pkg._capi.MARCH_MERGE if merge else 0,
-                                          C.c_void_p(status.data_ptr()), C.c_void_p(stream.cuda_stream)))
-        self._march_scratch = scratch  # alive until the stream has run the rounds
-        return rgba, (merge_sharded_aux(aux) if (want_aux and merge) else aux), status
+        with torch.cuda.stream(stream):  # allocations, the call and the merge on the stream the rounds run on
+            scratch = torch.empty(n // 4, dtype=torch.int32, device=dev)
+            rgba = torch.empty((height, width, 4), dtype=torch.float32, device=dev)
+            aux = torch.empty((height, width, pkg.AUX_FLOATS), dtype=torch.int32, device=dev) if want_aux else None
+            status = torch.zeros(2, dtype=torch.int32, device=dev)
+            pkg.check(pkg.lib.sdfv_slab_march(self.handle, C.byref(rp), C.byref(grid), C.c_void_p(slab.tex0.data_ptr()),
+                                              C.c_void_p(slab.tex1.data_ptr()), C.byref(camera), width, height,
+                                              C.c_void_p(rgba.data_ptr()), None if aux is None else C.c_void_p(aux.data_ptr()),
+                                              C.c_void_p(scratch.data_ptr()), n, capacity, pkg._capi.MARCH_MERGE if merge else 0,
+                                              C.c_void_p(status.data_ptr()), C.c_void_p(stream.cuda_stream)))
+            self._march_scratch = scratch  # alive until the stream has run the rounds
+            merged_aux = merge_sharded_aux(aux) if (want_aux and merge) else aux
+        return rgba, merged_aux, status
+
+    # ---- config 5's collectives over this communicator (SURVEY 8(e)); every rank calls, nothing synchronises ----
+    def gather_bands(self, part, height, dst=0, stream=None):
+        """sdfv_comm_gather_bands: part = [n_cam, band rows of this rank, W, C] rendered with bands=(rank, world) -> on `dst` the
+        images [n_cam, height, W, C] (None elsewhere)."""
+        pkg = self.pkg
+        stream = torch.cuda.current_stream() if stream is None else stream
+        n_cam, _, width, ch = (int(v) for v in part.shape)
+        with torch.cuda.stream(stream):
+            out = scratch = None
+            n = int(pkg.lib.sdfv_comm_gather_bands_scratch_bytes(self.handle, dst, n_cam, width, height, ch))
+            if self.rank == dst:
+                out = torch.empty((n_cam, height, width, ch), dtype=torch.float32, device=part.device)
+                scratch = torch.empty(max(n // 4, 4), dtype=torch.float32, device=part.device)
+            enter_stage("SlabComm.gather_bands: sdfv_comm_gather_bands over the library communicator")
+            pkg.check(pkg.lib.sdfv_comm_gather_bands(self.handle, C.c_void_p(part.data_ptr()) if part.numel() else None, n_cam, width,
+                                                     height, ch, dst, None if out is None else C.c_void_p(out.data_ptr()),
+                                                     None if scratch is None else C.c_void_p(scratch.data_ptr()), n,
+                                                     C.c_void_p(stream.cuda_stream)))
+        self._gather_scratch = scratch  # alive until the stream has run the scatter
+        return out
+
+    def gather_cameras(self, part, n_cameras, dst=0, stream=None):
+        """sdfv_comm_gather_cameras: part = [cameras of this rank, H, W, C] (split_cameras) -> on `dst` [n_cameras, H, W, C]."""
+        pkg = self.pkg
+        stream = torch.cuda.current_stream() if stream is None else stream
+        _, height, width, ch = (int(v) for v in part.shape)
+        with torch.cuda.stream(stream):
+            out = torch.empty((n_cameras, height, width, ch), dtype=torch.float32, device=part.device) if self.rank == dst else None
+            enter_stage("SlabComm.gather_cameras: sdfv_comm_gather_cameras over the library communicator")
+            pkg.check(pkg.lib.sdfv_comm_gather_cameras(self.handle, C.c_void_p(part.data_ptr()) if part.numel() else None, n_cameras,
+                                                       width, height, ch, dst, None if out is None else C.c_void_p(out.data_ptr()),
+                                                       C.c_void_p(stream.cuda_stream)))
+        return out
+
+    def allgather_slabs(self, slab, dims, dist=None, stream=None):
+        """sdfv_comm_allgather_slabs: the whole grid on every rank from the ranks' owned slices (slab_range split) ->
+        (tex0, tex1[, dist]) of the whole grid.  dist: the slab's distance volume incl. ghost slices, or None."""
+        pkg = self.pkg
+        stream = torch.cuda.current_stream() if stream is None else stream
+        bounds = [slab_range(dims[2], r, self.world)[0] for r in range(self.world)] + [int(dims[2])]
+        dev = slab.tex0.device
+        with torch.cuda.stream(stream):
+            out0 = torch.empty((dims[2], dims[1], dims[0], 4), dtype=torch.float32, device=dev)
+            out1 = torch.empty_like(out0)
+            outd = torch.empty((dims[2], dims[1], dims[0]), dtype=torch.float32, device=dev) if dist is not None else None
+            own_d = None if dist is None else dist[slab.ghost_lo:]
+            enter_stage("SlabComm.allgather_slabs: sdfv_comm_allgather_slabs over the library communicator")
+            pkg.check(pkg.lib.sdfv_comm_allgather_slabs(self.handle, (C.c_uint32 * 3)(*[int(d) for d in dims]),
+                                                        (C.c_uint32 * len(bounds))(*bounds), C.c_void_p(slab.owned0.data_ptr()),
+                                                        C.c_void_p(slab.owned1.data_ptr()),
+                                                        None if own_d is None else C.c_void_p(own_d.data_ptr()),
+                                                        C.c_void_p(out0.data_ptr()), C.c_void_p(out1.data_ptr()),
+                                                        None if outd is None else C.c_void_p(outd.data_ptr()),
+                                                        C.c_void_p(stream.cuda_stream)))
+        return (out0, out1) if dist is None else (out0, out1, outd)
 
     def join(self, stream=None):
         """sdfv_slab_comm_join: `stream` waits for the latest exchange (after steps taken with STEP_DEFER_JOIN)."""
@@ -445,11 +506,16 @@ def raymarch_sharded(pkg, rp, grid, slab, camera, width, height, rank, world, gr
     RCCL communicator (sdfv_slab_march: no host round trip per round); otherwise torch.distributed carries the rays, with a
     counter read-back and a count exchange per round (the gloo / CPU-test transport)."""
     if comm is not None and comm.handle and not comm.periodic:
-        rgba, aux, status = comm.march(rp, grid, slab, camera, width, height, want_aux=want_aux)
-        overflow, left = (int(v) for v in status.tolist())  # synchronises: the caller wants the image now
-        if overflow or left:
-            raise pkg.SdfvError(-1, f"sdfv_slab_march: ray lists overflowed ({overflow}) / {left} rays left over")
-        return (rgba, aux) if want_aux else rgba
+        for capacity in (None, width * height):  # the bounded default first; every rank sees the same (all-reduced) status
+            rgba, aux, status = comm.march(rp, grid, slab, camera, width, height, want_aux=want_aux, capacity=capacity)
+            st = status.clone()
+            if world > 1:  # an overflow on ONE rank must send EVERY rank round again: agree on it
+                enter_stage("raymarch_sharded: all_reduce(MAX) of the march status")
+                c10d.all_reduce(st, op=c10d.ReduceOp.MAX, group=group)
+            overflow, left = (int(v) for v in st.tolist())  # synchronises: the caller wants the image now
+            if not (overflow or left):
+                return (rgba, aux) if want_aux else rgba
+        raise pkg.SdfvError(-1, f"sdfv_slab_march: ray lists overflowed ({overflow}) / {left} rays left over")
     m = ShardedMarch(pkg, rp, grid, slab, camera, width, height, want_aux)
     incoming = None
     for _ in range(world):
@@ -474,9 +540,12 @@ def raymarch_sharded(pkg, rp, grid, slab, camera, width, height, rank, world, gr
     return rgba, merge_sharded_aux(merge(m.aux))
 
 
-def gather_replica(slab, dims, world, group=None):
+def gather_replica(slab, dims, world, group=None, comm=None):
     """Full grid on every rank from the slabs (all-gather; slabs may differ by one slice, so each is
-    padded to the deepest slab for the collective and trimmed afterwards)."""
+    padded to the deepest slab for the collective and trimmed afterwards).  comm: a (non-periodic) SlabComm -- the library's
+    own collective then (sdfv_comm_allgather_slabs); torch.distributed is the gloo / CPU-test transport."""
+    if comm is not None and comm.handle and not comm.periodic:
+        return comm.allgather_slabs(slab, dims)
     ranges = [slab_range(dims[2], r, world) for r in range(world)]
     deepest = max(z1 - z0 for z0, z1 in ranges)
     outs = []
@@ -528,10 +597,13 @@ def assemble_bands(parts, height):
     return out
 
 
-def gather_bands(part, height, rank, world, dst=0, group=None):
-    """Collect the band sets of split_bands on rank `dst` -> [n_cam, height, W, 4] (None elsewhere)."""
-    if world == 1:
+def gather_bands(part, height, rank, world, dst=0, group=None, comm=None):
+    """Collect the band sets of split_bands on rank `dst` -> [n_cam, height, W, 4] (None elsewhere).  comm: a SlabComm -- the
+    library's own collective then (sdfv_comm_gather_bands); torch.distributed is the gloo / CPU-test transport."""
+    if world == 1 and comm is None:
         return part
+    if comm is not None and comm.handle:
+        return comm.gather_bands(part, height, dst=dst)
     deepest = max(len(band_rows(height, r, world)) for r in range(world))
     staged = _needs_host_staging(part, group)
     dev = torch.device("cpu") if staged else part.device
@@ -563,12 +635,14 @@ def gather_rows(band, height, rank, world, dst=0, group=None, tile=16):
     return torch.cat([p[:, :y1 - y0] for p, (y0, y1) in zip(parts, ranges)], dim=1).to(band.device)
 
 
-def gather_images(rgba, n_cameras, rank, world, dst=0, group=None):
+def gather_images(rgba, n_cameras, rank, world, dst=0, group=None, comm=None):
     """Config 5's optional last step: collect every rank's rendered cameras ([n_local, H, W, 4]) on rank `dst` in
     camera order.  Camera counts may differ by one between ranks, so each block is padded to the largest count.
-    Returns [n_cameras, H, W, 4] on `dst`, None elsewhere."""
-    if world == 1:
+    Returns [n_cameras, H, W, 4] on `dst`, None elsewhere.  comm: a SlabComm -- sdfv_comm_gather_cameras then."""
+    if world == 1 and comm is None:
         return rgba
+    if comm is not None and comm.handle:
+        return comm.gather_cameras(rgba, n_cameras, dst=dst)
     counts = [len(split_cameras(n_cameras, r, world)) for r in range(world)]
     staged = _needs_host_staging(rgba, group)
     dev = torch.device("cpu") if staged else rgba.device

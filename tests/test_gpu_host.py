@@ -132,7 +132,7 @@ def test_texture_placement_is_measured_only_on_request(host, oracle):
     assert plain.texture_gap() == 0
     assert host.Viewer.tune(dims) == 0
     tuned = host.Viewer.new_voxels(dims, [-1, -1, -1, 1, 1, 1], 2)
-    assert tuned.texture_gap() in (0, 4096, 8192, 12288, 20480, 28672, 36864, 53248)
+    assert tuned.texture_gap() in range(0, 32768, 4096)
     assert host.Viewer.new_voxels((32, 32, 32), [-1, -1, -1, 1, 1, 1], 2).texture_gap() == 0
     sdf = host.SDF.demo()
     for v in (plain, tuned):

@@ -49,6 +49,11 @@ def test_bench_weak_scaling_path_two_ranks_one_gpu(world, geometry):
     assert b["value"] > 0 and b["split"] == "tiles" and b["rows_per_gpu"] == 512 // world and b["cameras_per_gpu"] == 64
     assert b["camera_split"]["value"] > 0 and b["camera_split"]["cameras_per_gpu"] == 64 // world
     assert b["contiguous_rows_split"]["value"] > 0 and b["contiguous_rows_split"]["rows_per_gpu"] == 512 // world
+    # SURVEY 8(e)'s collective of config 5 is in the line with its own number (torch.distributed here: gloo carries it)
+    for rep in (b, b["camera_split"], b["contiguous_rows_split"]):
+        assert rep["gather_ms"] > 0 and 0 < rep["value_incl_gather"] < rep["value"], rep
+        assert rep["gather_bytes_to_rank0"] == 64 * 512 * 512 * 16 * (world - 1) // world
+    assert "torch.distributed" in b["gather_transport"]
     assert d["sharded_fill_verified"] is True  # gathered slabs == dense fill, ghost slices == neighbour's slices
     c4 = d["config4"]  # the cube geometry next to the default one, in the same line
     assert c4["value"] > 0 and c4["voxels_per_gpu"] == 32 ** 3 and len(c4["grid_global"]) == 3, c4
@@ -86,6 +91,15 @@ def test_bench_line_carries_the_whole_contract():
     assert d["target_512"]["frac_8d"] == d["target_512"]["frac"] and 0 < d["target_512"]["fused_commit"]["frac_8d"] < d["target_512"]["fused_commit"]["frac"]
     rr = d["roofline_raymarch"]
     assert "note" in rr and rr["avg_launch_ms"] > 0
+    # round 4: the target configuration's fractions inside the nested object the driver's record keeps whole; the drop-in
+    # host's load through libsdfviewer_host.so; where the line was measured; no extra hung
+    t = d["roofline"]["target_512"]
+    assert t["plain"]["frac_8d"] == d["target_512"]["frac_8d"] and t["fused"]["frac_8d"] == d["target_512"]["fused_commit"]["frac_8d"]
+    assert d["incomplete"] is None and d["box"]["arch"].startswith("gfx950")
+    h = d["host_load"]["64"]
+    assert h["dense"]["update_calls"] == 1 and h["progressive"]["update_calls"] == 2 and h["dense"]["load_ms"] > 0
+    assert h["dense"]["iterations"] == 64 ** 3 + 32 ** 3 == h["progressive"]["iterations"]
+    assert d["progressive"]["64"]["virgin_load_2_passes"]["ms"] > 0
 
 
 def test_bench_multi_gpu_path_over_rccl_in_loopback():
@@ -106,6 +120,9 @@ def test_bench_multi_gpu_path_over_rccl_in_loopback():
     assert d["value"] > 0 and d["value_rays"] > 0 and d["pipeline"] == "fused"
     assert d["config4"]["value"] > 0, d["config4"]
     assert d["rccl_ranks"] == 1 and d["rccl_rank_of_rank0"] == 0 and d["torch_world_size"] == 1  # ncclCommCount of the library communicator
+    assert d["roofline"]["rccl_ranks"] == 1  # ... also inside the nested object the driver's record keeps whole
+    b = d["batch_raymarch"]  # the batch's gather ran over the library communicator (sdfv_comm_gather_bands)
+    assert b["gather_ms"] > 0 and "library RCCL communicator" in b["gather_transport"], b
     assert "skipped" in str(d["sharded_march"]["verified"])  # a periodic slab; the gloo runs above cover the sharded march
 
 

@@ -268,3 +268,86 @@ def test_config4_sized_slices_through_the_loopback_exchange(pkg, par, loop_comm)
     assert torch.equal(slab.owned0, c0) and torch.equal(slab.owned1, c1)
     for tex, ref in ((slab.tex0, c0), (slab.tex1, c1)):
         assert torch.equal(tex[0], ref[-1]) and torch.equal(tex[-1], ref[0])
+
+
+# ---- config 5's collectives behind the C ABI (VERDICT r03 missing 4) ----
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("height,width,n_cam", [(64, 48, 2), (90, 33, 3), (17, 20, 1)])
+def test_bands_scatter_assembles_what_raymarch_bands_rendered(pkg, par, world, height, width, n_cam):
+    """sdfv_bands_scatter is the inverse of sdfv_raymarch_bands' layout: the band sets of `world` ranks (rendered one after the
+    other on this GPU), scattered into one buffer, are the whole-image batch bit for bit -- rgba (16-byte path), the depth
+    plane (scalar path: widths that are no multiple of 4) and the aux record."""
+    prm = pkg.default_params()
+    g = pkg.make_grid((32, 32, 32))
+    t0, t1 = pkg.alloc_textures(g)
+    pkg.fill_grid(prm, g, t0, t1)
+    rp = pkg.default_render_params(g)
+    cams = pkg.orbit_cameras(n_cam, aspect=width / height)
+    want, want_depth, want_aux = pkg.raymarch(rp, t0, t1, cams, width, height, want_depth=True, want_aux=True)
+    out = torch.full_like(want, -3.0)
+    out_depth = torch.full_like(want_depth, -3.0)
+    out_aux = torch.full_like(want_aux, -3)
+    for r in range(world):
+        part, depth, aux = pkg.raymarch(rp, t0, t1, cams, width, height, bands=(r, world), want_depth=True, want_aux=True)
+        if part.shape[1] == 0:
+            continue
+        for src, dst, ch in ((part, out, 4), (depth, out_depth, 1), (aux.view(torch.float32), out_aux.view(torch.float32), pkg.AUX_FLOATS)):
+            pkg.check(pkg.lib.sdfv_bands_scatter(C.c_void_p(src.data_ptr()), r, world, n_cam, width, height, ch,
+                                                 C.c_void_p(dst.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int32), want.view(torch.int32))
+    assert torch.equal(out_depth.view(torch.int32), want_depth.view(torch.int32))
+    assert torch.equal(out_aux, want_aux)
+    assert torch.equal(out, par.assemble_bands([pkg.raymarch(rp, t0, t1, cams, width, height, bands=(r, world)) for r in range(world)], height))
+
+
+def test_gathers_over_the_library_communicator_in_loopback(pkg, par, oracle):
+    """sdfv_comm_gather_bands / _gather_cameras / _allgather_slabs with a world of one: every RCCL call of the path runs (a
+    group with no peers, the broadcasts from this rank), the scatter kernels and the copy run, and the results are the
+    inputs in place.  What a second device adds is the messages themselves (gloo covers the splits: test_parallel_cpu.py)."""
+    comm = par.SlabComm(pkg, 0, 1)
+    try:
+        prm = pkg.default_params()
+        dims = (24, 20, 12)
+        slab = par.alloc_slab(dims, 0, 1, "cuda", fill_value=-7.0)
+        grid = pkg.make_grid(dims)
+        dist = torch.full(tuple(slab.tex0.shape[:3]), -7.0, dtype=torch.float32, device="cuda")
+        comm.fill_step(prm, grid, slab, dist=dist)
+        full0, full1, fulld = comm.allgather_slabs(slab, dims, dist=dist)
+        a0, a1 = par.gather_replica(slab, dims, 1, comm=comm)
+        torch.cuda.synchronize()
+        r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims)
+        np.testing.assert_array_equal(bits(full0), r0.view(np.uint32))
+        np.testing.assert_array_equal(bits(full1), r1.view(np.uint32))
+        assert torch.equal(fulld, full0[..., 0]) and torch.equal(a0, full0) and torch.equal(a1, full1)
+        rp = pkg.default_render_params(grid)
+        W, H = 70, 50
+        cams = pkg.orbit_cameras(3, aspect=W / H)
+        whole = pkg.raymarch(rp, slab.owned0, slab.owned1, cams, W, H)
+        part = pkg.raymarch(rp, slab.owned0, slab.owned1, cams, W, H, bands=par.split_bands(H, 0, 1))
+        got = par.gather_bands(part, H, 0, 1, comm=comm)
+        got_cams = par.gather_images(whole, 3, 0, 1, comm=comm)
+        torch.cuda.synchronize()
+        assert torch.equal(got, whole) and torch.equal(got_cams, whole)
+        assert pkg.lib.sdfv_comm_gather_bands_scratch_bytes(comm.handle, 0, 3, W, H, 4) == 0  # no peers: nothing to stage
+        # argument errors are status codes
+        assert pkg.lib.sdfv_comm_gather_bands(comm.handle, C.c_void_p(part.data_ptr()), 3, W, H, 4, 5, None, None, 0, None) == -1
+        assert pkg.lib.sdfv_comm_gather_bands(comm.handle, C.c_void_p(part.data_ptr()), 3, W, H, 4, 0, None, None, 0, None) == -1
+        bad = (C.c_uint32 * 2)(1, 12)
+        assert pkg.lib.sdfv_comm_allgather_slabs(comm.handle, (C.c_uint32 * 3)(*dims), bad, C.c_void_p(slab.owned0.data_ptr()),
+                                                 C.c_void_p(slab.owned1.data_ptr()), None, C.c_void_p(full0.data_ptr()),
+                                                 C.c_void_p(full1.data_ptr()), None, None) == -1
+    finally:
+        comm.close()
+
+
+def test_gather_bands_scratch_accounting():
+    """The scratch the gathering rank needs is the other ranks' band sets, each rounded up to 16 bytes; 0 on every other rank
+    (checked against the band arithmetic without a communicator: sdfv_band_rows is pure)."""
+    import importlib
+    pkg = importlib.import_module("sdf-viewer_amd")
+    H, W, n = 1080, 1920, 64
+    rows = [pkg.lib.sdfv_band_rows(H, r, 8) for r in range(8)]
+    assert sum(rows) == H and max(rows) - min(rows) <= 16
+    assert rows == [len(importlib.import_module("sdf-viewer_amd.parallel").band_rows(H, r, 8)) for r in range(8)]
