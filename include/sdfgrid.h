@@ -34,7 +34,11 @@ extern "C" {
 /* 3 (round 3): the step forms other than SDFV_STEP_SIDE_BOUNDARY are gone; added sdfv_fill_grid_pass_ex, the pair and
  * interleaved volumes (sdfv_commit_pairs / _interleaved, sdfv_raymarch_pairs / _volumes, sdfv_march_volume_advice),
  * sdfv_raymarch_bands, the ray buffers with their count in band (sdfv_raymarch_slab_round, sdfv_slab_march). */
-#define SDFV_ABI_VERSION 3
+/* 4 (round 4): ONE raymarch entry point (sdfv_raymarch_ex over sdfv_march_desc) and ONE pass entry point (sdfv_fill_grid_pass_ex);
+ * the positional forms of version 3 are header-only wrappers (source compatible, no longer exported).  Added SDFV_PASS_VIRGIN_GRID,
+ * sdfv_grid_init_unvisited, SDFV_OPT_EXT_SRGB_QUANT, SDFV_OPT_PASS_INDEX_LIMIT, sdfv_bands_scatter and the sdfv_comm_* collectives.
+ * The descriptor is size-prefixed: further layouts / outputs are new fields, not new versions. */
+#define SDFV_ABI_VERSION 4
 
 typedef enum sdfv_status {
     SDFV_OK = 0,
@@ -250,23 +254,18 @@ int sdfv_tune_texture_placement(const sdfv_grid *grid, void *block, size_t block
  * second pass that re-reads tex0 (SDFViewer::update to completion followed by SDFViewer::commit, scene/sdf/mod.rs:128-239). */
 int sdfv_fill_grid_commit(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid, float *tex0,
                           float *tex1, float *dist, void *stream);
-/* One LoadingManager pass (loading.rs:50-76) with step `step` (a power of two >= 1) over the slab:
- * visits voxels whose x, y and GLOBAL z are multiples of step and applies update_required
- * (scene/sdf/mod.rs:184-190): tex0.r == AIR_DIST, or position inside changed_box (HOST, 6 floats
- * min.xyz max.xyz, may be NULL).  Requires initialised textures. */
-int sdfv_fill_grid_pass(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid,
-                        uint32_t step, const float *changed_box,
-                        float *tex0, float *tex1, void *stream);
-/* The same pass over textures that come with their compact distance volume (`dist`: DEVICE, one float per voxel, equal
- * to tex0.r on entry -- as sdfv_fill_grid_commit or sdfv_commit_distance leave it, also right after sdfv_grid_init).
- * update_required then reads 4 bytes instead of a 16-byte texel, updated voxels rewrite their dist entry, and
- * tex1.a is written as the AIR_DIST it holds in any grid this library initialised or filled (the reference never
- * writes it, scene/sdf/mod.rs:205-208) instead of being read back.  Same texels as sdfv_fill_grid_pass; a no-op pass
- * over a loaded 256^3 grid moves 67 MB instead of 268 MB.  dist == NULL is sdfv_fill_grid_pass. */
-int sdfv_fill_grid_pass_dist(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid, uint32_t step,
-                             const float *changed_box, float *tex0, float *tex1, float *dist, void *stream);
+/* One LoadingManager pass (loading.rs:50-76) with step `step` (a power of two >= 1) over the slab: sdfv_fill_grid_pass_ex below is
+ * the one exported form; sdfv_fill_grid_pass (no distance volume, no flags) and sdfv_fill_grid_pass_dist (no flags) are
+ * header-only wrappers at the end of this file.  The pass visits voxels whose x, y and GLOBAL z are multiples of step and
+ * applies update_required (scene/sdf/mod.rs:184-190): tex0.r == AIR_DIST, or position inside changed_box (HOST, 6 floats
+ * min.xyz max.xyz, may be NULL).  Requires initialised textures (or SDFV_PASS_VIRGIN_GRID).
+ * `dist` (DEVICE, one float per voxel, or NULL): the textures' compact distance volume, equal to tex0.r on entry -- as
+ * sdfv_fill_grid_commit or sdfv_commit_distance leave it, also right after sdfv_grid_init.  update_required then reads 4 bytes
+ * instead of a 16-byte texel, updated voxels rewrite their dist entry, and tex1.a is written as the AIR_DIST it holds in any
+ * grid this library initialised or filled (the reference never writes it, scene/sdf/mod.rs:205-208) instead of being read
+ * back.  Same texels; a no-op pass over a loaded 256^3 grid moves 67 MB instead of 268 MB. */
 
-/* The same pass with what the CALLER knows about the grid (flags; 0 = sdfv_fill_grid_pass_dist).  Whenever update_required
+/* `flags`: what the CALLER knows about the grid (0 = nothing).  Whenever update_required
  * is known to hold for every visited voxel the pass reads nothing: at step 1 it is the dense fill (+ the distance volume),
  * at larger steps a store-only strided pass.  The library finds one such case itself -- a changed_box that contains every
  * voxel of the slab (what the demo reports on any parameter edit, demo/mod.rs:135-144) -- the flags name the two a host
@@ -351,87 +350,78 @@ int sdfv_mesh_free(sdfv_mesh *mesh);
  * this releases it -- and the three side streams a batch of more than 64 cameras makes (SDFV_OPT_RAYMARCH_BATCH_STREAMS). */
 int sdfv_mesh_trim(void);
 
-/* ---- raymarch ---- */
-/* material.frag main() for every pixel of rows [y0, y1) of n_cameras W x H images (row 0 = top).
- * tex0/tex1: DEVICE, the FULL grid rp->tex_size.  cameras: HOST array.  rgba: DEVICE,
- * n_cameras x (y1-y0) x W x 4 floats (outColor).  aux: DEVICE or NULL, same pixel layout. */
-int sdfv_raymarch(const sdfv_render_params *rp, const float *tex0, const float *tex1,
-                  const sdfv_camera *cameras, uint32_t n_cameras,
-                  uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
-                  float *rgba, sdfv_march_aux *aux, void *stream);
+/* ---- raymarch ----
+ * ONE exported entry point, one descriptor: sdfv_raymarch_ex.  The forms earlier ABI versions exported one by one
+ * (sdfv_raymarch, _accel, _depth, _pairs, _volumes, _bands) are header-only wrappers at the end of this file that fill the
+ * descriptor; a new acceleration layout or output plane adds a FIELD, not a function and not an ABI version. */
+
+/* material.frag main() for every pixel of rows [y0, y1) -- or of the 16-row tile bands band_first, band_first + band_step, ...
+ * -- of n_cameras W x H images (row 0 = top).  `size` = sizeof(sdfv_march_desc) as the CALLER compiled it: the library reads
+ * that many bytes and takes every field beyond them as 0 / NULL, so a binder built against an older header keeps working.
+ *   rp                uniforms (material.rs:50-73); a light-list entry that is not SDFV_LIGHT_AMBIENT fails the call
+ *                     (SDFV_ERR_INVALID_ARGUMENT: three-d 0.18.2's shader source is not available)
+ *   tex0, tex1        DEVICE, the FULL grid rp->tex_size
+ *   dist              DEVICE or NULL: compact distance volume (sdfv_commit_distance / the fused fill): the march gathers
+ *                     4-byte distances instead of the r channel of 16-byte texels; bit-identical results
+ *   pairs             DEVICE (8-byte aligned) or NULL: y-pair volume (sdfv_commit_pairs) -- texel (x, y, z) = (d[y], d[min(y+1,
+ *                     H-1)]): a cell's z-level is 16 contiguous bytes, two 16-byte gathers per cell instead of four 8-byte
+ *                     ones (1080p over 256^3 -6.5 %, 64-camera batch -15 %).  8 B/voxel.  Bit-identical
+ *   ilv               DEVICE (8-byte aligned) or NULL: y-interleaved volume (sdfv_commit_interleaved) -- rows 2p, 2p + 1 of a
+ *                     slice as ONE row of pairs: 2 cache lines per cell for even y, 4 for odd, at 4 B/voxel (4K over 512^3
+ *                     -7..-13 %).  Bit-identical.  Given several volumes the launcher applies sdfv_march_volume_advice's
+ *                     rule; the pair / interleaved volumes serve the hand-written gfx950 loop (any grid size, power-of-two
+ *                     extents, symmetric box, <= 2^28 texels) on a CUBIC grid, every other launch reads dist / tex0.r
+ *   cameras           HOST array of n_cameras
+ *   y0, y1            rows [y0, y1) when band_step == 0
+ *   band_first, band_step   band_step >= 1: the balanced image-tile split of BASELINE config 5 -- rank r of N renders (r, N):
+ *                     the 16-row tile bands band_first, band_first + band_step, ... stored one after the other (outputs hold
+ *                     n_cameras x sdfv_band_rows(height, band_first, band_step) x width pixels; a band set that starts below the
+ *                     image renders nothing and succeeds); y0 / y1 are ignored.  Contiguous row ranges leave the outer ranks
+ *                     with background only (8 ranges of a 1080p orbit view scale 2.4x on 8 GPUs, 8 band sets 5-6x)
+ *   rgba              DEVICE, n_cameras x rows x W x 4 floats (outColor)
+ *   depth             DEVICE or NULL, n_cameras x rows x W floats: gl_FragDepth (material.frag:180-181: (BVP * vec4(hit, 1)).z /
+ *                     .w at a hit; 1.0 for a fragment that hits nothing, :147; 1.0 where the ray misses the box) -- equal bit for
+ *                     bit to sdfv_march_aux.depth without the 72-byte record
+ *   aux               DEVICE or NULL, same pixel layout: everything main() knows before shading */
+typedef struct sdfv_march_desc {
+    uint32_t size;
+    uint32_t reserved; /* 0 */
+    const sdfv_render_params *rp;
+    const float *tex0, *tex1;
+    const float *dist, *pairs, *ilv;
+    const sdfv_camera *cameras;
+    uint32_t n_cameras;
+    uint32_t width, height;
+    uint32_t y0, y1;
+    uint32_t band_first, band_step;
+    uint32_t reserved2; /* 0 */
+    float *rgba;
+    float *depth;
+    sdfv_march_aux *aux;
+} sdfv_march_desc;
+int sdfv_raymarch_ex(const sdfv_march_desc *desc, void *stream);
+uint32_t sdfv_band_rows(uint32_t height, uint32_t band_first, uint32_t band_step);
 
 /* Device-side analogue of SDFViewer::commit (scene/sdf/mod.rs:220-239).  The textures already live in HBM, so
  * there is nothing to upload; what a commit can do instead is derive the raymarch's acceleration data: `dist`
- * (DEVICE, W*H*D floats) receives a compact copy of tex0.r.  Optional: pass it to sdfv_raymarch_accel. */
+ * (DEVICE, W*H*D floats) receives a compact copy of tex0.r. */
 int sdfv_commit_distance(const sdfv_grid *grid, const float *tex0, float *dist, void *stream);
-/* sdfv_raymarch with the compact distance volume (`dist` may be NULL = sdfv_raymarch).  Results are identical
- * bit for bit; the march reads `dist` instead of the r channel of tex0. */
-int sdfv_raymarch_accel(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
-                        const sdfv_camera *cameras, uint32_t n_cameras,
-                        uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
-                        float *rgba, sdfv_march_aux *aux, void *stream);
-
-/* sdfv_raymarch_accel with a depth plane: `depth` (DEVICE, n_cameras x (y1-y0) x W floats, or NULL) receives
- * gl_FragDepth per pixel (material.frag:180-181: (BVP * vec4(hit, 1)).z / .w at a hit; 1.0 for a fragment that
- * hits nothing, material.frag:147; 1.0 where the ray misses the box and no fragment exists) -- 4 B/pixel, equal bit
- * for bit to sdfv_march_aux.depth without paying for the 72-byte record.  Fails with SDFV_ERR_INVALID_ARGUMENT when
- * rp->lights holds an entry that is not SDFV_LIGHT_AMBIENT (three-d 0.18.2's shader source is not available). */
-int sdfv_raymarch_depth(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
-                        const sdfv_camera *cameras, uint32_t n_cameras,
-                        uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
-                        float *rgba, float *depth, sdfv_march_aux *aux, void *stream);
-
-/* A second acceleration structure for hosts that render MANY frames per load (an interactive viewer, a batch of cameras):
- * the y-pair volume -- `pairs` (DEVICE, 8-byte aligned, 2 floats per voxel of the WHOLE grid): texel (x, y, z) holds
- * (dist[z][y][x], dist[z][min(y + 1, H - 1)][x]).  The four corners of a trilinear cell's z-level are then 16 contiguous
- * bytes, so the march's cell fetch is two 16-byte gathers over two cache lines instead of four 8-byte ones over four --
- * and the gather count is what a fetch costs (profiles/EXPERIMENTS.md): single 1080p frame over 256^3 -15 %, 4K over 512^3
- * -27 %, a 64-camera batch -23 %.  Built from the compact distance volume by sdfv_commit_pairs (12 B/voxel of traffic, once
- * per load: 0.03 ms at 256^3); costs 8 B/voxel of memory.  NOT part of the fill: the fused fill stays at 36 B/voxel. */
+/* The y-pair volume from the compact distance volume (12 B/voxel of traffic, once per load: 0.03 ms at 256^3; 8 B/voxel of
+ * memory; `pairs`: DEVICE, 8-byte aligned, 2 floats per voxel of the WHOLE grid).  NOT part of the fill: the fused fill stays
+ * at 36 B/voxel. */
 int sdfv_commit_pairs(const sdfv_grid *grid, const float *dist, float *pairs, void *stream);
-/* sdfv_raymarch_depth with the pair volume (`pairs` may be NULL = sdfv_raymarch_depth).  Bit-identical results: the march
- * gathers the same values from another layout.  The pair volume serves the hand-written gfx950 loop (any grid size,
- * power-of-two extents, symmetric box, <= 2^28 texels) on a CUBIC grid; any other launch -- and a grid that is not cubic
- * whenever `dist` is given -- reads `dist` / tex0.r as before. */
-int sdfv_raymarch_pairs(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
-                        const float *pairs, const sdfv_camera *cameras, uint32_t n_cameras,
-                        uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
-                        float *rgba, float *depth, sdfv_march_aux *aux, void *stream);
-
-/* A third layout of the same distances, WITHOUT duplication: the y-interleaved volume -- `ilv` (DEVICE, 8-byte aligned, one
- * float per voxel of the WHOLE grid, H even): rows 2p and 2p + 1 of a slice stored as ONE row of (d[2p][x], d[2p+1][x])
- * pairs, i.e. ilv[((z * H/2 + (y >> 1)) * W + x) * 2 + (y & 1)] = dist[z][y][x].  A trilinear cell then touches 2 cache
- * lines (even y) or 4 (odd y) instead of always 4, at the distance volume's 4 B/voxel: the march gathers fewer lines without
- * the doubled footprint the pair volume pays at large grids.  sdfv_commit_interleaved builds it from the compact distance
- * volume (8 B/voxel of traffic). */
+/* The y-interleaved volume from the compact distance volume (8 B/voxel of traffic; `ilv`: DEVICE, 8-byte aligned, one float per
+ * voxel of the WHOLE grid, H even): ilv[((z * H/2 + (y >> 1)) * W + x) * 2 + (y & 1)] = dist[z][y][x]. */
 int sdfv_commit_interleaved(const sdfv_grid *grid, const float *dist, float *ilv, void *stream);
 /* Which of the two a host that renders many frames per load should build for this grid on the current device:
  * the pair volume while its 8 B/voxel fit the last-level cache (MI355X: 256 MB -- up to 256^3 x 2), the interleaved volume
- * beyond (4K over 512^3: -10 % against either of the others; 1080p over 256^3: pairs -6 %, interleaved +-1 %).  Speed only. */
-#define SDFV_MARCH_VOLUME_NONE 0u /* a grid that is not cubic: neither pays over the distance volume */
+ * beyond (4K over 512^3: -10 % against either of the others; 1080p over 256^3: pairs -6 %, interleaved +-1 %); NONE for a grid
+ * that is not cubic, on a device that is not gfx950, or when the hand-written loop is switched off (the march would never read
+ * them).  Speed only. */
+#define SDFV_MARCH_VOLUME_NONE 0u
 #define SDFV_MARCH_VOLUME_PAIRS 1u
 #define SDFV_MARCH_VOLUME_INTERLEAVED 2u
 int sdfv_march_volume_advice(const sdfv_grid *grid, uint32_t *kind);
-/* The most general form of the march: any of the three acceleration volumes may be NULL (given both pairs and
- * ilv the launcher applies the rule of sdfv_march_volume_advice; where the hand-written loop does not apply: dist, else
- * tex0.r).  Bit-identical results in every combination. */
-int sdfv_raymarch_volumes(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
-                          const float *pairs, const float *ilv, const sdfv_camera *cameras, uint32_t n_cameras,
-                          uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
-                          float *rgba, float *depth, sdfv_march_aux *aux, void *stream);
-
-/* The balanced image-tile split (BASELINE config 5): the 16-row tile bands band_first, band_first + band_step, ... of the
- * image -- rank r of N renders (r, N) -- instead of one contiguous range of rows (the rows under the object cost ten times
- * the rows of background: 8 contiguous ranges of a 1080p orbit view scale 2.4x on 8 GPUs, 8 interleaved sets 6-7x).  The
- * bands are stored one after the other: rgba / depth / aux hold n_cameras x sdfv_band_rows(height, band_first, band_step)
- * x width pixels; band k of the output is rows [16 * (band_first + k * band_step), ...+16) of the image (the last band of
- * an image whose height is not a multiple of 16 is short; a band set that starts below the image renders nothing and
- * succeeds).  Otherwise sdfv_raymarch_volumes; same bits per pixel. */
-uint32_t sdfv_band_rows(uint32_t height, uint32_t band_first, uint32_t band_step);
-int sdfv_raymarch_bands(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
-                        const float *pairs, const float *ilv, const sdfv_camera *cameras, uint32_t n_cameras,
-                        uint32_t width, uint32_t height, uint32_t band_first, uint32_t band_step,
-                        float *rgba, float *depth, sdfv_march_aux *aux, void *stream);
 
 /* ---- raymarch over a z-sharded grid (multi-GPU; the consumer of the slab halo) ----
  * The grid stays sharded: rank r holds [ghost_lo][owned z_begin..z_end)[ghost_hi] as laid out for sdfv_slab_*.
@@ -603,6 +593,108 @@ int sdfv_comm_allgather_slabs(sdfv_slab_comm *comm, const uint32_t dims[3], cons
  * textures (or the ghost slices' share of the distance volume).  The owned slices never need it: the flag is honoured
  * only where the caller's stream fills every owned slice itself (packed messages). */
 int sdfv_slab_comm_join(sdfv_slab_comm *comm, void *stream);
+
+/* ---- header-only convenience forms (static inline over the exported calls above; NOT symbols of the library).  A binder in
+ * another language binds sdfv_raymarch_ex / sdfv_fill_grid_pass_ex and writes these few lines in its own idiom. ---- */
+#if defined(__GNUC__) || defined(__clang__)
+#define SDFV_INLINE static inline __attribute__((unused))
+#else
+#define SDFV_INLINE static inline
+#endif
+SDFV_INLINE int sdfv_fill_grid_pass_dist(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid, uint32_t step,
+                                         const float *changed_box, float *tex0, float *tex1, float *dist, void *stream) {
+    return sdfv_fill_grid_pass_ex(params, sdf_id, grid, step, changed_box, tex0, tex1, dist, 0u, stream);
+}
+SDFV_INLINE int sdfv_fill_grid_pass(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid, uint32_t step,
+                                    const float *changed_box, float *tex0, float *tex1, void *stream) {
+    return sdfv_fill_grid_pass_ex(params, sdf_id, grid, step, changed_box, tex0, tex1, (float *)0, 0u, stream);
+}
+/* The most general positional form: any of the three acceleration volumes may be NULL. */
+SDFV_INLINE int sdfv_raymarch_volumes(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
+                                      const float *pairs, const float *ilv, const sdfv_camera *cameras, uint32_t n_cameras,
+                                      uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, float *rgba, float *depth,
+                                      sdfv_march_aux *aux, void *stream) {
+    sdfv_march_desc d;
+    d.size = (uint32_t)sizeof d;
+    d.reserved = 0;
+    d.rp = rp;
+    d.tex0 = tex0;
+    d.tex1 = tex1;
+    d.dist = dist;
+    d.pairs = pairs;
+    d.ilv = ilv;
+    d.cameras = cameras;
+    d.n_cameras = n_cameras;
+    d.width = width;
+    d.height = height;
+    d.y0 = y0;
+    d.y1 = y1;
+    d.band_first = 0;
+    d.band_step = 0;
+    d.reserved2 = 0;
+    d.rgba = rgba;
+    d.depth = depth;
+    d.aux = aux;
+    return sdfv_raymarch_ex(&d, stream);
+}
+/* material.frag main() over tex0.r in place: the batched raymarch SURVEY 8(b) names */
+SDFV_INLINE int sdfv_raymarch(const sdfv_render_params *rp, const float *tex0, const float *tex1, const sdfv_camera *cameras,
+                              uint32_t n_cameras, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, float *rgba,
+                              sdfv_march_aux *aux, void *stream) {
+    return sdfv_raymarch_volumes(rp, tex0, tex1, (const float *)0, (const float *)0, (const float *)0, cameras, n_cameras, width,
+                                 height, y0, y1, rgba, (float *)0, aux, stream);
+}
+/* ... over the compact distance volume */
+SDFV_INLINE int sdfv_raymarch_accel(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
+                                    const sdfv_camera *cameras, uint32_t n_cameras, uint32_t width, uint32_t height, uint32_t y0,
+                                    uint32_t y1, float *rgba, sdfv_march_aux *aux, void *stream) {
+    return sdfv_raymarch_volumes(rp, tex0, tex1, dist, (const float *)0, (const float *)0, cameras, n_cameras, width, height, y0,
+                                 y1, rgba, (float *)0, aux, stream);
+}
+/* ... with the depth plane */
+SDFV_INLINE int sdfv_raymarch_depth(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
+                                    const sdfv_camera *cameras, uint32_t n_cameras, uint32_t width, uint32_t height, uint32_t y0,
+                                    uint32_t y1, float *rgba, float *depth, sdfv_march_aux *aux, void *stream) {
+    return sdfv_raymarch_volumes(rp, tex0, tex1, dist, (const float *)0, (const float *)0, cameras, n_cameras, width, height, y0,
+                                 y1, rgba, depth, aux, stream);
+}
+/* ... over the y-pair volume */
+SDFV_INLINE int sdfv_raymarch_pairs(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
+                                    const float *pairs, const sdfv_camera *cameras, uint32_t n_cameras, uint32_t width,
+                                    uint32_t height, uint32_t y0, uint32_t y1, float *rgba, float *depth, sdfv_march_aux *aux,
+                                    void *stream) {
+    return sdfv_raymarch_volumes(rp, tex0, tex1, dist, pairs, (const float *)0, cameras, n_cameras, width, height, y0, y1, rgba,
+                                 depth, aux, stream);
+}
+/* The balanced image-tile split: the 16-row tile bands band_first, band_first + band_step, ... (band_step >= 1) */
+SDFV_INLINE int sdfv_raymarch_bands(const sdfv_render_params *rp, const float *tex0, const float *tex1, const float *dist,
+                                    const float *pairs, const float *ilv, const sdfv_camera *cameras, uint32_t n_cameras,
+                                    uint32_t width, uint32_t height, uint32_t band_first, uint32_t band_step, float *rgba,
+                                    float *depth, sdfv_march_aux *aux, void *stream) {
+    sdfv_march_desc d;
+    d.size = (uint32_t)sizeof d;
+    d.reserved = 0;
+    d.rp = rp;
+    d.tex0 = tex0;
+    d.tex1 = tex1;
+    d.dist = dist;
+    d.pairs = pairs;
+    d.ilv = ilv;
+    d.cameras = cameras;
+    d.n_cameras = n_cameras;
+    d.width = width;
+    d.height = height;
+    d.y0 = 0;
+    d.y1 = height;
+    d.band_first = band_first;
+    d.band_step = band_step;
+    d.reserved2 = 0;
+    d.rgba = rgba;
+    d.depth = depth;
+    d.aux = aux;
+    if (band_step == 0) return SDFV_ERR_INVALID_ARGUMENT; /* (in the descriptor 0 means "rows [y0, y1)", not a band set) */
+    return sdfv_raymarch_ex(&d, stream);
+}
 
 #ifdef __cplusplus
 }

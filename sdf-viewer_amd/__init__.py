@@ -392,7 +392,7 @@ class options:
 def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=False, stream=None, out=None, dist=None,
              want_depth=False, depth_out=None, pairs=None, ilv=None, bands=None):
     """material.frag main() over rows [y0,y1) -- or, bands=(first, step), over the 16-row tile bands first, first + step, ...
-    stored one after the other (sdfv_raymarch_bands).  Returns rgba [n_cam, rows, W, 4] (+ aux [n_cam, rows, W, 18] words).
+    stored one after the other (sdfv_march_desc.band_first / band_step).  Returns rgba [n_cam, rows, W, 4] (+ aux [n_cam, rows, W, 18] words).
     `dist` = optional compact distance volume from commit_distance(); `pairs` = optional y-pair volume from commit_pairs()
     (sdfv_raymarch_pairs).  want_depth / depth_out: also return the
     gl_FragDepth plane [n_cam, rows, W] (sdfv_raymarch_depth); return order: rgba[, depth][, aux]."""
@@ -401,13 +401,18 @@ def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=Fal
     y1 = height if y1 is None else y1
     n = len(cameras)
     cam_arr = (Camera * n)(*cameras)
+    d = _capi.MarchDesc()
+    d.size = C.sizeof(d)
     if bands is not None:
         if (y0, y1) != (0, height):
             raise ValueError("bands and a row range exclude each other")
+        if int(bands[1]) < 1:
+            raise SdfvError(-1, "band_step is 0")
         rows = int(lib.sdfv_band_rows(height, int(bands[0]), int(bands[1])))
-        entry, a, b = lib.sdfv_raymarch_bands, int(bands[0]), int(bands[1])
+        d.y0, d.y1, d.band_first, d.band_step = 0, height, int(bands[0]), int(bands[1])
     else:
-        rows, entry, a, b = y1 - y0, lib.sdfv_raymarch_volumes, y0, y1
+        rows = y1 - y0
+        d.y0, d.y1 = y0, y1
     rgba = out if out is not None else torch.empty((n, rows, width, 4), dtype=torch.float32, device=tex0.device)
     aux = torch.empty((n, rows, width, AUX_FLOATS), dtype=torch.int32, device=tex0.device) if want_aux else None
     depth = depth_out
@@ -416,12 +421,15 @@ def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=Fal
     if rows == 0 and bands is not None and int(bands[1]) > 0:  # a band set below the image: nothing to render (empty tensors have no address)
         ret = (rgba,) + ((depth,) if (want_depth or depth_out is not None) else ()) + ((aux,) if want_aux else ())
         return ret if len(ret) > 1 else rgba
-    check(entry(C.byref(rp), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"),
-                None if dist is None else _dev_ptr(dist, "dist"),
-                None if pairs is None else _dev_ptr(pairs, "pairs"),
-                None if ilv is None else _dev_ptr(ilv, "ilv"), cam_arr, n, width, height,
-                a, b, C.c_void_p(rgba.data_ptr()),
-                None if depth is None else _dev_ptr(depth, "depth"),
-                C.c_void_p(aux.data_ptr()) if want_aux else None, _stream_ptr(stream)))
+    d.rp = C.pointer(rp)
+    d.tex0, d.tex1 = _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1")
+    d.dist = None if dist is None else _dev_ptr(dist, "dist")
+    d.pairs = None if pairs is None else _dev_ptr(pairs, "pairs")
+    d.ilv = None if ilv is None else _dev_ptr(ilv, "ilv")
+    d.cameras, d.n_cameras, d.width, d.height = cam_arr, n, width, height
+    d.rgba = rgba.data_ptr()
+    d.depth = None if depth is None else _dev_ptr(depth, "depth")
+    d.aux = aux.data_ptr() if want_aux else None
+    check(lib.sdfv_raymarch_ex(C.byref(d), _stream_ptr(stream)))
     ret = (rgba,) + ((depth,) if (want_depth or depth_out is not None) else ()) + ((aux,) if want_aux else ())
     return ret if len(ret) > 1 else rgba

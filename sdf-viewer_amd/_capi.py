@@ -71,7 +71,17 @@ class Mesh(C.Structure):
     _fields_ = [("vertices", C.c_void_p), ("indices", C.c_void_p), ("n_vertices", C.c_size_t), ("n_indices", C.c_size_t)]
 
 
+class MarchDesc(C.Structure):
+    """sdfv_march_desc: the one descriptor of sdfv_raymarch_ex (size-prefixed)."""
+    _fields_ = [("size", C.c_uint32), ("reserved", C.c_uint32), ("rp", C.POINTER(RenderParams)), ("tex0", C.c_void_p),
+                ("tex1", C.c_void_p), ("dist", C.c_void_p), ("pairs", C.c_void_p), ("ilv", C.c_void_p),
+                ("cameras", C.POINTER(Camera)), ("n_cameras", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("y0", C.c_uint32), ("y1", C.c_uint32), ("band_first", C.c_uint32), ("band_step", C.c_uint32),
+                ("reserved2", C.c_uint32), ("rgba", C.c_void_p), ("depth", C.c_void_p), ("aux", C.c_void_p)]
+
+
 PROTOTYPES = {
+    "sdfv_raymarch_ex": (C.c_int, [C.POINTER(MarchDesc), C.c_void_p]),
     "sdfv_abi_version": (C.c_uint32, []),
     "sdfv_last_error": (C.c_char_p, []),
     "sdfv_device_count": (C.c_int, []),
@@ -91,39 +101,17 @@ PROTOTYPES = {
                                               C.POINTER(C.c_size_t), C.c_void_p]),
     "sdfv_fill_grid_commit": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
-    "sdfv_fill_grid_pass": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_uint32,
-                                      C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
-    "sdfv_fill_grid_pass_dist": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_uint32,
-                                           C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_fill_grid_pass_ex": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_uint32,
                                          C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "sdfv_sample_points": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_int,
                                      C.c_void_p, C.c_void_p]),
     "sdfv_normal_points": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_float,
                                      C.c_int, C.c_void_p, C.c_void_p]),
-    "sdfv_raymarch": (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(Camera), C.c_uint32,
-                                C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
-                                C.c_void_p]),
     "sdfv_commit_distance": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
-    "sdfv_raymarch_accel": (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Camera),
-                                      C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
-                                      C.c_void_p, C.c_void_p]),
-    "sdfv_raymarch_depth": (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Camera),
-                                      C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.c_void_p]),
-    "sdfv_raymarch_pairs": (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Camera),
-                                      C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_commit_pairs": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_band_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
-    "sdfv_raymarch_bands": (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_march_volume_advice": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_uint32)]),
     "sdfv_commit_interleaved": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
-    "sdfv_raymarch_volumes": (C.c_int, [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
-                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_fill_grid_host": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p, C.c_void_p]),
     "sdfv_sample_points_host": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_int,
                                           C.c_void_p]),
@@ -175,6 +163,22 @@ PROTOTYPES = {
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 LIGHT_AMBIENT, LIGHT_DIRECTIONAL, MAX_LIGHTS = 0, 1, 4
+
+
+def raymarch_rc(rp, tex0, tex1, cameras, n_cameras, width, height, y0, y1, rgba, depth=None, aux=None, dist=None, pairs=None,
+                ilv=None, band_first=0, band_step=0, stream=None, size=None):
+    """sdfv_raymarch_ex from raw addresses (ints / c_void_p / None), returning the status code unchecked: what the argument-
+    error tests and the tools that bypass the torch harness call.  cameras: a Camera, a ctypes array of them, or None."""
+    d = MarchDesc()
+    d.size = C.sizeof(d) if size is None else size
+    d.rp = C.pointer(rp) if rp is not None else None
+    d.tex0, d.tex1, d.dist, d.pairs, d.ilv = tex0, tex1, dist, pairs, ilv
+    if cameras is not None:
+        d.cameras = C.cast(C.pointer(cameras), C.POINTER(Camera))
+    d.n_cameras, d.width, d.height, d.y0, d.y1 = n_cameras, width, height, y0, y1
+    d.band_first, d.band_step = band_first, band_step
+    d.rgba, d.depth, d.aux = rgba, depth, aux
+    return lib.sdfv_raymarch_ex(C.byref(d), stream)
 # sdfv_option / values (include/sdfgrid.h)
 OPT_FILL_NONTEMPORAL, OPT_FILL_FORM, OPT_RAYMARCH_DISABLE, OPT_RAYMARCH_KEEP_NORMAL, OPT_SLAB_STEP_FORM = 1, 2, 3, 4, 5
 OPT_RAYMARCH_TILE_GROUP = 6

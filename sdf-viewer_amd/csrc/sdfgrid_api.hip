@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 
@@ -796,16 +797,6 @@ int sdfv_fill_grid_pass_ex(const sdfv_demo_params* params, uint32_t sdf_id, cons
     return SDFV_OK;
 }
 
-int sdfv_fill_grid_pass_dist(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, uint32_t step,
-                             const float* changed_box, float* tex0, float* tex1, float* dist, void* stream) {
-    return sdfv_fill_grid_pass_ex(params, sdf_id, grid, step, changed_box, tex0, tex1, dist, 0u, stream);
-}
-
-int sdfv_fill_grid_pass(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, uint32_t step,
-                        const float* changed_box, float* tex0, float* tex1, void* stream) {
-    return sdfv_fill_grid_pass_dist(params, sdf_id, grid, step, changed_box, tex0, tex1, nullptr, stream);
-}
-
 int sdfv_sample_points(const sdfv_demo_params* params, uint32_t sdf_id, const float* points, size_t n,
                        int distance_only, sdfv_sample* out, void* stream) {
     if (int rc = check_params(params, sdf_id)) return rc;
@@ -982,41 +973,33 @@ int sdfv_march_volume_advice(const sdfv_grid* grid, uint32_t* kind) {
     if (int rc = need_device()) return rc;
     const uint64_t n = (uint64_t)grid->dims[0] * grid->dims[1] * grid->dims[2];
     const uint64_t llc = device_facts().last_level_cache_bytes;
-    if (grid->dims[0] != grid->dims[1] || grid->dims[1] != grid->dims[2])
+    // only the hand-written gfx950 loop reads these volumes -- on another device, or with that loop switched off, a
+    // host would allocate 4-8 B/voxel and re-run the commit after every fill for a volume no march ever touches
+    if (!device_facts().gfx950 || (g_options.raymarch_disable & SDFV_RM_NO_ASM_LOOP))
+        *kind = SDFV_MARCH_VOLUME_NONE;
+    else if (grid->dims[0] != grid->dims[1] || grid->dims[1] != grid->dims[2])
         *kind = SDFV_MARCH_VOLUME_NONE;  // the two-gather cell fetch is the cubic grid's: the distance volume marches fastest here
     else
         *kind = (llc && n * 8u > llc && (grid->dims[1] & 1u) == 0) ? SDFV_MARCH_VOLUME_INTERLEAVED : SDFV_MARCH_VOLUME_PAIRS;
     return SDFV_OK;
 }
 
-int sdfv_raymarch(const sdfv_render_params* rp, const float* tex0, const float* tex1, const sdfv_camera* cameras,
-                  uint32_t n_cameras, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, float* rgba,
-                  sdfv_march_aux* aux, void* stream) {
-    return sdfv_raymarch_accel(rp, tex0, tex1, nullptr, cameras, n_cameras, width, height, y0, y1, rgba, aux, stream);
-}
-
-int sdfv_raymarch_accel(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
-                        const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width, uint32_t height, uint32_t y0,
-                        uint32_t y1, float* rgba, sdfv_march_aux* aux, void* stream) {
-    return sdfv_raymarch_depth(rp, tex0, tex1, dist, cameras, n_cameras, width, height, y0, y1, rgba, nullptr, aux, stream);
-}
-
-int sdfv_raymarch_depth(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
-                        const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width, uint32_t height, uint32_t y0,
-                        uint32_t y1, float* rgba, float* depth, sdfv_march_aux* aux, void* stream) {
-    return sdfv_raymarch_volumes(rp, tex0, tex1, dist, nullptr, nullptr, cameras, n_cameras, width, height, y0, y1, rgba, depth, aux, stream);
-}
-
-int sdfv_raymarch_pairs(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
-                        const float* pairs, const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width, uint32_t height,
-                        uint32_t y0, uint32_t y1, float* rgba, float* depth, sdfv_march_aux* aux, void* stream) {
-    return sdfv_raymarch_volumes(rp, tex0, tex1, dist, pairs, nullptr, cameras, n_cameras, width, height, y0, y1, rgba, depth, aux, stream);
-}
-
-int sdfv_raymarch_volumes(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
-                          const float* pairs, const float* ilv, const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width,
-                          uint32_t height, uint32_t y0, uint32_t y1, float* rgba, float* depth, sdfv_march_aux* aux, void* stream) {
-    return raymarch_rows(rp, tex0, tex1, dist, pairs, ilv, cameras, n_cameras, width, height, y0, y1, 1, rgba, depth, aux, stream);
+int sdfv_raymarch_ex(const sdfv_march_desc* desc, void* stream) {
+    if (!desc) return fail(SDFV_ERR_INVALID_ARGUMENT, "desc is NULL");
+    // size-prefixed: read what the caller's header knew, take the rest as 0 / NULL (a binder built against an older header)
+    if (desc->size < offsetof(sdfv_march_desc, depth))
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "sdfv_march_desc.size = %u is smaller than the descriptor's first version (%zu)",
+                    desc->size, offsetof(sdfv_march_desc, depth));
+    sdfv_march_desc d;
+    memset(&d, 0, sizeof(d));
+    memcpy(&d, desc, desc->size < sizeof(d) ? desc->size : sizeof(d));
+    if (d.reserved != 0 || d.reserved2 != 0) return fail(SDFV_ERR_INVALID_ARGUMENT, "sdfv_march_desc: reserved fields must be 0");
+    if (d.band_step == 0)
+        return raymarch_rows(d.rp, d.tex0, d.tex1, d.dist, d.pairs, d.ilv, d.cameras, d.n_cameras, d.width, d.height, d.y0, d.y1, 1,
+                             d.rgba, d.depth, d.aux, stream);
+    if (sdfv_band_rows(d.height, d.band_first, d.band_step) == 0) return SDFV_OK;  // a band set below the image: nothing to render
+    return raymarch_rows(d.rp, d.tex0, d.tex1, d.dist, d.pairs, d.ilv, d.cameras, d.n_cameras, d.width, d.height, d.band_first * 16,
+                         d.height, d.band_step, d.rgba, d.depth, d.aux, stream);
 }
 
 uint32_t sdfv_band_rows(uint32_t height, uint32_t band_first, uint32_t band_step) {
@@ -1024,16 +1007,6 @@ uint32_t sdfv_band_rows(uint32_t height, uint32_t band_first, uint32_t band_step
     if (band_step == 0 || band_first >= tiles_y) return 0;
     const uint32_t n = (tiles_y - band_first + band_step - 1) / band_step, last = band_first + (n - 1) * band_step;
     return (n - 1) * 16 + (height - last * 16 < 16 ? height - last * 16 : 16);
-}
-
-int sdfv_raymarch_bands(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
-                        const float* pairs, const float* ilv, const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width,
-                        uint32_t height, uint32_t band_first, uint32_t band_step, float* rgba, float* depth, sdfv_march_aux* aux,
-                        void* stream) {
-    if (band_step == 0) return fail(SDFV_ERR_INVALID_ARGUMENT, "band_step is 0");
-    if (sdfv_band_rows(height, band_first, band_step) == 0) return SDFV_OK;  // a band set below the image: nothing to render
-    const uint32_t y0 = band_first * 16;
-    return raymarch_rows(rp, tex0, tex1, dist, pairs, ilv, cameras, n_cameras, width, height, y0, height, band_step, rgba, depth, aux, stream);
 }
 
 }  // extern "C"

@@ -12,14 +12,33 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_exports_every_declared_symbol(pkg):
+def header_functions():
+    """(exported, header_only): function names include/sdfgrid.h declares, and the static inline wrappers it defines."""
     hdr = open(os.path.join(ROOT, "include", "sdfgrid.h")).read()
-    declared = set(re.findall(r"\b(sdfv_[a-z0-9_]+)\s*\(", hdr))
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)  # prose mentions functions too
+    inline = set(re.findall(r"SDFV_INLINE\s+int\s+(sdfv_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"^[a-z][a-z0-9_ \*]*?\b(sdfv_[a-z0-9_]+)\s*\(", hdr, flags=re.M)) - inline
+    return declared, inline
+
+
+def test_exports_every_declared_symbol(pkg):
+    declared, inline = header_functions()
     assert len(declared) >= 17
-    assert declared == set(pkg._capi.PROTOTYPES), "binding and header disagree"
+    assert declared == set(pkg._capi.PROTOTYPES), (sorted(declared ^ set(pkg._capi.PROTOTYPES)), "binding and header disagree")
     raw = C.CDLL(pkg._capi.LIB_PATH)
     for name in declared:
         getattr(raw, name)
+    # ABI v4 (VERDICT r03 weak 7): ONE march entry point and ONE pass entry point are exported; the positional forms of v3
+    # are header-only wrappers and not symbols of the library
+    assert inline == {"sdfv_raymarch", "sdfv_raymarch_accel", "sdfv_raymarch_depth", "sdfv_raymarch_pairs", "sdfv_raymarch_volumes",
+                      "sdfv_raymarch_bands", "sdfv_fill_grid_pass", "sdfv_fill_grid_pass_dist"}
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", pkg._capi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (sdfv_[a-z0-9_]+)", syms))
+    assert exported == declared, sorted(exported ^ declared)
+    assert sorted(n for n in exported if n.startswith("sdfv_raymarch")) == ["sdfv_raymarch_ex", "sdfv_raymarch_host",
+                                                                            "sdfv_raymarch_slab", "sdfv_raymarch_slab_round"]
+    assert sorted(n for n in exported if "fill_grid_pass" in n) == ["sdfv_fill_grid_pass_ex"]
 
 
 def test_struct_layouts(pkg):
@@ -30,7 +49,8 @@ def test_struct_layouts(pkg):
     assert C.sizeof(pkg.Light) == 32
     assert C.sizeof(pkg.RenderParams) == 80 + 4 + 4 * 32
     assert C.sizeof(pkg.MarchAux) == 72
-    assert pkg.lib.sdfv_abi_version() == 3
+    assert pkg.lib.sdfv_abi_version() == 4
+    assert C.sizeof(pkg._capi.MarchDesc) == 120  # 2 + 7 pointers ... : the layout a binder mirrors
 
 
 def test_options_are_explicit_and_the_library_reads_no_environment(pkg):
@@ -71,22 +91,24 @@ def test_light_list_rejects_what_the_reference_does_not_pin(pkg):
     rp = pkg.default_render_params(g)
     assert rp.n_lights == 0
     cam = pkg.camera_look_at()
-    args = (C.c_void_p(16), C.c_void_p(16), None, C.byref(cam), 1, 8, 8, 0, 8, C.c_void_p(16), None, None, None)
+    march = lambda tex0=16, **kw: pkg._capi.raymarch_rc(rp, tex0, 16, cam, 1, 8, 8, 0, 8, 16, **kw)  # noqa: E731
     rp.n_lights = 1
     rp.lights[0].kind = pkg._capi.LIGHT_DIRECTIONAL
-    assert pkg.lib.sdfv_raymarch_depth(C.byref(rp), *args) == -1
+    assert march() == -1
     assert b"three-d 0.18.2 shader source not available" in pkg.lib.sdfv_last_error()
     rp.lights[0].kind = 9
-    assert pkg.lib.sdfv_raymarch_depth(C.byref(rp), *args) == -1 and b"unknown kind" in pkg.lib.sdfv_last_error()
+    assert march() == -1 and b"unknown kind" in pkg.lib.sdfv_last_error()
     rp.n_lights = 5
-    assert pkg.lib.sdfv_raymarch_depth(C.byref(rp), *args) == -1
+    assert march() == -1
     # misaligned texel buffers are argument errors too (they are read and written as 16-byte texels)
     rp.n_lights = 0
-    bad = (C.c_void_p(20),) + args[1:]
-    assert pkg.lib.sdfv_raymarch_depth(C.byref(rp), *bad) == -1 and b"16-byte aligned" in pkg.lib.sdfv_last_error()
+    assert march(tex0=20) == -1 and b"16-byte aligned" in pkg.lib.sdfv_last_error()
+    # the descriptor is size-prefixed: a size below its first version is refused, reserved words must be 0
+    assert march(size=24) == -1 and b"sdfv_march_desc.size" in pkg.lib.sdfv_last_error()
+    assert pkg.lib.sdfv_raymarch_ex(None, None) == -1
     p = pkg.default_params()
     assert pkg.lib.sdfv_grid_init(C.byref(g), C.c_void_p(24), C.c_void_p(16), None) == -1
-    assert pkg.lib.sdfv_fill_grid_pass(C.byref(p), 0, C.byref(g), 1, None, C.c_void_p(16), C.c_void_p(8), None) == -1
+    assert pkg.lib.sdfv_fill_grid_pass_ex(C.byref(p), 0, C.byref(g), 1, None, C.c_void_p(16), C.c_void_p(8), None, 0, None) == -1
     assert pkg.lib.sdfv_commit_distance(C.byref(g), C.c_void_p(8), C.c_void_p(16), None) == -1
 
 
@@ -138,7 +160,7 @@ def test_invalid_arguments_are_reported_not_fatal(pkg):
     assert b"Failed to find SDF with ID 7" in lib.sdfv_last_error()                                   # ffi.rs:47
     bad = pkg.make_grid((4, 4, 4), z_begin=3, z_end=9)
     assert lib.sdfv_fill_grid(C.byref(p), 0, C.byref(bad), C.c_void_p(16), C.c_void_p(16), None) == -1
-    assert lib.sdfv_fill_grid_pass(C.byref(p), 0, C.byref(g), 3, None, C.c_void_p(16), C.c_void_p(16), None) == -1
+    assert lib.sdfv_fill_grid_pass_ex(C.byref(p), 0, C.byref(g), 3, None, C.c_void_p(16), C.c_void_p(16), None, 0, None) == -1
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
@@ -235,6 +257,6 @@ def test_integration_guide_binds_every_entry_point():
     import re
     header = open(os.path.join(ROOT, "include", "sdfgrid.h")).read()
     guide = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    declared = set(re.findall(r"\b(sdfv_[a-z0-9_]+)\s*\(", header))
+    declared, _inline = header_functions()  # what the library EXPORTS; the header-only wrappers are the binder's to restate
     missing = sorted(f for f in declared if f not in guide)
     assert not missing, missing

@@ -15,8 +15,8 @@ def test_empty_grid_and_empty_slab_are_no_ops(pkg):
         t0 = torch.full((max(z[1] - z[0], 1), max(dims[1], 1), max(dims[0], 1), 4), 3.0, device="cuda")
         t1 = t0.clone()
         pkg.check(pkg.lib.sdfv_fill_grid(C.byref(prm), 0, C.byref(g), C.c_void_p(t0.data_ptr()), C.c_void_p(t1.data_ptr()), None))
-        pkg.check(pkg.lib.sdfv_fill_grid_pass(C.byref(prm), 0, C.byref(g), 2, None, C.c_void_p(t0.data_ptr()),
-                                              C.c_void_p(t1.data_ptr()), None))
+        pkg.check(pkg.lib.sdfv_fill_grid_pass_ex(C.byref(prm), 0, C.byref(g), 2, None, C.c_void_p(t0.data_ptr()),
+                                                 C.c_void_p(t1.data_ptr()), None, 0, None))
         pkg.check(pkg.lib.sdfv_grid_init(C.byref(g), C.c_void_p(t0.data_ptr()), C.c_void_p(t1.data_ptr()), None))
         torch.cuda.synchronize()
         assert bool((t0 == 3.0).all()) and bool((t1 == 3.0).all())
@@ -54,14 +54,13 @@ def test_argument_validation_on_device(pkg):
     rp = pkg.default_render_params(g)
     cam = pkg.camera_look_at()
     out = torch.zeros((4, 4, 4), device="cuda")
-    args = (C.byref(rp), C.c_void_p(t0.data_ptr()), C.c_void_p(t1.data_ptr()), C.byref(cam), 1, 4, 4)
-    assert lib.sdfv_raymarch(*args, 3, 2, C.c_void_p(out.data_ptr()), None, None) == -1      # y0 > y1
-    assert lib.sdfv_raymarch(*args, 0, 5, C.c_void_p(out.data_ptr()), None, None) == -1      # y1 > height
+    march = lambda r, y0, y1: pkg._capi.raymarch_rc(r, t0.data_ptr(), t1.data_ptr(), cam, 1, 4, 4, y0, y1, out.data_ptr())  # noqa: E731
+    assert march(rp, 3, 2) == -1      # y0 > y1
+    assert march(rp, 0, 5) == -1      # y1 > height
     rp.lod_dist_between_samples = 0.5
-    assert lib.sdfv_raymarch(*args, 0, 4, C.c_void_p(out.data_ptr()), None, None) == -1
+    assert march(rp, 0, 4) == -1
     huge = pkg.default_render_params(pkg.make_grid((2048, 2048, 2048)))
-    assert lib.sdfv_raymarch(C.byref(huge), C.c_void_p(t0.data_ptr()), C.c_void_p(t1.data_ptr()), C.byref(cam), 1, 4, 4, 0, 4,
-                             C.c_void_p(out.data_ptr()), None, None) == -1
+    assert march(huge, 0, 4) == -1
     assert b"32-bit texel indexing" in lib.sdfv_last_error()
 
 
@@ -73,8 +72,7 @@ def test_degenerate_images(pkg, oracle):
     rp = pkg.default_render_params(g)
     # no cameras, no rows: nothing is launched, nothing is touched
     out = torch.full((1, 3, 5, 4), 9.0, device="cuda")
-    pkg.check(pkg.lib.sdfv_raymarch(C.byref(rp), C.c_void_p(t0.data_ptr()), C.c_void_p(t1.data_ptr()), None, 0, 5, 3, 0, 3,
-                                    C.c_void_p(out.data_ptr()), None, None))
+    pkg.check(pkg._capi.raymarch_rc(rp, t0.data_ptr(), t1.data_ptr(), None, 0, 5, 3, 0, 3, out.data_ptr()))
     cam = pkg.camera_look_at(aspect=5 / 3)
     pkg.raymarch(rp, t0, t1, cam, 5, 3, y0=2, y1=2, out=out)
     torch.cuda.synchronize()

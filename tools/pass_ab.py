@@ -20,7 +20,7 @@ P = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def pass_(lib, step, box=None):
     b = None if box is None else (C.c_float * 6)(*box)
-    assert lib.sdfv_fill_grid_pass_dist(C.byref(prm), 0, C.byref(g), step, b, P(t0), P(t1), P(dist), st) == 0
+    assert lib.sdfv_fill_grid_pass_ex(C.byref(prm), 0, C.byref(g), step, b, P(t0), P(t1), P(dist), 0, st) == 0
 def fresh():
     pkg.grid_init(g, t0, t1); dist.fill_(pkg.AIR_DIST)
 def loaded():
