@@ -169,9 +169,23 @@ def progressive_block(pkg, torch, prm, sides, reps=7):
                                                "changed_box = [-0.5, 0.5]^3 (1/8 of the volume); updated count approximate for step > 1")
         res["noop_pass_step_1"] = case(timed(passes((1,)), loaded), n, 0, "step-1 pass over a loaded grid, no box: reads the volume, writes nothing")
         res["dense_fused_fill_ms"] = round(timed(lambda: pkg.fill_grid(prm, g, t0, t1, dist=dist), lambda: None), 4)
+        # HBM bytes per case from the committed PMC passes, and the same kernels' durations under rocprofv3 (warm, 100
+        # repetitions: tools/gpu_profile_pass.sh -> profiles/r04_pass_traffic.json) next to the times measured here
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r04_pass_traffic.json")))[str(side)]["cases"]
+        except Exception:  # noqa: BLE001
+            prof = {}
+        for name, c in res.items():
+            p = prof.get(name) if isinstance(c, dict) else None
+            if p and p.get("complete"):
+                c["traffic"] = p["hbm_bytes"]
+                c["traffic_over_algorithmic"] = round(p["hbm_bytes"] / c["algorithmic_bytes"], 3)
+                c["rocprof_ms"] = p["rocprof_ms"]
         out[str(side)] = res
         del t0, t1, dist
-    out["note"] = ("sdfv_fill_grid_pass_dist; frac = (36 B x updated + 4 B x visited-only voxels) / ms / 8 TB/s; every intermediate "
+    out["note"] = ("sdfv_fill_grid_pass_ex; traffic = HBM bytes of the case's kernels from the committed PMC passes (WRITE_SIZE + 2 x "
+                   "FETCH_SIZE), rocprof_ms = their kernel-only durations under rocprofv3 (no launch gaps: a few us per pass below "
+                   "`ms`); frac = (36 B x updated + 4 B x visited-only voxels) / ms / 8 TB/s; every intermediate "
                    "state is bit-identical to the oracle's LoadingManager loop (tests/test_gpu_fill.py)")
     return out
 

@@ -93,9 +93,12 @@ def compare(pkg, oracle, g, t0, t1, h0, h1, cam_kw, width, height, rp_edit=None,
 
 
 def test_default_camera_64(pkg, oracle):
-    """configs[0]: 64^3 grid, the reference's default camera (scene/mod.rs:82-95)."""
+    """configs[0] as BASELINE.json words it: 64^3 grid, 512 x 512 sphere-trace, the reference's default camera
+    (scene/mod.rs:82-95) -- every pixel, every march variant, against the oracle (this ran at 160 x 120)."""
     env = setup_grid(pkg, oracle, (64, 64, 64))
-    rgba, aux = compare(pkg, oracle, *env, cam_kw={}, width=160, height=120)
+    rgba, aux = compare(pkg, oracle, *env, cam_kw={}, width=512, height=512)
+    assert (aux["status"] == 1).sum() > 20000 and (aux["status"] == 0).sum() > 20000
+    rgba, aux = compare(pkg, oracle, *env, cam_kw={}, width=160, height=120)  # (an image that is not a multiple of the tile)
     assert (aux["status"] == 1).sum() > 1000 and (aux["status"] == 0).sum() > 1000
 
 
