@@ -90,8 +90,8 @@ def parse_args():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-overlapped", action="store_true",
                     help="N=1: skip the double-buffered (fill of step k+1 beside the march of step k) measurement")
-    ap.add_argument("--pipeline", choices=["both", "plain", "fused"], default="both",
-                    help="N=1: time both pipelines and report the faster one (default), or only one (profiling runs: "
+    ap.add_argument("--pipeline", choices=["both", "plain", "fused", "fused_ilv"], default="both",
+                    help="N=1: time all pipelines and report the fastest one (default \"both\", a name from when there were two), or only one (profiling runs: "
                          "per-kernel rocprof averages then belong to one kernel variant)")
     ap.add_argument("--no-progressive", action="store_true",
                     help="N=1: skip the progressive / changed_box block (LoadingManager passes, SURVEY 8(f)1)")
@@ -426,6 +426,23 @@ def run(redirect):
             march_dist_ms, march_dist_ev = region(lambda: pkg.raymarch(rp, owned0, owned1, cam0, W, H, out=rgba, dist=dist_vol),
                                                   K, Wm, torch, dist, 1, device)
             inter_fused_ms = both({"dist": dist_vol}, {"dist": dist_vol})
+        # third pipeline (round 4): the fused fill writes the march's y-INTERLEAVED volume itself (SDFV_PASS_VOLUME_INTERLEAVED: a
+        # step-1 virgin pass = the dense kernel, textures + that volume, 36 B/voxel) and the march gathers from it -- what
+        # SDFViewer does for grids beyond the last-level cache; no commit pass between the two
+        fill_ilv_ms = fill_ilv_ev = march_ilv_ms = march_ilv_ev = inter_ilv_ms = INF
+        ILV_FLAGS = pkg._capi.PASS_VIRGIN_GRID | pkg._capi.PASS_VOLUME_INTERLEAVED
+        if args.pipeline in ("both", "fused_ilv") and side % 2 == 0:
+            ilv_vol = torch.empty((side, side, side), dtype=torch.float32, device=device)
+
+            def fill_ilv():
+                pkg.fill_grid_pass(prm, grid, 1, owned0, owned1, dist=ilv_vol, flags=ILV_FLAGS)
+
+            def march_ilv():
+                pkg.raymarch(rp, owned0, owned1, cam0, W, H, out=rgba, ilv=ilv_vol)
+
+            fill_ilv_ms, fill_ilv_ev = region(fill_ilv, K, Wm, torch, dist, 1, device)
+            march_ilv_ms, march_ilv_ev = region(march_ilv, K, Wm, torch, dist, 1, device)
+            inter_ilv_ms = region(lambda: (fill_ilv(), march_ilv()), K, Wm, torch, dist, 1, device)[0]
         # The fused pipeline software-pipelined over TWO sets of buffers and two streams: the march of step k (latency-bound on
         # a few long waves, most of the machine idle) runs beside the fill of step k + 1 (HBM-store-bound) -- what the
         # reference's own frame loop does on one thread in turns (scene/mod.rs:166-200: fill passes and the render of the
@@ -482,15 +499,28 @@ def run(redirect):
                       "fill_frac_of_hbm_peak": round(36 * voxels_per_rank / (fill_fused_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       "fill_frac_8d": round(32 * voxels_per_rank / (fill_fused_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
-        chosen = "fused" if fill_fused_ms + march_dist_ms < fill_plain_ms + march_tex0_ms else "plain"
+        pipes["fused_ilv"] = {"fill": "sdfv_fill_grid_pass_ex(step 1, VIRGIN_GRID | VOLUME_INTERLEAVED) (36 B/voxel: textures + the y-interleaved volume)",
+                              "march": "sdfv_raymarch_ex over that volume (desc.ilv)",
+                              "ms_fill": round(fill_ilv_ms, 4), "ms_raymarch": round(march_ilv_ms, 4),
+                              "ms_per_step": round(fill_ilv_ms + march_ilv_ms, 4), "ms_per_step_interleaved": round(inter_ilv_ms, 4),
+                              "Mvoxels_s": round(voxels_per_rank / fill_ilv_ms / 1e3, 1), "Mrays_s": round(W * H / march_ilv_ms / 1e3, 1),
+                              "fill_frac_of_hbm_peak": round(36 * voxels_per_rank / (fill_ilv_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "fill_frac_8d": round(32 * voxels_per_rank / (fill_ilv_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        totals = {"plain": fill_plain_ms + march_tex0_ms, "fused": fill_fused_ms + march_dist_ms, "fused_ilv": fill_ilv_ms + march_ilv_ms}
+        chosen = min(totals, key=totals.get)
         if chosen == "fused":
             fill_ms, march_ms, kern_ms, march_ev, bpv = fill_fused_ms, march_dist_ms, fill_fused_ev, march_dist_ev, 36
+        elif chosen == "fused_ilv":
+            fill_ms, march_ms, kern_ms, march_ev, bpv = fill_ilv_ms, march_ilv_ms, fill_ilv_ev, march_ilv_ev, 36
         else:
             fill_ms, march_ms, kern_ms, march_ev, bpv = fill_plain_ms, march_tex0_ms, fill_plain_ev, march_tex0_ev, 32
         fill_mvox = voxels_per_rank / fill_ms / 1e3
         march_mrays = W * H / march_ms / 1e3
         # the distribution behind the two means (SURVEY 8d asks for the median): launches timed one by one
-        if chosen == "fused":
+        if chosen == "fused_ilv":
+            st_fill = per_step_stats(fill_ilv, args.per_step_samples, torch)
+            st_march = per_step_stats(march_ilv, args.per_step_samples, torch)
+        elif chosen == "fused":
             st_fill = per_step_stats(lambda: pkg.fill_grid(prm, grid, owned0, owned1, dist=dist_vol), args.per_step_samples, torch)
             st_march = per_step_stats(lambda: pkg.raymarch(rp, owned0, owned1, cam0, W, H, out=rgba, dist=dist_vol),
                                       args.per_step_samples, torch)
@@ -509,18 +539,20 @@ def run(redirect):
         out["pipeline"] = chosen
         out["pipeline_plain"] = pipes["plain"] if args.pipeline in ("both", "plain") else None
         out["pipeline_fused"] = pipes["fused"] if args.pipeline in ("both", "fused") else None
-        out["pipeline_note"] = ("two consistent pipelines over the same buffers; value, value_rays, ms_per_step and "
+        out["pipeline_fused_ilv"] = pipes["fused_ilv"] if (args.pipeline in ("both", "fused_ilv") and side % 2 == 0) else None
+        out["pipeline_note"] = ("three consistent pipelines over the same buffers (plain; fused = + the distance volume; fused_ilv = + the "
+                                "y-interleaved volume instead); value, value_rays, ms_per_step and "
                                 "roofline all come from `pipeline` (the faster one end to end); *_interleaved = K steps "
                                 "of fill immediately followed by its march in one timed region")
         out["pipeline_overlapped"] = overlapped
         out["commit_ms"] = round(commit_ms, 4) if commit_ms != INF else None
         out["commit_note"] = ("sdfv_commit_distance as a pass of its own (device-side SDFViewer::commit for a grid filled "
                               "without the volume); not part of either pipeline")
-        traffic = load_traffic(args.workload + ("_fused" if bpv == 36 else ""))
+        traffic = load_traffic(args.workload + ("_fused" if bpv == 36 else ""))  # (the interleaved variant stores the same bytes)
         out["roofline"] = fill_roofline(kern_ms, voxels_per_rank, bpv, traffic)
         out["roofline_raymarch"] = raymarch_traffic_report(args.workload, march_ev,
-                                                           "product_path" if chosen == "fused" else "tex0_path",
-                                                           args.workload + ("" if chosen == "fused" else "_tex0"))
+                                                           "tex0_path" if chosen == "plain" else "product_path",
+                                                           args.workload + ("_tex0" if chosen == "plain" else ""))
         transport, filler = None, None
         my_cams, r0, r1 = [cam0], owned0, owned1
     else:

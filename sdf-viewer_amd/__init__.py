@@ -159,10 +159,11 @@ def grid_init(grid, tex0, tex1, stream=None):
     check(lib.sdfv_grid_init(C.byref(grid), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"), _stream_ptr(stream)))
 
 
-def grid_init_unvisited(grid, step, tex0, tex1, dist=None, stream=None):
-    """[AIR_DIST; 4] into the rows a pass with `step` does not visit (0: every row) -- sdfv_grid_init_unvisited."""
-    check(lib.sdfv_grid_init_unvisited(C.byref(grid), int(step), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"),
-                                       None if dist is None else _dev_ptr(dist, "dist"), _stream_ptr(stream)))
+def grid_init_unvisited(grid, step, tex0, tex1, dist=None, stream=None, flags=0):
+    """[AIR_DIST; 4] into the rows a pass with `step` does not visit (0: every row) -- sdfv_grid_init_unvisited[_ex]; flags:
+    _capi.PASS_VOLUME_INTERLEAVED when `dist` is laid out y-interleaved."""
+    check(lib.sdfv_grid_init_unvisited_ex(C.byref(grid), int(step), _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"),
+                                          None if dist is None else _dev_ptr(dist, "dist"), int(flags), _stream_ptr(stream)))
 
 
 def fill_grid(params, grid, tex0, tex1, sdf_id=SDF_DEMO, stream=None, dist=None):

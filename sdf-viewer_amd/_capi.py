@@ -95,6 +95,7 @@ PROTOTYPES = {
                                       C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float]),
     "sdfv_grid_init": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_grid_init_unvisited": (C.c_int, [C.POINTER(Grid), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdfv_grid_init_unvisited_ex": (C.c_int, [C.POINTER(Grid), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "sdfv_fill_grid": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
     "sdfv_tune_texture_placement": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
@@ -192,7 +193,7 @@ OPT_TUNING_PRIORITY_MAP = 101
 OPT_TUNING_TILE_ORDER = 102
 RM_NO_FAST_INDEX, RM_NO_POW2_EXTENT, RM_NO_POW2_SIZE, RM_NO_SYMMETRIC, RM_NO_ASM_LOOP, RM_NO_INTERIOR_FETCH = 1, 2, 4, 8, 16, 32
 STEP_SIDE_BOUNDARY, STEP_UNPACKED, STEP_START_EVENT, STEP_DEFER_JOIN = 3, 4, 8, 16
-PASS_FRESH_GRID, PASS_SAME_LOAD, PASS_VIRGIN_GRID = 1, 2, 4
+PASS_FRESH_GRID, PASS_SAME_LOAD, PASS_VIRGIN_GRID, PASS_VOLUME_INTERLEAVED = 1, 2, 4, 8
 FILL_FORM = {"auto": 0, "rows": 1, "flat": 2}
 PLACEMENT_SLACK = 64 << 10
 COMM_ID_BYTES = 128

@@ -26,6 +26,10 @@ struct FillArgs {
     float4* tex1;
     float* dist;             // optional compact copy of tex0.r written in the same pass (fused SDFViewer::commit)
     uint32_t srgb_round;     // Srgba::from policy (SDFV_OPT_EXT_SRGB_QUANT): 0 truncate (default), 1 round
+    uint32_t dist_ilv;       // layout of `dist` (and PassArgs::dist): 0 = one float per voxel in texture order; 1 = y-interleaved
+                             // (rows 2p, 2p + 1 of the slab as one row of pairs: entry ((row >> 1) * W + x) * 2 + (row & 1), H even) --
+                             // the layout the march's hand-written loop gathers fastest from beyond the last-level cache, written
+                             // by the fill itself instead of by a commit pass
     // ---- boundary-first order (multi-GPU fill step, launch_fill_dense_ordered) ----
     // The slab's `order_lead` first slices and its last slice are the ones the z-neighbours wait for: the workgroups
     // that fill them come FIRST in dispatch order, the interior follows in memory order.
@@ -99,6 +103,6 @@ hipError_t launch_commit_interleaved(const float* dist, float* ilv, uint32_t W, 
 hipError_t launch_grid_init(float* tex0, float* tex1, uint64_t n_voxels, float air, hipStream_t stream);
 // [air; 4] (+ dist = air) into every row of the slab whose y or global z is not a multiple of step (step 0: every row)
 hipError_t launch_grid_init_unvisited(float* tex0, float* tex1, float* dist, uint32_t W, uint32_t H, uint32_t z_begin,
-                                      uint32_t slab_d, uint32_t step, float air, hipStream_t stream);
+                                      uint32_t slab_d, uint32_t step, float air, uint32_t dist_ilv, hipStream_t stream);
 
 }  // namespace sdfv

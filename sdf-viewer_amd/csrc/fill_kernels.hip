@@ -42,6 +42,11 @@ __device__ __forceinline__ void store_texel(float4* dst, const float4& v) {
     }
 }
 
+// Entry of the distance volume for voxel x of slab row `row` (= z_local * H + y) in either layout (FillArgs::dist_ilv).
+__device__ __forceinline__ uint64_t vol_index(uint32_t ilv, uint64_t row, uint32_t x, uint32_t W) {
+    return ilv ? ((row >> 1) * W + x) * 2 + (row & 1) : row * W + x;
+}
+
 // TX = lanes along x per row segment (64, 128 or 256); a workgroup owns TY = 256 / TX consecutive rows x TX
 // voxels and does ONE voxel per thread, so the grid walks memory front to back in dispatch order exactly
 // like a memset.  Measured on MI355X (profiles/r01/v1_fill_sweep.json, r01/v2_fill_sweep.json): persistent
@@ -114,16 +119,30 @@ __global__ __launch_bounds__(kBlock) void fill_dense_kernel(FillArgs a) {
     const uint32_t tx = tid % TX, ty = tid / TX;
     const uint32_t x = chunk * TX + tx;
     const uint32_t row = row0 + ty;
-    if (!ORDERED && (x >= a.W || row >= n_rows)) return;  // ordered launches cover whole workgroups only
-    const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
-    const float2 yz = s_yz[ty];
-    float4 v0, v1;
-    fill_voxel<Cfg>(a.prm, a.sdf_id, px, yz.x, yz.y, lut, a.air_dist, v0, v1);
+    const bool in_range = ORDERED || (x < a.W && row < n_rows);  // ordered launches cover whole workgroups only
+    const bool ilv = !ORDERED && TY >= 2 && a.dist_ilv;          // block-uniform; the launcher picks TY >= 2 for this layout
+    if (!ilv && !in_range) return;
+    float4 v0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), v1 = v0;
     const uint64_t o = (uint64_t)row * a.W + x;
-    if (!ORDERED || !a.stage_only) {
-        store_texel<NT>(a.tex0 + o, v0);
-        store_texel<NT>(a.tex1 + o, v1);
-        if (a.dist) a.dist[o] = v0.x;  // wave-uniform: +4 B/voxel instead of a second pass over tex0
+    if (in_range) {
+        const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
+        const float2 yz = s_yz[ty];
+        fill_voxel<Cfg>(a.prm, a.sdf_id, px, yz.x, yz.y, lut, a.air_dist, v0, v1);
+        if (!ORDERED || !a.stage_only) {
+            store_texel<NT>(a.tex0 + o, v0);
+            store_texel<NT>(a.tex1 + o, v1);
+            if (a.dist && !ilv) a.dist[o] = v0.x;  // wave-uniform: +4 B/voxel instead of a second pass over tex0
+        }
+    }
+    if (ilv) {
+        // y-interleaved volume: rows 2p and 2p + 1 of this workgroup meet in LDS and leave as ONE row of pairs -- 8-byte
+        // stores, whole lines, from the workgroup that computed both (two workgroups writing the halves of a line would make
+        // the memory side merge partial lines).  row0 is even (TY even), and so is the slab's row count (H even).
+        __shared__ float s_d[kBlock];
+        s_d[tid] = v0.x;
+        __syncthreads();
+        if ((ty & 1u) == 0 && in_range)
+            reinterpret_cast<float2*>(a.dist)[(uint64_t)(row >> 1) * a.W + x] = make_float2(s_d[tid], s_d[tid + TX]);
     }
     if (ORDERED && ob.boundary) store_staged(a, ob, o, v0, v1);  // wave-uniform
 }
@@ -218,7 +237,8 @@ __device__ __forceinline__ bool maybe_in_box(const FillArgs& a, const PassArgs& 
 // workgroups of a pass over a loaded grid have nothing to update and would pay the staging and its barrier for nothing; the
 // few lookups (the "normal" material only) read the 1 KiB table through the caches.
 template <typename Cfg>
-__device__ __forceinline__ void pass_store(const FillArgs& a, const PassArgs& p, float px, float py, float pz, uint64_t flat) {
+__device__ __forceinline__ void pass_store(const FillArgs& a, const PassArgs& p, float px, float py, float pz, uint64_t flat,
+                                           uint64_t row, uint32_t x) {
     const LdsLut lut{c_srgb_lut};
     float4 v0, v1;
     fill_voxel<Cfg>(a.prm, a.sdf_id, px, py, pz, lut, a.air_dist, v0, v1);
@@ -229,7 +249,7 @@ __device__ __forceinline__ void pass_store(const FillArgs& a, const PassArgs& p,
     if (p.dist) {
         // The volume's contract: the textures were initialised / filled by this library, so tex1.a holds AIR_DIST
         // everywhere (update() never writes it, scene/sdf/mod.rs:205-208) and need not be read back.
-        p.dist[flat] = v0.x;
+        p.dist[vol_index(a.dist_ilv, row, x, a.W)] = v0.x;
         v1.w = a.air_dist;
     } else {
         // tex1.a is not update()'s to touch: carry the stored value through a full 16-byte store (12-byte partial
@@ -249,9 +269,10 @@ __global__ __launch_bounds__(kBlock) void fill_pass_kernel(FillArgs a, PassArgs 
     const uint32_t r = div_u32(i, p.div_nx), ix = i - r * p.nx;
     const uint32_t iz = div_u32(r, p.div_ny), iy = r - iz * p.ny;
     const uint32_t x = ix * p.step, y = iy * p.step, z = p.z_first + iz * p.step;  // global z
-    const uint64_t flat = ((uint64_t)(z - a.z_begin) * a.H + y) * a.W + x;
+    const uint64_t row = (uint64_t)(z - a.z_begin) * a.H + y;
+    const uint64_t flat = row * a.W + x;
     if (!p.all_required) {
-        const bool is_air = (p.dist ? p.dist[flat] : a.tex0[flat].x) == a.air_dist;
+        const bool is_air = (p.dist ? p.dist[vol_index(a.dist_ilv, row, x, a.W)] : a.tex0[flat].x) == a.air_dist;
         // most visited voxels of a loaded grid need nothing: leave before paying three correctly rounded divides
         if (!is_air && (!p.has_box || !maybe_in_box(a, p, x, y, z))) return;
         const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
@@ -259,11 +280,11 @@ __global__ __launch_bounds__(kBlock) void fill_pass_kernel(FillArgs a, PassArgs 
         const float pz = voxel_coord(z, a.dm1[2], a.bb_size[2], a.bb_min[2]);
         if (!is_air && !(px >= p.box[0] && px <= p.box[3] && py >= p.box[1] && py <= p.box[4] && pz >= p.box[2] && pz <= p.box[5]))
             return;
-        pass_store<Cfg>(a, p, px, py, pz, flat);
+        pass_store<Cfg>(a, p, px, py, pz, flat, row, x);
         return;
     }
     pass_store<Cfg>(a, p, voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]), voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]),
-                    voxel_coord(z, a.dm1[2], a.bb_size[2], a.bb_min[2]), flat);
+                    voxel_coord(z, a.dm1[2], a.bb_size[2], a.bb_min[2]), flat, row, x);
 }
 
 // The step-1 pass over a grid with its distance volume.  A pass over a loaded grid is bound by per-wave latency (one
@@ -282,7 +303,15 @@ __global__ __launch_bounds__(kBlock) void fill_pass_quad_kernel(FillArgs a, Pass
     const uint32_t lane = threadIdx.x & 63;
     uint32_t air_bits = 0;
     if (4 * (uint64_t)q < n_vox) {
-        const float4 d = *reinterpret_cast<const float4*>(p.dist + (size_t)q * 4);
+        float4 d;
+        if (a.dist_ilv) {  // the quad's four x-neighbours are every other float of 32 contiguous bytes of its pair-row
+            const uint32_t qr = div_u32(4u * q, p.div_nx), qx = 4u * q - qr * a.W;
+            const float* b = p.dist + ((uint64_t)(qr >> 1) * a.W + qx) * 2;
+            const float4 lo = *reinterpret_cast<const float4*>(b), hi = *reinterpret_cast<const float4*>(b + 4);
+            d = (qr & 1u) ? make_float4(lo.y, lo.w, hi.y, hi.w) : make_float4(lo.x, lo.z, hi.x, hi.z);
+        } else {
+            d = *reinterpret_cast<const float4*>(p.dist + (size_t)q * 4);
+        }
         air_bits = (d.x == a.air_dist ? 1u : 0u) | (d.y == a.air_dist ? 2u : 0u) | (d.z == a.air_dist ? 4u : 0u) |
                    (d.w == a.air_dist ? 8u : 0u);
     }
@@ -309,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void fill_pass_quad_kernel(FillArgs a, Pass
         const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
         if (!is_air && !(px >= p.box[0] && px <= p.box[3] && py >= p.box[1] && py <= p.box[4] && pz >= p.box[2] && pz <= p.box[5]))
             continue;
-        pass_store<Cfg>(a, p, px, py, pz, v);
+        pass_store<Cfg>(a, p, px, py, pz, v, r, x);
     }
 }
 
@@ -344,7 +373,16 @@ __global__ __launch_bounds__(kBlock) void fill_pass_rows_kernel(FillArgs a, Pass
     }
     store_texel<true>(a.tex0 + flat, v0);
     store_texel<true>(a.tex1 + flat, v1);
-    if (p.dist) p.dist[flat] = v0.x;  // every lane: the volume equals tex0.r (its contract), so whole lines here too
+    if (!p.dist) return;
+    if (!a.dist_ilv) {
+        p.dist[flat] = v0.x;  // every lane: the volume equals tex0.r (its contract), so whole lines here too
+        return;
+    }
+    // y-interleaved volume: a visited row is an EVEN row (step >= 2, H even) and shares its pair-row with the odd row after
+    // it, which this pass does not visit.  Over a fresh / virgin grid that neighbour is (logically) AIR: whole pairs are
+    // written; otherwise its half of the pair is carried through.
+    float2* pr = reinterpret_cast<float2*>(p.dist) + ((uint64_t)(z - a.z_begin) * a.H + y) / 2 * a.W + x;
+    *pr = make_float2(v0.x, FRESH ? a.air_dist : pr->y);
 }
 
 __global__ __launch_bounds__(kBlock) void grid_init_kernel(float4* tex0, float4* tex1, uint64_t n, float air) {
@@ -361,7 +399,8 @@ __global__ __launch_bounds__(kBlock) void grid_init_kernel(float4* tex0, float4*
 // distance volume's entries of those rows.  One workgroup per row chunk (x chunks, y, local z): no index division, the
 // workgroups of written rows leave at once.
 __global__ __launch_bounds__(kBlock) void grid_init_unvisited_kernel(float4* tex0, float4* tex1, float* dist, uint32_t W,
-                                                                     uint32_t H, uint32_t z_begin, uint32_t step, float air) {
+                                                                     uint32_t H, uint32_t z_begin, uint32_t step, float air,
+                                                                     uint32_t dist_ilv) {
     const uint32_t y = blockIdx.y, zl = blockIdx.z;
     if (step != 0 && (y & (step - 1)) == 0 && ((z_begin + zl) & (step - 1)) == 0) return;  // a row the passes wrote whole
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -370,7 +409,7 @@ __global__ __launch_bounds__(kBlock) void grid_init_unvisited_kernel(float4* tex
     const float4 v = make_float4(air, air, air, air);
     store_texel<true>(tex0 + i, v);
     store_texel<true>(tex1 + i, v);
-    if (dist) dist[i] = air;
+    if (dist) dist[vol_index(dist_ilv, (uint64_t)zl * H + y, x, W)] = air;
 }
 
 bool is_default_config(const FillArgs& a) {
@@ -511,7 +550,7 @@ OrderedBlocks ordered_blocks(const FillArgs& a) {
 hipError_t launch_fill_dense_ordered(const FillArgs& args, uint32_t block_begin, uint32_t block_end, hipStream_t stream) {
     const OrderedPlan p = plan_ordered(args);
     if (p.tx < 0 || block_begin > block_end || block_end > p.total || args.order_lead == 0 ||
-        args.order_lead + 1 >= args.slab_d)
+        args.order_lead + 1 >= args.slab_d || args.dist_ilv)  // (the boundary-first order writes the plain volume only)
         return hipErrorInvalidValue;
     if (block_begin == block_end) return hipSuccess;
     FillArgs a = args;
@@ -554,6 +593,12 @@ hipError_t launch_fill_slices(const FillArgs& args, hipStream_t stream) {
 
 hipError_t launch_fill_dense(const FillArgs& a, const FillLaunch& cfg, hipStream_t stream) {
     if (a.W == 0 || a.H == 0 || a.slab_d == 0) return hipSuccess;
+    if (a.dist && a.dist_ilv) {
+        // the interleaved volume leaves from workgroups that hold BOTH rows of a pair: the row-chunk form with two or four
+        // rows per workgroup (TX 128 or 64), whatever the width
+        if ((a.H & 1u) || ((uintptr_t)a.dist & 7)) return hipErrorInvalidValue;
+        return a.W <= 64 ? launch_dense_tx<64>(a, cfg, stream) : launch_dense_tx<128>(a, cfg, stream);
+    }
     // Row-chunk form when the width fills its lanes, flat form otherwise (and always when forced for A/B runs).
     const uint32_t chunk = a.W <= 64 ? 64 : (a.W <= 128 ? 128 : 256);
     const bool lanes_full = a.W % chunk == 0;
@@ -631,7 +676,7 @@ hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& pass, const FillL
         }
         return hipGetLastError();
     }
-    const bool quad = p.step == 1 && p.dist && a.W % 4 == 0 && ((uintptr_t)p.dist & 15) == 0;
+    const bool quad = p.step == 1 && p.dist && a.W % 4 == 0 && ((uintptr_t)p.dist & 15) == 0;  // (either layout: 16-byte loads)
     const uint64_t threads = quad ? (n + 3) / 4 : n;
     const uint32_t blocks = (uint32_t)((threads + kBlock - 1) / kBlock);
     if (quad) {
@@ -679,12 +724,12 @@ hipError_t launch_commit_interleaved(const float* dist, float* ilv, uint32_t W, 
 }
 
 hipError_t launch_grid_init_unvisited(float* tex0, float* tex1, float* dist, uint32_t W, uint32_t H, uint32_t z_begin,
-                                      uint32_t slab_d, uint32_t step, float air, hipStream_t stream) {
+                                      uint32_t slab_d, uint32_t step, float air, uint32_t dist_ilv, hipStream_t stream) {
     if ((uint64_t)W * H * slab_d == 0) return hipSuccess;
     dim3 grid, block;
     if (!commit_grid(W, H, slab_d, grid, block)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(grid_init_unvisited_kernel, grid, block, 0, stream, reinterpret_cast<float4*>(tex0),
-                       reinterpret_cast<float4*>(tex1), dist, W, H, z_begin, step, air);
+                       reinterpret_cast<float4*>(tex1), dist, W, H, z_begin, step, air, dist_ilv);
     return hipGetLastError();
 }
 

@@ -638,7 +638,15 @@ int sdfv_grid_init(const sdfv_grid* grid, float* tex0, float* tex1, void* stream
 }
 
 int sdfv_grid_init_unvisited(const sdfv_grid* grid, uint32_t step, float* tex0, float* tex1, float* dist, void* stream) {
+    return sdfv_grid_init_unvisited_ex(grid, step, tex0, tex1, dist, 0u, stream);
+}
+
+int sdfv_grid_init_unvisited_ex(const sdfv_grid* grid, uint32_t step, float* tex0, float* tex1, float* dist, uint32_t flags,
+                                void* stream) {
     if (int rc = check_grid(grid)) return rc;
+    if (flags & ~SDFV_PASS_VOLUME_INTERLEAVED) return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", flags);
+    if ((flags & SDFV_PASS_VOLUME_INTERLEAVED) && dist && ((grid->dims[1] & 1u) || ((uintptr_t)dist & 7)))
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "the interleaved volume pairs rows: H even, 8-byte aligned");
     if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
     if (step & (step - 1)) return fail(SDFV_ERR_INVALID_ARGUMENT, "step %u is neither 0 nor a power of two", step);
     if (int rc = check_texel_alignment(tex0, tex1)) return rc;
@@ -646,7 +654,8 @@ int sdfv_grid_init_unvisited(const sdfv_grid* grid, uint32_t step, float* tex0, 
     if (int rc = need_device()) return rc;
     if (step == 1) return SDFV_OK;  // a step-1 pass wrote every row
     SDFV_HIP(sdfv::launch_grid_init_unvisited(tex0, tex1, dist, grid->dims[0], grid->dims[1], grid->z_begin,
-                                              grid->z_end - grid->z_begin, step, air_dist(), (hipStream_t)stream));
+                                              grid->z_end - grid->z_begin, step, air_dist(),
+                                              (flags & SDFV_PASS_VOLUME_INTERLEAVED) ? 1u : 0u, (hipStream_t)stream));
     return SDFV_OK;
 }
 
@@ -753,14 +762,21 @@ int sdfv_fill_grid_pass_ex(const sdfv_demo_params* params, uint32_t sdf_id, cons
     if (int rc = check_grid(grid)) return rc;
     if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
     if (step == 0 || (step & (step - 1))) return fail(SDFV_ERR_INVALID_ARGUMENT, "step %u is not a power of two", step);
-    if (flags & ~(SDFV_PASS_FRESH_GRID | SDFV_PASS_SAME_LOAD | SDFV_PASS_VIRGIN_GRID))
+    if (flags & ~(SDFV_PASS_FRESH_GRID | SDFV_PASS_SAME_LOAD | SDFV_PASS_VIRGIN_GRID | SDFV_PASS_VOLUME_INTERLEAVED))
         return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown pass flags 0x%x", flags);
+    if (flags & SDFV_PASS_VOLUME_INTERLEAVED) {
+        if (!dist) return fail(SDFV_ERR_INVALID_ARGUMENT, "SDFV_PASS_VOLUME_INTERLEAVED without a volume");
+        if ((grid->dims[1] & 1u) || ((uintptr_t)dist & 7))
+            return fail(SDFV_ERR_INVALID_ARGUMENT, "the interleaved volume pairs rows: H = %u must be even and the volume 8-byte aligned", grid->dims[1]);
+    }
     if ((flags & SDFV_PASS_VIRGIN_GRID) && changed_box)
         return fail(SDFV_ERR_INVALID_ARGUMENT, "SDFV_PASS_VIRGIN_GRID with a changed box: a box test reads the grid (sdfv_grid_init_unvisited first)");
     if (int rc = check_texel_alignment(tex0, tex1)) return rc;
     if ((uintptr_t)dist & 3) return fail(SDFV_ERR_INVALID_ARGUMENT, "dist must be 4-byte aligned");
     if (int rc = need_device()) return rc;
     sdfv::FillArgs a = make_fill_args(*params, sdf_id, *grid, tex0, tex1);
+    a.dist_ilv = (flags & SDFV_PASS_VOLUME_INTERLEAVED) ? 1u : 0u;
+    const uint32_t knowledge = flags & ~SDFV_PASS_VOLUME_INTERLEAVED;  // what the caller KNOWS about the grid (the layout bit says nothing)
     sdfv::PassArgs p;
     memset(&p, 0, sizeof(p));
     p.step = step;
@@ -792,7 +808,7 @@ int sdfv_fill_grid_pass_ex(const sdfv_demo_params* params, uint32_t sdf_id, cons
     p.fresh = (flags & SDFV_PASS_FRESH_GRID) ? 1u : 0u;
     p.virgin = (flags & SDFV_PASS_VIRGIN_GRID) ? 1u : 0u;
     p.index_limit = g_options.pass_index_limit;
-    p.all_required = (flags != 0 || covers) ? 1u : 0u;
+    p.all_required = (knowledge != 0 || covers) ? 1u : 0u;
     SDFV_HIP(sdfv::launch_fill_pass(a, p, fill_launch_config(dist != nullptr), (hipStream_t)stream));
     return SDFV_OK;
 }

@@ -175,6 +175,7 @@ int sdfvh_viewer_render_device(void* v, uint32_t width, uint32_t height, const f
 }
 // 0: the frames march over the distance volume; 1: over the pair volume commit() built; 2: over the interleaved volume
 int sdfvh_viewer_pairs_valid(void* v) {
+    if (V(v).material.dist && V(v).material.dist_interleaved) return V(v).material.lod_dist_between_samples == 1.0f ? 2 : 0;
     return V(v).material.pairs && V(v).material.pairs_valid ? (V(v).material.pairs_interleaved ? 2 : 1) : 0;
 }
 int sdfvh_viewer_sync(void* v) { return hipStreamSynchronize((hipStream_t)V(v).stream) == hipSuccess ? 0 : -1; }

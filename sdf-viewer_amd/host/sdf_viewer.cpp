@@ -73,7 +73,8 @@ int SDFViewerMaterial::materialize(void* stream) const {
     sdfv_grid g{};
     for (int i = 0; i < 3; ++i) g.dims[i] = tex_size[i];
     g.z_end = g.dims[2];  // (the bounding box plays no part in an initialisation)
-    const int rc = sdfv_grid_init_unvisited(&g, defined_step, tex0->f32(), tex1->f32(), dist ? dist->f32() : nullptr, stream);
+    const int rc = sdfv_grid_init_unvisited_ex(&g, defined_step, tex0->f32(), tex1->f32(), dist ? dist->f32() : nullptr,
+                                               dist && dist_interleaved ? SDFV_PASS_VOLUME_INTERLEAVED : 0u, stream);
     if (rc == 0) undefined_rows = false;
     return rc;
 }
@@ -86,6 +87,9 @@ int SDFViewerMaterial::render(const Camera& camera, float* rgba_device, sdfv_mar
     const sdfv_camera cam = camera.to_device();
     // the distance volume is only meaningful for the fully loaded grid (LINEAR filter, lod == 1)
     const float* d = (dist && lod_dist_between_samples == 1.0f) ? dist->f32() : nullptr;
+    if (d && dist_interleaved)  // the volume the fill wrote IS the march's y-interleaved volume
+        return sdfv_raymarch_volumes(&rp, tex0->f32(), tex1->f32(), nullptr, nullptr, d, &cam, 1, camera.viewport_width,
+                                     camera.viewport_height, 0, camera.viewport_height, rgba_device, nullptr, aux_device, stream);
     // a viewer renders many frames per load: the pair volume commit() built halves the march's gathers (same bits)
     const float* p = (d && pairs && pairs_valid) ? pairs->f32() : nullptr;
     return sdfv_raymarch_volumes(&rp, tex0->f32(), tex1->f32(), d, pairs_interleaved ? nullptr : p, pairs_interleaved ? p : nullptr,
@@ -174,6 +178,15 @@ std::unique_ptr<SDFViewer> SDFViewer::new_voxels(std::array<size_t, 3> voxels, c
     v->material.dist = std::make_shared<DeviceBuffer>(v->material.tex0->bytes() / 4);
     v->dist_synced_ = v->material.dist->ok();
     if (!v->dist_synced_) v->material.dist.reset();  // out of memory: march tex0.r in place, passes read tex0
+    // Beyond the last-level cache the march gathers fastest from the y-interleaved volume (sdfv_march_volume_advice): the
+    // fills and passes of THIS viewer write the volume in that layout from the start, so a load ends with the march's volume
+    // in place and commit() builds nothing (512^3: 0.70 + 0.20 ms -> 0.70).  Smaller cubic grids keep the plain volume and
+    // let commit() derive the pair volume from it.
+    if (v->dist_synced_) {
+        const sdfv_grid g = v->grid();
+        uint32_t kind = SDFV_MARCH_VOLUME_NONE;
+        if (sdfv_march_volume_advice(&g, &kind) == 0 && kind == SDFV_MARCH_VOLUME_INTERLEAVED) v->material.dist_interleaved = true;
+    }
     return v;
 }
 
@@ -252,7 +265,29 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
     if (all_passes_fit && ((fresh_ && !changed_box) || box_covers_grid())) {
         // The fill writes the distance volume in the same pass (+4 B/voxel instead of a second pass over tex0).
         float* dist_out = dist_synced_ ? material.dist->f32() : nullptr;
-        if (sdfv_fill_grid_commit(&dev->params, dev->sdf_id, &g, tex0_device(), tex1_device(), dist_out, stream) != 0) {
+        int rc;
+        if (dist_out && material.dist_interleaved) {
+            // the same dense launch through the pass entry point, which carries the volume's layout: a step-1 pass in which
+            // update_required holds everywhere (a virgin / fresh grid, or a box that covers it) IS the dense fused fill
+            float box[6];
+            const float* box_ptr = nullptr;
+            uint32_t flags = SDFV_PASS_VOLUME_INTERLEAVED;
+            if (changed_box) {
+                box[0] = (*changed_box)[0].x; box[1] = (*changed_box)[0].y; box[2] = (*changed_box)[0].z;
+                box[3] = (*changed_box)[1].x; box[4] = (*changed_box)[1].y; box[5] = (*changed_box)[1].z;
+                box_ptr = box;
+                if (material.materialize(stream) != 0) {  // (a box test is no virgin pass; the dense launch overwrites it all anyway)
+                    error_ = sdfv_last_error();
+                    return 0;
+                }
+            } else {
+                flags |= (material.undefined_rows ? SDFV_PASS_VIRGIN_GRID : SDFV_PASS_FRESH_GRID) | SDFV_PASS_SAME_LOAD;
+            }
+            rc = sdfv_fill_grid_pass_ex(&dev->params, dev->sdf_id, &g, 1u, box_ptr, tex0_device(), tex1_device(), dist_out, flags, stream);
+        } else {
+            rc = sdfv_fill_grid_commit(&dev->params, dev->sdf_id, &g, tex0_device(), tex1_device(), dist_out, stream);
+        }
+        if (rc != 0) {
             error_ = sdfv_last_error();
             return 0;
         }
@@ -290,6 +325,7 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
             error_ = sdfv_last_error();
             break;
         }
+        if (dist_synced_ && material.dist_interleaved) flags |= SDFV_PASS_VOLUME_INTERLEAVED;
         if (sdfv_fill_grid_pass_ex(&dev->params, dev->sdf_id, &g, (uint32_t)step, box_ptr, tex0_device(), tex1_device(),
                                    dist_synced_ ? material.dist->f32() : nullptr, flags, stream) != 0) {
             error_ = sdfv_last_error();
@@ -325,6 +361,7 @@ void SDFViewer::commit() {
     // creation) the march reads tex0.r in place.
     // What a commit of the fully loaded grid does derive is the pair volume: the frames that follow (the reference renders
     // one per repaint) march over it.  12 B/voxel of traffic -- against the reference's re-upload of 32 B/voxel over PCIe.
+    if (dist_synced_ && material.dist_interleaved) return;  // the fills wrote the march's volume themselves
     if (dist_synced_ && loading_mgr.step_size() == 0 && !material.pairs_valid) {
         const sdfv_grid g = grid();
         if (!material.pairs && !material.no_march_volume) {
@@ -342,8 +379,10 @@ void SDFViewer::commit() {
                                                     : sdfv_commit_pairs(&g, material.dist->f32(), material.pairs->f32(), stream);
         if (rc == 0)
             material.pairs_valid = true;
-        else
-            material.pairs.reset();  // out of memory: the march keeps reading the distance volume
+        else {
+            material.pairs.reset();  // out of memory: the march keeps reading the distance volume ...
+            material.no_march_volume = true;  // ... and later commits do not retry the allocation
+        }
     }
 }
 

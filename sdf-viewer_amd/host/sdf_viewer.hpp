@@ -68,7 +68,10 @@ class DeviceBuffer {
 struct SDFViewerMaterial {
     std::shared_ptr<DeviceBuffer> tex0;  // distance (R), colour (GBA)
     std::shared_ptr<DeviceBuffer> tex1;  // material properties (RGB)
-    std::shared_ptr<DeviceBuffer> dist;  // compact copy of tex0.r built by SDFViewer::commit (may be null)
+    std::shared_ptr<DeviceBuffer> dist;  // the distance volume (tex0.r, 4 B/voxel), kept in sync by every fill and pass (may be null)
+    bool dist_interleaved = false;       // ... laid out y-interleaved (SDFV_PASS_VOLUME_INTERLEAVED): for grids beyond the last-
+                                         // level cache the fill writes the volume the march gathers fastest from ITSELF -- commit()
+                                         // then has nothing to build, render() passes it as the descriptor's `ilv`
     std::shared_ptr<DeviceBuffer> pairs;  // y-pair volume (sdfv_commit_pairs) of the LOADED grid, or null / stale
     bool pairs_valid = false;             // pairs mirrors dist: set by SDFViewer::commit, cleared by every fill
     bool no_march_volume = false;         // sdfv_march_volume_advice said neither pays for this grid: commit() builds none

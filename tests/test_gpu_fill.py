@@ -594,3 +594,97 @@ def test_passes_over_slabs_beyond_32_bit_indices_run_in_pieces(pkg, oracle):
         assert_bits_equal(results[0][0], r0)
     with pytest.raises(pkg.SdfvError):
         pkg.set_option(K.OPT_PASS_INDEX_LIMIT, 1)
+
+
+def interleave_rows(d):
+    """[D, H, W] -> the y-interleaved volume's layout as a [D, H, W]-shaped tensor (rows 2p, 2p + 1 as one row of pairs)."""
+    D, H, W = d.shape
+    return torch.stack([d[:, 0::2], d[:, 1::2]], dim=-1).reshape(D, H, W).contiguous()
+
+
+@pytest.mark.parametrize("dims,z_range", [((64, 64, 64), (0, 64)), ((128, 6, 5), (0, 5)), ((256, 4, 7), (2, 7)), ((300, 10, 3), (0, 3)),
+                                          ((40, 12, 29), (7, 22)), ((20, 18, 12), (0, 12)), ((512, 2, 2), (0, 2))])
+def test_fill_and_passes_maintain_the_interleaved_volume(pkg, oracle, dims, z_range):
+    """SDFV_PASS_VOLUME_INTERLEAVED: the volume every fill and pass writes / reads is laid out as the march's y-interleaved
+    volume.  Dense fused fill (= a step-1 virgin pass), the virgin chain with its lazy initialisation, unflagged passes over an
+    initialised grid (general + quad kernels), a boxed edit, a whole-box edit (copy-through rows), the piecewise path: the
+    textures equal the plain path's bit for bit and the volume is interleave(tex0.r) after every step."""
+    K = pkg._capi
+    ILV = K.PASS_VOLUME_INTERLEAVED
+    g = pkg.make_grid(dims, z_begin=z_range[0], z_end=z_range[1])
+    prm, edited = pkg.default_params(), pkg.default_params(sphere_radius=0.8, cube_material=1)
+    want0, want1 = gpu_fill(pkg, prm, dims, z0=z_range[0], z1=z_range[1])
+
+    def check(t0, t1, vol, ref0=None, ref1=None):
+        torch.cuda.synchronize()
+        if ref0 is not None:
+            assert torch.equal(t0, ref0) and torch.equal(t1, ref1)
+        assert torch.equal(vol, interleave_rows(t0[..., 0]))
+
+    t0, t1 = pkg.alloc_textures(g)
+    t0.fill_(-7.0)
+    t1.fill_(-7.0)
+    vol = torch.full(tuple(t0.shape[:-1]), -7.0, dtype=torch.float32, device="cuda")
+    # (1) the dense fused fill that writes the interleaved volume itself
+    pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=vol, flags=K.PASS_VIRGIN_GRID | ILV)
+    check(t0, t1, vol, want0, want1)
+    assert torch.equal(vol, pkg.commit_interleaved(pkg.make_grid((dims[0], dims[1], z_range[1] - z_range[0])), t0[..., 0].contiguous()))
+    # (2) the virgin chain + lazy initialisation
+    t0.fill_(-7.0)
+    t1.fill_(float("nan"))
+    vol.fill_(123.0)
+    a0, a1 = pkg.alloc_textures(g)
+    pkg.grid_init(g, a0, a1)
+    for step in (4, 2, 1):
+        pkg.fill_grid_pass(prm, g, step, t0, t1, dist=vol, flags=K.PASS_VIRGIN_GRID | K.PASS_SAME_LOAD | ILV)
+        pkg.fill_grid_pass(prm, g, step, a0, a1)  # the plain path over an initialised grid: the reference state at this boundary
+        c0, c1, cv = t0.clone(), t1.clone(), vol.clone()
+        pkg.grid_init_unvisited(g, step, c0, c1, dist=cv, flags=ILV)
+        check(c0, c1, cv, a0, a1)
+    check(t0, t1, vol, want0, want1)
+    # (3) unflagged passes over an initialised grid, both fresh-flagged and not, then edits
+    for flags in (0, None):
+        pkg.grid_init(g, t0, t1)
+        vol.fill_(pkg.AIR_DIST)
+        for k, step in enumerate((4, 2, 1)):
+            f = ILV | (0 if flags == 0 else ((K.PASS_FRESH_GRID if k == 0 else 0) | K.PASS_SAME_LOAD))
+            pkg.fill_grid_pass(prm, g, step, t0, t1, dist=vol, flags=f)
+            check(t0, t1, vol)
+        check(t0, t1, vol, want0, want1)
+    box = (-0.5, -1.0, -0.25, 0.5, 0.1, 1.0)
+    b0, b1 = want0.clone(), want1.clone()
+    for step in (4, 2, 1):
+        pkg.fill_grid_pass(edited, g, step, t0, t1, changed_box=box, dist=vol, flags=ILV)
+        pkg.fill_grid_pass(edited, g, step, b0, b1, changed_box=box)
+        check(t0, t1, vol, b0, b1)
+    whole = (-2, -2, -2, 2, 2, 2)
+    with pkg.options({K.OPT_PASS_INDEX_LIMIT: dims[0] * dims[1] * 2 + 1}):  # ... in pieces of two slices
+        for step in (4, 2, 1):
+            pkg.fill_grid_pass(prm, g, step, t0, t1, changed_box=whole, dist=vol, flags=ILV)
+            pkg.fill_grid_pass(prm, g, step, b0, b1, changed_box=whole)
+            check(t0, t1, vol, b0, b1)
+    check(t0, t1, vol, want0, want1)
+
+
+def test_interleaved_volume_argument_checks_and_the_march_over_it(pkg, oracle):
+    K = pkg._capi
+    prm = pkg.default_params()
+    odd = pkg.make_grid((16, 7, 4))
+    t0, t1 = pkg.alloc_textures(odd)
+    vol = torch.empty(tuple(t0.shape[:-1]), dtype=torch.float32, device="cuda")
+    with pytest.raises(pkg.SdfvError):  # rows are paired: H must be even
+        pkg.fill_grid_pass(prm, odd, 1, t0, t1, dist=vol, flags=K.PASS_VIRGIN_GRID | K.PASS_VOLUME_INTERLEAVED)
+    with pytest.raises(pkg.SdfvError):  # the layout bit needs a volume
+        pkg.fill_grid_pass(prm, odd, 1, t0, t1, flags=K.PASS_VOLUME_INTERLEAVED)
+    # the volume the fill wrote IS the march's ilv volume: same image as over the distance volume, bit for bit
+    g = pkg.make_grid((64, 64, 64))
+    t0, t1 = pkg.alloc_textures(g)
+    vol = torch.empty((64, 64, 64), dtype=torch.float32, device="cuda")
+    pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=vol, flags=K.PASS_VIRGIN_GRID | K.PASS_VOLUME_INTERLEAVED)
+    rp = pkg.default_render_params(g)
+    cam = pkg.camera_look_at(aspect=1.5)
+    dist = pkg.commit_distance(g, t0)
+    a = pkg.raymarch(rp, t0, t1, cam, 192, 128, ilv=vol)
+    b = pkg.raymarch(rp, t0, t1, cam, 192, 128, dist=dist)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and bool((a[..., 3] > 0).any())

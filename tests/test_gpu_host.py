@@ -215,18 +215,45 @@ def test_commit_of_a_loaded_grid_builds_the_pair_volume_and_edits_retire_it(host
     assert np.abs(edited - want).max() <= 1e-4 and not np.array_equal(before, edited)
 
 
-def test_commit_of_a_grid_beyond_the_last_level_cache_builds_the_interleaved_volume(host):
-    """512^3: the pair volume (1 GB) would not fit the Infinity Cache, so commit() asks sdfv_march_volume_advice and builds the
-    y-interleaved volume instead; the frames over it are the frames over the distance volume, bit for bit."""
+def test_commit_of_a_grid_beyond_the_last_level_cache_builds_the_interleaved_volume(host, pkg):
+    """512^3: the pair volume (1 GB) would not fit the Infinity Cache: sdfv_march_volume_advice names the y-interleaved volume,
+    and since round 4 the viewer's FILLS write it (SDFV_PASS_VOLUME_INTERLEAVED) -- the load ends with the march's volume in
+    place, commit() builds nothing; the frames over it are the frames over the plain distance volume, bit for bit; a
+    progressive load and an edit keep it in sync."""
+    import torch
     sdf = host.SDF.demo()
     v = host.Viewer.new_voxels((512, 512, 512), [-1, -1, -1, 1, 1, 1], 1)
     while v.update(sdf, 1.0):
         pass
-    assert v.march_volume() == "distance"
-    before = v.render(1280, 720)
+    assert v.march_volume() == "interleaved"   # before any commit
+    frame = v.render(1280, 720)
     v.commit()
     assert v.march_volume() == "interleaved"
-    np.testing.assert_array_equal(before.view(np.uint32), v.render(1280, 720).view(np.uint32))
+    np.testing.assert_array_equal(frame.view(np.uint32), v.render(1280, 720).view(np.uint32))
+    # the same frame from the library's plain path (dense fill + distance volume)
+    g = pkg.make_grid((512, 512, 512))
+    t0, t1 = pkg.alloc_textures(g)
+    dist = torch.empty((512, 512, 512), dtype=torch.float32, device="cuda")
+    pkg.fill_grid(pkg.default_params(), g, t0, t1, dist=dist)
+    want = pkg.raymarch(pkg.default_render_params(g), t0, t1, pkg.camera_look_at(aspect=1280 / 720), 1280, 720, dist=dist)[0]
+    np.testing.assert_array_equal(frame.view(np.uint32), want.cpu().numpy().view(np.uint32))
+    del t0, t1, dist
+    # pass by pass (2 passes, one per call), then a parameter edit: same frames as a viewer of the edited SDF loaded densely
+    p = host.Viewer.new_voxels((512, 512, 512), [-1, -1, -1, 1, 1, 1], 2)
+    while p.update(sdf, 0.0):
+        pass
+    np.testing.assert_array_equal(frame.view(np.uint32), p.render(1280, 720).view(np.uint32))
+    edited = host.SDF.demo()
+    assert edited.children()[1].set_parameter(1, 0.9) is None
+    for _ in range(12):
+        if p.update(edited, 0.0) == 0 and not p.has_changed_box():
+            break
+    q = host.Viewer.new_voxels((512, 512, 512), [-1, -1, -1, 1, 1, 1], 1)
+    fresh_edit = host.SDF.demo("-s", "0.9")
+    while q.update(fresh_edit, 1.0):
+        pass
+    np.testing.assert_array_equal(p.render(1280, 720).view(np.uint32), q.render(1280, 720).view(np.uint32))
+    del v, p, q
     small = host.Viewer.new_voxels((64, 64, 64), [-1, -1, -1, 1, 1, 1], 1)
     while small.update(sdf, 1.0):
         pass
