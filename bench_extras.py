@@ -372,7 +372,8 @@ def run_extras(c):
             batch_step()
             batch_dt, _ = timed_region(batch_step, batch_steps, torch, dist, world, device)
             ms = batch_dt / batch_steps * 1e3
-            rep = {"split": split if world > 1 else None, "cameras_per_gpu": len(mine), "rows_per_gpu": n_rows,
+            rep = {"split": split if world > 1 else None, "band_height": where["bands"][2] if "bands" in where else None,
+                   "cameras_per_gpu": len(mine), "rows_per_gpu": n_rows,
                    "value": round(n_batch * W * H / ms / 1e3, 1), "unit": "Mrays/s", "ms_per_batch": round(ms, 4),
                    "march_over": (f"y-{volume_kind} volume" if volume_kind == "interleaved" else "y-pair volume") if use_pairs
                                  else "distance volume"}
@@ -385,7 +386,7 @@ def run_extras(c):
 
                 def gather_step():
                     if split == "tiles" and world > 1:
-                        return par.gather_bands(batch_out, H, rank, world, comm=lib_comm)
+                        return par.gather_bands(batch_out, H, rank, world, comm=lib_comm, band_height=where["bands"][2])
                     if split == "cameras":
                         return par.gather_images(batch_out, n_batch, rank, world, comm=lib_comm)
                     return par.gather_rows(batch_out, H, rank, world) if world > 1 else batch_out

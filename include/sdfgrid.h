@@ -384,9 +384,11 @@ int sdfv_mesh_trim(void);
  *                     extents, symmetric box, <= 2^28 texels) on a CUBIC grid, every other launch reads dist / tex0.r
  *   cameras           HOST array of n_cameras
  *   y0, y1            rows [y0, y1) when band_step == 0
- *   band_first, band_step   band_step >= 1: the balanced image-tile split of BASELINE config 5 -- rank r of N renders (r, N):
- *                     the 16-row tile bands band_first, band_first + band_step, ... stored one after the other (outputs hold
- *                     n_cameras x sdfv_band_rows(height, band_first, band_step) x width pixels; a band set that starts below the
+ *   band_first, band_step, band_height   band_step >= 1: the balanced image-tile split of BASELINE config 5 -- rank r of N renders
+ *                     (r, N): the bands band_first, band_first + band_step, ... of band_height = 16 (also 0) or 8 rows -- a
+ *                     workgroup's / a wave's tile -- stored one after the other (outputs hold n_cameras x sdfv_band_rows_ex(height,
+ *                     band_first, band_step, band_height) x width pixels; 8-row bands deal the rows under the object more evenly when
+ *                     a rank gets few bands: 8 ranks at 1080p 4.9x -> 5.4x, 4 ranks -2 %: tools/split_balance.py; a band set that starts below the
  *                     image renders nothing and succeeds); y0 / y1 are ignored.  Contiguous row ranges leave the outer ranks
  *                     with background only (8 ranges of a 1080p orbit view scale 2.4x on 8 GPUs, 8 band sets 5-6x)
  *   rgba              DEVICE, n_cameras x rows x W x 4 floats (outColor)
@@ -405,13 +407,15 @@ typedef struct sdfv_march_desc {
     uint32_t width, height;
     uint32_t y0, y1;
     uint32_t band_first, band_step;
-    uint32_t reserved2; /* 0 */
+    uint32_t band_height; /* rows per band: 16 (also 0) or 8 */
     float *rgba;
     float *depth;
     sdfv_march_aux *aux;
 } sdfv_march_desc;
 int sdfv_raymarch_ex(const sdfv_march_desc *desc, void *stream);
-uint32_t sdfv_band_rows(uint32_t height, uint32_t band_first, uint32_t band_step);
+/* rows a band set holds: bands of band_height (16 or 8; 0 = 16) rows, the last one of the image possibly short */
+uint32_t sdfv_band_rows_ex(uint32_t height, uint32_t band_first, uint32_t band_step, uint32_t band_height);
+uint32_t sdfv_band_rows(uint32_t height, uint32_t band_first, uint32_t band_step); /* = ..._ex(..., 16) */
 
 /* Device-side analogue of SDFViewer::commit (scene/sdf/mod.rs:220-239).  The textures already live in HBM, so
  * there is nothing to upload; what a commit can do instead is derive the raymarch's acceleration data: `dist`
@@ -571,21 +575,20 @@ int sdfv_slab_march(sdfv_slab_comm *comm, const sdfv_render_params *rp, const sd
  * all-gather of slabs).  Every rank of the communicator calls; everything is enqueued on `stream`, nothing synchronises. ---- */
 
 /* The inverse of sdfv_raymarch_bands' output layout, on one device (no communicator): moves the band set `part` (DEVICE,
- * n_cameras x sdfv_band_rows(height, band_first, band_step) x width x channels floats) to its rows of the images `out` (DEVICE,
+ * n_cameras x sdfv_band_rows_ex(height, band_first, band_step, band_height) x width x channels floats) to its rows of the images `out` (DEVICE,
  * n_cameras x height x width x channels).  channels: 4 for rgba, 1 for the depth plane, 18 for the aux record.  What
  * sdfv_comm_gather_bands runs per received set; a host with another transport (MPI, torch.distributed) calls it itself. */
-int sdfv_bands_scatter(const float *part, uint32_t band_first, uint32_t band_step, uint32_t n_cameras, uint32_t width,
-                       uint32_t height, uint32_t channels, float *out, void *stream);
-/* The image-tile split's gather: rank r passes the band set it rendered with sdfv_raymarch_bands(band_first = r, band_step =
- * world); rank `dst` receives every other rank's set whole (one message per peer, all xGMI links at once) into `scratch` and
+int sdfv_bands_scatter(const float *part, uint32_t band_first, uint32_t band_step, uint32_t band_height, uint32_t n_cameras,
+                       uint32_t width, uint32_t height, uint32_t channels, float *out, void *stream);
+/* The image-tile split's gather: rank r passes the band set it rendered with (band_first = r, band_step = world, band_height); rank `dst` receives every other rank's set whole (one message per peer, all xGMI links at once) into `scratch` and
  * assembles the n_cameras images in `out` (DEVICE, n_cameras x height x width x channels floats; ignored elsewhere, may be
  * NULL).  scratch: DEVICE, 16-byte aligned, sdfv_comm_gather_bands_scratch_bytes() bytes on dst (0 elsewhere).  64 cameras x
  * 1080p are 2.1 GB into ONE rank: tens of milliseconds over seven links against the 0.3 ms a rank spends rendering its share --
  * a host that can consume the bands where they were rendered should. */
-size_t sdfv_comm_gather_bands_scratch_bytes(const sdfv_slab_comm *comm, int dst, uint32_t n_cameras, uint32_t width,
-                                            uint32_t height, uint32_t channels);
-int sdfv_comm_gather_bands(sdfv_slab_comm *comm, const float *part, uint32_t n_cameras, uint32_t width, uint32_t height,
-                           uint32_t channels, int dst, float *out, void *scratch, size_t scratch_bytes, void *stream);
+size_t sdfv_comm_gather_bands_scratch_bytes(const sdfv_slab_comm *comm, int dst, uint32_t band_height, uint32_t n_cameras,
+                                            uint32_t width, uint32_t height, uint32_t channels);
+int sdfv_comm_gather_bands(sdfv_slab_comm *comm, const float *part, uint32_t band_height, uint32_t n_cameras, uint32_t width,
+                           uint32_t height, uint32_t channels, int dst, float *out, void *scratch, size_t scratch_bytes, void *stream);
 /* The camera split's gather: rank r rendered cameras [n_cameras * r / world, n_cameras * (r + 1) / world) whole (`part`); dst
  * receives them in place, in camera order (`out`: n_cameras x height x width x channels floats).  No scratch. */
 int sdfv_comm_gather_cameras(sdfv_slab_comm *comm, const float *part, uint32_t n_cameras, uint32_t width, uint32_t height,
@@ -642,7 +645,7 @@ SDFV_INLINE int sdfv_raymarch_volumes(const sdfv_render_params *rp, const float 
     d.y1 = y1;
     d.band_first = 0;
     d.band_step = 0;
-    d.reserved2 = 0;
+    d.band_height = 0;
     d.rgba = rgba;
     d.depth = depth;
     d.aux = aux;
@@ -699,7 +702,7 @@ SDFV_INLINE int sdfv_raymarch_bands(const sdfv_render_params *rp, const float *t
     d.y1 = height;
     d.band_first = band_first;
     d.band_step = band_step;
-    d.reserved2 = 0;
+    d.band_height = 0;
     d.rgba = rgba;
     d.depth = depth;
     d.aux = aux;

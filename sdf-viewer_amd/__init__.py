@@ -409,8 +409,11 @@ def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=Fal
             raise ValueError("bands and a row range exclude each other")
         if int(bands[1]) < 1:
             raise SdfvError(-1, "band_step is 0")
-        rows = int(lib.sdfv_band_rows(height, int(bands[0]), int(bands[1])))
-        d.y0, d.y1, d.band_first, d.band_step = 0, height, int(bands[0]), int(bands[1])
+        bh = int(bands[2]) if len(bands) > 2 else 16  # bands = (first, step[, rows per band: 16 or 8])
+        if bh not in (8, 16):
+            raise SdfvError(-1, f"band_height {bh}: 8 or 16")
+        rows = int(lib.sdfv_band_rows_ex(height, int(bands[0]), int(bands[1]), bh))
+        d.y0, d.y1, d.band_first, d.band_step, d.band_height = 0, height, int(bands[0]), int(bands[1]), bh
     else:
         rows = y1 - y0
         d.y0, d.y1 = y0, y1

@@ -77,7 +77,7 @@ class MarchDesc(C.Structure):
                 ("tex1", C.c_void_p), ("dist", C.c_void_p), ("pairs", C.c_void_p), ("ilv", C.c_void_p),
                 ("cameras", C.POINTER(Camera)), ("n_cameras", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
                 ("y0", C.c_uint32), ("y1", C.c_uint32), ("band_first", C.c_uint32), ("band_step", C.c_uint32),
-                ("reserved2", C.c_uint32), ("rgba", C.c_void_p), ("depth", C.c_void_p), ("aux", C.c_void_p)]
+                ("band_height", C.c_uint32), ("rgba", C.c_void_p), ("depth", C.c_void_p), ("aux", C.c_void_p)]
 
 
 PROTOTYPES = {
@@ -111,6 +111,7 @@ PROTOTYPES = {
     "sdfv_commit_distance": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_commit_pairs": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_band_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    "sdfv_band_rows_ex": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "sdfv_march_volume_advice": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_uint32)]),
     "sdfv_commit_interleaved": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_fill_grid_host": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p, C.c_void_p]),
@@ -153,10 +154,10 @@ PROTOTYPES = {
     "sdfv_slab_fill_step_commit": (C.c_int, [C.c_void_p, C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdfv_slab_comm_join": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "sdfv_bands_scatter": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+    "sdfv_bands_scatter": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_void_p, C.c_void_p]),
-    "sdfv_comm_gather_bands_scratch_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
-    "sdfv_comm_gather_bands": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+    "sdfv_comm_gather_bands_scratch_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "sdfv_comm_gather_bands": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sdfv_comm_gather_cameras": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                            C.c_void_p, C.c_void_p]),
@@ -167,7 +168,7 @@ LIGHT_AMBIENT, LIGHT_DIRECTIONAL, MAX_LIGHTS = 0, 1, 4
 
 
 def raymarch_rc(rp, tex0, tex1, cameras, n_cameras, width, height, y0, y1, rgba, depth=None, aux=None, dist=None, pairs=None,
-                ilv=None, band_first=0, band_step=0, stream=None, size=None):
+                ilv=None, band_first=0, band_step=0, stream=None, size=None, band_height=0):
     """sdfv_raymarch_ex from raw addresses (ints / c_void_p / None), returning the status code unchecked: what the argument-
     error tests and the tools that bypass the torch harness call.  cameras: a Camera, a ctypes array of them, or None."""
     d = MarchDesc()
@@ -177,7 +178,7 @@ def raymarch_rc(rp, tex0, tex1, cameras, n_cameras, width, height, y0, y1, rgba,
     if cameras is not None:
         d.cameras = C.cast(C.pointer(cameras), C.POINTER(Camera))
     d.n_cameras, d.width, d.height, d.y0, d.y1 = n_cameras, width, height, y0, y1
-    d.band_first, d.band_step = band_first, band_step
+    d.band_first, d.band_step, d.band_height = band_first, band_step, band_height
     d.rgba, d.depth, d.aux = rgba, depth, aux
     return lib.sdfv_raymarch_ex(C.byref(d), stream)
 # sdfv_option / values (include/sdfgrid.h)

@@ -44,8 +44,9 @@ struct RaymarchArgs {
     uint64_t last_level_cache_bytes;    // Infinity Cache (MI355X: 256 MB); 0 = unknown
     uint32_t cube_box;           // symmetric box with bounds_max[0] == [1] == [2]: two-instruction out-of-bounds test
     uint32_t rows_out;           // rows per camera in the outputs: y1 - y0, or the rows of the rendered bands (band_skip != 0)
-    uint32_t band_skip;          // 0: rows [y0, y1).  16 * (step - 1): the 16-row tile bands y0/16, y0/16 + step, ... below y1,
-                                 // stored one after the other (sdfv_raymarch_bands: the balanced image-tile split)
+    uint32_t band_skip;          // 0: rows [y0, y1).  B * (step - 1): the B-row bands y0/B, y0/B + step, ... below y1, stored one
+                                 // after the other (the balanced image-tile split); B = 1 << band_shift = 16 or 8 (a wave's tile)
+    uint32_t band_shift;
     float4* rgba;                // n_cameras x rows_out x width
     sdfv_march_aux* aux;         // same layout or nullptr
     float* depth;                // gl_FragDepth plane, same pixel layout, or nullptr

@@ -823,7 +823,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
     }
     const uint32_t px = bx * 16 + (wave & 1) * 8 + (lane & 7);
     const uint32_t row = by * 16 + (wave >> 1) * 8 + (lane >> 3);  // row of the output: within [y0, y1), or of the bands
-    const uint32_t py = a.y0 + row + by * a.band_skip;
+    const uint32_t py = a.y0 + row + (row >> a.band_shift) * a.band_skip;  // band k of the set = rows [k << shift, ...) of the output
     const uint32_t cam_idx = blockIdx.z;
     const bool in_image = px < a.width && py < a.y1;
     const sdfv_camera& cam = a.cameras[cam_idx];

@@ -415,7 +415,7 @@ int fill_boundary_slices(const sdfv_demo_params* params, uint32_t sdf_id, const 
 #pragma GCC visibility push(default)
 static int raymarch_rows(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
                          const float* pairs, const float* ilv, const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width,
-                         uint32_t height, uint32_t y0, uint32_t y1, uint32_t band_step, float* rgba, float* depth,
+                         uint32_t height, uint32_t y0, uint32_t y1, uint32_t band_step, uint32_t band_height, float* rgba, float* depth,
                          sdfv_march_aux* aux, void* stream);
 
 extern "C" {
@@ -1009,27 +1009,34 @@ int sdfv_raymarch_ex(const sdfv_march_desc* desc, void* stream) {
     sdfv_march_desc d;
     memset(&d, 0, sizeof(d));
     memcpy(&d, desc, desc->size < sizeof(d) ? desc->size : sizeof(d));
-    if (d.reserved != 0 || d.reserved2 != 0) return fail(SDFV_ERR_INVALID_ARGUMENT, "sdfv_march_desc: reserved fields must be 0");
+    if (d.reserved != 0) return fail(SDFV_ERR_INVALID_ARGUMENT, "sdfv_march_desc: reserved fields must be 0");
     if (d.band_step == 0)
-        return raymarch_rows(d.rp, d.tex0, d.tex1, d.dist, d.pairs, d.ilv, d.cameras, d.n_cameras, d.width, d.height, d.y0, d.y1, 1,
+        return raymarch_rows(d.rp, d.tex0, d.tex1, d.dist, d.pairs, d.ilv, d.cameras, d.n_cameras, d.width, d.height, d.y0, d.y1, 1, 16,
                              d.rgba, d.depth, d.aux, stream);
-    if (sdfv_band_rows(d.height, d.band_first, d.band_step) == 0) return SDFV_OK;  // a band set below the image: nothing to render
-    return raymarch_rows(d.rp, d.tex0, d.tex1, d.dist, d.pairs, d.ilv, d.cameras, d.n_cameras, d.width, d.height, d.band_first * 16,
-                         d.height, d.band_step, d.rgba, d.depth, d.aux, stream);
+    const uint32_t B = d.band_height ? d.band_height : 16u;
+    if (B != 8u && B != 16u) return fail(SDFV_ERR_INVALID_ARGUMENT, "band_height %u: 8 or 16 (0 = 16)", d.band_height);
+    if (sdfv_band_rows_ex(d.height, d.band_first, d.band_step, B) == 0) return SDFV_OK;  // a band set below the image: nothing to render
+    return raymarch_rows(d.rp, d.tex0, d.tex1, d.dist, d.pairs, d.ilv, d.cameras, d.n_cameras, d.width, d.height, d.band_first * B,
+                         d.height, d.band_step, B, d.rgba, d.depth, d.aux, stream);
 }
 
+uint32_t sdfv_band_rows_ex(uint32_t height, uint32_t band_first, uint32_t band_step, uint32_t band_height) {
+    const uint32_t B = band_height ? band_height : 16u;
+    if (B != 8u && B != 16u) return 0;
+    const uint32_t bands = (height + B - 1) / B;
+    if (band_step == 0 || band_first >= bands) return 0;
+    const uint32_t n = (bands - band_first + band_step - 1) / band_step, last = band_first + (n - 1) * band_step;
+    return (n - 1) * B + (height - last * B < B ? height - last * B : B);
+}
 uint32_t sdfv_band_rows(uint32_t height, uint32_t band_first, uint32_t band_step) {
-    const uint32_t tiles_y = (height + 15) / 16;
-    if (band_step == 0 || band_first >= tiles_y) return 0;
-    const uint32_t n = (tiles_y - band_first + band_step - 1) / band_step, last = band_first + (n - 1) * band_step;
-    return (n - 1) * 16 + (height - last * 16 < 16 ? height - last * 16 : 16);
+    return sdfv_band_rows_ex(height, band_first, band_step, 16u);
 }
 
 }  // extern "C"
 // Rows [y0, y1) of the image (band_step 1), or the 16-row bands y0 / 16, y0 / 16 + band_step, ... below y1 == height.
 static int raymarch_rows(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
                          const float* pairs, const float* ilv, const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width,
-                         uint32_t height, uint32_t y0, uint32_t y1, uint32_t band_step, float* rgba, float* depth,
+                         uint32_t height, uint32_t y0, uint32_t y1, uint32_t band_step, uint32_t band_height, float* rgba, float* depth,
                          sdfv_march_aux* aux, void* stream) {
     if (!rp || !tex0 || !tex1 || !rgba) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
     if (int rc = check_lights(rp)) return rc;
@@ -1056,8 +1063,9 @@ static int raymarch_rows(const sdfv_render_params* rp, const float* tex0, const 
     a.height = height;
     a.y0 = y0;
     a.y1 = y1;
-    a.band_skip = 16u * (band_step - 1u);
-    a.rows_out = band_step > 1 ? sdfv_band_rows(height, y0 / 16, band_step) : y1 - y0;
+    a.band_skip = band_height * (band_step - 1u);
+    a.band_shift = band_height == 8u ? 3u : 4u;
+    a.rows_out = band_step > 1 ? sdfv_band_rows_ex(height, y0 / band_height, band_step, band_height) : y1 - y0;
     // sdfNormal's result only feeds calculate_lighting (material.frag:155,163), and the one AmbientLight the scene
     // configures (scene/mod.rs:106-112) does not read it: dead code a GLSL compiler removes.  It is evaluated when the
     // aux record asks for it; SDFV_OPT_RAYMARCH_KEEP_NORMAL evaluates it per hit regardless (what it would cost once a
@@ -1158,6 +1166,7 @@ static int slab_round_args(const sdfv_render_params* rp, const sdfv_grid* slab, 
     a.y1 = height;
     a.rows_out = height;
     a.band_skip = 0;
+    a.band_shift = 4;
     a.n_cameras = 1;
     a.cameras[0] = *camera;
     a.rgba = reinterpret_cast<float4*>(rgba);

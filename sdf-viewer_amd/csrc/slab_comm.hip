@@ -232,28 +232,31 @@ int enqueue_exchange_packed(const Rccl* lib, const sdfv_slab_comm* c, const sdfv
     return sdfv::copy_texel_segments(src, dst, n, r_out, stream);
 }
 
-// sdfv_raymarch_bands stores a band set as [camera][band k][<= 16 rows][width]: pixel row j of the set is row
-// 16 * (band_first + (j / 16) * band_step) + j % 16 of the image.  One thread per 16-byte group of a pixel row.
+// A band set is stored as [camera][band k][<= B rows][width], B = 16 or 8: pixel row j of the set is row
+// B * (band_first + (j / B) * band_step) + j % B of the image.  One thread per 16-byte group of a pixel row.
 __global__ __launch_bounds__(256) void bands_scatter_kernel(const float4* __restrict__ part, float4* __restrict__ out,
                                                             uint32_t row_vec4, uint32_t rows_part, uint32_t height,
-                                                            uint32_t band_first, uint32_t band_step) {
+                                                            uint32_t band_first, uint32_t band_step, uint32_t band_shift) {
     const uint32_t x = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, cam = blockIdx.z;
     if (x >= row_vec4) return;
-    const uint32_t y = 16u * (band_first + (j >> 4) * band_step) + (j & 15u);
+    const uint32_t y = ((band_first + (j >> band_shift) * band_step) << band_shift) + (j & ((1u << band_shift) - 1u));
     out[((size_t)cam * height + y) * row_vec4 + x] = part[((size_t)cam * rows_part + j) * row_vec4 + x];
 }
 __global__ __launch_bounds__(256) void bands_scatter_scalar_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                                    uint32_t row_floats, uint32_t rows_part, uint32_t height,
-                                                                   uint32_t band_first, uint32_t band_step) {
+                                                                   uint32_t band_first, uint32_t band_step, uint32_t band_shift) {
     const uint32_t x = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, cam = blockIdx.z;
     if (x >= row_floats) return;
-    const uint32_t y = 16u * (band_first + (j >> 4) * band_step) + (j & 15u);
+    const uint32_t y = ((band_first + (j >> band_shift) * band_step) << band_shift) + (j & ((1u << band_shift) - 1u));
     out[((size_t)cam * height + y) * row_floats + x] = part[((size_t)cam * rows_part + j) * row_floats + x];
 }
 
-int scatter_bands(const float* part, uint32_t band_first, uint32_t band_step, uint32_t n_cameras, uint32_t width, uint32_t height,
-                  uint32_t channels, float* out, hipStream_t st) {
-    const uint32_t rows = sdfv_band_rows(height, band_first, band_step);
+int scatter_bands(const float* part, uint32_t band_first, uint32_t band_step, uint32_t band_height, uint32_t n_cameras, uint32_t width,
+                  uint32_t height, uint32_t channels, float* out, hipStream_t st) {
+    if (band_height != 0 && band_height != 8 && band_height != 16)
+        return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "band_height %u: 8 or 16 (0 = 16)", band_height);
+    const uint32_t shift = band_height == 8 ? 3u : 4u;
+    const uint32_t rows = sdfv_band_rows_ex(height, band_first, band_step, band_height);
     if (rows == 0 || n_cameras == 0 || width == 0) return SDFV_OK;
     const uint64_t row_floats = (uint64_t)width * channels;
     if (rows > 65535u || n_cameras > 65535u || row_floats >= (1ull << 32))
@@ -261,18 +264,18 @@ int scatter_bands(const float* part, uint32_t band_first, uint32_t band_step, ui
     if (row_floats % 4 == 0 && !(((uintptr_t)part | (uintptr_t)out) & 15)) {
         const uint32_t v = (uint32_t)(row_floats / 4);
         hipLaunchKernelGGL(bands_scatter_kernel, dim3((v + 255) / 256, rows, n_cameras), dim3(256), 0, st,
-                           reinterpret_cast<const float4*>(part), reinterpret_cast<float4*>(out), v, rows, height, band_first, band_step);
+                           reinterpret_cast<const float4*>(part), reinterpret_cast<float4*>(out), v, rows, height, band_first, band_step, shift);
     } else {
         hipLaunchKernelGGL(bands_scatter_scalar_kernel, dim3(((uint32_t)row_floats + 255) / 256, rows, n_cameras), dim3(256), 0, st,
-                           part, out, (uint32_t)row_floats, rows, height, band_first, band_step);
+                           part, out, (uint32_t)row_floats, rows, height, band_first, band_step, shift);
     }
     SDFV_HIPC(hipGetLastError());
     return SDFV_OK;
 }
 
 // floats of rank r's band set (band_first = r, band_step = world) of n_cameras images
-size_t band_set_floats(uint32_t height, int r, int world, uint32_t n_cameras, uint32_t width, uint32_t channels) {
-    return (size_t)n_cameras * sdfv_band_rows(height, (uint32_t)r, (uint32_t)world) * width * channels;
+size_t band_set_floats(uint32_t height, int r, int world, uint32_t band_height, uint32_t n_cameras, uint32_t width, uint32_t channels) {
+    return (size_t)n_cameras * sdfv_band_rows_ex(height, (uint32_t)r, (uint32_t)world, band_height) * width * channels;
 }
 
 }  // namespace
@@ -282,8 +285,8 @@ extern "C" {
 
 // ---- config 5's collectives ("gather of RGBA tiles to rank 0", replicas "by ncclAllGather of slabs") ----
 
-int sdfv_bands_scatter(const float* part, uint32_t band_first, uint32_t band_step, uint32_t n_cameras, uint32_t width,
-                       uint32_t height, uint32_t channels, float* out, void* stream) {
+int sdfv_bands_scatter(const float* part, uint32_t band_first, uint32_t band_step, uint32_t band_height, uint32_t n_cameras,
+                       uint32_t width, uint32_t height, uint32_t channels, float* out, void* stream) {
     if (!part || !out) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "NULL buffer");
     if (band_step == 0 || channels == 0) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "band_step or channels is 0");
     if (((uintptr_t)part | (uintptr_t)out) & 3) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "buffers must be 4-byte aligned");
@@ -292,24 +295,26 @@ int sdfv_bands_scatter(const float* part, uint32_t band_first, uint32_t band_ste
         (void)hipGetLastError();
         return sdfv::set_error(SDFV_ERR_NO_DEVICE, "no HIP device visible: libsdfgrid has no CPU path");
     }
-    return scatter_bands(part, band_first, band_step, n_cameras, width, height, channels, out, (hipStream_t)stream);
+    return scatter_bands(part, band_first, band_step, band_height, n_cameras, width, height, channels, out, (hipStream_t)stream);
 }
 
-size_t sdfv_comm_gather_bands_scratch_bytes(const sdfv_slab_comm* c, int dst, uint32_t n_cameras, uint32_t width, uint32_t height,
-                                            uint32_t channels) {
+size_t sdfv_comm_gather_bands_scratch_bytes(const sdfv_slab_comm* c, int dst, uint32_t band_height, uint32_t n_cameras, uint32_t width,
+                                            uint32_t height, uint32_t channels) {
     if (!c || c->rank != dst) return 0;
     size_t floats = 0;
     for (int r = 0; r < c->world; ++r)
-        if (r != dst) floats += (band_set_floats(height, r, c->world, n_cameras, width, channels) + 3) & ~(size_t)3;  // 16-byte aligned parts
+        if (r != dst) floats += (band_set_floats(height, r, c->world, band_height, n_cameras, width, channels) + 3) & ~(size_t)3;  // 16-byte aligned parts
     return floats * sizeof(float);
 }
 
-int sdfv_comm_gather_bands(sdfv_slab_comm* c, const float* part, uint32_t n_cameras, uint32_t width, uint32_t height,
-                           uint32_t channels, int dst, float* out, void* scratch, size_t scratch_bytes, void* stream) {
+int sdfv_comm_gather_bands(sdfv_slab_comm* c, const float* part, uint32_t band_height, uint32_t n_cameras, uint32_t width,
+                           uint32_t height, uint32_t channels, int dst, float* out, void* scratch, size_t scratch_bytes, void* stream) {
     if (!c) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "communicator is NULL");
     if (dst < 0 || dst >= c->world) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "dst %d is not a rank of a world of %d", dst, c->world);
     if (channels == 0) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "channels is 0");
-    const size_t mine = band_set_floats(height, c->rank, c->world, n_cameras, width, channels);
+    if (band_height != 0 && band_height != 8 && band_height != 16)
+        return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "band_height %u: 8 or 16 (0 = 16)", band_height);
+    const size_t mine = band_set_floats(height, c->rank, c->world, band_height, n_cameras, width, channels);
     if (mine && !part) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "part is NULL");
     const Rccl* lib;
     if (int rc = need_rccl(lib)) return rc;
@@ -319,7 +324,7 @@ int sdfv_comm_gather_bands(sdfv_slab_comm* c, const float* part, uint32_t n_came
         return SDFV_OK;
     }
     if (!out) return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "out is NULL on the gathering rank");
-    const size_t need = sdfv_comm_gather_bands_scratch_bytes(c, dst, n_cameras, width, height, channels);
+    const size_t need = sdfv_comm_gather_bands_scratch_bytes(c, dst, band_height, n_cameras, width, height, channels);
     if (need && (!scratch || scratch_bytes < need || ((uintptr_t)scratch & 15)))
         return sdfv::set_error(SDFV_ERR_INVALID_ARGUMENT, "scratch: 16-byte aligned, at least sdfv_comm_gather_bands_scratch_bytes() = %zu bytes", need);
     // every peer's set arrives whole, side by side in the scratch block (all links at once), then one launch per set moves
@@ -329,7 +334,7 @@ int sdfv_comm_gather_bands(sdfv_slab_comm* c, const float* part, uint32_t n_came
     size_t at = 0;
     for (int r = 0; r < c->world; ++r) {
         if (r == dst) continue;
-        const size_t n = band_set_floats(height, r, c->world, n_cameras, width, channels);
+        const size_t n = band_set_floats(height, r, c->world, band_height, n_cameras, width, channels);
         if (n && first_error == kNcclSuccess) first_error = lib->Recv(static_cast<float*>(scratch) + at, n, kNcclFloat, r, c->comm, st);
         at += (n + 3) & ~(size_t)3;
     }
@@ -339,8 +344,8 @@ int sdfv_comm_gather_bands(sdfv_slab_comm* c, const float* part, uint32_t n_came
     at = 0;
     for (int r = 0; r < c->world; ++r) {
         const float* src = r == dst ? part : static_cast<const float*>(scratch) + at;
-        if (int rc = scatter_bands(src, (uint32_t)r, (uint32_t)c->world, n_cameras, width, height, channels, out, st)) return rc;
-        if (r != dst) at += (band_set_floats(height, r, c->world, n_cameras, width, channels) + 3) & ~(size_t)3;
+        if (int rc = scatter_bands(src, (uint32_t)r, (uint32_t)c->world, band_height, n_cameras, width, height, channels, out, st)) return rc;
+        if (r != dst) at += (band_set_floats(height, r, c->world, band_height, n_cameras, width, channels) + 3) & ~(size_t)3;
     }
     return SDFV_OK;
 }

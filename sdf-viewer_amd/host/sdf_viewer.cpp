@@ -138,7 +138,11 @@ SDFViewer::SDFViewer(std::array<size_t, 3> voxels, const BoundingBox& bb, size_t
     const size_t bytes = voxels[0] * voxels[1] * voxels[2] * 16;
     // Both textures in one block, tex1 at the distance tune() measured for this size on this device (0 when nobody asked:
     // allocation only, nothing is launched or waited for here).  If the block cannot be had, two plain allocations do.
-    size_t skew = 0;
+    // Untuned default: what MI355X boxes have shown reproducibly since round 1 for the texture sizes that matter (the fill's
+    // rate is periodic in the distance between the textures, EXPERIMENTS R4.1, profiles/r04_place_width.json): textures of
+    // 256 MiB (256^3 and every other shape of that size) run 6-8 % faster with tex1 12 KiB after tex0's end, textures of 1 GiB
+    // with 20 KiB, 4 GiB (512^3) with none.  Anything else: none.  tune() replaces the guess by a measurement.
+    size_t skew = bytes == ((size_t)1 << 28) ? 12288 : (bytes == ((size_t)1 << 30) ? 20480 : 0);
     {
         std::lock_guard<std::mutex> lock(g_placement_mutex);
         const auto it = g_placement_skew.find({current_device(), bytes});

@@ -104,7 +104,8 @@ class SDFViewer {
     // bases (include/sdfgrid.h, sdfv_tune_texture_placement).  tune() MEASURES it for grids of this size on the current
     // device -- tens of milliseconds, blocking -- and remembers the verdict process-wide; viewers created afterwards for a
     // grid of the same byte size on that device are placed accordingly.  Never called implicitly: from_bb / new_voxels
-    // allocate and return (untuned placement: tex1 right after tex0).  Returns 0, or the library's error code.
+    // allocate and return (untuned placement: tex1 right after tex0, or at the small distance MI355X has shown to be best
+    // for textures of exactly 256 MiB / 1 GiB -- sdf_viewer.cpp).  Returns 0, or the library's error code.
     static int tune(std::array<size_t, 3> voxels, void* stream = nullptr);
 
     // scene/sdf/mod.rs:128-217.  Returns the number of LoadingManager iterations consumed, like the reference.

@@ -276,21 +276,21 @@ class SlabComm:
         return rgba, merged_aux, status
 
     # ---- config 5's collectives over this communicator; every rank calls, nothing synchronises ----
-    def gather_bands(self, part, height, dst=0, stream=None):
-        """sdfv_comm_gather_bands: part = [n_cam, band rows of this rank, W, C] rendered with bands=(rank, world) -> on `dst` the
-        images [n_cam, height, W, C] (None elsewhere)."""
+    def gather_bands(self, part, height, dst=0, stream=None, band_height=16):
+        """sdfv_comm_gather_bands: part = [n_cam, band rows of this rank, W, C] rendered with bands=(rank, world, band_height) -> on
+        `dst` the images [n_cam, height, W, C] (None elsewhere)."""
         pkg = self.pkg
         stream = torch.cuda.current_stream() if stream is None else stream
         n_cam, _, width, ch = (int(v) for v in part.shape)
         with torch.cuda.stream(stream):
             out = scratch = None
-            n = int(pkg.lib.sdfv_comm_gather_bands_scratch_bytes(self.handle, dst, n_cam, width, height, ch))
+            n = int(pkg.lib.sdfv_comm_gather_bands_scratch_bytes(self.handle, dst, band_height, n_cam, width, height, ch))
             if self.rank == dst:
                 out = torch.empty((n_cam, height, width, ch), dtype=torch.float32, device=part.device)
                 scratch = torch.empty(max(n // 4, 4), dtype=torch.float32, device=part.device)
             enter_stage("SlabComm.gather_bands: sdfv_comm_gather_bands over the library communicator")
-            pkg.check(pkg.lib.sdfv_comm_gather_bands(self.handle, C.c_void_p(part.data_ptr()) if part.numel() else None, n_cam, width,
-                                                     height, ch, dst, None if out is None else C.c_void_p(out.data_ptr()),
+            pkg.check(pkg.lib.sdfv_comm_gather_bands(self.handle, C.c_void_p(part.data_ptr()) if part.numel() else None, band_height, n_cam,
+                                                     width, height, ch, dst, None if out is None else C.c_void_p(out.data_ptr()),
                                                      None if scratch is None else C.c_void_p(scratch.data_ptr()), n,
                                                      C.c_void_p(stream.cuda_stream)))
         self._gather_scratch = scratch  # alive until the stream has run the scatter
@@ -573,11 +573,18 @@ def split_rows(height, rank, world, tile=16):
     return min(height, tiles * rank // world * tile), min(height, tiles * (rank + 1) // world * tile)
 
 
-def split_bands(height, rank, world):
-    """The BALANCED image-tile split of config 5: rank r renders the 16-row tile bands r, r + world, r + 2 world, ... of every
-    image (sdfv_raymarch_bands) -- the rows under the object cost ten times the background's, so contiguous ranges leave the
-    outer ranks idle; -> (band_first, band_step) for raymarch(bands=...)."""
-    return rank, world
+def band_height_for(height, world):
+    """Rows per band of the image-tile split: a workgroup's 16, or a wave's 8 when a rank would get fewer than 12 bands of 16
+    (the rows under the object are then dealt too coarsely: 8 ranks at 1080p hold 4 or 5 object bands each -- tools/
+    split_balance.py: 4.9x -> 5.4x with 8-row bands; 4 ranks lose 2 % to the finer bands and keep 16)."""
+    return 8 if (height + 15) // 16 < 12 * world else 16
+
+
+def split_bands(height, rank, world, band_height=None):
+    """The BALANCED image-tile split of config 5: rank r renders the tile bands r, r + world, r + 2 world, ... of every image
+    (sdfv_march_desc.band_*) -- the rows under the object cost ten times the background's, so contiguous ranges leave the outer
+    ranks idle; -> (band_first, band_step, band_height) for raymarch(bands=...)."""
+    return rank, world, band_height_for(height, world) if band_height is None else band_height
 
 
 def band_rows(height, first, step, tile=16):
@@ -588,23 +595,25 @@ def band_rows(height, first, step, tile=16):
     return rows
 
 
-def assemble_bands(parts, height):
+def assemble_bands(parts, height, band_height=None):
     """The image [n_cam, height, W, ...] from the `world` band sets of split_bands, parts[r] = what rank r rendered."""
     world = len(parts)
+    band_height = band_height_for(height, world) if band_height is None else band_height
     out = torch.empty((parts[0].shape[0], height) + tuple(parts[0].shape[2:]), dtype=parts[0].dtype, device=parts[0].device)
     for r, part in enumerate(parts):
-        out[:, torch.as_tensor(band_rows(height, r, world), dtype=torch.long, device=out.device)] = part
+        out[:, torch.as_tensor(band_rows(height, r, world, band_height), dtype=torch.long, device=out.device)] = part
     return out
 
 
-def gather_bands(part, height, rank, world, dst=0, group=None, comm=None):
+def gather_bands(part, height, rank, world, dst=0, group=None, comm=None, band_height=None):
     """Collect the band sets of split_bands on rank `dst` -> [n_cam, height, W, 4] (None elsewhere).  comm: a SlabComm -- the
     library's own collective then (sdfv_comm_gather_bands); torch.distributed is the gloo / CPU-test transport."""
+    band_height = band_height_for(height, world) if band_height is None else band_height  # (split_bands' default)
     if world == 1 and comm is None:
         return part
     if comm is not None and comm.handle:
-        return comm.gather_bands(part, height, dst=dst)
-    deepest = max(len(band_rows(height, r, world)) for r in range(world))
+        return comm.gather_bands(part, height, dst=dst, band_height=band_height)
+    deepest = max(len(band_rows(height, r, world, band_height)) for r in range(world))
     staged = _needs_host_staging(part, group)
     dev = torch.device("cpu") if staged else part.device
     padded = torch.zeros((part.shape[0], deepest) + tuple(part.shape[2:]), dtype=part.dtype, device=dev)
@@ -614,7 +623,7 @@ def gather_bands(part, height, rank, world, dst=0, group=None, comm=None):
     c10d.gather(padded, got, dst=dst, group=group)
     if rank != dst:
         return None
-    return assemble_bands([g[:, :len(band_rows(height, r, world))] for r, g in enumerate(got)], height).to(part.device)
+    return assemble_bands([g[:, :len(band_rows(height, r, world, band_height))] for r, g in enumerate(got)], height, band_height).to(part.device)
 
 
 def gather_rows(band, height, rank, world, dst=0, group=None, tile=16):

@@ -563,13 +563,14 @@ def test_interleaved_tile_bands_assemble_to_the_frame(pkg):
         for vols in (dict(), dict(dist=dist), dict(dist=dist, pairs=pairs)):
             whole, whole_depth, whole_aux = pkg.raymarch(rp, t0, t1, cams, W, H, want_depth=True, want_aux=True, **vols)
             for world in (1, 2, 3, 8):
-                parts = [pkg.raymarch(rp, t0, t1, cams, W, H, bands=par.split_bands(H, r, world), want_depth=True, want_aux=True, **vols)
-                         for r in range(world)]
-                for r, (rgba, depth, aux) in enumerate(parts):
-                    assert rgba.shape[1] == len(par.band_rows(H, r, world)) == int(pkg.lib.sdfv_band_rows(H, r, world))
-                for k, ref in enumerate((whole, whole_depth, whole_aux)):
-                    got = par.assemble_bands([p[k] for p in parts], H)
-                    assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (W, H, lod, list(vols), world, k)
+                for bh in (16, 8):  # a workgroup's rows per band, or a wave's (what split_bands picks when bands are few)
+                    parts = [pkg.raymarch(rp, t0, t1, cams, W, H, bands=par.split_bands(H, r, world, bh), want_depth=True, want_aux=True, **vols)
+                             for r in range(world)]
+                    for r, (rgba, depth, aux) in enumerate(parts):
+                        assert rgba.shape[1] == len(par.band_rows(H, r, world, bh)) == int(pkg.lib.sdfv_band_rows_ex(H, r, world, bh))
+                    for k, ref in enumerate((whole, whole_depth, whole_aux)):
+                        got = par.assemble_bands([p[k] for p in parts], H, bh)
+                        assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (W, H, lod, list(vols), world, bh, k)
     # a compact buffer with a canary behind it; a band set beyond the image renders nothing
     rp = pkg.default_render_params(g)
     W, H = 64, 40
@@ -582,6 +583,9 @@ def test_interleaved_tile_bands_assemble_to_the_frame(pkg):
     assert pkg.raymarch(rp, t0, t1, cam, W, H, bands=(3, 4)).shape[1] == 0
     with pytest.raises(pkg.SdfvError):
         pkg.raymarch(rp, t0, t1, cam, W, H, bands=(0, 0))
+    with pytest.raises(pkg.SdfvError):
+        pkg.raymarch(rp, t0, t1, cam, W, H, bands=(0, 2, 12))  # bands are a workgroup's 16 rows or a wave's 8
+    assert par.band_height_for(1080, 8) == 8 and par.band_height_for(1080, 4) == 16 and par.band_height_for(2160, 8) == 16
 
 
 def test_small_launches_of_a_batch_overlap_on_side_streams_and_change_nothing(pkg):

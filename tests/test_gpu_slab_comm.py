@@ -272,9 +272,10 @@ def test_config4_sized_slices_through_the_loopback_exchange(pkg, par, loop_comm)
 
 # ---- config 5's collectives behind the C ABI (VERDICT r03 missing 4) ----
 
+@pytest.mark.parametrize("bh", [16, 8])
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 @pytest.mark.parametrize("height,width,n_cam", [(64, 48, 2), (90, 33, 3), (17, 20, 1)])
-def test_bands_scatter_assembles_what_raymarch_bands_rendered(pkg, par, world, height, width, n_cam):
+def test_bands_scatter_assembles_what_raymarch_bands_rendered(pkg, par, world, height, width, n_cam, bh):
     """sdfv_bands_scatter is the inverse of sdfv_raymarch_bands' layout: the band sets of `world` ranks (rendered one after the
     other on this GPU), scattered into one buffer, are the whole-image batch bit for bit -- rgba (16-byte path), the depth
     plane (scalar path: widths that are no multiple of 4) and the aux record."""
@@ -289,17 +290,17 @@ def test_bands_scatter_assembles_what_raymarch_bands_rendered(pkg, par, world, h
     out_depth = torch.full_like(want_depth, -3.0)
     out_aux = torch.full_like(want_aux, -3)
     for r in range(world):
-        part, depth, aux = pkg.raymarch(rp, t0, t1, cams, width, height, bands=(r, world), want_depth=True, want_aux=True)
+        part, depth, aux = pkg.raymarch(rp, t0, t1, cams, width, height, bands=(r, world, bh), want_depth=True, want_aux=True)
         if part.shape[1] == 0:
             continue
         for src, dst, ch in ((part, out, 4), (depth, out_depth, 1), (aux.view(torch.float32), out_aux.view(torch.float32), pkg.AUX_FLOATS)):
-            pkg.check(pkg.lib.sdfv_bands_scatter(C.c_void_p(src.data_ptr()), r, world, n_cam, width, height, ch,
+            pkg.check(pkg.lib.sdfv_bands_scatter(C.c_void_p(src.data_ptr()), r, world, bh, n_cam, width, height, ch,
                                                  C.c_void_p(dst.data_ptr()), None))
     torch.cuda.synchronize()
     assert torch.equal(out.view(torch.int32), want.view(torch.int32))
     assert torch.equal(out_depth.view(torch.int32), want_depth.view(torch.int32))
     assert torch.equal(out_aux, want_aux)
-    assert torch.equal(out, par.assemble_bands([pkg.raymarch(rp, t0, t1, cams, width, height, bands=(r, world)) for r in range(world)], height))
+    assert torch.equal(out, par.assemble_bands([pkg.raymarch(rp, t0, t1, cams, width, height, bands=(r, world, bh)) for r in range(world)], height, bh))
 
 
 def test_gathers_over_the_library_communicator_in_loopback(pkg, par, oracle):
@@ -330,10 +331,11 @@ def test_gathers_over_the_library_communicator_in_loopback(pkg, par, oracle):
         got_cams = par.gather_images(whole, 3, 0, 1, comm=comm)
         torch.cuda.synchronize()
         assert torch.equal(got, whole) and torch.equal(got_cams, whole)
-        assert pkg.lib.sdfv_comm_gather_bands_scratch_bytes(comm.handle, 0, 3, W, H, 4) == 0  # no peers: nothing to stage
+        assert pkg.lib.sdfv_comm_gather_bands_scratch_bytes(comm.handle, 0, 16, 3, W, H, 4) == 0  # no peers: nothing to stage
         # argument errors are status codes
-        assert pkg.lib.sdfv_comm_gather_bands(comm.handle, C.c_void_p(part.data_ptr()), 3, W, H, 4, 5, None, None, 0, None) == -1
-        assert pkg.lib.sdfv_comm_gather_bands(comm.handle, C.c_void_p(part.data_ptr()), 3, W, H, 4, 0, None, None, 0, None) == -1
+        assert pkg.lib.sdfv_comm_gather_bands(comm.handle, C.c_void_p(part.data_ptr()), 16, 3, W, H, 4, 5, None, None, 0, None) == -1
+        assert pkg.lib.sdfv_comm_gather_bands(comm.handle, C.c_void_p(part.data_ptr()), 16, 3, W, H, 4, 0, None, None, 0, None) == -1
+        assert pkg.lib.sdfv_comm_gather_bands(comm.handle, C.c_void_p(part.data_ptr()), 12, 3, W, H, 4, 0, None, None, 0, None) == -1
         bad = (C.c_uint32 * 2)(1, 12)
         assert pkg.lib.sdfv_comm_allgather_slabs(comm.handle, (C.c_uint32 * 3)(*dims), bad, C.c_void_p(slab.owned0.data_ptr()),
                                                  C.c_void_p(slab.owned1.data_ptr()), None, C.c_void_p(full0.data_ptr()),

@@ -74,8 +74,8 @@ def _worker(rank, world, port, dims, q, halo_hi=1):
             ok &= whole is None
         # the balanced image-tile split: rank r's 16-row tile bands r, r + world, ...; every pixel carries its image row
         for Himg in (50, 64, 7):
-            first, step = par.split_bands(Himg, rank, world)
-            rows = par.band_rows(Himg, first, step)
+            first, step, bh = par.split_bands(Himg, rank, world)
+            rows = par.band_rows(Himg, first, step, bh)
             part = torch.tensor(rows, dtype=torch.float32).reshape(1, -1, 1, 1).expand(2, -1, 6, 4).contiguous()
             whole = par.gather_bands(part, Himg, rank, world, dst=0)
             if rank == 0:
