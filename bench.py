@@ -548,11 +548,13 @@ def run(redirect):
         out["commit_ms"] = round(commit_ms, 4) if commit_ms != INF else None
         out["commit_note"] = ("sdfv_commit_distance as a pass of its own (device-side SDFViewer::commit for a grid filled "
                               "without the volume); not part of either pipeline")
-        traffic = load_traffic(args.workload + ("_fused" if bpv == 36 else ""))  # (the interleaved variant stores the same bytes)
+        traffic = None
+        for key in {"plain": ("",), "fused": ("_fused",), "fused_ilv": ("_fused_ilv", "_fused")}[chosen]:  # (ilv: the same bytes)
+            traffic = traffic if traffic is not None else load_traffic(args.workload + key)
         out["roofline"] = fill_roofline(kern_ms, voxels_per_rank, bpv, traffic)
         out["roofline_raymarch"] = raymarch_traffic_report(args.workload, march_ev,
                                                            "tex0_path" if chosen == "plain" else "product_path",
-                                                           args.workload + ("_tex0" if chosen == "plain" else ""))
+                                                           args.workload + {"plain": "_tex0", "fused": "", "fused_ilv": "_ilv"}[chosen])
         transport, filler = None, None
         my_cams, r0, r1 = [cam0], owned0, owned1
     else:

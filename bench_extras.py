@@ -21,6 +21,8 @@ def raymarch_traffic_report(workload_key, launch_ms, path_key="product_path", tr
     rep = {"kernel": "raymarch_kernel", "bound": "latency (<=255 dependent gathers per ray), not hbm",
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": round(launch_ms, 5)}
     traffic = load_traffic(traffic_key or workload_key, "raymarch_pmc_traffic.json") if workload_key else None
+    if traffic is None and traffic_key and traffic_key.endswith("_ilv"):  # no PMC pass of the interleaved march yet: the distance-volume one
+        traffic = load_traffic(workload_key, "raymarch_pmc_traffic.json")
     model = None
     try:
         model = json.load(open(os.path.join(ROOT, "profiles", "raymarch_model_bytes.json"))).get(workload_key)
@@ -88,7 +90,10 @@ def progressive_block(pkg, torch, prm, sides, reps=7):
     out = {}
     for side in sides:
         g = pkg.make_grid((side,) * 3)
-        t0, t1 = pkg.alloc_textures(g)
+        # one block, tex1 at the viewer's default distance from tex0 (host/sdf_viewer.cpp, pkg.default_texture_skew): the product
+        # host's placement is what is timed.  (The whole-rows pass stays bimodal from PROCESS to process all the same -- 28 or 44 us
+        # at 256^3 on one box, whichever way the textures are placed virtually: EXPERIMENTS R4.4.)
+        t0, t1 = pkg.alloc_textures_placed(g)
         dist = torch.empty((side,) * 3, dtype=torch.float32, device=t0.device)
         n = side ** 3
 

@@ -105,6 +105,23 @@ def _fill_rate_probe(grid, pairs, rounds=2):
     return [t / rounds for t in total]
 
 
+def default_texture_skew(texture_bytes):
+    """host/sdf_viewer.cpp's untuned placement: bytes between the end of tex0 and the start of tex1 in ONE block that MI355X has
+    shown to be best, reproducibly, for the texture sizes that matter (EXPERIMENTS R4.1: the fill's rate is periodic in that
+    distance)."""
+    return {1 << 28: 12288, 1 << 30: 20480}.get(int(texture_bytes), 0)
+
+
+def alloc_textures_placed(grid, device="cuda"):
+    """Both textures in one block at default_texture_skew(): what SDFViewer::new_voxels allocates (no probe, deterministic)."""
+    shape = (int(grid.z_end) - int(grid.z_begin), int(grid.dims[1]), int(grid.dims[0]), 4)
+    n = shape[0] * shape[1] * shape[2] * 4
+    skew = default_texture_skew(n * 4) // 4
+    block = torch.empty(2 * n + skew + 64, dtype=torch.float32, device=device)
+    pad = ((-block.data_ptr()) % 256) // 4
+    return block[pad:pad + n].view(shape), block[pad + n + skew:pad + 2 * n + skew].view(shape)
+
+
 def alloc_textures(grid, device="cuda", tuned=False, attempts=4):
     """Two RGBA32F textures for the slab described by `grid` (uninitialised device memory).
 

@@ -39,7 +39,6 @@ struct Rccl {
     int (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
-    int (*Broadcast)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     const char* load_error = nullptr;
 };
@@ -70,7 +69,6 @@ const Rccl* rccl() {
         ok = bind(r.handle, "ncclSend", r.Send) && ok;
         ok = bind(r.handle, "ncclRecv", r.Recv) && ok;
         ok = bind(r.handle, "ncclAllReduce", r.AllReduce) && ok;
-        ok = bind(r.handle, "ncclBroadcast", r.Broadcast) && ok;
         ok = bind(r.handle, "ncclGetErrorString", r.GetErrorString) && ok;
         if (!ok) r.load_error = "librccl.so.1 lacks an ncclSend/ncclRecv entry point";
         return r;
@@ -395,19 +393,28 @@ int sdfv_comm_allgather_slabs(sdfv_slab_comm* c, const uint32_t dims[3], const u
     if (int rc = need_rccl(lib)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const size_t slice = (size_t)dims[0] * dims[1];
-    // one broadcast per slab and buffer, all in one group: slabs may differ in depth (ncclAllGather wants equal shares)
+    // Point-to-point only, in ONE group (the primitive the halo exchange already rests on; slabs may differ in depth, which
+    // ncclAllGather does not take): this rank's slab goes to every peer, every peer's slab arrives at its place in the output;
+    // this rank's own share is a local copy.
+    struct Buf { const float* mine; float* out; size_t per_voxel; };
+    const Buf bufs[3] = {{tex0_owned, out0, 4}, {tex1_owned, out1, 4}, {dist_owned, out_dist, 1}};
+    const size_t my_z0 = z_bounds[c->rank], my_n = (size_t)(z_bounds[c->rank + 1] - z_bounds[c->rank]) * slice;
+    for (const Buf& b : bufs)
+        if (b.out && my_n && b.out + my_z0 * slice * b.per_voxel != b.mine)
+            SDFV_HIPC(hipMemcpyAsync(b.out + my_z0 * slice * b.per_voxel, b.mine, my_n * b.per_voxel * sizeof(float), hipMemcpyDeviceToDevice, st));
     SDFV_RCCL(lib, GroupStart());
     int first_error = kNcclSuccess;
     auto post = [&](int r) {
         if (first_error == kNcclSuccess) first_error = r;
     };
     for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank) continue;
         const size_t z0 = z_bounds[r], n = (size_t)(z_bounds[r + 1] - z_bounds[r]) * slice;
-        if (n == 0) continue;
-        const bool me = r == c->rank;
-        post(lib->Broadcast(me ? tex0_owned : out0 + z0 * slice * 4, out0 + z0 * slice * 4, n * 4, kNcclFloat, r, c->comm, st));
-        post(lib->Broadcast(me ? tex1_owned : out1 + z0 * slice * 4, out1 + z0 * slice * 4, n * 4, kNcclFloat, r, c->comm, st));
-        if (out_dist) post(lib->Broadcast(me ? dist_owned : out_dist + z0 * slice, out_dist + z0 * slice, n, kNcclFloat, r, c->comm, st));
+        for (const Buf& b : bufs) {
+            if (!b.out) continue;
+            if (my_n) post(lib->Send(b.mine, my_n * b.per_voxel, kNcclFloat, r, c->comm, st));
+            if (n) post(lib->Recv(b.out + z0 * slice * b.per_voxel, n * b.per_voxel, kNcclFloat, r, c->comm, st));
+        }
     }
     post(lib->GroupEnd());
     if (first_error != kNcclSuccess) return sdfv::set_error(SDFV_ERR_COMM, "RCCL all-gather of the slabs: %s", lib->GetErrorString(first_error));

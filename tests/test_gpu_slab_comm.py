@@ -305,7 +305,7 @@ def test_bands_scatter_assembles_what_raymarch_bands_rendered(pkg, par, world, h
 
 def test_gathers_over_the_library_communicator_in_loopback(pkg, par, oracle):
     """sdfv_comm_gather_bands / _gather_cameras / _allgather_slabs with a world of one: every RCCL call of the path runs (a
-    group with no peers, the broadcasts from this rank), the scatter kernels and the copy run, and the results are the
+    group with no peers, the local copies of this rank's own share), the scatter kernels run, and the results are the
     inputs in place.  What a second device adds is the messages themselves (gloo covers the splits: test_parallel_cpu.py)."""
     comm = par.SlabComm(pkg, 0, 1)
     try:

@@ -33,7 +33,7 @@ def cores():
 
 
 AUX_FIELDS = ["status", "steps", "hit_pos", "t", "raw0", "raw1", "normal", "depth"]
-PIPELINES = ("plain", "fused")
+PIPELINES = ("plain", "fused", "fused_ilv")
 
 
 def check(side, threads=None, log=print, eye=(2.5, 3.0, 5.0), pipeline="plain", **param_overrides):
@@ -55,15 +55,23 @@ def check(side, threads=None, log=print, eye=(2.5, 3.0, 5.0), pipeline="plain", 
     oprm = oracle.params_from(prm)
     g = pkg.make_grid(dims)
     t0, t1 = pkg.alloc_textures(g)
-    dist = None
+    dist = ilv_vol = None
     if pipeline == "fused":
         dist = torch.full((side, side, side), -3.0, dtype=torch.float32, device=t0.device)
         pkg.fill_grid(prm, g, t0, t1, dist=dist)   # sdfv_fill_grid_commit, default options (auto-nt)
+    elif pipeline == "fused_ilv":
+        # round 4's third pipeline: the dense fill writes the march's y-interleaved volume itself (a step-1 virgin pass with
+        # SDFV_PASS_VOLUME_INTERLEAVED); compared below as the de-interleaved distance volume
+        ilv_vol = torch.full((side, side, side), -3.0, dtype=torch.float32, device=t0.device)
+        pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=ilv_vol, flags=pkg._capi.PASS_VIRGIN_GRID | pkg._capi.PASS_VOLUME_INTERLEAVED)
     else:
         pkg.fill_grid(prm, g, t0, t1)              # sdfv_fill_grid
     torch.cuda.synchronize()
     h0, h1 = t0.cpu().numpy(), t1.cpu().numpy()
     hd = None if dist is None else dist.cpu().numpy()
+    if ilv_vol is not None:  # rows 2p, 2p + 1 as one row of pairs -> [D, H, W]
+        v = ilv_vol.view(side, side // 2, side, 2)
+        hd = torch.stack([v[..., 0], v[..., 1]], dim=2).reshape(side, side, side).cpu().numpy()
     t = time.time()
     bad = 0
     chunk = 32
@@ -79,8 +87,8 @@ def check(side, threads=None, log=print, eye=(2.5, 3.0, 5.0), pipeline="plain", 
     rp = pkg.default_render_params(g)
     cam = pkg.camera_look_at(eye=eye, aspect=W / H)
     # the kernel bench.py times: no aux record, default options (hand-written loop, interior fetch, box-first order)
-    rgba = pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist)
-    rgba_aux, aux = pkg.raymarch(rp, t0, t1, cam, W, H, want_aux=True, dist=dist)
+    rgba = pkg.raymarch(rp, t0, t1, cam, W, H, dist=dist, ilv=ilv_vol)
+    rgba_aux, aux = pkg.raymarch(rp, t0, t1, cam, W, H, want_aux=True, dist=dist, ilv=ilv_vol)
     pairs_diff = None
     if dist is not None:  # the y-pair volume (what a host that renders many frames per load marches over): same bits
         pairs = pkg.commit_pairs(g, dist)
@@ -103,7 +111,7 @@ def check(side, threads=None, log=print, eye=(2.5, 3.0, 5.0), pipeline="plain", 
         diff["rgba_ilv_vs_dist"] = ilv_diff
     err = float(np.abs(rgba[0].cpu().numpy() - want_rgba).max())
     hits = int((want_aux["status"] == 1).sum())
-    log(f"[{pipeline}] {W}x{H} no-aux march over {'the distance volume' if dist is not None else 'tex0.r'} of {side}^3: "
+    log(f"[{pipeline}] {W}x{H} no-aux march over {'the distance volume' if dist is not None else ('the y-interleaved volume the fill wrote' if ilv_vol is not None else 'tex0.r')} of {side}^3: "
         f"{W * H} pixels ({hits} hits, {int(want_aux['steps'].sum())} march steps) compared in {time.time() - t:.1f} s: "
         f"differing words per aux field / no-aux RGBA vs aux RGBA {diff}; max |RGBA - oracle| = {err:.3g}")
     return bad, diff, err

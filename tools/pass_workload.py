@@ -14,7 +14,7 @@ side = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 group = sys.argv[2] if len(sys.argv) > 2 else "load_virgin"
 REPS = int(os.environ.get("PASS_REPS", "100"))
 prm = pkg.default_params(); g = pkg.make_grid((side,) * 3)
-t0, t1 = pkg.alloc_textures(g); dist = torch.empty((side,) * 3, dtype=torch.float32, device="cuda")
+t0, t1 = pkg.alloc_textures_placed(g); dist = torch.empty((side,) * 3, dtype=torch.float32, device="cuda")  # bench.py's placement
 whole, eighth = (-1, -1, -1, 1, 1, 1), (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5)
 VS = K.PASS_VIRGIN_GRID | K.PASS_SAME_LOAD
 
