@@ -196,21 +196,23 @@ def progressive_block(pkg, torch, prm, sides, reps=7):
 
 
 def batch_valu_roofline(workload_key, world, ms_per_batch):
-    """The 64-camera batch fills the machine with short waves and is bound by VALU ISSUE, not by HBM: one wave64 VALU
-    instruction occupies its SIMD's issue port for 4 cycles (16 lanes per cycle), so a SIMD retires at most clock / 4 wave
-    instructions per second.  frac = (VALU wave-instructions of one batch, PMC SQ_INSTS_VALU, committed pass) /
-    (1024 SIMDs x clock / 4 x batch time)."""
+    """The 64-camera batch fills the machine with short waves; is it bound by VALU ISSUE?  CDNA4's SIMDs are 32 lanes wide
+    (MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues over 2 cycles; 157.3 TFLOP/s fp32 = 64 FLOP/clk/SIMD),
+    so a SIMD retires at most clock / 2 wave instructions per second.  frac = (VALU wave-instructions of one batch, PMC
+    SQ_INSTS_VALU, committed pass) / (1024 SIMDs x clock / 2 x batch time).  Rounds 2-3 priced this with clock / 4 (the 16-lane
+    SIMD of earlier CDNA): their 0.67-0.72 is 0.34-0.36 on this scale -- the batch is not VALU-issue bound either way (removing a
+    sixth of its instructions moved nothing, EXPERIMENTS R3.9); its gathers are what it waits for."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "raymarch_batch_valu.json")))[workload_key]
     except Exception:  # noqa: BLE001
         return None
     simds, clock = 1024 * world, float(d.get("clock_GHz", 2.4))
-    peak = simds * clock * 1e9 / 4.0
+    peak = simds * clock * 1e9 / 2.0
     rate = d["valu_wave_instructions_per_batch"] / (ms_per_batch * 1e-3)
     return {"bound": "valu issue", "valu_wave_instructions_per_batch": d["valu_wave_instructions_per_batch"],
             "achieved": round(rate / 1e12, 3), "peak": round(peak / 1e12, 3), "unit": "T wave-instructions/s",
             "frac": round(rate / peak, 4), "simds": simds, "clock_GHz": clock, "source": d.get("source"),
-            "note": "wave64 VALU instruction = 4 issue cycles on its SIMD; peak = SIMDs x clock / 4"}
+            "note": "wave64 VALU instruction = 2 issue cycles on a CDNA4 SIMD-32; peak = SIMDs x clock / 2 (rounds 2-3 used / 4: twice this frac)"}
 
 
 def raymarch_rank_cameras_report(workload_key, world, launch_ms):
@@ -440,7 +442,7 @@ def run_extras(c):
             batch_report["steady_state_frame"] = {"march_over": batch_report["march_over"], "ms_per_frame": round(f_acc, 4),
                                                   "value": round(W * H / f_acc / 1e3, 1), "unit": "Mrays/s",
                                                   "over_distance_volume_ms": round(f_dist, 4)}
-        # the batch is issue-bound, not HBM-bound: VALU wave-instructions per batch / (SIMDs x clock / 4 cycles per wave64
+        # how far the batch is from the VALU ISSUE roofline: VALU wave-instructions per batch / (SIMDs x clock / 2 cycles per wave64
         # VALU instruction) -- the roofline that actually bounds it (counts: profiles/raymarch_batch_valu.json)
         batch_report["roofline_raymarch_batch"] = batch_valu_roofline(args.workload, world, batch_report["ms_per_batch"])
 

@@ -10,7 +10,7 @@ pkg = importlib.import_module("sdf-viewer_amd"); K = pkg._capi
 prev_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "sdf-viewer_amd", "libsdfgrid_prev.so")
 side = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 prev = C.CDLL(prev_path)
-for name in ("sdfv_fill_grid_pass_dist", "sdfv_grid_init", "sdfv_fill_grid_commit"):
+for name in ("sdfv_fill_grid_pass_ex", "sdfv_grid_init", "sdfv_fill_grid_commit"):
     getattr(prev, name).restype = C.c_int
     getattr(prev, name).argtypes = K.PROTOTYPES[name][1]
 libs = {"new": pkg.lib, "prev": prev}
@@ -44,7 +44,25 @@ cases = {"fresh_step_1": (lambda lib: (lambda: pass_(lib, 1), fresh)),
          "noop_step_2": (lambda lib: (lambda: pass_(lib, 2), loaded)),
          "box8_step_1": (lambda lib: (lambda: pass_(lib, 1, eighth), loaded)),
          "box8_step_2": (lambda lib: (lambda: pass_(lib, 2, eighth), loaded)),
+         "box8_step_4": (lambda lib: (lambda: pass_(lib, 4, eighth), loaded)),
          "dense_fused": (lambda lib: (lambda: lib.sdfv_fill_grid_commit(C.byref(prm), 0, C.byref(g), P(t0), P(t1), P(dist), st), (lambda: None)))}
+# same texels from both builds: a fresh 3-pass load, then a boxed edit with other parameters
+import copy
+states = {}
+for label, lib in libs.items():
+    fresh()
+    for stp in (4, 2, 1):
+        pass_(lib, stp)
+    keep = (t0.clone(), t1.clone(), dist.clone())
+    prm2 = pkg.default_params(sphere_radius=0.8, cube_material=1)
+    prm_saved, prm = prm, prm2
+    for stp in (4, 2, 1):
+        pass_(lib, stp, eighth)
+    prm = prm_saved
+    states[label] = keep + (t0.clone(), t1.clone(), dist.clone())
+torch.cuda.synchronize()
+assert all(torch.equal(x, y) for x, y in zip(states["new"], states["prev"])), "the two builds disagree"
+del states
 res = {}
 for name, mk in cases.items():
     r = {"new": [], "prev": []}
