@@ -1112,7 +1112,12 @@ __global__ __launch_bounds__(256) void raymarch_slab_kernel(RaymarchArgs a, Slab
     const bool mine = marching;  // this rank reports the ray's end unless it hands the ray over
     int status = 0, steps = 0;
     bool exported = false;
+    int export_dir = 0;
     Footprint hit_fp{};
+    // one-cell cache (round 4), as in the single-GPU kernels: the eight corner distances are re-fetched only when the ray
+    // enters another cell -- (o000, o111) identify the cell with its clamps -- and the longest rays are the ones that crawl
+    uint32_t cell0 = 0xffffffffu, cell7 = 0xffffffffu;
+    float c000 = 0.0f, c100 = 0.0f, c010 = 0.0f, c110 = 0.0f, c001 = 0.0f, c101 = 0.0f, c011 = 0.0f, c111 = 0.0f;
     for (;;) {
         marching = marching && i < 255;  // sdfRaycast's `for (i < 255)`; a ray that runs out keeps status 0 for now
         if (__ballot(marching) == 0ull) break;
@@ -1126,27 +1131,21 @@ __global__ __launch_bounds__(256) void raymarch_slab_kernel(RaymarchArgs a, Slab
         int k0c;
         const Footprint f = footprint_slab(tex, to_p01<XF>(a, ray_pos), k0c);
         if (k0c < (int)s.own_begin || k0c >= (int)s.own_end) {
-            // the cell belongs to a z-neighbour: hand the ray over exactly as it is
-            const int dir = k0c < (int)s.own_begin ? 0 : 1;
-            const uint32_t at = atomicAdd(dir == 0 ? s.count_down : s.count_up, 1u);
-            if (at >= s.capacity && s.overflow) *s.overflow = 1u;  // the caller's capacity was too small: the image is incomplete
-            if (s.leftover) atomicAdd(s.leftover, 1u);
-            if (at < s.capacity) {
-                sdfv_ray_state st;
-                st.pixel = pixel;
-                st.iteration = (uint32_t)i;
-                st.pos[0] = ray_pos.x; st.pos[1] = ray_pos.y; st.pos[2] = ray_pos.z;
-                st.t = dist_from_origin;
-                (dir == 0 ? s.out_down : s.out_up)[at] = st;
-            }
+            // the cell belongs to a z-neighbour: hand the ray over exactly as it is -- after the loop, a wave at a time
+            export_dir = k0c < (int)s.own_begin ? 0 : 1;
             exported = true;
             marching = false;
             continue;
         }
-        const float sample_dist =
-            trilerp(dist_r[(uint64_t)f.o000 * 4], dist_r[(uint64_t)f.o100 * 4], dist_r[(uint64_t)f.o010 * 4],
-                    dist_r[(uint64_t)f.o110 * 4], dist_r[(uint64_t)f.o001 * 4], dist_r[(uint64_t)f.o101 * 4],
-                    dist_r[(uint64_t)f.o011 * 4], dist_r[(uint64_t)f.o111 * 4], f.ax, f.ay, f.az) - 1e-1f;
+        if (f.o000 != cell0 || f.o111 != cell7) {
+            cell0 = f.o000;
+            cell7 = f.o111;
+            c000 = dist_r[(uint64_t)f.o000 * 4]; c100 = dist_r[(uint64_t)f.o100 * 4];
+            c010 = dist_r[(uint64_t)f.o010 * 4]; c110 = dist_r[(uint64_t)f.o110 * 4];
+            c001 = dist_r[(uint64_t)f.o001 * 4]; c101 = dist_r[(uint64_t)f.o101 * 4];
+            c011 = dist_r[(uint64_t)f.o011 * 4]; c111 = dist_r[(uint64_t)f.o111 * 4];
+        }
+        const float sample_dist = trilerp(c000, c100, c010, c110, c001, c101, c011, c111, f.ax, f.ay, f.az) - 1e-1f;
         ++i;  // one more tex0 fetch done
         if (sample_dist < 1e-5f) {  // material.frag:117-121
             status = 1;
@@ -1156,6 +1155,35 @@ __global__ __launch_bounds__(256) void raymarch_slab_kernel(RaymarchArgs a, Slab
         } else {  // material.frag:124-125
             dist_from_origin += sample_dist;
             ray_pos = madd(ray_pos, ray_dir, sample_dist);
+        }
+    }
+    // Rays for the neighbours: one counter update per wave and direction (round 4; it was one same-address atomic per ray,
+    // two with `leftover`, which serialise in one L2 channel), the states stored side by side.  All lanes of the wave are here:
+    // the loop ends on a ballot and every return above is wave-uniform.
+    if (__ballot(exported) != 0ull) {
+        const uint32_t lane = __lane_id();
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            const uint64_t m = __ballot(exported && export_dir == dir);
+            if (m == 0ull) continue;
+            const uint32_t n = (uint32_t)__popcll(m);
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if ((int)lane == leader) {
+                base = atomicAdd(dir == 0 ? s.count_down : s.count_up, n);
+                if (base + n > s.capacity && s.overflow) *s.overflow = 1u;  // the caller's capacity was too small: the image is incomplete
+                if (s.leftover) atomicAdd(s.leftover, n);
+            }
+            base = __shfl(base, leader);
+            const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (exported && export_dir == dir && at < s.capacity) {
+                sdfv_ray_state st;
+                st.pixel = pixel;
+                st.iteration = (uint32_t)i;
+                st.pos[0] = ray_pos.x; st.pos[1] = ray_pos.y; st.pos[2] = ray_pos.z;
+                st.t = dist_from_origin;
+                (dir == 0 ? s.out_down : s.out_up)[at] = st;
+            }
         }
     }
     if (!mine || exported) return;
