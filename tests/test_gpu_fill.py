@@ -262,6 +262,46 @@ def test_randomised_parameters_and_grids(pkg, oracle):
         torch.cuda.synchronize()
         o0, o1 = gpu_fill(pkg, other, dims, lo, hi, sdf_id=sdf_id)
         assert torch.equal(p0, o0) and torch.equal(p1, o1) and torch.equal(dvol, o0[..., 0]), (trial, kw, dims, "whole box")
+        # round 4's forms: the same load over a VIRGIN grid (undefined bytes, nothing initialised), plain or y-interleaved
+        # volume, random steps, its lazily initialised intermediate states against the plain path's; then the other
+        # Srgba::from policy against the oracle evaluating the same one
+        ilv = K.PASS_VOLUME_INTERLEAVED if trial % 3 == 0 and dims[1] % 2 == 0 else 0  # (the layout pairs rows: even heights)
+        p0.fill_(float("nan"))
+        p1.fill_(-3.0)
+        dvol.fill_(float("nan"))
+        a0, a1 = pkg.alloc_textures(g)
+        pkg.grid_init(g, a0, a1)
+        for step in steps:
+            pkg.fill_grid_pass(prm, g, step, p0, p1, sdf_id=sdf_id, dist=dvol if trial % 4 else None,
+                               flags=K.PASS_VIRGIN_GRID | K.PASS_SAME_LOAD | (ilv if trial % 4 else 0))
+            pkg.fill_grid_pass(prm, g, step, a0, a1, sdf_id=sdf_id)
+            if step > 1:
+                c0, c1, cv = p0.clone(), p1.clone(), dvol.clone()
+                pkg.grid_init_unvisited(g, step, c0, c1, dist=cv if trial % 4 else None, flags=ilv if trial % 4 else 0)
+                torch.cuda.synchronize()
+                assert torch.equal(c0, a0) and torch.equal(c1, a1), (trial, kw, dims, steps, step, "virgin state")
+                if trial % 4:
+                    assert torch.equal(cv, interleave_rows(a0[..., 0]) if ilv else a0[..., 0]), (trial, dims, steps, step, "virgin volume")
+        torch.cuda.synchronize()
+        assert torch.equal(p0, t0) and torch.equal(p1, t1), (trial, kw, dims, steps, "virgin load")
+        if trial % 4:
+            assert torch.equal(dvol, interleave_rows(t0[..., 0]) if ilv else t0[..., 0]), (trial, dims, steps, "virgin load's volume")
+        if trial % 2 == 0:
+            flag = oracle.EXT_VARIANTS["srgb_quant_round"]
+            before = oracle.L.or_get_ext_variant()
+            oracle.L.or_set_ext_variant(before | flag)
+            try:
+                with pkg.options({K.OPT_EXT_SRGB_QUANT: 1}):
+                    e0, e1 = gpu_fill(pkg, prm, dims, lo, hi, sdf_id=sdf_id)
+                    for step in steps:
+                        pkg.fill_grid_pass(prm, g, step, p0, p1, sdf_id=sdf_id, flags=K.PASS_VIRGIN_GRID | K.PASS_SAME_LOAD)
+                    torch.cuda.synchronize()
+                x0, x1 = oracle.fill_dense(oracle.params_from(prm), dims, lo, hi, sdf_id=sdf_id, threads=2)
+            finally:
+                oracle.L.or_set_ext_variant(before)
+            assert_bits_equal(e0, x0)
+            assert_bits_equal(e1, x1)
+            assert torch.equal(p0, e0) and torch.equal(p1, e1), (trial, kw, dims, steps, "rounding policy, virgin load")
 
 
 @pytest.mark.parametrize("dims", [(64, 64, 64), (33, 5, 70), (130, 3, 9), (1, 5, 7), (256, 8, 4)])
