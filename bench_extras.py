@@ -379,11 +379,21 @@ def run_extras(c):
             batch_step()
             batch_dt, _ = timed_region(batch_step, batch_steps, torch, dist, world, device)
             ms = batch_dt / batch_steps * 1e3
+            # the cameras are a HOST array here, as a host that moves them every batch hands them over: beyond 16 the launcher
+            # copies them to stream-ordered device memory inside the call (timed above).  Resident cameras, for comparison:
+            ms_resident = None
+            if len(mine) > 16:
+                host_cams, mine = mine, pkg.upload_cameras(mine, device=device)
+                batch_step()
+                ms_resident = timed_region(batch_step, batch_steps, torch, dist, world, device)[0] / batch_steps * 1e3
+                mine = host_cams
             rep = {"split": split if world > 1 else None, "band_height": where["bands"][2] if "bands" in where else None,
                    "cameras_per_gpu": len(mine), "rows_per_gpu": n_rows,
                    "value": round(n_batch * W * H / ms / 1e3, 1), "unit": "Mrays/s", "ms_per_batch": round(ms, 4),
                    "march_over": (f"y-{volume_kind} volume" if volume_kind == "interleaved" else "y-pair volume") if use_pairs
                                  else "distance volume"}
+            if ms_resident is not None:
+                rep["ms_per_batch_cameras_in_device_memory"] = round(ms_resident, 4)
             if multi and use_pairs:
                 # SURVEY 8(e)'s collective of config 5: the images assembled on rank 0.  Over the library communicator when the
                 # step runs on it (sdfv_comm_gather_bands / _gather_cameras: one message per peer, all links into one rank),

@@ -180,6 +180,11 @@ typedef enum sdfv_option {
                                         * several launches over pieces of whole slices, each below v (the pass kernels index with 32
                                         * bits; slabs from ~1626^3 voxels up, which fit in 288 GB, need it).  A test hook: small
                                         * values exercise the piecewise path on small grids.  Same texels */
+    SDFV_OPT_RAYMARCH_CAMERA_STAGING = 12, /* 1 (default) | 0: a launch carries up to 16 cameras in its kernel arguments; a larger batch handed
+                                        * over as a HOST array is written into a per-thread ring of device memory on the caller's
+                                        * stream (kernels that carry 32 cameras each as arguments: no copy engine, no allocation
+                                        * per call), so that 64 cameras are one launch; 0 = launches of 16 cameras instead (what a
+                                        * stream under capture gets anyway).  A DEVICE array is always read in place.  Same pixels */
     SDFV_OPT_TUNING_WAVE_TIMING = 100, /* tuning build only (-DSDFV_TUNING): DEVICE address of 32 B per raymarch wave */
     SDFV_OPT_TUNING_TILE_ORDER = 102,  /* tuning build only: DEVICE address of tiles_x * tiles_y uint32 tile numbers (row-major
                                         * tile index by * tiles_x + bx): workgroup L of a single-camera launch renders tile
@@ -358,7 +363,8 @@ int sdfv_mesh_extract(const sdfv_demo_params *params, uint32_t sdf_id, const flo
                       uint32_t max_voxels_per_axis, uint32_t algorithm, sdfv_mesh *out, void *stream);
 int sdfv_mesh_free(sdfv_mesh *mesh);
 /* sdfv_mesh_extract keeps its scratch (about 13 bytes per lattice point) for the calling thread's next extraction;
- * this releases it -- and the three side streams a batch of more than 64 cameras makes (SDFV_OPT_RAYMARCH_BATCH_STREAMS). */
+ * this releases it -- and the three side streams a batch of more than 64 cameras makes (SDFV_OPT_RAYMARCH_BATCH_STREAMS) and the
+ * camera ring (SDFV_OPT_RAYMARCH_CAMERA_STAGING). */
 int sdfv_mesh_trim(void);
 
 /* ---- raymarch ----
@@ -382,7 +388,10 @@ int sdfv_mesh_trim(void);
  *                     -7..-13 %).  Bit-identical.  Given several volumes the launcher applies sdfv_march_volume_advice's
  *                     rule; the pair / interleaved volumes serve the hand-written gfx950 loop (any grid size, power-of-two
  *                     extents, symmetric box, <= 2^28 texels) on a CUBIC grid, every other launch reads dist / tex0.r
- *   cameras           HOST array of n_cameras
+ *   cameras           HOST array of n_cameras, free again when the call returns (up to 16 ride in a launch's kernel arguments; a
+ *                     larger batch goes through the library's ring of device memory, SDFV_OPT_RAYMARCH_CAMERA_STAGING, so that
+ *                     64 cameras are one launch).  An array of MORE than 16 cameras may instead lie in DEVICE memory: read
+ *                     in place by the launches, nothing copied
  *   y0, y1            rows [y0, y1) when band_step == 0
  *   band_first, band_step, band_height   band_step >= 1: the balanced image-tile split of BASELINE config 5 -- rank r of N renders
  *                     (r, N): the bands band_first, band_first + band_step, ... of band_height = 16 (also 0) or 8 rows -- a

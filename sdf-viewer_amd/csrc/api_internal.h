@@ -13,6 +13,7 @@ struct Options {
     uint32_t raymarch_disable = 0;   // SDFV_RM_NO_*
     bool raymarch_keep_normal = false;
     uint32_t raymarch_batch_streams = 1;  // batches of several SMALL launches overlap on side streams
+    uint32_t raymarch_camera_staging = 1;  // host arrays of more than kInlineCameras cameras are copied to stream-ordered device memory
     uint32_t raymarch_box_first = 1;   // single frames: groups under the projected bounding box are launched first
     uint32_t raymarch_waves_per_simd = 0;  // 0 = no cap
     uint32_t raymarch_tile_group = 0;  // 0 auto, 1 launch order, v >= 2: XCD-aware order over groups of 2^(v-1) x 2^(v-1) tiles

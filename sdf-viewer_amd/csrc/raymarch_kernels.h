@@ -25,7 +25,7 @@ struct RaymarchArgs {
     float cull_radius2;
     const float4* tex0;          // full grid, rp.tex_size
     const float4* tex1;
-    uint32_t n_cameras;          // cameras in this launch (<= kMaxCamerasPerLaunch), by value in kernarg
+    uint32_t n_cameras;          // cameras in this launch (<= kMaxCamerasPerLaunch): cameras[] or camera_list, see below
     uint32_t width, height;      // full image
     uint32_t y0, y1;             // rows rendered by this launch
     uint32_t compute_normal;     // evaluate sdfNormal per hit even when no aux is stored
@@ -55,11 +55,17 @@ struct RaymarchArgs {
     const unsigned char* priority_map;  // tuning build only: one byte per tile, non-zero = raise the waves' priority
     unsigned long long* wave_timing;  // tuning build only: per wave {start, end, iterations, covered mask} or nullptr
 #endif
-    sdfv_camera cameras[64];
+    // Cameras: a launch of up to kInlineCameras carries them by value in this block (16 x 120 B; the whole block stays below
+    // HIP's documented 4 KB of kernel arguments -- round 3 carried 64 in an 8 KB block); a larger launch reads them
+    // from `camera_list` (DEVICE, n_cameras entries: the caller's own array when it lies in device memory, else a stream-ordered
+    // copy the launcher makes).  Wave-uniform either way: scalar loads into SGPRs.
+    const sdfv_camera* camera_list;  // nullptr: cameras[]
+    sdfv_camera cameras[16];
 };
 
-// 64 x 120 B: an 8 KB kernel-argument block (beyond HIP's documented 4 KB, accepted by ROCm 7 on gfx950 -- the 64-camera tests
-// render through it).  One launch for BASELINE config 5's batch: 1.59 -> 1.48 ms, and a rank's share of it is one launch too.
+constexpr uint32_t kInlineCameras = 16;
+// One launch for BASELINE config 5's 64-camera batch (1.59 -> 1.48 ms against four launches of 16, and a rank's share of it
+// is one launch too); larger batches are several launches of this many (small ones overlap on side streams).
 constexpr uint32_t kMaxCamerasPerLaunch = 64;
 constexpr uint32_t kGroupAuto = 255;  // RaymarchArgs::group_shift as handed to launch_raymarch: let the launcher choose
 
@@ -85,5 +91,8 @@ struct SlabMarchArgs {
 hipError_t launch_raymarch_slab(const RaymarchArgs& a, const SlabMarchArgs& s, hipStream_t stream);
 
 hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream);
+// n cameras from a HOST array into DEVICE memory, stream-ordered, without a copy engine: launches that carry 32 cameras each
+// in their kernel arguments (the host array is free again on return)
+hipError_t launch_store_cameras(const sdfv_camera* host, uint32_t n, sdfv_camera* device, hipStream_t stream);
 
 }  // namespace sdfv

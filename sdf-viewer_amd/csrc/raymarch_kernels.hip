@@ -25,6 +25,7 @@
 #include "raymarch_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <string.h>
 
 namespace sdfv {
 namespace {
@@ -826,7 +827,10 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
     const uint32_t py = a.y0 + row + (row >> a.band_shift) * a.band_skip;  // band k of the set = rows [k << shift, ...) of the output
     const uint32_t cam_idx = blockIdx.z;
     const bool in_image = px < a.width && py < a.y1;
-    const sdfv_camera& cam = a.cameras[cam_idx];
+    // (two scalar-load sequences under a uniform branch; a reference chosen by `?:` would mix the address spaces)
+    sdfv_camera cam;
+    if (a.camera_list) cam = a.camera_list[cam_idx];
+    else cam = a.cameras[cam_idx];
     const uint64_t out_index = ((uint64_t)cam_idx * a.rows_out + row) * a.width + px;
 #ifdef SDFV_TUNING
     if (a.priority_map && a.priority_map[by * ((a.width + 15) / 16) + bx]) __builtin_amdgcn_s_setprio(3);
@@ -1291,6 +1295,30 @@ void launch_fast(const RaymarchArgs& a, dim3 grid, hipStream_t stream) {
 }
 
 }  // namespace
+
+namespace {
+constexpr uint32_t kStoreChunk = 32;  // 32 x 120 B + the two scalars: 3 856 B of kernel arguments
+struct CameraChunk {
+    sdfv_camera c[kStoreChunk];
+};
+static_assert(sizeof(sdfv_camera) % 4 == 0, "cameras are copied word by word");
+__global__ __launch_bounds__(256) void store_cameras_kernel(CameraChunk chunk, uint32_t words, uint32_t* __restrict__ out) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&chunk);
+    for (uint32_t w = threadIdx.x; w < words; w += 256) out[w] = src[w];
+}
+}  // namespace
+
+hipError_t launch_store_cameras(const sdfv_camera* host, uint32_t n, sdfv_camera* device, hipStream_t stream) {
+    for (uint32_t c0 = 0; c0 < n; c0 += kStoreChunk) {
+        const uint32_t nc = n - c0 < kStoreChunk ? n - c0 : kStoreChunk;
+        CameraChunk chunk;
+        memcpy(chunk.c, host + c0, nc * sizeof(sdfv_camera));
+        hipLaunchKernelGGL(store_cameras_kernel, dim3(1), dim3(256), 0, stream, chunk, (uint32_t)(nc * sizeof(sdfv_camera) / 4),
+                           reinterpret_cast<uint32_t*>(device + c0));
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
+}
 
 hipError_t launch_raymarch_slab(const RaymarchArgs& a, const SlabMarchArgs& s, hipStream_t stream) {
     const bool device_counts = s.in_count[0] || s.in_count[1];

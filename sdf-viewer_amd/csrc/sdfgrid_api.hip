@@ -201,6 +201,40 @@ struct BatchStreams {
     }
 };
 thread_local BatchStreams g_batch_streams;  // released by sdfv_mesh_trim(); a thread that exits without it leaks three streams
+
+// Cameras of a launch of more than kInlineCameras that arrive as a HOST array (the kernel-argument block carries 16): the
+// launch reads them from a slot of this per-thread ring of device memory, written on the launch's own stream by small
+// kernels that carry 32 cameras each as THEIR arguments -- no copy engine, no allocation per call, nothing the host waits
+// for.  A slot is reused every kSlots launches; the event recorded behind its last reader orders the rewrite after it,
+// whatever stream that reader ran on.  Allocated on first use (122 KB), released by sdfv_mesh_trim().
+struct CameraRing {
+    static constexpr uint32_t kSlots = 16;
+    sdfv_camera* base = nullptr;  // kSlots x kMaxCamerasPerLaunch
+    hipEvent_t read[kSlots] = {};
+    bool recorded[kSlots] = {};
+    uint32_t next = 0;
+    int device = -1;
+    void release() {
+        for (uint32_t i = 0; i < kSlots; ++i)
+            if (read[i]) (void)hipEventDestroy(read[i]);
+        if (base) (void)hipFree(base);
+        *this = CameraRing{};
+    }
+    hipError_t ensure(int device_now) {
+        if (device == device_now && base) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), (size_t)kSlots * sdfv::kMaxCamerasPerLaunch * sizeof(sdfv_camera));
+        for (uint32_t i = 0; i < kSlots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&read[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            release();
+        } else {
+            device = device_now;
+        }
+        return e;
+    }
+};
+thread_local CameraRing g_camera_ring;
 thread_local MeshScratch g_mesh_scratch;  // freed by sdfv_mesh_trim(); a thread that exits without it leaks the block
 
 // Per-point callers (the reference's ffi.rs ABI: one sample() per call) would otherwise pay two hipMalloc/hipFree per
@@ -466,6 +500,10 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             if (value > 1) break;
             g_options.raymarch_batch_streams = (uint32_t)value;
             return SDFV_OK;
+        case SDFV_OPT_RAYMARCH_CAMERA_STAGING:
+            if (value > 1) break;
+            g_options.raymarch_camera_staging = (uint32_t)value;
+            return SDFV_OK;
         case SDFV_OPT_SLAB_STEP_FORM: {
             const uint64_t form = value & ~(uint64_t)(SDFV_STEP_UNPACKED | SDFV_STEP_START_EVENT | SDFV_STEP_DEFER_JOIN);
             if (form != 0 && form != SDFV_STEP_SIDE_BOUNDARY) break;
@@ -522,6 +560,7 @@ int sdfv_get_option(uint32_t option, uint64_t* value) {
         case SDFV_OPT_RAYMARCH_TILE_GROUP: *value = g_options.raymarch_tile_group; return SDFV_OK;
         case SDFV_OPT_RAYMARCH_BOX_FIRST: *value = g_options.raymarch_box_first; return SDFV_OK;
         case SDFV_OPT_RAYMARCH_BATCH_STREAMS: *value = g_options.raymarch_batch_streams; return SDFV_OK;
+        case SDFV_OPT_RAYMARCH_CAMERA_STAGING: *value = g_options.raymarch_camera_staging; return SDFV_OK;
         case SDFV_OPT_TUNING_WAVE_TIMING: *value = g_options.wave_timing; return SDFV_OK;
         case SDFV_OPT_TUNING_PRIORITY_MAP: *value = g_options.priority_map; return SDFV_OK;
         case SDFV_OPT_TUNING_TILE_ORDER: *value = g_options.tile_order; return SDFV_OK;
@@ -936,6 +975,7 @@ int sdfv_mesh_trim(void) {
     if (g_mesh_scratch.p) (void)hipFree(g_mesh_scratch.p);
     g_mesh_scratch = MeshScratch{};
     g_batch_streams.release();
+    g_camera_ring.release();
     return SDFV_OK;
 }
 
@@ -1094,21 +1134,45 @@ static int raymarch_rows(const sdfv_render_params* rp, const float* tex0, const 
     a.tile_order = n_cameras == 1 ? reinterpret_cast<const uint32_t*>(g_options.tile_order) : nullptr;
 #endif
     const uint64_t pixels_per_cam = (uint64_t)a.rows_out * width;
+    hipStream_t main = (hipStream_t)stream;
+    // Cameras.  Up to kInlineCameras ride in the kernel-argument block.  A larger batch is read from device memory, so that
+    // kMaxCamerasPerLaunch of them still make ONE launch: the caller's own array if that is where it lies, else a slot of the
+    // camera ring per launch (CameraRing).  While the stream is being captured (the ring's events do not belong in somebody's
+    // graph), with the option off, or if the ring cannot be had, the batch goes out as launches of kInlineCameras instead
+    // (same pixels).
+    a.camera_list = nullptr;
+    const sdfv_camera* device_cameras = nullptr;
+    bool ring = false;
+    if (n_cameras > sdfv::kInlineCameras) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, cameras) == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged)) {
+            device_cameras = cameras;
+        } else {
+            (void)hipGetLastError();
+            hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(main, &capturing) != hipSuccess) (void)hipGetLastError();
+            ring = capturing == hipStreamCaptureStatusNone && g_options.raymarch_camera_staging &&
+                   g_camera_ring.ensure(current_device()) == hipSuccess;
+        }
+    }
+    const uint32_t per_launch = device_cameras || ring ? sdfv::kMaxCamerasPerLaunch : sdfv::kInlineCameras;
     // several launches, each small (tools/split_balance.py: a launch of 17 000 workgroups gains 34 % from overlapping with its
     // siblings, one of 35 000 11 %, one of 65 000 nothing, one of 130 000 loses 4 %): side streams, see BatchStreams
-    const uint64_t groups_per_launch = (uint64_t)((width + 15) / 16) * ((a.rows_out + 15) / 16) * sdfv::kMaxCamerasPerLaunch;
-    const bool overlap = n_cameras > sdfv::kMaxCamerasPerLaunch && groups_per_launch <= 40000 && g_options.raymarch_batch_streams;
-    hipStream_t main = (hipStream_t)stream;
+    const uint64_t groups_per_launch = (uint64_t)((width + 15) / 16) * ((a.rows_out + 15) / 16) * per_launch;
+    const bool overlap = n_cameras > per_launch && groups_per_launch <= 40000 && g_options.raymarch_batch_streams;
     uint32_t used = 0;  // side streams that carry a launch of this call
-    if (overlap) {
-        SDFV_HIP(g_batch_streams.ensure(current_device()));
-        SDFV_HIP(hipEventRecord(g_batch_streams.fork, main));
-    }
+    int rc = SDFV_OK;
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == SDFV_OK) rc = hip_fail(e, what);
+        return e == hipSuccess;
+    };
+    if (overlap) hip_ok(g_batch_streams.ensure(current_device()), "batch streams") && hip_ok(hipEventRecord(g_batch_streams.fork, main), "hipEventRecord");
     uint32_t launch = 0;
-    for (uint32_t c0 = 0; c0 < n_cameras; c0 += sdfv::kMaxCamerasPerLaunch, ++launch) {
-        const uint32_t nc = n_cameras - c0 < sdfv::kMaxCamerasPerLaunch ? n_cameras - c0 : sdfv::kMaxCamerasPerLaunch;
+    for (uint32_t c0 = 0; c0 < n_cameras && rc == SDFV_OK; c0 += per_launch, ++launch) {
+        const uint32_t nc = n_cameras - c0 < per_launch ? n_cameras - c0 : per_launch;
         a.n_cameras = nc;
-        memcpy(a.cameras, cameras + c0, nc * sizeof(sdfv_camera));
+        if (device_cameras) a.camera_list = device_cameras + c0;
+        else if (!ring) memcpy(a.cameras, cameras + c0, nc * sizeof(sdfv_camera));
         a.rgba = reinterpret_cast<float4*>(rgba) + c0 * pixels_per_cam;
         a.aux = aux ? aux + c0 * pixels_per_cam : nullptr;
         a.depth = depth ? depth + c0 * pixels_per_cam : nullptr;
@@ -1117,17 +1181,27 @@ static int raymarch_rows(const sdfv_render_params* rp, const float* tex0, const 
         if (overlap && lane != 0) {
             on = g_batch_streams.side[lane - 1];
             if (lane > used) {
-                SDFV_HIP(hipStreamWaitEvent(on, g_batch_streams.fork, 0));
+                if (!hip_ok(hipStreamWaitEvent(on, g_batch_streams.fork, 0), "hipStreamWaitEvent")) break;
                 used = lane;
             }
         }
-        SDFV_HIP(sdfv::launch_raymarch(a, on));
+        if (ring) {
+            CameraRing& r = g_camera_ring;
+            const uint32_t slot = r.next++ % CameraRing::kSlots;
+            sdfv_camera* at = r.base + (size_t)slot * sdfv::kMaxCamerasPerLaunch;
+            if (r.recorded[slot] && !hip_ok(hipStreamWaitEvent(on, r.read[slot], 0), "hipStreamWaitEvent")) break;
+            if (!hip_ok(sdfv::launch_store_cameras(cameras + c0, nc, at, on), "store_cameras")) break;
+            a.camera_list = at;
+            hip_ok(sdfv::launch_raymarch(a, on), "launch_raymarch") && hip_ok(hipEventRecord(r.read[slot], on), "hipEventRecord");
+            r.recorded[slot] = true;  // (a failed record leaves the event as it was: waiting on it is harmless)
+            continue;
+        }
+        hip_ok(sdfv::launch_raymarch(a, on), "launch_raymarch");
     }
-    for (uint32_t i = 0; i < used; ++i) {
-        SDFV_HIP(hipEventRecord(g_batch_streams.join[i], g_batch_streams.side[i]));
-        SDFV_HIP(hipStreamWaitEvent(main, g_batch_streams.join[i], 0));
-    }
-    return SDFV_OK;
+    for (uint32_t i = 0; i < used; ++i)  // (joined even after an error: the side streams must not run on behind the caller's)
+        hip_ok(hipEventRecord(g_batch_streams.join[i], g_batch_streams.side[i]), "hipEventRecord") &&
+            hip_ok(hipStreamWaitEvent(main, g_batch_streams.join[i], 0), "hipStreamWaitEvent");
+    return rc;
 }
 extern "C" {
 
@@ -1168,6 +1242,7 @@ static int slab_round_args(const sdfv_render_params* rp, const sdfv_grid* slab, 
     a.band_skip = 0;
     a.band_shift = 4;
     a.n_cameras = 1;
+    a.camera_list = nullptr;
     a.cameras[0] = *camera;
     a.rgba = reinterpret_cast<float4*>(rgba);
     a.aux = aux;

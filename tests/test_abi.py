@@ -72,6 +72,7 @@ def test_options_are_explicit_and_the_library_reads_no_environment(pkg):
     assert pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_BOX_FIRST, 2) == -1 and pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_TILE_GROUP, 6) == -1
     assert pkg.get_option(K.OPT_RAYMARCH_WAVES_PER_SIMD) == 0
     assert pkg.get_option(K.OPT_RAYMARCH_BATCH_STREAMS) == 1 and pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_BATCH_STREAMS, 2) == -1
+    assert pkg.get_option(K.OPT_RAYMARCH_CAMERA_STAGING) == 1 and pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_CAMERA_STAGING, 2) == -1
     assert pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_WAVES_PER_SIMD, 1) == -1 and pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_WAVES_PER_SIMD, 8) == -1
     assert pkg.lib.sdfv_set_option(K.OPT_FILL_FORM, 3) == -1
     assert pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_DISABLE, 64) == -1
@@ -236,6 +237,32 @@ def test_power_of_two_modulus_identity():
     # symmetric box: max(-m - p, p - m) == |p| - m
     mx = np.float32(1.0)
     np.testing.assert_array_equal(np.maximum(-mx - d, d - mx).view(np.uint32), (np.abs(d) - mx).view(np.uint32))
+
+
+def test_no_kernel_needs_more_than_4_kb_of_arguments(tmp_path):
+    """HIP documents 4 KB of kernel arguments; round 3's march carried 64 cameras in an 8 KB block.  Every gfx950
+    code object inside libsdfgrid.so is unbundled and its kernels' kernarg sizes read from the metadata notes."""
+    import subprocess
+    tools = "/opt/rocm/lib/llvm/bin"
+    lib = os.path.join(ROOT, "sdf-viewer_amd", "libsdfgrid.so")
+    if not all(os.path.exists(os.path.join(tools, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
+        pytest.skip("LLVM binary tools not installed")
+    fat = tmp_path / "fat.bin"
+    subprocess.run([f"{tools}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", lib, str(tmp_path / "unused.so")], check=True)
+    blob = fat.read_bytes()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(magic, blob)]
+    assert starts, "no offload bundle in the library"
+    sizes = []
+    for k, at in enumerate(starts):
+        piece = tmp_path / f"bundle{k}.bin"
+        piece.write_bytes(blob[at:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        co = tmp_path / f"bundle{k}.co"
+        subprocess.run([f"{tools}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        f"--input={piece}", f"--output={co}"], check=True)
+        notes = subprocess.run([f"{tools}/llvm-readelf", "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+        sizes += [int(v) for v in re.findall(r"\.kernarg_segment_size:\s+(\d+)", notes)]
+    assert len(sizes) > 100 and max(sizes) <= 4096, (len(sizes), max(sizes))
 
 
 def test_headers_compile_as_plain_c_and_the_library_links(tmp_path):

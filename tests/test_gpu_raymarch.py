@@ -588,6 +588,63 @@ def test_interleaved_tile_bands_assemble_to_the_frame(pkg):
     assert par.band_height_for(1080, 8) == 8 and par.band_height_for(1080, 4) == 16 and par.band_height_for(2160, 8) == 16
 
 
+@pytest.mark.parametrize("n", [17, 64, 70])
+def test_batches_beyond_the_cameras_a_launch_carries_in_its_arguments(pkg, n):
+    """Up to 16 cameras ride in a launch's kernel-argument block (the block is back under 4 KB); a larger batch is read
+    from device memory -- the caller's own device array in place, or the launcher's stream-ordered copy of a host array -- so
+    that 64 cameras stay ONE launch; with the copy switched off, or under capture, it goes out as launches of 16.  The same
+    pixels, depth and aux records every way, equal to one call per camera; the host array is free again when the call returns."""
+    K = pkg._capi
+    g = pkg.make_grid((32, 32, 32))
+    t0, t1 = pkg.alloc_textures(g)
+    pkg.fill_grid(pkg.default_params(), g, t0, t1)
+    dist = pkg.commit_distance(g, t0)
+    rp = pkg.default_render_params(g)
+    W, H = 72, 40
+    cams = pkg.orbit_cameras(n, aspect=W / H)
+    singles = [pkg.raymarch(rp, t0, t1, c, W, H, want_aux=True, want_depth=True, dist=dist) for c in cams]
+    ref = tuple(torch.cat([s[k] for s in singles]) for k in range(3))
+    torch.cuda.synchronize()
+
+    def same(got, what):
+        torch.cuda.synchronize()
+        for a, b in zip(got, ref):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (n, what)
+
+    host = [type(c).from_buffer_copy(bytes(c)) for c in cams]
+    got = pkg.raymarch(rp, t0, t1, host, W, H, want_aux=True, want_depth=True, dist=dist)
+    for c in host:  # (the launcher took its copy before returning)
+        c.eye[0] = float("nan")
+    same(got, "host array, staged")
+    with pkg.options({K.OPT_RAYMARCH_CAMERA_STAGING: 0}):
+        same(pkg.raymarch(rp, t0, t1, cams, W, H, want_aux=True, want_depth=True, dist=dist), "host array, launches of 16")
+    dev = pkg.upload_cameras(cams)
+    assert dev.numel() == n * 120
+    same(pkg.raymarch(rp, t0, t1, dev, W, H, want_aux=True, want_depth=True, dist=dist), "device array")
+    same(pkg.raymarch(rp, t0, t1, dev, W, H, want_aux=True, want_depth=True), "device array, tex0.r")
+    # bands of a batch, and a stream of the caller's
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        parts = [pkg.raymarch(rp, t0, t1, cams, W, H, bands=(r, 2, 8), dist=dist, stream=side) for r in range(2)]
+        side.synchronize()
+    rows = [[y for y in range(H) if (y // 8) % 2 == r] for r in range(2)]
+    for r in range(2):
+        assert torch.equal(parts[r].view(torch.int32), ref[0][:, rows[r]].view(torch.int32)), (n, "bands", r)
+    # captured: a host array goes out as launches of 16 (no allocation inside a capture), a device array in place
+    for what, arg in (("host", cams), ("device", dev)):
+        out = torch.zeros_like(ref[0])
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                pkg.raymarch(rp, t0, t1, arg, W, H, out=out, dist=dist, stream=side)
+            out.zero_()
+            graph.replay()
+            side.synchronize()
+        assert torch.equal(out.view(torch.int32), ref[0].view(torch.int32)), (n, "captured", what)
+    with pytest.raises(pkg.SdfvError):
+        pkg.raymarch(rp, t0, t1, pkg.upload_cameras(cams[:16]), W, H)
+
+
 def test_small_launches_of_a_batch_overlap_on_side_streams_and_change_nothing(pkg):
     """A batch of more than 64 cameras is several launches; small ones (low-resolution views, band shares) are forked onto the
     library's side streams and joined back into the caller's stream.  Same images as one launch after the other; ordered
