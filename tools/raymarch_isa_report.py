@@ -56,8 +56,8 @@ def main():
                                "-fvisibility=hidden", "-S", "--cuda-device-only", "-o", out, SRC], stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
     pre = "_ZN4sdfv12_GLOBAL__N_115raymarch_kernelILi2ELb1ELi2ELb1ELb0ELb"
-    asmk = kernel(lines, pre + "1EEEvNS_12RaymarchArgsE")
-    ck = kernel(lines, pre + "0EEEvNS_12RaymarchArgsE")
+    asmk = kernel(lines, pre + "1ELb0EEEvNS_12RaymarchArgsE")
+    ck = kernel(lines, pre + "0ELb0EEEvNS_12RaymarchArgsE")
     starts = [i for i, l in enumerate(asmk) if "ASMSTART" in l]
     ends = [i for i, l in enumerate(asmk) if "ASMEND" in l]
     blocks = [[l.strip() for l in asmk[a + 1:b] if l.strip()] for a, b in zip(starts, ends)]
@@ -86,10 +86,10 @@ def main():
            "hand_fetch_block_interior_cell": count(hand[i_fetch:i_border]),
            "hand_fetch_block_border_cell": count(hand[i_fetch:i_test + 1] + hand[i_border:i_done]),
            "hipcc_common_path": count(comp[:i14] + comp[i18:]), "hipcc_fetch_block_listed": count(comp[i14:i18])}
-    for name in (pre + "1EEEvNS_12RaymarchArgsE", pre + "0EEEvNS_12RaymarchArgsE"):
+    for name in (pre + "1ELb0EEEvNS_12RaymarchArgsE", pre + "0ELb0EEEvNS_12RaymarchArgsE"):
         i = [k for k, l in enumerate(lines) if ".name:" in l and name in l][0]
         meta = "\n".join(lines[i:i + 12])
-        res["vgpr_sgpr_" + ("asm" if name.endswith("Lb1EEEvNS_12RaymarchArgsE") else "hipcc")] = \
+        res["vgpr_sgpr_" + ("asm" if name.endswith("Lb1ELb0EEEvNS_12RaymarchArgsE") else "hipcc")] = \
             [int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1)), int(re.search(r"\.sgpr_count:\s+(\d+)", meta).group(1))]
     print(json.dumps(res, indent=1))
     if "--listing" in sys.argv:
