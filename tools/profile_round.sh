@@ -11,6 +11,10 @@ for t in r04_256_ilv r04_256_plain r04_256_fused r04_512_ilv r04_512_plain r04_p
   cp gpurun_out/prof_$t/summary.txt gpurun_out/r04final/${t}_rocprof_summary.txt
   cp gpurun_out/prof_$t/trace/trace_kernel_stats.csv gpurun_out/r04final/${t}_kernel_stats.csv 2>/dev/null
 done
+# the raw traces and counter CSVs (13 MB per run) stay on the box: gpurun copies back at most 64 MiB
+for t in r04_256_ilv r04_256_plain r04_256_fused r04_512_ilv r04_512_plain r04_probe256; do
+  rm -rf gpurun_out/prof_$t/trace gpurun_out/prof_$t/pmc_* gpurun_out/prof_$t/*.log
+done
 python tools/full_parity.py 256 512 1024 > gpurun_out/r04final/full_workload_parity.txt 2>&1
 SDFV_BENCH_FORCE_MULTI=1 WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29655 python bench.py --gpus 1 --no-cpu-baseline > gpurun_out/r04final/bench_rccl_loopback_256.json 2> gpurun_out/r04final/loopback.err
 (rocm-smi --showclocks --showuniqueid 2>&1 | grep -i "sclk\|mclk\|fclk\|unique") > gpurun_out/r04final/box_after.txt
