@@ -1,110 +1,95 @@
-// loading_manager.hpp -- C++ mirror of the progressive-LOD iterator,
-// reference src/app/scene/sdf/loading.rs:5-115 (struct LoadingManager, Iterator, ExactSizeIterator).
-// Same field names and semantics; `pass_*` helpers expose a whole pass at once, which is the unit the
-// GPU path launches (one kernel per pass instead of one sample() per next()).
+// loading_manager.hpp -- the progressive-LOD schedule of a grid load as the GPU path sees it: a list of PASSES, each a
+// lattice of the grid (every step-th voxel on every axis, step = 2^(passes-1) ... 2, 1), each launched as one kernel.
+//
+// It stands in for the reference's LoadingManager (src/app/scene/sdf/loading.rs:5-115), whose observable behaviour the drop-in
+// SDFViewer needs -- the sequence next() yields (x fastest, then y, then z, pass after pass), len(), total_iterations(),
+// passes_left() -- and the reference's own five unit tests (loading.rs:117-171) run against this class
+// (tests/test_host_cpu.py).  The reference keeps a 3-D "next index" and carries it voxel by voxel; here the state is the
+// pass and a CURSOR into it, the index is decoded from the cursor on demand, and everything a whole-pass launcher asks
+// (how many voxels a pass holds, how many are left) is closed form.  Per-voxel next() exists for hosts that sample on the CPU.
 #pragma once
 
 #include <array>
-#include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <optional>
 
 namespace sdfviewer {
 
-// loading.rs:108-115
-inline uint32_t prev_power_of_2(uint32_t x) {
-    x = x | (x >> 1);
-    x = x | (x >> 2);
-    x = x | (x >> 4);
-    x = x | (x >> 8);
-    x = x | (x >> 16);
-    return x - (x >> 1);
-}
+// The largest power of two <= x (0 for 0): loading.rs:108-115 computes the same by bit smearing.
+inline uint32_t prev_power_of_2(uint32_t x) { return x ? 1u << (31 - __builtin_clz(x)) : 0u; }
 
 class LoadingManager {
    public:
     using Index = std::array<size_t, 3>;
 
-    // loading.rs:23-35
     LoadingManager(Index limits_, size_t passes_) : limits(limits_), passes(passes_) { reset(passes_); }
 
-    // loading.rs:38-44
+    // Back to the first (coarsest) pass: step 2^(max(passes, 1) - 1), nothing handed out.
     void reset(size_t passes_) {
         passes = passes_;
-        const uint32_t p = passes_ > 1 ? (uint32_t)passes_ : 1u;
-        step_size_ = (size_t)1 << (p - 1);  // 2usize.pow(max(passes, 1) - 1)
-        next_index_ = {0, 0, 0};
-        iterations_ = 0;
-        total_iterations_ = 0;
+        step_ = (size_t)1 << ((passes_ > 1 ? passes_ : 1) - 1);
+        cursor_ = 0;
+        handed_out_ = 0;
     }
 
-    // Iterator::next, loading.rs:50-76
+    // The next voxel of the schedule, or nothing once every pass is through.
     std::optional<Index> next() {
-        if (step_size_ == 0) return std::nullopt;
-        iterations_ += 1;
-        total_iterations_ += 1;
-        const Index res = next_index_;
-        next_index_[0] += step_size_;
-        if (next_index_[0] >= limits[0]) {
-            next_index_[0] = 0;
-            next_index_[1] += step_size_;
-            if (next_index_[1] >= limits[1]) {
-                next_index_[1] = 0;
-                next_index_[2] += step_size_;
-                if (next_index_[2] >= limits[2]) {
-                    step_size_ = prev_power_of_2((uint32_t)(step_size_ - 1));
-                    next_index_ = {0, 0, 0};
-                    iterations_ = 0;
-                }
-            }
-        }
-        return res;
+        if (step_ == 0) return std::nullopt;
+        const Index at = lattice_point(step_, cursor_);
+        ++handed_out_;
+        if (++cursor_ == pass_points(step_)) next_pass();
+        return at;
     }
 
-    // ExactSizeIterator::len, loading.rs:80-89
+    // Voxels still to be handed out: the passes from the current one down to step 1, less the cursor.
     size_t len() const {
-        size_t step = step_size_, iterations = 0;
-        while (step > 0) {
-            iterations += pass_len(step);
-            step = prev_power_of_2((uint32_t)(step - 1));
-        }
-        return iterations - iterations_;
+        size_t left = 0;
+        for (size_t s = step_; s != 0; s >>= 1) left += pass_len(s);
+        return left - cursor_;
     }
 
-    size_t total_iterations() const { return total_iterations_; }  // loading.rs:93-95
+    size_t total_iterations() const { return handed_out_; }
 
-    // loading.rs:99-105
-    size_t passes_left() const {
-        if (step_size_ == 0) return 0;
-        return (size_t)std::log2((float)step_size_) + 1;
-    }
+    // 1 + log2(step) while loading, 0 when loaded: the shader reads it as lod_dist_between_samples = 2^passes_left.
+    size_t passes_left() const { return step_ ? (size_t)(64 - __builtin_clzll((unsigned long long)step_)) : 0; }
 
-    // ---- whole-pass view (GPU path) ----
-    size_t step_size() const { return step_size_; }
-    bool at_pass_start() const { return iterations_ == 0; }
-    size_t pass_len(size_t step) const {
-        return ((limits[0] + step - 1) / step) * ((limits[1] + step - 1) / step) * ((limits[2] + step - 1) / step);
-    }
-    // Consume the rest of the current pass exactly as pass_len - iterations calls of next() would.
+    // ---- whole passes (what the GPU path launches) ----
+    size_t step_size() const { return step_; }
+    bool at_pass_start() const { return cursor_ == 0; }
+    // Lattice points of a pass, as the reference's len() counts them: ceil(limit / step) per axis.
+    size_t pass_len(size_t step) const { return axis_points(0, step) * axis_points(1, step) * axis_points(2, step); }
+    // Hand out the rest of the current pass at once; returns how many voxels that were.
     size_t finish_pass() {
-        if (step_size_ == 0) return 0;
-        const size_t n = pass_len(step_size_) - iterations_;
-        total_iterations_ += n;
-        step_size_ = prev_power_of_2((uint32_t)(step_size_ - 1));
-        next_index_ = {0, 0, 0};
-        iterations_ = 0;
+        if (step_ == 0) return 0;
+        const size_t n = pass_len(step_) - cursor_;
+        handed_out_ += n;
+        next_pass();
         return n;
     }
 
-    Index limits;   // pub(crate) limits
-    size_t passes;  // pub(crate) passes
+    Index limits;   // voxels per axis
+    size_t passes;  // as configured (--loading-passes)
 
    private:
-    size_t step_size_ = 0;
-    Index next_index_{0, 0, 0};
-    size_t iterations_ = 0;
-    size_t total_iterations_ = 0;
+    size_t axis_points(int axis, size_t step) const { return (limits[axis] + step - 1) / step; }
+    // What next() walks through: an axis without voxels still yields its index 0 (the reference returns the index before it
+    // tests the limit), so the walk uses at least one point per axis.  Never differs from pass_len on a grid that has voxels.
+    size_t walk_points(int axis, size_t step) const { return axis_points(axis, step) ? axis_points(axis, step) : 1; }
+    size_t pass_points(size_t step) const { return walk_points(0, step) * walk_points(1, step) * walk_points(2, step); }
+    // The cursor-th point of the pass: x fastest, then y, then z.
+    Index lattice_point(size_t step, size_t cursor) const {
+        const size_t nx = walk_points(0, step), ny = walk_points(1, step);
+        return {(cursor % nx) * step, (cursor / nx % ny) * step, (cursor / (nx * ny)) * step};
+    }
+    void next_pass() {
+        step_ >>= 1;  // ... 4, 2, 1, 0 = loaded
+        cursor_ = 0;
+    }
+
+    size_t step_ = 0;        // lattice spacing of the current pass; 0 = loaded
+    size_t cursor_ = 0;      // points of the current pass already handed out
+    size_t handed_out_ = 0;  // since the last reset
 };
 
 }  // namespace sdfviewer

@@ -61,6 +61,20 @@ def test_loading_manager_matches_oracle_sequence(host, oracle):
         assert m.total_iterations() == o.total_iterations
 
 
+def test_loading_manager_walks_a_grid_without_voxels_like_the_reference(host, oracle):
+    """An axis of 0 voxels: the reference hands out index 0 on it anyway (it returns the index before it tests the limit,
+    loading.rs:57-75); the pass / cursor form keeps that walk.  (len() underflows there in the reference: not compared.)"""
+    for limits, passes in [((0, 3, 2), 2), ((2, 0, 0), 3), ((0, 0, 0), 2)]:
+        m, o = host.LoadingManager(limits, passes), oracle.lm_new(limits, passes)
+        for _ in range(64):
+            assert m.passes_left() == oracle.L.or_lm_passes_left(C.byref(o))
+            a, b = m.next(), oracle.lm_next(o)
+            assert a == b, (limits, a, b)
+            if a is None:
+                break
+        assert a is None and m.total_iterations() == o.total_iterations
+
+
 def test_finish_pass_equals_stepping(host):
     a, b = host.LoadingManager((9, 7, 5), 3), host.LoadingManager((9, 7, 5), 3)
     for _ in range(4):  # partially consume the first pass of a
