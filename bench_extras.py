@@ -85,7 +85,6 @@ def progressive_block(pkg, torch, prm, sides, reps=7):
     (sdfv_fill_grid_pass_dist).  Per case: median ms over `reps` runs (HIP events; the state is re-created, untimed, before
     every run), visited voxels, updated voxels, and the fraction of the HBM roofline on SURVEY 8(d)'s incremental figure,
     36 B per UPDATED voxel (4 B read + 32 B written) + 4 B per voxel that is visited only."""
-    import ctypes as C
     AIR = pkg.AIR_DIST
     out = {}
     for side in sides:

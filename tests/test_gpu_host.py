@@ -1,7 +1,6 @@
 """GPU tests of the C++ host mirror above the C ABI: SDFViewer::{from_bb,new_voxels,update,commit} driving the
 pass kernels, SDFViewerMaterial::render, per-point sample()/normal() of the SDFSurface mirror and of the
 provider library (the reference's ffi.rs ABI) -- all against the oracle."""
-import ctypes as C
 
 import numpy as np
 import pytest

@@ -16,7 +16,6 @@ principles, so the conventions are this file's own.
                       (positive distance), checked below against the trilinear interpolant of the corner signs.
 Run: python tools/gen_mc_table.py            (rewrites the .inc; the committed copy must match -- tests check)
 """
-import itertools
 import os
 
 import numpy as np

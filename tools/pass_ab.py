@@ -47,7 +47,6 @@ cases = {"fresh_step_1": (lambda lib: (lambda: pass_(lib, 1), fresh)),
          "box8_step_4": (lambda lib: (lambda: pass_(lib, 4, eighth), loaded)),
          "dense_fused": (lambda lib: (lambda: lib.sdfv_fill_grid_commit(C.byref(prm), 0, C.byref(g), P(t0), P(t1), P(dist), st), (lambda: None)))}
 # same texels from both builds: a fresh 3-pass load, then a boxed edit with other parameters
-import copy
 states = {}
 for label, lib in libs.items():
     fresh()

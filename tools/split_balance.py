@@ -3,7 +3,7 @@
 contiguous row bands, whole cameras, interleaved 16-row tile bands -- timed one share after the other.  The slowest share
 is what a barrier-to-barrier measurement over `world` GPUs sees; mean / max = the split's balance.
 python tools/split_balance.py [world]"""
-import importlib, json, os, sys, time
+import importlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
