@@ -147,6 +147,42 @@ __global__ __launch_bounds__(kBlock) void fill_dense_kernel(FillArgs a) {
     if (ORDERED && ob.boundary) store_staged(a, ob, o, v0, v1);  // wave-uniform
 }
 
+// The dense fused fill that writes the y-INTERLEAVED volume, for widths that are multiples of 256: a thread owns voxel x of
+// BOTH rows of a pair (2p, 2p + 1), so the pair's distances meet in its registers -- no LDS exchange, no second barrier --
+// and a workgroup stores whole 4 KiB row segments like the plain kernel (the TX = 128 / TY = 2 form above stores 2 KiB ones
+// and makes its even-row waves wait for the odd-row ones).  512^3: 0.734 against 0.800 ms (the plain-volume fused fill: 0.686).
+template <bool NT, typename Cfg>
+__global__ __launch_bounds__(kBlock) void fill_dense_pairrows_kernel(FillArgs a) {
+    __shared__ float s_lut[256];
+    __shared__ float2 s_yz[2];
+    const uint32_t tid = threadIdx.x;
+    if (a.signal && blockIdx.x == 0 && tid == 0)  // see fill_dense_kernel
+        __hip_atomic_store(a.signal, a.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t pair = a.x_chunks == 1 ? blockIdx.x : blockIdx.x / a.x_chunks;  // pair-row p of the slab: rows 2p, 2p + 1
+    const uint32_t chunk = blockIdx.x - pair * a.x_chunks;
+    s_lut[tid] = c_srgb_lut[tid];
+    if (tid < 2) {
+        const uint32_t row = 2 * pair + tid;
+        const uint32_t zl = row / a.H, y = row - zl * a.H;  // (H is even: both rows lie in one slice)
+        s_yz[tid] = make_float2(voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]),
+                                voxel_coord(a.z_begin + zl, a.dm1[2], a.bb_size[2], a.bb_min[2]));
+    }
+    __syncthreads();
+    const LdsLut lut{s_lut};
+    const uint32_t x = chunk * kBlock + tid;  // W is a multiple of kBlock: always inside
+    const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
+    const uint64_t o = (uint64_t)(2 * pair) * a.W + x;
+    float4 v0, v1, w0, w1;
+    const float2 yz0 = s_yz[0], yz1 = s_yz[1];
+    fill_voxel<Cfg>(a.prm, a.sdf_id, px, yz0.x, yz0.y, lut, a.air_dist, v0, v1);
+    store_texel<NT>(a.tex0 + o, v0);
+    store_texel<NT>(a.tex1 + o, v1);
+    fill_voxel<Cfg>(a.prm, a.sdf_id, px, yz1.x, yz1.y, lut, a.air_dist, w0, w1);
+    store_texel<NT>(a.tex0 + o + a.W, w0);
+    store_texel<NT>(a.tex1 + o + a.W, w1);
+    reinterpret_cast<float2*>(a.dist)[(uint64_t)pair * a.W + x] = make_float2(v0.x, w0.x);
+}
+
 // Flat form of the dense kernel for widths that do not fill the row-chunk form's lanes (W not a multiple of the
 // 64 / 128 / 256 chunk): thread <-> voxel over the slab's flat index, so every wave is full and every store burst
 // is 1 KiB whatever W is.  x and row come from an exact division by W done as a 64-bit multiply-high with
@@ -489,6 +525,16 @@ hipError_t launch_dense_cfg(const FillArgs& args, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <bool NT>
+hipError_t launch_dense_pairrows(const FillArgs& args, hipStream_t stream) {
+    FillArgs a = args;
+    a.x_chunks = a.W / kBlock;
+    const uint64_t blocks = a.x_chunks * ((uint64_t)a.H * a.slab_d / 2);
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    SDFV_LAUNCH_CFG(a, (fill_dense_pairrows_kernel<NT, Cfg>), dim3((uint32_t)blocks), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
 template <int TX>
 hipError_t launch_dense_tx(const FillArgs& a, const FillLaunch& cfg, hipStream_t stream) {
     return cfg.nontemporal ? launch_dense_cfg<TX, true>(a, stream) : launch_dense_cfg<TX, false>(a, stream);
@@ -597,6 +643,10 @@ hipError_t launch_fill_dense(const FillArgs& a, const FillLaunch& cfg, hipStream
         // the interleaved volume leaves from workgroups that hold BOTH rows of a pair: the row-chunk form with two or four
         // rows per workgroup (TX 128 or 64), whatever the width
         if ((a.H & 1u) || ((uintptr_t)a.dist & 7)) return hipErrorInvalidValue;
+        // a thread per x of both rows of a pair where rows are at least two workgroups wide (512^3 -5..-8 %, 768^3 -3 %, 1024^3
+        // even; one workgroup per row pair, W = 256, loses 14 %: tools/ilv_fill_ab.py); force_rows = the row-chunk form (A/B, tests)
+        if (a.W % kBlock == 0 && a.W >= 2 * kBlock && !cfg.force_rows)
+            return cfg.nontemporal ? launch_dense_pairrows<true>(a, stream) : launch_dense_pairrows<false>(a, stream);
         return a.W <= 64 ? launch_dense_tx<64>(a, cfg, stream) : launch_dense_tx<128>(a, cfg, stream);
     }
     // Row-chunk form when the width fills its lanes, flat form otherwise (and always when forced for A/B runs).

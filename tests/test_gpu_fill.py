@@ -643,7 +643,8 @@ def interleave_rows(d):
 
 
 @pytest.mark.parametrize("dims,z_range", [((64, 64, 64), (0, 64)), ((128, 6, 5), (0, 5)), ((256, 4, 7), (2, 7)), ((300, 10, 3), (0, 3)),
-                                          ((40, 12, 29), (7, 22)), ((20, 18, 12), (0, 12)), ((512, 2, 2), (0, 2))])
+                                          ((40, 12, 29), (7, 22)), ((20, 18, 12), (0, 12)), ((512, 2, 2), (0, 2)),
+                                          ((768, 4, 3), (1, 3)), ((512, 6, 4), (0, 4))])
 def test_fill_and_passes_maintain_the_interleaved_volume(pkg, oracle, dims, z_range):
     """SDFV_PASS_VOLUME_INTERLEAVED: the volume every fill and pass writes / reads is laid out as the march's y-interleaved
     volume.  Dense fused fill (= a step-1 virgin pass), the virgin chain with its lazy initialisation, unflagged passes over an
@@ -669,6 +670,18 @@ def test_fill_and_passes_maintain_the_interleaved_volume(pkg, oracle, dims, z_ra
     pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=vol, flags=K.PASS_VIRGIN_GRID | ILV)
     check(t0, t1, vol, want0, want1)
     assert torch.equal(vol, pkg.commit_interleaved(pkg.make_grid((dims[0], dims[1], z_range[1] - z_range[0])), t0[..., 0].contiguous()))
+    # widths of two or more workgroups take the form with a thread per x of BOTH rows of a pair; SDFV_OPT_FILL_FORM 1 pins the
+    # row-chunk form (the pair meets in LDS), both store forms, the run-time configuration too: the same bits
+    for nt in (1, 2):
+        for p_ in (prm, pkg.default_params(cube_material=1, sphere_material=0)):
+            ref0, ref1 = gpu_fill(pkg, p_, dims, z0=z_range[0], z1=z_range[1])
+            for form in (0, 1):
+                t0.fill_(-7.0)
+                vol.fill_(-7.0)
+                with pkg.options({K.OPT_FILL_FORM: form, K.OPT_FILL_NONTEMPORAL: nt}):
+                    pkg.fill_grid_pass(p_, g, 1, t0, t1, dist=vol, flags=K.PASS_VIRGIN_GRID | ILV)
+                check(t0, t1, vol, ref0, ref1)
+    pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=vol, flags=K.PASS_VIRGIN_GRID | ILV)
     # (2) the virgin chain + lazy initialisation
     t0.fill_(-7.0)
     t1.fill_(float("nan"))
