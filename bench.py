@@ -552,6 +552,8 @@ def run(redirect):
         for key in {"plain": ("",), "fused": ("_fused",), "fused_ilv": ("_fused_ilv", "_fused")}[chosen]:  # (ilv: the same bytes)
             traffic = traffic if traffic is not None else load_traffic(args.workload + key)
         out["roofline"] = fill_roofline(kern_ms, voxels_per_rank, bpv, traffic)
+        if chosen == "fused_ilv" and side % 256 == 0 and side >= 512:  # (csrc/fill_kernels.hip launch_fill_dense: rows two workgroups wide)
+            out["roofline"]["kernel"] = "fill_dense_pairrows_kernel"
         out["roofline_raymarch"] = raymarch_traffic_report(args.workload, march_ev,
                                                            "tex0_path" if chosen == "plain" else "product_path",
                                                            args.workload + {"plain": "_tex0", "fused": "", "fused_ilv": "_ilv"}[chosen])
