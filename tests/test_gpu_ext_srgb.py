@@ -69,6 +69,26 @@ def test_dense_fill_both_policies(pkg, oracle, rounding, dims):
             np.testing.assert_array_equal(bits(t0), r0.view(np.uint32))
 
 
+@pytest.mark.parametrize("rounding", [False, True])
+def test_interleaved_volume_fills_both_policies(pkg, oracle, rounding):
+    """The fills that write the y-interleaved volume -- the row-chunk form and, from widths of 512, the kernel with a thread per
+    x of both rows of a pair -- under either policy, default and run-time configurations, against the oracle."""
+    K = pkg._capi
+    for dims in ((512, 4, 3), (128, 6, 5)):
+        for prm in (pkg.default_params(), pkg.default_params(cube_material=1, sphere_material=0, sphere_radius=0.9)):
+            with policy(pkg, oracle, rounding):
+                g = pkg.make_grid(dims)
+                t0, t1 = pkg.alloc_textures(g)
+                vol = torch.full(tuple(t0.shape[:-1]), -7.0, dtype=torch.float32, device="cuda")
+                pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=vol, flags=K.PASS_VIRGIN_GRID | K.PASS_VOLUME_INTERLEAVED)
+                torch.cuda.synchronize()
+                r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims)
+            np.testing.assert_array_equal(bits(t0), r0.view(np.uint32))
+            np.testing.assert_array_equal(bits(t1), r1.view(np.uint32))
+            d = t0[..., 0]
+            assert torch.equal(vol, torch.stack([d[:, 0::2], d[:, 1::2]], dim=-1).reshape(vol.shape))
+
+
 def test_the_two_policies_differ_where_the_sensitivity_study_says(pkg, oracle):
     """The switch is not a no-op: at 64^3 the default demo's custom material (0.5, 0.6, 0.7 -> 127/153/178 truncated,
     128/153/179 rounded) and the sphere's |n| colours move; distances and tex1 do not."""
