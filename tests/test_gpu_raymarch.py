@@ -645,6 +645,38 @@ def test_batches_beyond_the_cameras_a_launch_carries_in_its_arguments(pkg, n):
         pkg.raymarch(rp, t0, t1, pkg.upload_cameras(cams[:16]), W, H)
 
 
+def test_camera_ring_slots_are_reused_in_order_across_streams(pkg):
+    """The ring that carries a host array of more than 16 cameras to the device has 16 slots: the 17th launch rewrites the
+    first one's.  Sixty batches with sixty different camera sets, dealt to three streams that run ahead of one another with
+    no synchronisation in between -- every image must be the one of ITS cameras (a slot rewritten before its reader has
+    finished, or read before its writer, shows as a frame from another set)."""
+    g = pkg.make_grid((64, 64, 64))
+    t0, t1 = pkg.alloc_textures(g)
+    pkg.fill_grid(pkg.default_params(), g, t0, t1)
+    dist = pkg.commit_distance(g, t0)
+    rp = pkg.default_render_params(g)
+    W, H, n = 96, 64, 20
+    sets = [pkg.orbit_cameras(n, aspect=W / H, eye0=(2.5 + 0.03 * k, 3.0 - 0.02 * k, 5.0)) for k in range(60)]
+    want = []
+    for cams in sets:  # one call per set, the device array in place: no ring involved
+        want.append(pkg.raymarch(rp, t0, t1, pkg.upload_cameras(cams), W, H, dist=dist))
+    torch.cuda.synchronize()
+    assert not torch.equal(want[0], want[1])
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [torch.zeros_like(want[0]) for _ in sets]
+    for k, cams in enumerate(sets):
+        s = streams[k % 3]
+        with torch.cuda.stream(s):
+            pkg.raymarch(rp, t0, t1, cams, W, H, out=outs[k], dist=dist, stream=s)
+    torch.cuda.synchronize()
+    for k in range(len(sets)):
+        assert torch.equal(outs[k].view(torch.int32), want[k].view(torch.int32)), k
+    assert pkg.lib.sdfv_mesh_trim() == 0  # releases the ring; the next batch allocates a new one
+    again = pkg.raymarch(rp, t0, t1, sets[7], W, H, dist=dist)
+    torch.cuda.synchronize()
+    assert torch.equal(again.view(torch.int32), want[7].view(torch.int32))
+
+
 def test_small_launches_of_a_batch_overlap_on_side_streams_and_change_nothing(pkg):
     """A batch of more than 64 cameras is several launches; small ones (low-resolution views, band shares) are forked onto the
     library's side streams and joined back into the caller's stream.  Same images as one launch after the other; ordered
