@@ -155,8 +155,9 @@ typedef enum sdfv_option {
                                         * messages from there) | SDFV_STEP_SIDE_BOUNDARY, optionally with the SDFV_STEP_* flags below */
     SDFV_OPT_RAYMARCH_TILE_GROUP = 6,  /* raymarch workgroup-tile order: 0 auto (default: for a single frame XCD-aware groups of
                                         * 2 x 2 tiles with the box-first order below, 4 x 4 where that does not apply; launch order
-                                        * for camera batches) | 1 launch order | v = 2..5: XCD-aware groups of 2^(v-1) x 2^(v-1)
-                                        * tiles (each group's tiles run on one XCD = one L2) */
+                                        * with the tile columns rotated by row and camera for camera batches and tile bands, so that
+                                        * the eight XCDs' shares of a launch balance) | 1 plain launch order | v = 2..5: XCD-aware
+                                        * groups of 2^(v-1) x 2^(v-1) tiles (each group's tiles run on one XCD = one L2) */
     SDFV_OPT_RAYMARCH_BOX_FIRST = 7,   /* 1 (default) | 0: with an XCD-aware tile order and one camera, the groups of tiles under
                                         * the screen rectangle of the projected bounding box are launched before the others (the
                                         * frame is as long as its longest wave; those all start at once then).  Order only */

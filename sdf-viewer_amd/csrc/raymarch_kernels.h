@@ -38,6 +38,8 @@ struct RaymarchArgs {
     uint32_t box_first;          // option: use that order (default 1)
     uint32_t first_gx0, first_gy0, first_w, first_h, m_groups_x, m_first_w, m_rest_w;
     uint32_t no_interior_fetch;  // hand-written loop: always take the clamping fetch block (tests, A/B)
+    uint32_t rotate_columns;     // launch order only (group_shift == 0): workgroup (x, y, z) renders tile column (x + y + z) mod
+                                 // tiles_x -- see raymarch_kernel; set by the API layer on eight-XCD parts, order only
     uint32_t lds_cap_bytes;      // unused dynamic LDS per workgroup: caps the resident waves per SIMD (0 = no cap); set by the launcher
     uint32_t waves_per_simd;     // option: 0 = the launcher's occupancy rule, 7 = never cap, 2..6 = that cap
     uint32_t wave_slots_per_simd_unit;  // SIMDs of the device (CUs x 4): resident waves at w per SIMD = w x this; 0 = unknown

@@ -783,7 +783,18 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
         by = t / tiles_x;
     } else
 #endif
-    if (a.group_shift) {
+    if (a.group_shift == 0 && a.rotate_columns) {
+        // Launch order (batches of cameras, tile bands).  The workgroups of a launch are dealt to the eight XCDs round robin by
+        // their linear number and every XCD works through ITS share at its own pace: the launch is as long as the busiest
+        // XCD's share.  With a tile row a multiple of 8 wide (1080p: 120, 4K: 240, 1440p: 160) XCD k would render tile columns
+        // k, k + 8, ... of EVERY row of EVERY camera -- and an object 44 columns wide gives six columns to some XCDs and five
+        // to others: 24 % more marching on the busiest XCD than on the idlest (tools/batch_timeline.py: they finish 290 us
+        // apart in a 1.75 ms batch).  Rotating the columns by row and camera deals every XCD every column in turn.
+        const uint32_t tiles_x = gridDim.x;
+        const uint32_t r = (blockIdx.y + blockIdx.z) % tiles_x;  // scalar
+        bx = blockIdx.x + r;
+        if (bx >= tiles_x) bx -= tiles_x;
+    } else if (a.group_shift) {
         // XCD-aware order (a.group_shift = g): the launch is 1-D over workgroups; workgroup L runs on XCD L % 8 (observed
         // placement, used for speed only).  The image is cut into groups of 2^g x 2^g tiles; group number G goes to XCD
         // G % 8, so that the tiles one XCD's L2 serves are compact patches spread evenly over the image.

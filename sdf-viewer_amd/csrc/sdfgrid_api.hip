@@ -1128,6 +1128,9 @@ static int raymarch_rows(const sdfv_render_params* rp, const float* tex0, const 
     const bool xcd_order_ok = dev.xcds == 8;
     a.group_shift = g_options.raymarch_tile_group == 0 ? (n_cameras == 1 && xcd_order_ok ? sdfv::kGroupAuto : 0u)
                                                        : (g_options.raymarch_tile_group == 1 ? 0u : g_options.raymarch_tile_group - 1u);
+    // launches that keep launch order (batches, tile bands): tile columns rotated by row and camera, so that the XCDs' static
+    // shares balance (auto only: SDFV_OPT_RAYMARCH_TILE_GROUP 1 is the plain launch order, for A/B runs)
+    a.rotate_columns = g_options.raymarch_tile_group == 0 && xcd_order_ok ? 1u : 0u;
 #ifdef SDFV_TUNING
     a.wave_timing = reinterpret_cast<unsigned long long*>(g_options.wave_timing);  // 32 B per wave, or 0
     a.priority_map = reinterpret_cast<const unsigned char*>(g_options.priority_map);

@@ -426,6 +426,17 @@ def test_randomised_tile_orders(pkg):
                 with pkg.options({K.OPT_RAYMARCH_TILE_GROUP: group, K.OPT_RAYMARCH_BOX_FIRST: first}):
                     pkg.raymarch(rp, t0, t1, cam, W, H, y0=y0, y1=y1, out=out, dist=use_dist)
                 assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), (trial, W, H, y0, y1, group, first)
+        # launches that keep launch order -- batches of cameras, tile bands -- rotate the tile columns by row and camera
+        # (the XCDs' static shares balance); SDFV_OPT_RAYMARCH_TILE_GROUP 1 is the plain order
+        cams = [cam] + pkg.orbit_cameras(int(rng.integers(1, 5)), aspect=W / H)
+        bands = (int(rng.integers(0, 3)), int(rng.integers(1, 4)), int(rng.choice([8, 16]))) if trial % 2 else None
+        kw = {"bands": bands} if bands else {"y0": y0, "y1": y1}
+        with pkg.options({K.OPT_RAYMARCH_TILE_GROUP: 1}):
+            ref = pkg.raymarch(rp, t0, t1, cams, W, H, dist=use_dist, **kw)
+        if ref.numel():
+            out = torch.full(tuple(ref.shape), float("nan"), dtype=torch.float32, device="cuda")
+            pkg.raymarch(rp, t0, t1, cams, W, H, out=out, dist=use_dist, **kw)
+            assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), (trial, W, H, kw, len(cams), "rotated columns")
 
 
 def test_occupancy_cap_changes_nothing_but_speed(pkg):
