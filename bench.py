@@ -216,6 +216,7 @@ def cpu_baseline(workload, budget_s):
         frames += 1
     all_rays = frames * W * H / all_rays_dt / 1e6
     return {"value": round(fill_mvox, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+            "sample_short": f"{loads} load(s) of {side}^3 in LoadingManager order ({fill_dt:.1f} s); {rows_done} rows of {W}x{H}",
             "sample": f"{loads} complete load(s) of the {side}^3 grid in LoadingManager order, 2 passes "
                       f"({loads * n_vox} voxels, {fill_dt:.1f} s), oracle/grid_fill.c gcc -O3 -ffp-contract=off, 1 thread",
             "all_cores": {"value": round(all_mvox, 3), "unit": "Mvoxels/s", "cores": threads,
@@ -225,6 +226,119 @@ def cpu_baseline(workload, budget_s):
             "sample_rays": f"{rows_done} central rows of the {W}x{H} image, 1 thread",
             "all_cores_rays": {"value": round(all_rays, 3), "unit": "Mrays/s", "cores": threads,
                                "sample": f"{frames} whole {W}x{H} frame(s), OpenMP over rows ({all_rays_dt:.1f} s)"}}
+
+
+CONTRACT_LIMIT = 4096  # bytes: the driver's capture parsed round 3's 15 KB line and lost round 4's 22 KB one
+
+
+def _finite(v):
+    """json.dumps would write NaN / Infinity (not JSON); the contract line carries null instead."""
+    if isinstance(v, float):
+        return v if v == v and abs(v) != float("inf") else None
+    if isinstance(v, dict):
+        return {k: _finite(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_finite(x) for x in v]
+    return v
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def contract_line(line, full_path):
+    """The ONE short JSON line of the contract (the reference's analogue is one timing log line, scene/mod.rs:180-191): metric,
+    value, ms_per_step, config, dtype, roofline, cpu_baseline and a handful of numbers beside them.  Everything else the run
+    measured -- progressive, host_load, batch, loopback, per-step distributions, the prose -- is `line`, written to
+    `full_path` and to stderr."""
+    c = _pick(line, "metric", "value", "unit", "value_rays", "unit_rays", "n_gpus", "steps", "warmup", "ms_per_step",
+              "ms_per_step_fill", "ms_per_step_raymarch", "ms_per_step_median", "ms_per_step_p95", "higher_is_better", "scaling",
+              "vs_baseline", "dtype")
+    c["data"] = "synthetic"
+    cfg = line["config"]
+    c["config"] = {"workload": cfg["workload"], "grid": cfg["grid_global"], "image": cfg["image"],
+                   "voxels_per_gpu": cfg["voxels_per_gpu"], "cameras_per_gpu": cfg["cameras_per_gpu"],
+                   "parallelism": cfg["parallelism"]}
+    c["pipeline"] = line.get("pipeline")
+    r = line.get("roofline") or {}
+    c["roofline"] = _pick(r, "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                          "avg_launch_ms", "frac_bus", "rccl_ranks")
+    t = r.get("target_512")
+    if isinstance(t, dict):
+        c["roofline"]["target_512"] = {k: _pick(v, "ms", "frac_8d") for k, v in t.items() if isinstance(v, dict)}
+    rr = line.get("roofline_raymarch") or {}
+    c["roofline_raymarch"] = _pick(rr, "bound", "achieved", "frac", "traffic", "compulsory_bytes", "avg_launch_ms")
+    if "bound" in c["roofline_raymarch"]:
+        c["roofline_raymarch"]["bound"] = "latency"
+    cb = line.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind", "value_rays", "unit_rays")
+        c["cpu_baseline"]["sample"] = cb.get("sample_short", "")
+        for k in ("all_cores", "all_cores_rays"):
+            if isinstance(cb.get(k), dict):
+                c["cpu_baseline"][k] = _pick(cb[k], "value", "cores")
+    b = line.get("batch_raymarch")
+    if isinstance(b, dict):
+        c["batch_raymarch"] = _pick(b, "cameras", "value", "unit", "ms_per_batch", "split", "gather_ms", "value_incl_gather")
+        for k in ("camera_split", "contiguous_rows_split"):
+            if isinstance(b.get(k), dict):
+                c["batch_raymarch"][k] = _pick(b[k], "value", "ms_per_batch", "gather_ms")
+    h = line.get("host_load")
+    if isinstance(h, dict):
+        c["host_load"] = {k: {"update_ms": v["dense"].get("update_ms"), "load_ms": v["dense"].get("load_ms"),
+                              "progressive_load_ms": (v.get("progressive") or {}).get("load_ms")}
+                          for k, v in h.items() if isinstance(v, dict) and isinstance(v.get("dense"), dict)}
+    p = line.get("progressive")
+    if isinstance(p, dict):
+        c["progressive"] = {side: {name: [case.get("ms"), case.get("frac")] for name, case in cases.items()
+                                   if isinstance(case, dict) and "ms" in case}
+                            for side, cases in p.items() if isinstance(cases, dict)}
+    hl = line.get("halo_loopback")
+    if isinstance(hl, dict) and isinstance(hl.get("by_side"), dict):
+        c["halo_loopback"] = {k: _pick(v, "ms_per_step", "plain_fill_ms", "fraction_of_plain_fill_rate", "ghosts_verified")
+                              for k, v in hl["by_side"].items()}
+    if line.get("n_gpus", 1) > 1 or line.get("loopback"):
+        c.update(_pick(line, "loopback", "backend", "rccl_ranks", "torch_world_size", "sharded_fill_verified",
+                       "fill_step_fraction_of_plain_fill"))
+        c["halo_transport"] = (line.get("halo_transport") or "").split(" ")[0] or None
+        if isinstance(line.get("config4"), dict):
+            c["config4"] = _pick(line["config4"], "grid_global", "value", "ms_per_step_fill", "plain_fill_ms", "error")
+        if isinstance(line.get("sharded_march"), dict):
+            c["sharded_march"] = _pick(line["sharded_march"], "verified", "ms")
+    c["incomplete"] = line.get("incomplete")
+    if "watchdog" in line:
+        c["watchdog"] = str(line["watchdog"])[:160]
+    box = line.get("box") or {}
+    smi = box.get("rocm_smi") if isinstance(box.get("rocm_smi"), dict) else {}
+    c["box"] = {"uuid": smi.get("Unique ID") or box.get("uuid"), "arch": box.get("arch"),
+                "sclk": (smi.get("sclk clock speed:") or "").strip("()") or None}
+    c["full"] = full_path
+    c = _finite(c)
+    # the limit is part of the contract: drop the optional blocks, least important first, should the line ever outgrow it
+    for drop in ("progressive", "halo_loopback", "host_load", "batch_raymarch", "roofline_raymarch", "box"):
+        if len(json.dumps(c, separators=(",", ":"), allow_nan=False)) < CONTRACT_LIMIT:
+            break
+        c.pop(drop, None)
+    return c
+
+
+def emit(line, redirect):
+    """Full record -> $SDFV_BENCH_FULL_JSON (default gpurun_out/bench_full_n<N>.json) and stderr; the contract line -> the LAST
+    line of stdout."""
+    full_path = os.environ.get("SDFV_BENCH_FULL_JSON") or os.path.join("gpurun_out", f"bench_full_n{line.get('n_gpus', 1)}.json")
+    full = json.dumps(_finite(line), allow_nan=False)
+    try:
+        absolute = full_path if os.path.isabs(full_path) else os.path.join(ROOT, full_path)
+        os.makedirs(os.path.dirname(absolute), exist_ok=True)
+        with open(absolute, "w") as f:
+            f.write(full + "\n")
+    except OSError as e:
+        full_path = f"(not written: {e})"
+    print("[bench full record] " + full, file=sys.stderr, flush=True)
+    text = json.dumps(contract_line(line, full_path), separators=(",", ":"), allow_nan=False)
+    if redirect is not None:
+        redirect.restore()
+    print(text, flush=True)
 
 
 class NativeStdoutToStderr:
@@ -294,9 +408,7 @@ def main():
                         line = dict(PARTIAL["line"])
                         line["incomplete"] = True  # a hang in an extra must not look like a clean run
                         line["watchdog"] = f"an extra did not finish: stuck in stage '{name}' for {age:.0f} s; the line carries what was measured before it"
-                        if PARTIAL["redirect"] is not None:
-                            PARTIAL["redirect"].restore()
-                        print(json.dumps(line), flush=True)
+                        emit(line, PARTIAL["redirect"])
             finally:
                 os._exit(code)
 
@@ -663,8 +775,7 @@ def run(redirect):
     if rank == 0:
         if not args.no_cpu_baseline and not multi:  # rank 0, N = 1 only
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_seconds)
-        redirect.restore()
-        print(json.dumps(line), flush=True)
+        emit(line, redirect)
     if multi:
         if getattr(filler, "comm", None) is not None:
             torch.cuda.synchronize()

@@ -18,12 +18,14 @@ def load_tool():
     return mod
 
 
-@pytest.mark.parametrize("pipeline", ["plain", "fused"])
+@pytest.mark.parametrize("pipeline", ["plain", "fused", "fused_ilv"])
 @pytest.mark.parametrize("side", [256, 512])
 def test_whole_grid_and_whole_frame(pkg, oracle, side, pipeline):
-    """Both pipelines bench.py times, with the kernel instantiations it times (default options): plain = sdfv_fill_grid +
+    """All three pipelines bench.py times, with the kernel instantiations it times (default options): plain = sdfv_fill_grid +
     the no-aux march over tex0.r; fused = sdfv_fill_grid_commit (nt texture stores, distance volume in the same launch) +
-    the no-aux hand-written march over that volume in box-first order.  Textures (and the volume) word for word, the
+    the no-aux hand-written march over that volume in box-first order; fused_ilv = the fill that writes the march's
+    y-interleaved volume itself (256^3: the LDS pair form, 512^3: fill_dense_pairrows_kernel -- what SDFViewer runs beyond
+    the last-level cache) + the march over that volume.  Textures (and the volume) word for word, the
     no-aux RGBA on every pixel against the oracle and bit for bit against the aux kernel's."""
     bad_words, aux_diff, rgba_err = load_tool().check(side, log=lambda m: None, pipeline=pipeline)
     assert bad_words == 0

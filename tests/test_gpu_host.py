@@ -2,6 +2,8 @@
 pass kernels, SDFViewerMaterial::render, per-point sample()/normal() of the SDFSurface mirror and of the
 provider library (the reference's ffi.rs ABI) -- all against the oracle."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -214,7 +216,7 @@ def test_commit_of_a_loaded_grid_builds_the_pair_volume_and_edits_retire_it(host
     assert np.abs(edited - want).max() <= 1e-4 and not np.array_equal(before, edited)
 
 
-def test_commit_of_a_grid_beyond_the_last_level_cache_builds_the_interleaved_volume(host, pkg):
+def test_commit_of_a_grid_beyond_the_last_level_cache_builds_the_interleaved_volume(host, pkg, oracle):
     """512^3: the pair volume (1 GB) would not fit the Infinity Cache: sdfv_march_volume_advice names the y-interleaved volume,
     and since round 4 the viewer's FILLS write it (SDFV_PASS_VOLUME_INTERLEAVED) -- the load ends with the march's volume in
     place, commit() builds nothing; the frames over it are the frames over the plain distance volume, bit for bit; a
@@ -237,6 +239,21 @@ def test_commit_of_a_grid_beyond_the_last_level_cache_builds_the_interleaved_vol
     want = pkg.raymarch(pkg.default_render_params(g), t0, t1, pkg.camera_look_at(aspect=1280 / 720), 1280, 720, dist=dist)[0]
     np.testing.assert_array_equal(frame.view(np.uint32), want.cpu().numpy().view(np.uint32))
     del t0, t1, dist
+    # ... and against the ORACLE directly, not only through the library's other path: every word of both
+    # textures as SDFViewer::update left them (scene/sdf/mod.rs:173-215), and one 3840 x 2160 frame (material.frag:92-182)
+    h0, h1 = v.download()
+    threads = len(os.sched_getaffinity(0))
+    oprm = oracle.default_params()
+    bad = 0
+    for z in range(0, 512, 32):
+        r0, r1 = oracle.fill_dense(oprm, (512, 512, 512), z0=z, z1=z + 32, threads=threads)
+        bad += int((h0[z:z + 32].view(np.uint32) != r0.view(np.uint32)).sum()) + int((h1[z:z + 32].view(np.uint32) != r1.view(np.uint32)).sum())
+    assert bad == 0
+    frame4k = v.render(3840, 2160)
+    want4k, _ = oracle.raymarch(oracle.default_render_params((512, 512, 512)), h0, h1, oracle.camera_look_at(aspect=3840 / 2160),
+                                3840, 2160, threads=threads, want_aux=False)
+    assert np.abs(frame4k - want4k).max() <= 1e-4 and (want4k[..., 3] > 0).sum() > 500000
+    del h0, h1, frame4k, want4k
     # pass by pass (2 passes, one per call), then a parameter edit: same frames as a viewer of the edited SDF loaded densely
     p = host.Viewer.new_voxels((512, 512, 512), [-1, -1, -1, 1, 1, 1], 2)
     while p.update(sdf, 0.0):
