@@ -391,8 +391,8 @@ int sdfv_mesh_trim(void);
  *                     extents, symmetric box, <= 2^28 texels) on a CUBIC grid, every other launch reads dist / tex0.r
  *   cameras           HOST array of n_cameras, free again when the call returns (up to 16 ride in a launch's kernel arguments; a
  *                     larger batch goes through the library's ring of device memory, SDFV_OPT_RAYMARCH_CAMERA_STAGING, so that
- *                     64 cameras are one launch).  An array of MORE than 16 cameras may instead lie in DEVICE memory: read
- *                     in place by the launches, nothing copied
+ *                     64 cameras are one launch).  The array may instead lie in DEVICE (or managed) memory, whatever its
+ *                     length: read in place by the launches, nothing copied (the library asks hipPointerGetAttributes)
  *   y0, y1            rows [y0, y1) when band_step == 0
  *   band_first, band_step, band_height   band_step >= 1: the balanced image-tile split of BASELINE config 5 -- rank r of N renders
  *                     (r, N): the bands band_first, band_first + band_step, ... of band_height = 16 (also 0) or 8 rows -- a

@@ -408,8 +408,8 @@ class options:
 
 
 def upload_cameras(cameras, device="cuda"):
-    """The cameras as a device tensor (120 bytes each) that raymarch() hands to the library as it is: a batch of more than 16
-    cameras in DEVICE memory is read in place, a host array of that size is copied by the launcher on every call."""
+    """The cameras as a device tensor (120 bytes each) that raymarch() hands to the library as it is: an array in DEVICE memory
+    is read in place whatever its length; a host array of more than 16 is staged by the launcher on every call."""
     arr = (Camera * len(cameras))(*cameras)
     return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
 
@@ -418,17 +418,15 @@ def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=Fal
              want_depth=False, depth_out=None, pairs=None, ilv=None, bands=None):
     """material.frag main() over rows [y0,y1) -- or, bands=(first, step), over the 16-row tile bands first, first + step, ...
     stored one after the other (sdfv_march_desc.band_first / band_step).  Returns rgba [n_cam, rows, W, 4] (+ aux [n_cam, rows, W, 18] words).
-    cameras: a Camera, a list of them, or upload_cameras()'s device tensor (more than 16 cameras).
+    cameras: a Camera, a list of them, or upload_cameras()'s device tensor (any number of cameras).
     `dist` = optional compact distance volume from commit_distance(); `pairs` = optional y-pair volume from commit_pairs()
     (sdfv_raymarch_pairs).  want_depth / depth_out: also return the
     gl_FragDepth plane [n_cam, rows, W] (sdfv_raymarch_depth); return order: rgba[, depth][, aux]."""
     if isinstance(cameras, Camera):
         cameras = [cameras]
     y1 = height if y1 is None else y1
-    if isinstance(cameras, torch.Tensor):  # upload_cameras(): more than 16 cameras may lie in device memory, read in place
+    if isinstance(cameras, torch.Tensor):  # upload_cameras(): cameras in device memory, read in place
         n = cameras.numel() * cameras.element_size() // C.sizeof(Camera)
-        if n <= 16:
-            raise SdfvError(-1, "a device array of cameras must hold more than 16 (smaller batches ride in the kernel arguments)")
         cam_arr = C.cast(C.c_void_p(cameras.data_ptr()), C.POINTER(Camera))
     else:
         n = len(cameras)

@@ -93,6 +93,8 @@ struct SlabMarchArgs {
 hipError_t launch_raymarch_slab(const RaymarchArgs& a, const SlabMarchArgs& s, hipStream_t stream);
 
 hipError_t launch_raymarch(const RaymarchArgs& a, hipStream_t stream);
+// would the launcher march over a pair (kind 3) / y-interleaved (kind 4) volume for these arguments, pointers apart?
+bool march_volume_applicable(const RaymarchArgs& a, int kind);
 // n cameras from a HOST array into DEVICE memory, stream-ordered, without a copy engine: launches that carry 32 cameras each
 // in their kernel arguments (the host array is free again on return)
 hipError_t launch_store_cameras(const sdfv_camera* host, uint32_t n, sdfv_camera* device, hipStream_t stream);

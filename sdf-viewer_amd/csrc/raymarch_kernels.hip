@@ -1399,17 +1399,28 @@ static void box_first_rectangle(RaymarchArgs& ag, uint32_t groups_y) {
 // volume, 0 neither (the loop's specialisation does not apply, or neither was given).  With both: the pair volume while its
 // 8 B/voxel fit the last-level cache (fewest gathers), the interleaved one beyond (half the footprint) --
 // tools/pairs_bench.py, profiles/r03_pairs_bench.json.
-static int march_volume_mode(const RaymarchArgs& a) {
+// Does the hand-written loop's specialisation apply to these render parameters, and may it address a volume of `kind` (3 the
+// pair volume, 4 the y-interleaved one)?  Pointers apart, everything march_volume_mode decides on -- sdfv_march_volume_advice
+// asks the same question BEFORE a volume exists (the advice once checked less than the launcher, so a host could
+// be advised a layout no march would ever read and then gather 16-byte tex0 texels instead of its 4-byte distance volume).
+bool march_volume_applicable(const RaymarchArgs& a, int kind) {
     const uint64_t texels = (uint64_t)a.rp.tex_size[0] * a.rp.tex_size[1] * a.rp.tex_size[2];
     const bool loop_ok = a.rp.lod_dist_between_samples == 1.0f && a.fast_index && a.pow2_extent && a.pow2_size && a.symmetric_box &&
                          a.asm_loop && a.rp.tex_size[0] >= 2 && asm_addressing_ok(a);
     // 32-bit byte offsets: 8 B/texel of pairs reach 2^28 texels with the loop's shifts, 4 B/voxel of ilv 2^30 (like dist)
+    if (kind == 3) return loop_ok && texels <= (1ull << 28);
+    if (kind == 4) return loop_ok && a.rp.tex_size[1] >= 2 && (a.rp.tex_size[1] & 1u) == 0 && texels <= (1ull << 30);
+    return false;
+}
+
+static int march_volume_mode(const RaymarchArgs& a) {
+    const uint64_t texels = (uint64_t)a.rp.tex_size[0] * a.rp.tex_size[1] * a.rp.tex_size[2];
     // a non-cubic grid never takes the loop's interior fetch (one compare for all three cell indices), and the border fetch of
     // these two volumes is eight single loads against the distance volume's four 8-byte ones: with `dist` at hand, use it
     const bool cubic = a.rp.tex_size[0] == a.rp.tex_size[1] && a.rp.tex_size[1] == a.rp.tex_size[2];
     if (!cubic && a.dist) return 0;
-    const bool pairs_ok = loop_ok && a.pairs && texels <= (1ull << 28);
-    const bool ilv_ok = loop_ok && a.ilv && a.rp.tex_size[1] >= 2 && (a.rp.tex_size[1] & 1u) == 0 && texels <= (1ull << 30);
+    const bool pairs_ok = a.pairs && march_volume_applicable(a, 3);
+    const bool ilv_ok = a.ilv && march_volume_applicable(a, 4);
     if (pairs_ok && ilv_ok) return (a.last_level_cache_bytes && texels * 8u > a.last_level_cache_bytes) ? 4 : 3;
     return ilv_ok ? 4 : (pairs_ok ? 3 : 0);
 }

@@ -1030,13 +1030,24 @@ int sdfv_march_volume_advice(const sdfv_grid* grid, uint32_t* kind) {
     const uint64_t n = (uint64_t)grid->dims[0] * grid->dims[1] * grid->dims[2];
     const uint64_t llc = device_facts().last_level_cache_bytes;
     // only the hand-written gfx950 loop reads these volumes -- on another device, or with that loop switched off, a
-    // host would allocate 4-8 B/voxel and re-run the commit after every fill for a volume no march ever touches
-    if (!device_facts().gfx950 || (g_options.raymarch_disable & SDFV_RM_NO_ASM_LOOP))
-        *kind = SDFV_MARCH_VOLUME_NONE;
-    else if (grid->dims[0] != grid->dims[1] || grid->dims[1] != grid->dims[2])
+    // host would allocate 4-8 B/voxel and re-run the commit after every fill for a volume no march ever touches.  ADVICE r04:
+    // and the loop's OTHER conditions (power-of-two extents, symmetric box, clamp-for-mirror, its addressing limits) are
+    // asked of the launcher itself, over the render parameters a march of this grid would carry (sdfv_render_params_default).
+    sdfv_render_params rp;
+    memset(&rp, 0, sizeof(rp));
+    for (int i = 0; i < 3; ++i) rp.tex_size[i] = grid->dims[i], rp.bounds_min[i] = grid->bb_min[i], rp.bounds_max[i] = grid->bb_max[i];
+    rp.lod_dist_between_samples = 1.0f;
+    sdfv::RaymarchArgs a;
+    derive_raymarch_args(&rp, a);
+    if (!device_facts().gfx950) a.asm_loop = 0;
+    const bool cubic = grid->dims[0] == grid->dims[1] && grid->dims[1] == grid->dims[2];
+    const bool pairs_ok = sdfv::march_volume_applicable(a, 3), ilv_ok = sdfv::march_volume_applicable(a, 4);
+    if (!cubic)
         *kind = SDFV_MARCH_VOLUME_NONE;  // the two-gather cell fetch is the cubic grid's: the distance volume marches fastest here
+    else if (ilv_ok && (!pairs_ok || (llc && n * 8u > llc)))
+        *kind = SDFV_MARCH_VOLUME_INTERLEAVED;
     else
-        *kind = (llc && n * 8u > llc && (grid->dims[1] & 1u) == 0) ? SDFV_MARCH_VOLUME_INTERLEAVED : SDFV_MARCH_VOLUME_PAIRS;
+        *kind = pairs_ok ? SDFV_MARCH_VOLUME_PAIRS : SDFV_MARCH_VOLUME_NONE;
     return SDFV_OK;
 }
 
@@ -1146,12 +1157,14 @@ static int raymarch_rows(const sdfv_render_params* rp, const float* tex0, const 
     a.camera_list = nullptr;
     const sdfv_camera* device_cameras = nullptr;
     bool ring = false;
-    if (n_cameras > sdfv::kInlineCameras) {
-        hipPointerAttribute_t attr;
-        if (hipPointerGetAttributes(&attr, cameras) == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged)) {
-            device_cameras = cameras;
-        } else {
-            (void)hipGetLastError();
+    // (asked for ANY count -- ADVICE r04: a device array of <= kInlineCameras cameras, e.g. a rank's share of a resident batch,
+    // used to be memcpy'd from on the host; the kernel reads camera_list for any count)
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, cameras) == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged)) {
+        device_cameras = cameras;
+    } else {
+        (void)hipGetLastError();
+        if (n_cameras > sdfv::kInlineCameras) {
             hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(main, &capturing) != hipSuccess) (void)hipGetLastError();
             ring = capturing == hipStreamCaptureStatusNone && g_options.raymarch_camera_staging &&

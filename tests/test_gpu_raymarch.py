@@ -652,8 +652,12 @@ def test_batches_beyond_the_cameras_a_launch_carries_in_its_arguments(pkg, n):
             graph.replay()
             side.synchronize()
         assert torch.equal(out.view(torch.int32), ref[0].view(torch.int32)), (n, "captured", what)
-    with pytest.raises(pkg.SdfvError):
-        pkg.raymarch(rp, t0, t1, pkg.upload_cameras(cams[:16]), W, H)
+    # a DEVICE array of 16 or fewer cameras (a rank's share of a resident batch) is read in place too -- it used to
+    # be dereferenced on the host
+    for k in (1, 8, 16):
+        part = pkg.raymarch(rp, t0, t1, pkg.upload_cameras(cams[:k]), W, H, dist=dist)
+        torch.cuda.synchronize()
+        assert torch.equal(part.view(torch.int32), ref[0][:k].view(torch.int32)), (n, "device array of", k)
 
 
 def test_camera_ring_slots_are_reused_in_order_across_streams(pkg):
