@@ -8,8 +8,8 @@ halves are timed in two separately bracketed regions of exactly K steps each:
     value_rays  = Mrays/s of the raymarch (all W*H pixels counted, misses included)
     ms_per_step = fill ms + raymarch ms.
 Both halves belong to ONE pipeline over the same buffers: at N = 1 two are timed -- `pipeline_plain` (sdfv_fill_grid,
-32 B/voxel -> sdfv_raymarch over tex0.r) and `pipeline_fused` (sdfv_fill_grid_commit, 36 B/voxel -> sdfv_raymarch_accel
-over the compact distance volume that fill wrote) -- and value / value_rays / ms_per_step / roofline come from the one
+32 B/voxel -> sdfv_raymarch_ex over tex0.r) and `pipeline_fused` (sdfv_fill_grid_commit, 36 B/voxel -> sdfv_raymarch_ex with
+desc.dist = the compact distance volume that fill wrote) -- and value / value_rays / ms_per_step / roofline come from the one
 that is faster end to end (`pipeline`).  The N = 1 line also carries `target_512` (the 512^3 fill the north-star target
 is stated on), `roofline_raymarch` with SURVEY 8(d)'s modelled bytes, and `halo_loopback`; N > 1 lines carry `config4`
 (cube geometry at 512^3 voxels per rank: 8 ranks = BASELINE config 4's 1024^3) next to the default slab geometry.
@@ -509,7 +509,7 @@ def run(redirect):
     if not multi:
         # ---------------- N = 1: two CONSISTENT pipelines over the SAME buffers ----------------
         #   plain: sdfv_fill_grid (32 B/voxel)         -> sdfv_raymarch over tex0.r in place
-        #   fused: sdfv_fill_grid_commit (36 B/voxel)  -> sdfv_raymarch_accel over the compact distance volume it wrote
+        #   fused: sdfv_fill_grid_commit (36 B/voxel)  -> sdfv_raymarch_ex (desc.dist) over the compact distance volume it wrote
         # Each half is timed in its own region of exactly K steps (voxels and rays are different units); the textures
         # the march reads are the ones the timed fill wrote.  value / value_rays / ms_per_step all come from ONE
         # pipeline: the one that is faster end to end.
@@ -603,7 +603,7 @@ def run(redirect):
                       "fill_frac_of_hbm_peak": round(32 * voxels_per_rank / (fill_plain_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       "fill_frac_8d": round(32 * voxels_per_rank / (fill_plain_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "fused": {"fill": "sdfv_fill_grid_commit (36 B/voxel: textures + compact distance volume)",
-                      "march": "sdfv_raymarch_accel over the distance volume",
+                      "march": "sdfv_raymarch_ex over the distance volume (desc.dist)",
                       "ms_fill": round(fill_fused_ms, 4), "ms_raymarch": round(march_dist_ms, 4),
                       "ms_per_step": round(fill_fused_ms + march_dist_ms, 4),
                       "ms_per_step_interleaved": round(inter_fused_ms, 4),

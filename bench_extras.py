@@ -82,7 +82,7 @@ def host_load_block(sides):
 def progressive_block(pkg, torch, prm, sides, reps=7):
     """SURVEY 8(f)1 under the bench's measurement discipline: the LoadingManager passes (loading.rs:50-76) with
     update_required (scene/sdf/mod.rs:184-190) on the device, over textures that travel with their distance volume
-    (sdfv_fill_grid_pass_dist).  Per case: median ms over `reps` runs (HIP events; the state is re-created, untimed, before
+    (sdfv_fill_grid_pass_ex with its `dist` argument).  Per case: median ms over `reps` runs (HIP events; the state is re-created, untimed, before
     every run), visited voxels, updated voxels, and the fraction of the HBM roofline on SURVEY 8(d)'s incremental figure,
     36 B per UPDATED voxel (4 B read + 32 B written) + 4 B per voxel that is visited only."""
     AIR = pkg.AIR_DIST
@@ -157,7 +157,7 @@ def progressive_block(pkg, torch, prm, sides, reps=7):
         res["fresh_pass_step_2_flagged"] = case(timed(passes((2,), flagged=True), fresh), visited((2,)), visited((2,)),
                                                 "first pass of that load alone (whole visited rows written: 1/4 of the textures)")
         res["fresh_load_2_passes_unflagged"] = case(timed(passes((2, 1)), fresh), visited((2, 1)), n,
-                                                    "the same load through sdfv_fill_grid_pass_dist (update_required read from the volume)")
+                                                    "the same load, the caller saying nothing (sdfv_fill_grid_pass_ex, flags 0; update_required read from the volume)")
         res["fresh_pass_step_2"] = case(timed(passes((2,)), fresh), visited((2,)), visited((2,)), "first pass, unflagged")
 
         def after_step2():
@@ -356,7 +356,7 @@ def run_extras(c):
 
         def time_split(split, use_pairs=True):
             """tiles = BASELINE config 5 as named (image-tile split), balanced: the 16-row tile bands r, r + N, ... of EVERY
-            camera per rank (sdfv_raymarch_bands); rows = one contiguous range of rows of every camera per rank; cameras =
+            camera per rank (sdfv_march_desc.band_first / band_step); rows = one contiguous range of rows of every camera per rank; cameras =
             whole cameras dealt to the ranks.  At N = 1 all three are the same call."""
             where = {}
             if split == "tiles" and world > 1:

@@ -186,6 +186,9 @@ typedef enum sdfv_option {
                                         * stream (kernels that carry 32 cameras each as arguments: no copy engine, no allocation
                                         * per call), so that 64 cameras are one launch; 0 = launches of 16 cameras instead (what a
                                         * stream under capture gets anyway).  A DEVICE array is always read in place.  Same pixels */
+    SDFV_OPT_PASS_FORM = 13,           /* 0 auto (default) | 1: a pass the caller says nothing about (no flags, no box) with step >= 2 takes
+                                        * the per-voxel kernel (one texel in every `step`) instead of the whole-rows kernel whose
+                                        * waves decide on the volume they read (sdfv_fill_grid_pass_ex).  A/B runs; same texels */
     SDFV_OPT_TUNING_WAVE_TIMING = 100, /* tuning build only (-DSDFV_TUNING): DEVICE address of 32 B per raymarch wave */
     SDFV_OPT_TUNING_TILE_ORDER = 102,  /* tuning build only: DEVICE address of tiles_x * tiles_y uint32 tile numbers (row-major
                                         * tile index by * tiles_x + bx): workgroup L of a single-camera launch renders tile
@@ -712,11 +715,12 @@ SDFV_INLINE int sdfv_raymarch_bands(const sdfv_render_params *rp, const float *t
     d.y1 = height;
     d.band_first = band_first;
     d.band_step = band_step;
-    d.band_height = 0;
+    /* in the descriptor band_step 0 means "rows [y0, y1)", not a band set: a band height WITH step 0 is what the library
+     * refuses, so the error (and sdfv_last_error's text) comes from there */
+    d.band_height = band_step == 0 ? 16u : 0u;
     d.rgba = rgba;
     d.depth = depth;
     d.aux = aux;
-    if (band_step == 0) return SDFV_ERR_INVALID_ARGUMENT; /* (in the descriptor 0 means "rows [y0, y1)", not a band set) */
     return sdfv_raymarch_ex(&d, stream);
 }
 

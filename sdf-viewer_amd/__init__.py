@@ -195,7 +195,7 @@ def fill_grid(params, grid, tex0, tex1, sdf_id=SDF_DEMO, stream=None, dist=None)
 
 def fill_grid_pass(params, grid, step, tex0, tex1, changed_box=None, sdf_id=SDF_DEMO, stream=None, dist=None, flags=0):
     """One LoadingManager pass (loading.rs:50-76) with update_required (scene/sdf/mod.rs:184-190).  `dist`: the
-    textures' compact distance volume, read instead of tex0 and kept in sync (sdfv_fill_grid_pass_dist).  `flags`:
+    textures' compact distance volume, read instead of tex0 and kept in sync (sdfv_fill_grid_pass_ex's `dist`).  `flags`:
     _capi.PASS_FRESH_GRID / PASS_SAME_LOAD -- what the caller knows about the grid (sdfv_fill_grid_pass_ex)."""
     box = None if changed_box is None else (C.c_float * 6)(*[float(x) for x in changed_box])
     check(lib.sdfv_fill_grid_pass_ex(C.byref(params), sdf_id, C.byref(grid), int(step), box, _dev_ptr(tex0, "tex0"),
@@ -420,8 +420,8 @@ def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=Fal
     stored one after the other (sdfv_march_desc.band_first / band_step).  Returns rgba [n_cam, rows, W, 4] (+ aux [n_cam, rows, W, 18] words).
     cameras: a Camera, a list of them, or upload_cameras()'s device tensor (any number of cameras).
     `dist` = optional compact distance volume from commit_distance(); `pairs` = optional y-pair volume from commit_pairs()
-    (sdfv_raymarch_pairs).  want_depth / depth_out: also return the
-    gl_FragDepth plane [n_cam, rows, W] (sdfv_raymarch_depth); return order: rgba[, depth][, aux]."""
+    (sdfv_march_desc.pairs), `ilv` = the y-interleaved volume (desc.ilv).  want_depth / depth_out: also return the
+    gl_FragDepth plane [n_cam, rows, W] (desc.depth); return order: rgba[, depth][, aux].  One export: sdfv_raymarch_ex."""
     if isinstance(cameras, Camera):
         cameras = [cameras]
     y1 = height if y1 is None else y1

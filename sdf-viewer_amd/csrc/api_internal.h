@@ -19,6 +19,7 @@ struct Options {
     uint32_t raymarch_tile_group = 0;  // 0 auto, 1 launch order, v >= 2: XCD-aware order over groups of 2^(v-1) x 2^(v-1) tiles
     uint32_t slab_step_form = 0;     // 0 auto, SDFV_STEP_* otherwise
     uint32_t ext_srgb_quant = 0;     // Srgba::from(Vec3): 0 truncate (default), 1 round
+    uint32_t pass_form = 0;          // 0 auto, 1 = unflagged passes take the per-voxel kernels only
     unsigned long long pass_index_limit = 0;  // 0 = 2^32: voxels per piece of a pass over a slab too large for 32-bit indices
     unsigned long long wave_timing = 0;  // tuning build only
     unsigned long long priority_map = 0;  // tuning build only

@@ -421,6 +421,90 @@ __global__ __launch_bounds__(kBlock) void fill_pass_rows_kernel(FillArgs a, Pass
     *pr = make_float2(v0.x, FRESH ? a.air_dist : pr->y);
 }
 
+// A pass with step >= 2 over a grid the caller says NOTHING about (no flags, no box), with its distance volume: the whole
+// visited rows again, but each wave decides for itself what it is looking at ("a caller that says nothing
+// stops paying 3x").  Each lane answers for FOUR x-neighbours of a visited row with one 16-byte load of the volume (the same
+// cache lines a load of the lattice points alone would touch, a quarter of the threads); a wave none of whose 256 voxels has a
+// lattice point holding AIR_DIST leaves after that load (a pass over a loaded grid).  Where there is work, four rounds of 64
+// consecutive voxels as in the quad kernel: a round ALL of whose voxels hold AIR_DIST -- the fresh grid, or the rows a
+// coarser pass has not visited -- is written WHOLE, samples on the lattice and new_voxels' [AIR_DIST; 4] between them, no
+// texel read and no partial line (the memory side read-modify-writes a line that receives one 16-byte texel in every
+// `step`: 2.2x the bytes at step 2); any other round stores its lattice samples alone, as fill_pass_kernel does.
+// "tex0.r == AIR_DIST means the voxel holds new_voxels' state" is the reference's own reading of that value
+// (update_required, scene/sdf/mod.rs:184-190) and, with a volume, this library's contract for the textures behind it.
+// Needs W % 4 == 0, a 16-byte aligned volume (either layout), < 2^32 voxels in the visited rows.
+template <typename Cfg>
+__global__ __launch_bounds__(kBlock) void fill_pass_rows_adaptive_kernel(FillArgs a, PassArgs p) {
+    const uint32_t n_row_vox = a.W * p.ny * p.nz;  // voxels of the visited rows (< 2^32: checked by the launcher)
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;  // this lane's quad [4q, 4q + 4) of that index space
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t bits = 0;  // bit k: voxel k of the quad holds AIR_DIST; bit 4 + k: it is on the visited lattice
+    float4 odd = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // interleaved volume: the quad's partners in the odd row of the pair
+    if (4 * (uint64_t)q < n_row_vox) {
+        const uint32_t rr = div_u32(4u * q, p.div_w), x = 4u * q - rr * a.W;
+        const uint32_t iz = div_u32(rr, p.div_ny), iy = rr - iz * p.ny;
+        const uint64_t row = (uint64_t)(p.z_first - a.z_begin + iz * p.step) * a.H + iy * p.step;
+        float4 d;
+        if (a.dist_ilv) {  // a visited row is an even row (step >= 2, H even): the .x halves of its pair-row
+            const float* b = p.dist + ((row >> 1) * a.W + x) * 2;
+            const float4 lo = *reinterpret_cast<const float4*>(b), hi = *reinterpret_cast<const float4*>(b + 4);
+            d = make_float4(lo.x, lo.z, hi.x, hi.z);
+            odd = make_float4(lo.y, lo.w, hi.y, hi.w);
+        } else {
+            d = *reinterpret_cast<const float4*>(p.dist + row * a.W + x);
+        }
+        const uint32_t m = p.step - 1u;
+        bits = (d.x == a.air_dist ? 1u : 0u) | (d.y == a.air_dist ? 2u : 0u) | (d.z == a.air_dist ? 4u : 0u) |
+               (d.w == a.air_dist ? 8u : 0u) | ((x & m) == 0 ? 16u : 0u) | (((x + 1u) & m) == 0 ? 32u : 0u) |
+               (((x + 2u) & m) == 0 ? 64u : 0u) | (((x + 3u) & m) == 0 ? 128u : 0u);
+    }
+    if (__ballot((bits & (bits >> 4)) != 0) == 0ull) return;  // wave-uniform: no lattice point of these 256 voxels is AIR
+    const uint32_t span0 = (q - lane) * 4;
+    const uint32_t k = lane & 3u;
+    uint32_t row_cached = 0xffffffffu;
+    float py = 0.0f, pz = 0.0f;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const int src = (int)(j * 16 + (lane >> 2));
+        const uint32_t b = (uint32_t)__shfl((int)bits, src);
+        const uint32_t v = span0 + j * 64 + lane;
+        const bool in = v < n_row_vox;
+        const bool is_air = ((b >> k) & 1u) != 0, is_lat = ((b >> (4u + k)) & 1u) != 0;
+        const bool need = in && is_air && is_lat;  // update_required without a box: the stored distance is AIR_DIST
+        if (__ballot(need) == 0ull) continue;      // wave-uniform
+        const bool whole = __ballot(in && !is_air) == 0ull;  // wave-uniform: every voxel of the round is still new_voxels'
+        float partner = 0.0f;
+        if (whole && a.dist_ilv) {  // (wave-uniform) the odd row's half of this voxel's pair, from the lane that loaded it
+            const float o0 = __shfl(odd.x, src), o1 = __shfl(odd.y, src), o2 = __shfl(odd.z, src), o3 = __shfl(odd.w, src);
+            partner = k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : o3));
+        }
+        const uint32_t rr = div_u32(v, p.div_w), x = v - rr * a.W;
+        const uint32_t iz = div_u32(rr, p.div_ny), iy = rr - iz * p.ny;
+        const uint32_t y = iy * p.step, z = p.z_first + iz * p.step;
+        if (__ballot(need && rr != row_cached) != 0ull) {  // wave-uniform: some lane entered a new row
+            row_cached = rr;
+            py = voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]);
+            pz = voxel_coord(z, a.dm1[2], a.bb_size[2], a.bb_min[2]);
+        }
+        if (!in) continue;
+        const uint64_t row = (uint64_t)(z - a.z_begin) * a.H + y, flat = row * a.W + x;
+        if (!whole) {
+            if (need) pass_store<Cfg>(a, p, voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]), py, pz, flat, row, x);
+            continue;
+        }
+        float4 v0 = make_float4(a.air_dist, a.air_dist, a.air_dist, a.air_dist), v1 = v0;
+        if (is_lat) {
+            const LdsLut lut{c_srgb_lut};
+            fill_voxel<Cfg>(a.prm, a.sdf_id, voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]), py, pz, lut, a.air_dist, v0, v1);
+            v1.w = a.air_dist;  // the volume's contract (pass_store)
+        }
+        store_texel<true>(a.tex0 + flat, v0);
+        store_texel<true>(a.tex1 + flat, v1);
+        if (a.dist_ilv) reinterpret_cast<float2*>(p.dist)[(row >> 1) * a.W + x] = make_float2(v0.x, partner);
+        else p.dist[flat] = v0.x;  // every lane: whole lines here too
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void grid_init_kernel(float4* tex0, float4* tex1, uint64_t n, float air) {
     const float4 v = make_float4(air, air, air, air);
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;  // memory order, like the dense fill
@@ -726,7 +810,14 @@ hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& pass, const FillL
         }
         return hipGetLastError();
     }
-    const bool quad = p.step == 1 && p.dist && a.W % 4 == 0 && ((uintptr_t)p.dist & 15) == 0;  // (either layout: 16-byte loads)
+    const bool vol16 = p.dist && a.W % 4 == 0 && ((uintptr_t)p.dist & 15) == 0;  // (either layout: 16-byte loads of the volume)
+    if (!p.all_required && !p.has_box && p.step >= 2 && vol16 && !p.no_adaptive && (uint64_t)a.W * p.ny * p.nz < (1ull << 32)) {
+        // nothing known, nothing boxed: whole visited rows, every wave deciding on what it reads (rows_adaptive above)
+        const uint32_t blocks = (uint32_t)((((uint64_t)a.W * p.ny * p.nz + 3) / 4 + kBlock - 1) / kBlock);
+        SDFV_LAUNCH_CFG(a, (fill_pass_rows_adaptive_kernel<Cfg>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
+        return hipGetLastError();
+    }
+    const bool quad = p.step == 1 && vol16;
     const uint64_t threads = quad ? (n + 3) / 4 : n;
     const uint32_t blocks = (uint32_t)((threads + kBlock - 1) / kBlock);
     if (quad) {

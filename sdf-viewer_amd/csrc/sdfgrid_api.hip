@@ -518,6 +518,10 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             if (value > 1) break;
             g_options.ext_srgb_quant = (uint32_t)value;
             return SDFV_OK;
+        case SDFV_OPT_PASS_FORM:
+            if (value > 1) break;
+            g_options.pass_form = (uint32_t)value;
+            return SDFV_OK;
         case SDFV_OPT_RAYMARCH_WAVES_PER_SIMD:
             if (value == 1 || value > 7) break;  // 0 auto (the launcher's rule) | 2..6 cap | 7 never cap
             g_options.raymarch_waves_per_simd = (uint32_t)value;
@@ -567,6 +571,7 @@ int sdfv_get_option(uint32_t option, uint64_t* value) {
         case SDFV_OPT_RAYMARCH_WAVES_PER_SIMD: *value = g_options.raymarch_waves_per_simd; return SDFV_OK;
         case SDFV_OPT_EXT_SRGB_QUANT: *value = g_options.ext_srgb_quant; return SDFV_OK;
         case SDFV_OPT_PASS_INDEX_LIMIT: *value = g_options.pass_index_limit; return SDFV_OK;
+        case SDFV_OPT_PASS_FORM: *value = g_options.pass_form; return SDFV_OK;
         default: return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown option %u", option);
     }
 }
@@ -847,6 +852,7 @@ int sdfv_fill_grid_pass_ex(const sdfv_demo_params* params, uint32_t sdf_id, cons
     p.fresh = (flags & SDFV_PASS_FRESH_GRID) ? 1u : 0u;
     p.virgin = (flags & SDFV_PASS_VIRGIN_GRID) ? 1u : 0u;
     p.index_limit = g_options.pass_index_limit;
+    p.no_adaptive = g_options.pass_form == 1 ? 1u : 0u;
     p.all_required = (knowledge != 0 || covers) ? 1u : 0u;
     SDFV_HIP(sdfv::launch_fill_pass(a, p, fill_launch_config(dist != nullptr), (hipStream_t)stream));
     return SDFV_OK;
@@ -1061,6 +1067,14 @@ int sdfv_raymarch_ex(const sdfv_march_desc* desc, void* stream) {
     memset(&d, 0, sizeof(d));
     memcpy(&d, desc, desc->size < sizeof(d) ? desc->size : sizeof(d));
     if (d.reserved != 0) return fail(SDFV_ERR_INVALID_ARGUMENT, "sdfv_march_desc: reserved fields must be 0");
+    // a NEWER caller's descriptor: fields this library does not know may only be zero (0 / NULL = "not used" by the
+    // descriptor's rule); anything else would be dropped silently
+    for (uint32_t i = (uint32_t)sizeof(d); i < desc->size; ++i)
+        if (reinterpret_cast<const unsigned char*>(desc)[i] != 0)
+            return fail(SDFV_ERR_INVALID_ARGUMENT, "sdfv_march_desc.size = %u: this library knows %zu bytes and byte %u beyond them is not 0",
+                        desc->size, sizeof(d), i);
+    if (d.band_step == 0 && d.band_height != 0)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "band_height %u with band_step 0: a band set needs band_step >= 1 (0 = rows [y0, y1))", d.band_height);
     if (d.band_step == 0)
         return raymarch_rows(d.rp, d.tex0, d.tex1, d.dist, d.pairs, d.ilv, d.cameras, d.n_cameras, d.width, d.height, d.y0, d.y1, 1, 16,
                              d.rgba, d.depth, d.aux, stream);

@@ -489,6 +489,9 @@ def _exchange_rays(down, up, rank, world, group):
     return torch.cat([b.to(dev) for b in bufs], dim=0)
 
 
+_SHARDED_CAPACITY = {}  # (width, height, world) -> ray-list capacity the last frame of that size needed (None = the default)
+
+
 def merge_sharded_aux(aux_sum):
     """Merge of the ranks' aux images (summed bit patterns) -> the single-GPU record: pixels no rank reports (status 0) get the
     cleared record's depth of 1.0 back (aux words: status, steps, hit_pos[3], t, raw0[4], raw1[4], normal[3], depth)."""
@@ -506,15 +509,29 @@ def raymarch_sharded(pkg, rp, grid, slab, camera, width, height, rank, world, gr
     RCCL communicator (sdfv_slab_march: no host round trip per round); otherwise torch.distributed carries the rays, with a
     counter read-back and a count exchange per round (the gloo / CPU-test transport)."""
     if comm is not None and comm.handle and not comm.periodic:
-        for capacity in (None, width * height):  # the bounded default first; every rank sees the same (all-reduced) status
+        # Ray lists: the bounded default (an eighth of the pixels) first, all pixels after an overflow -- remembered per image
+        # size, so that the frames that follow start where this one ended (ADVICE r04).  The retry needs every rank to agree
+        # (an overflow on ONE rank sends all of them round again): that takes a torch.distributed group; with the library
+        # communicator alone the lists simply hold every pixel and nothing can overflow.
+        agree = world > 1 and c10d.is_available() and c10d.is_initialized()
+        key = (int(width), int(height), int(world))
+        if world > 1 and not agree:
+            attempts = [width * height]
+        else:
+            attempts = [_SHARDED_CAPACITY.get(key), width * height] if _SHARDED_CAPACITY.get(key) != width * height else [width * height]
+        overflow = left = 0
+        for capacity in attempts:
             rgba, aux, status = comm.march(rp, grid, slab, camera, width, height, want_aux=want_aux, capacity=capacity)
             st = status.clone()
-            if world > 1:  # an overflow on ONE rank must send EVERY rank round again: agree on it
+            if agree:
                 enter_stage("raymarch_sharded: all_reduce(MAX) of the march status")
                 c10d.all_reduce(st, op=c10d.ReduceOp.MAX, group=group)
             overflow, left = (int(v) for v in st.tolist())  # synchronises: the caller wants the image now
             if not (overflow or left):
                 return (rgba, aux) if want_aux else rgba
+            if not overflow:
+                break  # rays left over after `world` rounds without any list overflowing: larger lists cannot help
+            _SHARDED_CAPACITY[key] = width * height
         raise pkg.SdfvError(-1, f"sdfv_slab_march: ray lists overflowed ({overflow}) / {left} rays left over")
     m = ShardedMarch(pkg, rp, grid, slab, camera, width, height, want_aux)
     incoming = None

@@ -271,16 +271,6 @@ class Scene:
     def lod(self):
         return H.sdfvh_scene_lod(self.h)
 
-    @staticmethod
-    def tune(dims):
-        """SDFViewer::tune: measure the texture placement for grids of this size (blocking), remember it process-wide."""
-        return H.sdfvh_viewer_tune(dims[0], dims[1], dims[2])
-
-    def texture_gap(self):
-        """Bytes between the end of tex0 and the start of tex1 (the placement the constructor used)."""
-        w, h, d = self.dims()
-        return H.sdfvh_viewer_tex1(self.h) - H.sdfvh_viewer_tex0(self.h) - w * h * d * 16
-
     def dims(self):
         out = (C.c_uint32 * 3)()
         H.sdfvh_scene_dims(self.h, out)

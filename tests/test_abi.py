@@ -107,6 +107,25 @@ def test_light_list_rejects_what_the_reference_does_not_pin(pkg):
     # the descriptor is size-prefixed: a size below its first version is refused, reserved words must be 0
     assert march(size=24) == -1 and b"sdfv_march_desc.size" in pkg.lib.sdfv_last_error()
     assert pkg.lib.sdfv_raymarch_ex(None, None) == -1
+    # a band height without a band step is refused BY THE LIBRARY (the header's sdfv_raymarch_bands wrapper hands
+    # band_step == 0 over in that shape, so sdfv_last_error names it); a newer caller's longer descriptor is read as far as this
+    # library knows it -- provided the rest is zero
+    assert march(band_step=0, band_height=16) == -1 and b"band_step 0" in pkg.lib.sdfv_last_error()
+
+    class Longer(C.Structure):
+        _fields_ = [("d", pkg._capi.MarchDesc), ("future", C.c_uint64 * 2)]
+    lg = Longer()
+    lg.d.size = C.sizeof(lg)
+    lg.d.rp = C.pointer(rp)
+    lg.d.tex0, lg.d.tex1, lg.d.rgba = 16, 16, 16
+    lg.d.cameras = C.pointer(cam)
+    lg.d.n_cameras, lg.d.width, lg.d.height, lg.d.y0, lg.d.y1 = 1, 8, 8, 0, 8
+    lg.future[1] = 7
+    assert pkg.lib.sdfv_raymarch_ex(C.cast(C.pointer(lg), C.POINTER(pkg._capi.MarchDesc)), None) == -1
+    assert b"beyond them is not 0" in pkg.lib.sdfv_last_error()
+    lg.future[1] = 0
+    rc = pkg.lib.sdfv_raymarch_ex(C.cast(C.pointer(lg), C.POINTER(pkg._capi.MarchDesc)), None)
+    assert b"beyond them" not in pkg.lib.sdfv_last_error() and rc != 0  # (accepted as a descriptor; no device here / bogus pointers)
     p = pkg.default_params()
     assert pkg.lib.sdfv_grid_init(C.byref(g), C.c_void_p(24), C.c_void_p(16), None) == -1
     assert pkg.lib.sdfv_fill_grid_pass_ex(C.byref(p), 0, C.byref(g), 1, None, C.c_void_p(16), C.c_void_p(8), None, 0, None) == -1

@@ -719,6 +719,67 @@ def test_fill_and_passes_maintain_the_interleaved_volume(pkg, oracle, dims, z_ra
     check(t0, t1, vol, want0, want1)
 
 
+@pytest.mark.parametrize("dims,z_range", [((64, 64, 64), (0, 64)), ((256, 6, 10), (0, 10)), ((40, 12, 29), (7, 22)), ((300, 10, 6), (0, 6)),
+                                          ((1024, 4, 4), (0, 4)), ((8, 6, 5), (0, 5)), ((132, 9, 7), (1, 6))])
+@pytest.mark.parametrize("ilv", [False, True])
+def test_unflagged_strided_passes_decide_per_wave(pkg, oracle, dims, z_range, ilv):
+    """a step >= 2 pass the caller says nothing about (no flags, no box) over a grid with its volume takes
+    fill_pass_rows_adaptive_kernel -- whole visited rows, every wave deciding on the volume it reads.  Against the per-voxel
+    kernels (no volume; SDFV_OPT_PASS_FORM 1) after EVERY pass, textures and volume bit for bit: a fresh grid (every round
+    written whole), the descending chain (rows a coarser pass visited hold samples: mixed rounds), a grid loaded in its lower
+    half only, a loaded grid (nothing to do), other parameters over a loaded grid (still nothing: no box); then the oracle."""
+    K = pkg._capi
+    if ilv and dims[1] % 2:
+        pytest.skip("the interleaved volume pairs rows: H must be even")
+    flags = K.PASS_VOLUME_INTERLEAVED if ilv else 0
+    lo, hi = (-1.0, -0.75, -1.0), (1.0, 1.0, 0.5)
+    g = pkg.make_grid(dims, lo, hi, *z_range)
+    prm, other = pkg.default_params(), pkg.default_params(sphere_radius=0.8, cube_material=1)
+    layout = interleave_rows if ilv else (lambda d: d)
+
+    def fresh():
+        t0, t1 = pkg.alloc_textures(g)
+        pkg.grid_init(g, t0, t1)
+        return t0, t1, torch.full(tuple(t0.shape[:-1]), pkg.AIR_DIST, dtype=torch.float32, device="cuda")
+
+    def same(a, b, what):
+        torch.cuda.synchronize()
+        assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[1].view(torch.int32), b[1].view(torch.int32)), what
+        assert torch.equal(a[2].view(torch.int32), layout(a[0][..., 0]).view(torch.int32)), (what, "volume")
+        assert torch.equal(b[2].view(torch.int32), layout(b[0][..., 0]).view(torch.int32)), (what, "reference volume")
+
+    for steps in ((8, 4, 2, 1), (2, 1), (4,), (2, 4, 2)):
+        a, b = fresh(), fresh()
+        for k, step in enumerate(steps):
+            pkg.fill_grid_pass(prm, g, step, a[0], a[1], dist=a[2], flags=flags)
+            with pkg.options({K.OPT_PASS_FORM: 1}):
+                pkg.fill_grid_pass(prm, g, step, b[0], b[1], dist=b[2], flags=flags)
+            same(a, b, (steps, k))
+        if steps[-1] == 1:
+            r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims, lo, hi, *z_range)
+            assert_bits_equal(a[0], r0)
+            assert_bits_equal(a[1], r1)
+    # the lower half loaded (a dense fill of those slices), the upper half fresh
+    a, b = fresh(), fresh()
+    half = max(1, (z_range[1] - z_range[0]) // 2)
+    gh = pkg.make_grid(dims, lo, hi, z_range[0], z_range[0] + half)
+    for t in (a, b):
+        v = torch.empty(tuple(t[0][:half].shape[:-1]), dtype=torch.float32, device="cuda")
+        pkg.fill_grid(other, gh, t[0][:half], t[1][:half], dist=v)
+        t[2][:half] = layout(v) if (not ilv) else interleave_rows(v)
+    for step in (4, 2):
+        pkg.fill_grid_pass(prm, g, step, a[0], a[1], dist=a[2], flags=flags)
+        with pkg.options({K.OPT_PASS_FORM: 1}):
+            pkg.fill_grid_pass(prm, g, step, b[0], b[1], dist=b[2], flags=flags)
+        same(a, b, ("half loaded", step))
+    # a loaded grid: nothing is AIR, nothing happens -- whatever the parameters
+    pkg.fill_grid_pass(prm, g, 1, a[0], a[1], dist=a[2], flags=flags)
+    before = (a[0].clone(), a[1].clone(), a[2].clone())
+    for step in (8, 2):
+        pkg.fill_grid_pass(other, g, step, a[0], a[1], dist=a[2], flags=flags)
+    same(a, before, "loaded grid")
+
+
 def test_interleaved_volume_argument_checks_and_the_march_over_it(pkg, oracle):
     K = pkg._capi
     prm = pkg.default_params()
