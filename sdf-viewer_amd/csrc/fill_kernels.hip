@@ -433,39 +433,40 @@ __global__ __launch_bounds__(kBlock) void fill_pass_rows_kernel(FillArgs a, Pass
 // "tex0.r == AIR_DIST means the voxel holds new_voxels' state" is the reference's own reading of that value
 // (update_required, scene/sdf/mod.rs:184-190) and, with a volume, this library's contract for the textures behind it.
 // Needs W % 4 == 0, a 16-byte aligned volume (either layout), < 2^32 voxels in the visited rows.
-template <typename Cfg>
+template <typename Cfg, int Q>
 __global__ __launch_bounds__(kBlock) void fill_pass_rows_adaptive_kernel(FillArgs a, PassArgs p) {
+    // Q voxels per lane = ONE 16-byte load of the volume: four x-neighbours of a plain volume (Q = 4), two of the interleaved
+    // one, whose 16 bytes hold (even row, odd row) of two x (Q = 2; two loads per lane ran a no-op pass at 0.57 of this rate)
+    static_assert(Q == 4 || Q == 2, "one 16-byte load per lane");
     const uint32_t n_row_vox = a.W * p.ny * p.nz;  // voxels of the visited rows (< 2^32: checked by the launcher)
-    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;  // this lane's quad [4q, 4q + 4) of that index space
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;  // this lane's voxels [Q q, Q q + Q) of that index space
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t bits = 0;  // bit k: voxel k of the quad holds AIR_DIST; bit 4 + k: it is on the visited lattice
-    float4 odd = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // interleaved volume: the quad's partners in the odd row of the pair
-    if (4 * (uint64_t)q < n_row_vox) {
-        const uint32_t rr = div_u32(4u * q, p.div_w), x = 4u * q - rr * a.W;
+    uint32_t bits = 0;  // bit k: voxel k of the lane holds AIR_DIST; bit 4 + k: it is on the visited lattice
+    float odd0 = 0.0f, odd1 = 0.0f;  // interleaved volume: the lane's partners in the odd row of the pair
+    if (Q * (uint64_t)q < n_row_vox) {
+        const uint32_t rr = div_u32(Q * q, p.div_w), x = Q * q - rr * a.W;
         const uint32_t iz = div_u32(rr, p.div_ny), iy = rr - iz * p.ny;
         const uint64_t row = (uint64_t)(p.z_first - a.z_begin + iz * p.step) * a.H + iy * p.step;
-        float4 d;
-        if (a.dist_ilv) {  // a visited row is an even row (step >= 2, H even): the .x halves of its pair-row
-            const float* b = p.dist + ((row >> 1) * a.W + x) * 2;
-            const float4 lo = *reinterpret_cast<const float4*>(b), hi = *reinterpret_cast<const float4*>(b + 4);
-            d = make_float4(lo.x, lo.z, hi.x, hi.z);
-            odd = make_float4(lo.y, lo.w, hi.y, hi.w);
-        } else {
-            d = *reinterpret_cast<const float4*>(p.dist + row * a.W + x);
-        }
         const uint32_t m = p.step - 1u;
-        bits = (d.x == a.air_dist ? 1u : 0u) | (d.y == a.air_dist ? 2u : 0u) | (d.z == a.air_dist ? 4u : 0u) |
-               (d.w == a.air_dist ? 8u : 0u) | ((x & m) == 0 ? 16u : 0u) | (((x + 1u) & m) == 0 ? 32u : 0u) |
-               (((x + 2u) & m) == 0 ? 64u : 0u) | (((x + 3u) & m) == 0 ? 128u : 0u);
+        if (Q == 2) {  // a visited row is an even row (step >= 2, H even): the .x halves of its pair-row
+            const float4 d = *reinterpret_cast<const float4*>(p.dist + ((row >> 1) * a.W + x) * 2);
+            odd0 = d.y, odd1 = d.w;
+            bits = (d.x == a.air_dist ? 1u : 0u) | (d.z == a.air_dist ? 2u : 0u) | ((x & m) == 0 ? 16u : 0u) | (((x + 1u) & m) == 0 ? 32u : 0u);
+        } else {
+            const float4 d = *reinterpret_cast<const float4*>(p.dist + row * a.W + x);
+            bits = (d.x == a.air_dist ? 1u : 0u) | (d.y == a.air_dist ? 2u : 0u) | (d.z == a.air_dist ? 4u : 0u) |
+                   (d.w == a.air_dist ? 8u : 0u) | ((x & m) == 0 ? 16u : 0u) | (((x + 1u) & m) == 0 ? 32u : 0u) |
+                   (((x + 2u) & m) == 0 ? 64u : 0u) | (((x + 3u) & m) == 0 ? 128u : 0u);
+        }
     }
-    if (__ballot((bits & (bits >> 4)) != 0) == 0ull) return;  // wave-uniform: no lattice point of these 256 voxels is AIR
-    const uint32_t span0 = (q - lane) * 4;
-    const uint32_t k = lane & 3u;
+    if (__ballot((bits & (bits >> 4)) != 0) == 0ull) return;  // wave-uniform: no lattice point of these 64 Q voxels is AIR
+    const uint32_t span0 = (q - lane) * Q;
+    const uint32_t k = lane & (Q - 1u);
     uint32_t row_cached = 0xffffffffu;
     float py = 0.0f, pz = 0.0f;
 #pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-        const int src = (int)(j * 16 + (lane >> 2));
+    for (uint32_t j = 0; j < Q; ++j) {
+        const int src = (int)(j * (64 / Q) + lane / Q);
         const uint32_t b = (uint32_t)__shfl((int)bits, src);
         const uint32_t v = span0 + j * 64 + lane;
         const bool in = v < n_row_vox;
@@ -474,9 +475,9 @@ __global__ __launch_bounds__(kBlock) void fill_pass_rows_adaptive_kernel(FillArg
         if (__ballot(need) == 0ull) continue;      // wave-uniform
         const bool whole = __ballot(in && !is_air) == 0ull;  // wave-uniform: every voxel of the round is still new_voxels'
         float partner = 0.0f;
-        if (whole && a.dist_ilv) {  // (wave-uniform) the odd row's half of this voxel's pair, from the lane that loaded it
-            const float o0 = __shfl(odd.x, src), o1 = __shfl(odd.y, src), o2 = __shfl(odd.z, src), o3 = __shfl(odd.w, src);
-            partner = k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : o3));
+        if (Q == 2 && whole) {  // (wave-uniform) the odd row's half of this voxel's pair, from the lane that loaded it
+            const float o0 = __shfl(odd0, src), o1 = __shfl(odd1, src);
+            partner = k == 0 ? o0 : o1;
         }
         const uint32_t rr = div_u32(v, p.div_w), x = v - rr * a.W;
         const uint32_t iz = div_u32(rr, p.div_ny), iy = rr - iz * p.ny;
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(kBlock) void fill_pass_rows_adaptive_kernel(FillArg
         }
         store_texel<true>(a.tex0 + flat, v0);
         store_texel<true>(a.tex1 + flat, v1);
-        if (a.dist_ilv) reinterpret_cast<float2*>(p.dist)[(row >> 1) * a.W + x] = make_float2(v0.x, partner);
+        if (Q == 2) reinterpret_cast<float2*>(p.dist)[(row >> 1) * a.W + x] = make_float2(v0.x, partner);
         else p.dist[flat] = v0.x;  // every lane: whole lines here too
     }
 }
@@ -813,8 +814,13 @@ hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& pass, const FillL
     const bool vol16 = p.dist && a.W % 4 == 0 && ((uintptr_t)p.dist & 15) == 0;  // (either layout: 16-byte loads of the volume)
     if (!p.all_required && !p.has_box && p.step >= 2 && vol16 && !p.no_adaptive && (uint64_t)a.W * p.ny * p.nz < (1ull << 32)) {
         // nothing known, nothing boxed: whole visited rows, every wave deciding on what it reads (rows_adaptive above)
-        const uint32_t blocks = (uint32_t)((((uint64_t)a.W * p.ny * p.nz + 3) / 4 + kBlock - 1) / kBlock);
-        SDFV_LAUNCH_CFG(a, (fill_pass_rows_adaptive_kernel<Cfg>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
+        const uint64_t lanes = ((uint64_t)a.W * p.ny * p.nz + (a.dist_ilv ? 1 : 3)) / (a.dist_ilv ? 2 : 4);
+        const uint32_t blocks = (uint32_t)((lanes + kBlock - 1) / kBlock);
+        if (a.dist_ilv) {
+            SDFV_LAUNCH_CFG(a, (fill_pass_rows_adaptive_kernel<Cfg, 2>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
+        } else {
+            SDFV_LAUNCH_CFG(a, (fill_pass_rows_adaptive_kernel<Cfg, 4>), dim3(blocks), dim3(kBlock), 0, stream, a, p);
+        }
         return hipGetLastError();
     }
     const bool quad = p.step == 1 && vol16;

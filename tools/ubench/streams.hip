@@ -40,6 +40,17 @@ __global__ __launch_bounds__(256) void k_sep(char* t0, char* t1, char* d, uint32
     st4nt(t1 + (size_t)i * 16, v);
     *reinterpret_cast<float*>(d + (size_t)i * 4) = v;
 }
+// k_sep with the launch's workgroups dealt over S equal parts of the grid (workgroup b -> part b % S, chunk b / S of it): S times
+// as many store streams in flight, each in memory order.  vol = 0: the plain fill's two streams only.
+__global__ __launch_bounds__(256) void k_split(char* t0, char* t1, char* d, uint32_t n, uint32_t S, uint32_t chunks_per_part) {
+    const uint32_t b = (blockIdx.x % S) * chunks_per_part + blockIdx.x / S;
+    const uint32_t i = b * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = work((float)i);
+    st4nt(t0 + (size_t)i * 16, v);
+    st4nt(t1 + (size_t)i * 16, v);
+    if (d) *reinterpret_cast<float*>(d + (size_t)i * 4) = v;
+}
 // one buffer; a unit of U voxels (a row: U = W; a workgroup chunk: U = 256) is [16 U | 16 U | 4 U] bytes
 __global__ __launch_bounds__(256) void k_unit(char* base, uint32_t n, uint32_t unit_shift) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -169,7 +180,31 @@ static int sweep(uint32_t side) {
     return 0;
 }
 
+// ./streams split [side]: how many streams per texture should a launch run?
+static int split(uint32_t side) {
+    const uint32_t n = side * side * side;
+    const size_t tex = (size_t)n * 16, vol = (size_t)n * 4;
+    const dim3 grid(n / 256), block(256);
+    char* blk;
+    CK(hipMalloc(&blk, 2 * tex + vol + (1 << 20)));
+    const int reps = side >= 512 ? 10 : 50;
+    printf("{\"side\": %u, \"split\": [", side);
+    bool first = true;
+    for (uint32_t S : {1u, 2u, 4u, 8u, 16u, 32u, 64u}) {
+        const uint32_t cpp = (n / 256) / S;
+        const float fused = timed([&] { hipLaunchKernelGGL(k_split, grid, block, 0, 0, blk, blk + tex, blk + 2 * tex + (1 << 19), n, S, cpp); }, reps, first ? 300 : 30);
+        const float plain = timed([&] { hipLaunchKernelGGL(k_split, grid, block, 0, 0, blk, blk + tex, (char*)nullptr, n, S, cpp); }, reps, 30);
+        printf("%s{\"S\": %u, \"fused_ms\": %.4f, \"fused_bus_TBps\": %.2f, \"plain_ms\": %.4f, \"plain_TBps\": %.2f}", first ? "" : ", ", S, fused,
+               36.0 * n / 1e9 / fused, plain, 32.0 * n / 1e9 / plain);
+        first = false;
+        fflush(stdout);
+    }
+    printf("]}\n");
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "split")) return split(argc > 2 ? atoi(argv[2]) : 512);
     if (argc > 1 && !strcmp(argv[1], "sweep")) return sweep(argc > 2 ? atoi(argv[2]) : 512);
     const uint32_t side = argc > 1 ? atoi(argv[1]) : 512;
     const size_t dummy = (argc > 2 ? (size_t)atoll(argv[2]) : 0) << 20;
