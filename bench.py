@@ -665,7 +665,7 @@ def run(redirect):
             traffic = traffic if traffic is not None else load_traffic(args.workload + key)
         out["roofline"] = fill_roofline(kern_ms, voxels_per_rank, bpv, traffic)
         if chosen == "fused_ilv" and side % 256 == 0 and side >= 512:  # (csrc/fill_kernels.hip launch_fill_dense: rows two workgroups wide)
-            out["roofline"]["kernel"] = "fill_dense_pairrows_kernel"
+            out["roofline"]["kernel"] = "fill_dense_ilv_paired_kernel"
         out["roofline_raymarch"] = raymarch_traffic_report(args.workload, march_ev,
                                                            "tex0_path" if chosen == "plain" else "product_path",
                                                            args.workload + {"plain": "_tex0", "fused": "", "fused_ilv": "_ilv"}[chosen])

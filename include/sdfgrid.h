@@ -148,7 +148,9 @@ float       sdfv_air_dist(void);     /* AIR_DIST, scene/sdf/mod.rs:42 */
 typedef enum sdfv_option {
     SDFV_OPT_FILL_NONTEMPORAL = 1,     /* texture stores of the dense fill: 0 auto (default: nt when the same launch also
                                         * writes the distance volume, plain otherwise) | 1 always nt | 2 never */
-    SDFV_OPT_FILL_FORM = 2,            /* 0 auto (default) | 1 row-chunk form | 2 flat form of the dense fill */
+    SDFV_OPT_FILL_FORM = 2,            /* 0 auto (default) | 1 row-chunk form | 2 flat form of the dense fill | interleaved-volume fill of
+                                        * widths that are multiples of 256 only: 3 one row per workgroup, pairs on one XCD | 4 a thread per
+                                        * x of both rows of a pair.  A/B runs and tests; same texels */
     SDFV_OPT_RAYMARCH_DISABLE = 3,     /* mask of SDFV_RM_NO_*: exact-arithmetic specialisations left out (default 0) */
     SDFV_OPT_RAYMARCH_KEEP_NORMAL = 4, /* 0 (default) | 1: evaluate sdfNormal per hit although nothing consumes it */
     SDFV_OPT_SLAB_STEP_FORM = 5,       /* sdfv_slab_fill_step: 0 auto (default: packed messages for slabs below 2^26 voxels, per-texture

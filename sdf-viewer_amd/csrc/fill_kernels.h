@@ -73,6 +73,8 @@ struct PassArgs {
 struct FillLaunch {
     bool nontemporal;  // global_store_dwordx4 ... nt (measured: within noise of plain stores)
     bool force_flat = false, force_rows = false;  // A/B runs: pin the kernel form
+    bool force_paired = false, force_pairrows = false;  // interleaved-volume fill: pin the XCD-paired / the thread-per-pair form
+    bool xcd_pairing = false;                     // the device places workgroup b on XCD b % 8 (eight XCDs)
 };
 
 hipError_t launch_fill_dense(const FillArgs& a, const FillLaunch& cfg, hipStream_t stream);

@@ -183,6 +183,42 @@ __global__ __launch_bounds__(kBlock) void fill_dense_pairrows_kernel(FillArgs a)
     reinterpret_cast<float2*>(a.dist)[(uint64_t)pair * a.W + x] = make_float2(v0.x, w0.x);
 }
 
+// The interleaved-volume fill in the PLAIN kernel's shape (EXPERIMENTS R5.3): (one voxel per thread, a workgroup = 256 x of ONE
+// row: three store segments per workgroup, like the fused fill that writes the plain volume), the two rows of a pair filled by
+// two workgroups of the SAME XCD one dispatch slot apart, so that the halves of every volume line (4 bytes in every 8) meet in
+// that XCD's write-back L2 instead of at the memory side.  Workgroup b runs on XCD b % 8 (the placement the march's tile orders
+// rest on): slot = b / 8, unit = (slot / 2) * 8 + b % 8 = (pair-row, x chunk), half = slot & 1 = which row of the pair.
+template <bool NT, typename Cfg>
+__global__ __launch_bounds__(kBlock) void fill_dense_ilv_paired_kernel(FillArgs a, uint32_t n_units) {
+    __shared__ float s_lut[256];
+    __shared__ float2 s_yz;
+    const uint32_t tid = threadIdx.x;
+    if (a.signal && blockIdx.x == 0 && tid == 0)  // see fill_dense_kernel
+        __hip_atomic_store(a.signal, a.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t slot = blockIdx.x >> 3, unit = (slot >> 1) * 8u + (blockIdx.x & 7u), half = slot & 1u;
+    if (unit >= n_units) return;  // (the grid is padded to whole groups of 16)
+    const uint32_t pair = a.x_chunks == 1 ? unit : unit / a.x_chunks;
+    const uint32_t chunk = unit - pair * a.x_chunks;
+    const uint32_t row = 2u * pair + half;
+    s_lut[tid] = c_srgb_lut[tid];
+    if (tid == 0) {
+        const uint32_t zl = row / a.H, y = row - zl * a.H;
+        s_yz = make_float2(voxel_coord(y, a.dm1[1], a.bb_size[1], a.bb_min[1]),
+                           voxel_coord(a.z_begin + zl, a.dm1[2], a.bb_size[2], a.bb_min[2]));
+    }
+    __syncthreads();
+    const LdsLut lut{s_lut};
+    const uint32_t x = chunk * kBlock + tid;  // W is a multiple of kBlock: always inside
+    const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
+    const uint64_t o = (uint64_t)row * a.W + x;
+    float4 v0, v1;
+    const float2 yz = s_yz;
+    fill_voxel<Cfg>(a.prm, a.sdf_id, px, yz.x, yz.y, lut, a.air_dist, v0, v1);
+    store_texel<NT>(a.tex0 + o, v0);
+    store_texel<NT>(a.tex1 + o, v1);
+    a.dist[((uint64_t)pair * a.W + x) * 2 + half] = v0.x;
+}
+
 // Flat form of the dense kernel for widths that do not fill the row-chunk form's lanes (W not a multiple of the
 // 64 / 128 / 256 chunk): thread <-> voxel over the slab's flat index, so every wave is full and every store burst
 // is 1 KiB whatever W is.  x and row come from an exact division by W done as a 64-bit multiply-high with
@@ -620,6 +656,17 @@ hipError_t launch_dense_pairrows(const FillArgs& args, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <bool NT>
+hipError_t launch_dense_ilv_paired(const FillArgs& args, hipStream_t stream) {
+    FillArgs a = args;
+    a.x_chunks = a.W / kBlock;
+    const uint64_t units = a.x_chunks * ((uint64_t)a.H * a.slab_d / 2);
+    const uint64_t blocks = ((units + 7) / 8) * 16;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    SDFV_LAUNCH_CFG(a, (fill_dense_ilv_paired_kernel<NT, Cfg>), dim3((uint32_t)blocks), dim3(kBlock), 0, stream, a, (uint32_t)units);
+    return hipGetLastError();
+}
+
 template <int TX>
 hipError_t launch_dense_tx(const FillArgs& a, const FillLaunch& cfg, hipStream_t stream) {
     return cfg.nontemporal ? launch_dense_cfg<TX, true>(a, stream) : launch_dense_cfg<TX, false>(a, stream);
@@ -728,9 +775,14 @@ hipError_t launch_fill_dense(const FillArgs& a, const FillLaunch& cfg, hipStream
         // the interleaved volume leaves from workgroups that hold BOTH rows of a pair: the row-chunk form with two or four
         // rows per workgroup (TX 128 or 64), whatever the width
         if ((a.H & 1u) || ((uintptr_t)a.dist & 7)) return hipErrorInvalidValue;
-        // a thread per x of both rows of a pair where rows are at least two workgroups wide (512^3 -5..-8 %, 768^3 -3 %, 1024^3
-        // even; one workgroup per row pair, W = 256, loses 14 %: tools/ilv_fill_ab.py); force_rows = the row-chunk form (A/B, tests)
-        if (a.W % kBlock == 0 && a.W >= 2 * kBlock && !cfg.force_rows)
+        // Rows of two or more workgroups (W a multiple of 256, >= 512): ONE row per workgroup like the plain kernel, the rows of a
+        // pair on the same XCD one dispatch slot apart -- the halves of every volume line merge in that XCD's L2 (R5.3: 512^3
+        // 0.763 ms against 0.803 for the thread-per-pair form of R4.10 and 0.745 for the fused fill with the plain volume;
+        // 1024^3 6.25 / 6.62 / 6.05).  Without the eight-XCD placement: a thread per x of both rows of the pair (R4.10).  One
+        // workgroup per row (W = 256) keeps the LDS form (paired: +8 %, thread-per-pair: +14 %).  force_*: A/B runs, tests.
+        if (a.W % kBlock == 0 && (cfg.force_paired || (cfg.xcd_pairing && a.W >= 2 * kBlock && !cfg.force_rows && !cfg.force_pairrows)))
+            return cfg.nontemporal ? launch_dense_ilv_paired<true>(a, stream) : launch_dense_ilv_paired<false>(a, stream);
+        if (a.W % kBlock == 0 && (cfg.force_pairrows || (a.W >= 2 * kBlock && !cfg.force_rows)))
             return cfg.nontemporal ? launch_dense_pairrows<true>(a, stream) : launch_dense_pairrows<false>(a, stream);
         return a.W <= 64 ? launch_dense_tx<64>(a, cfg, stream) : launch_dense_tx<128>(a, cfg, stream);
     }

@@ -116,11 +116,18 @@ sdfv::FillArgs make_fill_args(const sdfv_demo_params& p, uint32_t sdf_id, const 
 // under the hits, while the distance volume, which the march gathers from, keeps its place in the caches: the fused
 // fill itself runs 6 % faster (0.097 -> 0.091 ms at 256^3) and fill + march 0.188 -> 0.177 ms (tools/pipeline_nt.py).
 // The plain fill keeps plain stores (nt: within noise alone, +3 % on the 256^3 pipeline, -3 % on the 512^3 one).
+struct DeviceFacts;
+const DeviceFacts& device_facts();
+static bool device_has_eight_xcds();
 sdfv::FillLaunch fill_launch_config(bool writes_distance_volume) {
     sdfv::FillLaunch c;
     c.nontemporal = g_options.fill_nontemporal == 1 || (g_options.fill_nontemporal == 0 && writes_distance_volume);
     c.force_rows = g_options.fill_form == 1;
     c.force_flat = g_options.fill_form == 2;
+    c.force_paired = g_options.fill_form == 3;
+    c.force_pairrows = g_options.fill_form == 4;
+    // the interleaved-volume fill with the rows of a pair on one XCD rests on workgroup b -> XCD b % 8 (as the march's tile orders do)
+    c.xcd_pairing = device_has_eight_xcds();
     return c;
 }
 
@@ -164,6 +171,8 @@ const DeviceFacts& device_facts() {
     }
     return f;
 }
+
+static bool device_has_eight_xcds() { return device_facts().xcds == 8; }
 
 struct MeshScratch {
     void* p = nullptr;
@@ -476,7 +485,7 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             g_options.fill_nontemporal = (uint32_t)value;
             return SDFV_OK;
         case SDFV_OPT_FILL_FORM:
-            if (value > 2) break;
+            if (value > 4) break;
             g_options.fill_form = (uint32_t)value;
             return SDFV_OK;
         case SDFV_OPT_RAYMARCH_DISABLE:

@@ -670,12 +670,13 @@ def test_fill_and_passes_maintain_the_interleaved_volume(pkg, oracle, dims, z_ra
     pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=vol, flags=K.PASS_VIRGIN_GRID | ILV)
     check(t0, t1, vol, want0, want1)
     assert torch.equal(vol, pkg.commit_interleaved(pkg.make_grid((dims[0], dims[1], z_range[1] - z_range[0])), t0[..., 0].contiguous()))
-    # widths of two or more workgroups take the form with a thread per x of BOTH rows of a pair; SDFV_OPT_FILL_FORM 1 pins the
-    # row-chunk form (the pair meets in LDS), both store forms, the run-time configuration too: the same bits
+    # widths of two or more workgroups take the form with one row per workgroup and the rows of a pair on one XCD (round 5; a
+    # thread per x of BOTH rows of a pair without the eight-XCD placement); SDFV_OPT_FILL_FORM pins each form (1 = the pair meets
+    # in LDS), both store forms, the run-time configuration too: the same bits
     for nt in (1, 2):
         for p_ in (prm, pkg.default_params(cube_material=1, sphere_material=0)):
             ref0, ref1 = gpu_fill(pkg, p_, dims, z0=z_range[0], z1=z_range[1])
-            for form in (0, 1):
+            for form in (0, 1, 3, 4):  # auto | LDS row-chunk form | one row per workgroup, pairs on one XCD | a thread per pair
                 t0.fill_(-7.0)
                 vol.fill_(-7.0)
                 with pkg.options({K.OPT_FILL_FORM: form, K.OPT_FILL_NONTEMPORAL: nt}):

@@ -15,7 +15,7 @@ mkdir -p $OUT
 # loopback probe; --no-tuned-placement: the placement probe launches the same kernel over the first slices only, which
 # would mix shorter launches into the averages
 # PROFILE_TUNED=1 keeps the probe (its launches are fill_dense_kernel<256, false>: another kernel NAME than the fused_ilv
-# pipeline's fill at 512^3, fill_dense_pairrows_kernel, so nothing mixes there)
+# pipeline's fill at 512^3, fill_dense_ilv_paired_kernel, so nothing mixes there)
 PLACE=${PROFILE_TUNED:+}
 [ -z "$PROFILE_TUNED" ] && PLACE="--no-tuned-placement"
 CMD="python bench.py --steps 10 --warmup 2 --workload $WL --pipeline $PIPE --no-cpu-baseline --no-batch $PLACE --no-overlapped"

@@ -25,19 +25,30 @@ for side in [int(s) for s in sys.argv[1:]] or [256, 512]:
     vol = torch.empty((side,) * 3, dtype=torch.float32, device="cuda")
     flags = K.PASS_VIRGIN_GRID | K.PASS_VOLUME_INTERLEAVED
     n = 40 if side <= 256 else 12
-    pair = lambda: pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=vol, flags=flags)
+    def pair():  # R4.10: a thread per x of both rows of a pair
+        with pkg.options({K.OPT_FILL_FORM: 4}):
+            pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=vol, flags=flags)
     plain = lambda: pkg.fill_grid(prm, g, t0, t1, dist=vol)
     def chunk():
         with pkg.options({K.OPT_FILL_FORM: 1}):
             pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=vol, flags=flags)
-    ms = {"pair_rows": [], "row_chunk_lds": [], "plain_volume": []}
+    def paired():  # R5.3: one row per workgroup, the rows of a pair on one XCD (volume halves merge in its L2)
+        with pkg.options({K.OPT_FILL_FORM: 3}):
+            pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=vol, flags=flags)
+    just_plain = lambda: pkg.fill_grid(prm, g, t0, t1)
+    ms = {"pair_rows": [], "row_chunk_lds": [], "xcd_paired": [], "plain_volume": [], "no_volume": []}
     for rnd in range(4):
         ms["pair_rows"].append(run(pair, n))
         ms["row_chunk_lds"].append(run(chunk, n))
+        ms["xcd_paired"].append(run(paired, n))
         ms["plain_volume"].append(run(plain, n))
+        ms["no_volume"].append(run(just_plain, n))
     pair(); torch.cuda.synchronize(); a = (t0.clone(), t1.clone(), vol.clone())
-    chunk(); torch.cuda.synchronize()
-    same = all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(a, (t0, t1, vol)))
+    same = True
+    for other in (chunk, paired):
+        t0.fill_(-7.0); vol.fill_(-7.0)
+        other(); torch.cuda.synchronize()
+        same = same and all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(a, (t0, t1, vol)))
     res[str(side)] = {**{k: round(min(v), 4) for k, v in ms.items()}, "rounds": {k: [round(x, 4) for x in v] for k, v in ms.items()}, "same_bits": same}
     del t0, t1, vol
 print(json.dumps(res))
