@@ -256,7 +256,10 @@ int sdfv_fill_grid(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_g
  * between the two bases -- reproducibly, by up to 12 % (256^3: tex1 starting 0 / 4 / 12 KiB after tex0's end:
  * 0.0886 / 0.0826 / 0.0783 ms; 512^3 prefers 0) -- in a way that follows the device's address hashing, not a rule a
  * caller could know.  This helper measures: it times the dense fill of `grid` (default demo parameters, a handful of
- * launches per candidate) for a few small skews and returns the byte offsets of the fastest placement.  `block`:
+ * launches per candidate) for a few small skews and returns the byte offsets of the fastest placement.  On entry
+ * *tex1_offset names the INCUMBENT -- the placement the caller would use without the probe (a value that is no placement
+ * inside the block's slack means "tex1 right after tex0") -- which only gives way to a candidate that beats it by 2 % in both
+ * of the probe's rounds: the result is never a coin toss between equals.  `block`:
  * DEVICE, 16-byte aligned, at least 2 * texture_bytes + SDFV_PLACEMENT_SLACK bytes; its contents are overwritten.
  * Synchronises `stream`.  Optional: any 16-byte aligned pair of pointers is a valid placement. */
 #define SDFV_PLACEMENT_SLACK (64u << 10)

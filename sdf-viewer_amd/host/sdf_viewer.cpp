@@ -111,6 +111,11 @@ int current_device() {
     }
     return d;
 }
+
+// The untuned distance of tex1 from tex0's end (see the constructor).
+size_t default_skew(size_t texture_bytes) {
+    return texture_bytes == ((size_t)1 << 28) ? 12288 : (texture_bytes == ((size_t)1 << 30) ? 20480 : 0);
+}
 }  // namespace
 
 int SDFViewer::tune(std::array<size_t, 3> voxels, void* stream) {
@@ -125,7 +130,7 @@ int SDFViewer::tune(std::array<size_t, 3> voxels, void* stream) {
         g.bb_max[i] = 1.0f;
     }
     g.z_end = g.dims[2];
-    size_t o0 = 0, o1 = bytes;
+    size_t o0 = 0, o1 = bytes + default_skew(bytes);  // the incumbent: what the constructor would use untuned
     const int rc = sdfv_tune_texture_placement(&g, block.get(), block.bytes(), &o0, &o1, stream);
     if (rc != 0) return rc;
     std::lock_guard<std::mutex> lock(g_placement_mutex);
@@ -142,7 +147,7 @@ SDFViewer::SDFViewer(std::array<size_t, 3> voxels, const BoundingBox& bb, size_t
     // rate is periodic in the distance between the textures, EXPERIMENTS R4.1, profiles/r04_place_width.json): textures of
     // 256 MiB (256^3 and every other shape of that size) run 6-8 % faster with tex1 12 KiB after tex0's end, textures of 1 GiB
     // with 20 KiB, 4 GiB (512^3) with none.  Anything else: none.  tune() replaces the guess by a measurement.
-    size_t skew = bytes == ((size_t)1 << 28) ? 12288 : (bytes == ((size_t)1 << 30) ? 20480 : 0);
+    size_t skew = default_skew(bytes);
     {
         std::lock_guard<std::mutex> lock(g_placement_mutex);
         const auto it = g_placement_skew.find({current_device(), bytes});
