@@ -174,9 +174,9 @@ def progressive_block(pkg, torch, prm, sides, reps=7):
         res["noop_pass_step_1"] = case(timed(passes((1,)), loaded), n, 0, "step-1 pass over a loaded grid, no box: reads the volume, writes nothing")
         res["dense_fused_fill_ms"] = round(timed(lambda: pkg.fill_grid(prm, g, t0, t1, dist=dist), lambda: None), 4)
         # HBM bytes per case from the committed PMC passes, and the same kernels' durations under rocprofv3 (warm, 100
-        # repetitions: tools/gpu_profile_pass.sh -> profiles/r04_pass_traffic.json) next to the times measured here
+        # repetitions: tools/gpu_profile_pass.sh -> profiles/pass_traffic.json, regenerated per round) next to the times measured here
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r04_pass_traffic.json")))[str(side)]["cases"]
+            prof = json.load(open(os.path.join(ROOT, "profiles", "pass_traffic.json")))[str(side)]["cases"]
         except Exception:  # noqa: BLE001
             prof = {}
         for name, c in res.items():

@@ -28,7 +28,11 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_calwr -o pmc -
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_calrd -o pmc --output-format csv -- python tools/pmc_calibrate.py $WL > $OUT/pmc_calrd.log 2>&1
 {
   echo "# rocprofv3 --kernel-trace --stats -- $CMD"
+  python tools/bench_line_of.py $OUT/trace.log
   cat $OUT/trace/trace_kernel_stats.csv
+  echo
+  echo "# per (kernel, grid size) of the same trace"
+  python tools/kernel_trace_avg.py $OUT/trace 8
   echo
   echo "# PMC passes (one rocprofv3 --pmc run each; per-dispatch averages)"
   python tools/summarize_pmc.py $OUT

@@ -12,7 +12,7 @@ CMD="python bench.py --steps 20 --warmup 3 --workload $WL --no-cpu-baseline --no
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $CMD > $OUT/trace.log 2>&1
 {
   echo "# rocprofv3 --kernel-trace --stats -- $CMD   (placement probe ON: the line bench.py prints describes this run)"
-  grep '^{' $OUT/trace.log | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('# bench line:', json.dumps({k: d[k] for k in ('value','value_rays','ms_per_step','ms_per_step_fill','ms_per_step_raymarch','pipeline','texture_placement','raymarch_kernel_ms')})); print('# roofline:', json.dumps(d['roofline']))"
+  python tools/bench_line_of.py $OUT/trace.log
   cat $OUT/trace/trace_kernel_stats.csv
   echo
   echo "# per (kernel, grid size): whole-grid launches vs the placement probe's first-slices launches"

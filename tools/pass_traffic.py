@@ -39,12 +39,13 @@ def pmc(group, which):
 # (name prefix, name suffix): the configuration policy in between is spelled DefaultCfgT<false> since round 4
 DENSE, ROWS_T, ROWS_F, PASS, QUAD = (("fill_dense_kernel<256, true", ""), ("fill_pass_rows_kernel<", ", true>"), ("fill_pass_rows_kernel<", ", false>"),
                                      ("fill_pass_kernel<", ""), ("fill_pass_quad_kernel<", ""))
+ADAPT = ("fill_pass_rows_adaptive_kernel<", "")  # round 5: an unflagged, unboxed pass with step >= 2 (a lane per 4 voxels of the visited rows)
 CASES = {
     "virgin_load_2_passes": ("load_virgin", [(ROWS_T, rows2), (DENSE, n)]),
     "fresh_load_2_passes": ("load_virgin", [(ROWS_T, rows2), (DENSE, n)]),
     "fresh_pass_step_2_flagged": ("load_virgin", [(ROWS_T, rows2)]),
-    "fresh_load_2_passes_unflagged": ("load_unflagged", [(PASS, n // 8), (QUAD, n // 4)]),
-    "fresh_pass_step_2": ("load_unflagged", [(PASS, n // 8)]),
+    "fresh_load_2_passes_unflagged": ("load_unflagged", [(ADAPT, rows2 // 4), (QUAD, n // 4)]),
+    "fresh_pass_step_2": ("load_unflagged", [(ADAPT, rows2 // 4)]),
     "fresh_pass_step_1_after_step_2": ("load_unflagged", [(QUAD, n // 4)]),
     "fresh_pass_step_1": ("fresh_step1", [(QUAD, n // 4)]),
     "edit_full_box_3_passes": ("edit_full", [(ROWS_F, rows4), (ROWS_F, rows2), (DENSE, n)]),

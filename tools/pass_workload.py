@@ -32,7 +32,7 @@ def load_virgin():   # what SDFViewer::update enqueues for the default 2-pass lo
     pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=dist, flags=VS)
 
 
-def load_unflagged():  # fill_pass_kernel (step 2, every visited voxel AIR), fill_pass_quad_kernel (step 1, 7/8 AIR)
+def load_unflagged():  # fill_pass_rows_adaptive_kernel (step 2, every visited row AIR), fill_pass_quad_kernel (step 1, 7/8 AIR)
     fresh()
     pkg.fill_grid_pass(prm, g, 2, t0, t1, dist=dist)
     pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=dist)
