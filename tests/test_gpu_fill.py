@@ -286,6 +286,25 @@ def test_randomised_parameters_and_grids(pkg, oracle):
         assert torch.equal(p0, t0) and torch.equal(p1, t1), (trial, kw, dims, steps, "virgin load")
         if trial % 4:
             assert torch.equal(dvol, interleave_rows(t0[..., 0]) if ilv else t0[..., 0]), (trial, dims, steps, "virgin load's volume")
+        # round 5: a load the caller says NOTHING about, over a volume in either layout, on a width the whole-rows kernel of
+        # step >= 2 takes (W % 4 == 0: four random dimensions are widened to it) -- every intermediate state against the
+        # plain path's (the per-voxel kernels over tex0.r)
+        dims5 = (dims[0] + (-dims[0]) % 4, dims[1] + (dims[1] % 2 if trial % 3 == 0 else 0), dims[2])
+        ilv5 = K.PASS_VOLUME_INTERLEAVED if trial % 3 == 0 else 0
+        g5 = pkg.make_grid(dims5, lo, hi)
+        u0, u1 = pkg.alloc_textures(g5)
+        w0, w1 = pkg.alloc_textures(g5)
+        pkg.grid_init(g5, u0, u1)
+        pkg.grid_init(g5, w0, w1)
+        v5 = torch.full(tuple(u0.shape[:-1]), pkg.AIR_DIST, dtype=torch.float32, device="cuda")
+        steps5 = [int(2 ** rng.integers(0, 4)) for _ in range(3)] + [1]  # any order, coarse after fine included
+        for step in steps5:
+            pkg.fill_grid_pass(prm, g5, step, u0, u1, sdf_id=sdf_id, dist=v5, flags=ilv5)
+            pkg.fill_grid_pass(prm, g5, step, w0, w1, sdf_id=sdf_id)
+            torch.cuda.synchronize()
+            assert torch.equal(u0.view(torch.int32), w0.view(torch.int32)) and torch.equal(u1.view(torch.int32), w1.view(torch.int32)), (trial, kw, dims5, steps5, step, "unflagged")
+            assert torch.equal(v5, interleave_rows(w0[..., 0]) if ilv5 else w0[..., 0]), (trial, dims5, steps5, step, "unflagged volume")
+        del u0, u1, w0, w1, v5
         if trial % 2 == 0:
             flag = oracle.EXT_VARIANTS["srgb_quant_round"]
             before = oracle.L.or_get_ext_variant()
