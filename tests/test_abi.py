@@ -74,7 +74,8 @@ def test_options_are_explicit_and_the_library_reads_no_environment(pkg):
     assert pkg.get_option(K.OPT_RAYMARCH_BATCH_STREAMS) == 1 and pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_BATCH_STREAMS, 2) == -1
     assert pkg.get_option(K.OPT_RAYMARCH_CAMERA_STAGING) == 1 and pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_CAMERA_STAGING, 2) == -1
     assert pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_WAVES_PER_SIMD, 1) == -1 and pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_WAVES_PER_SIMD, 8) == -1
-    assert pkg.lib.sdfv_set_option(K.OPT_FILL_FORM, 3) == -1
+    assert pkg.lib.sdfv_set_option(K.OPT_FILL_FORM, 5) == -1  # (3, 4: the two pinned forms of the interleaved-volume fill, round 5)
+    assert pkg.get_option(K.OPT_PASS_FORM) == 0 and pkg.lib.sdfv_set_option(K.OPT_PASS_FORM, 2) == -1
     assert pkg.lib.sdfv_set_option(K.OPT_RAYMARCH_DISABLE, 64) == -1
     assert pkg.lib.sdfv_set_option(77, 0) == -1 and b"unknown option" in pkg.lib.sdfv_last_error()
     # the wave-timing stamps exist only in the tuning build
