@@ -388,6 +388,22 @@ __global__ __launch_bounds__(kBlock) void fill_pass_quad_kernel(FillArgs a, Pass
                    (d.w == a.air_dist ? 8u : 0u);
     }
     if (!p.has_box && __ballot(air_bits != 0) == 0ull) return;  // wave-uniform: nothing to update in these 256 voxels
+    if (p.has_box) {
+        // ... and with a box: a wave none of whose quads holds AIR or can reach into the box leaves here too, on ONE coordinate
+        // estimate per lane (its quad's row and x range against the box, maybe_in_box's margins) instead of four rounds of
+        // per-voxel estimates -- seven waves in eight of an edit that touches an eighth of the grid (round 5)
+        bool reach = false;
+        if (4 * (uint64_t)q < n_vox) {
+            const uint32_t qr = div_u32(4u * q, p.div_nx), qx = 4u * q - qr * a.W;
+            const uint32_t qz = div_u32(qr, p.div_ny), qy = qr - qz * a.H;
+            // either end of the quad may be in the box, or the box's x range lies strictly between the quad's ends (whichever way
+            // the coordinates run)
+            const float e0 = (float)qx * p.approx_scale[0] + a.bb_min[0], e3 = (float)(qx + 3u) * p.approx_scale[0] + a.bb_min[0];
+            reach = maybe_in_box(a, p, qx, qy, p.z_first + qz) || maybe_in_box(a, p, qx + 3u, qy, p.z_first + qz) ||
+                    (fminf(e0, e3) < p.box[0] && fmaxf(e0, e3) > p.box[3]);
+        }
+        if (__ballot(air_bits != 0 || reach) == 0ull) return;
+    }
     const uint32_t span0 = (q - lane) * 4;  // first voxel of the wave's span (flat index within the slab)
     uint32_t row_cached = 0xffffffffu;
     float py = 0.0f, pz = 0.0f;

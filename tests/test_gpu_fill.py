@@ -376,14 +376,24 @@ def test_changed_box_whose_faces_lie_exactly_on_voxel_coordinates(pkg, oracle):
     """The pass kernel leaves early for voxels that are clearly outside the box (a cheap coordinate estimate with a
     proven margin) and decides the rest with the exact coordinates: a box bounded by exact voxel coordinates, where
     `>=` / `<=` (scene/sdf/mod.rs:186-188) flip from one voxel to the next, must refill exactly the oracle's voxels."""
-    dims = (23, 31, 19)
-    bb = ((-1.0, -0.9, -1.3), (0.7, 1.0, 0.4))
-    g = pkg.make_grid(dims, *bb)
     prm, edited = pkg.default_params(), pkg.default_params(cube_half_side=0.5, sphere_radius=0.6)
+    bb = ((-1.0, -0.9, -1.3), (0.7, 1.0, 0.4))
+    # (24 / 256 wide: the step-1 pass over a volume is the quad kernel, whose waves leave on ONE estimate per lane -- its quad's
+    # ends against the box -- since round 5: boxes that hold a single voxel INSIDE a quad, or no voxel at all, must still match)
+    for dims in ((23, 31, 19), (24, 31, 19), (256, 9, 6)):
+        def coord(i, axis):
+            return float(oracle.L.or_voxel_coord(i, dims[axis], bb[0][axis], bb[1][axis]))
+        mid = lambda i, axis: 0.5 * (coord(i, axis) + coord(i + 1, axis))  # noqa: E731
+        boxes = [(coord(5, 0), coord(7, 1), coord(3, 2), coord(17, 0), coord(min(22, dims[1] - 1), 1), coord(min(11, dims[2] - 1), 2)),
+                 (mid(5, 0), coord(2, 1), coord(1, 2), mid(6, 0), coord(4, 1), coord(3, 2)),      # x = 6 alone: inside the quad 4..7
+                 (mid(9, 0), coord(2, 1), coord(1, 2), 0.5 * (mid(9, 0) + coord(10, 0)), coord(4, 1), coord(3, 2)),  # between voxels: nothing
+                 (coord(0, 0), coord(0, 1), coord(2, 2), coord(dims[0] - 1, 0), coord(0, 1), coord(2, 2))]  # one whole row
+        for box in boxes:
+            check_boxed_edit(pkg, oracle, dims, bb, prm, edited, box, expect_change=box is not boxes[2])
 
-    def coord(i, axis):
-        return float(oracle.L.or_voxel_coord(i, dims[axis], bb[0][axis], bb[1][axis]))
-    box = (coord(5, 0), coord(7, 1), coord(3, 2), coord(17, 0), coord(22, 1), coord(11, 2))
+
+def check_boxed_edit(pkg, oracle, dims, bb, prm, edited, box, expect_change):
+    g = pkg.make_grid(dims, *bb)
     for use_dist in (False, True):
         t0, t1 = pkg.alloc_textures(g)
         dist = torch.empty(tuple(t0.shape[:-1]), dtype=torch.float32, device="cuda") if use_dist else None
@@ -397,7 +407,7 @@ def test_changed_box_whose_faces_lie_exactly_on_voxel_coordinates(pkg, oracle):
         assert_bits_equal(t0, r0)
         assert_bits_equal(t1, r1)
         n_changed = int((t0.cpu().numpy() != oracle.fill_dense(oracle.params_from(prm), dims, *bb)[0]).any(axis=-1).sum())
-        assert n_changed > 0
+        assert (n_changed > 0) == expect_change, (dims, box, n_changed)
         if use_dist:
             assert torch.equal(dist, t0[..., 0])
 
