@@ -19,8 +19,14 @@ for f in files:
     if not isinstance(d, dict) or "box" not in d or "metric" not in d:
         continue
     smi = d["box"].get("rocm_smi", {})
+    if not isinstance(smi, dict):
+        smi = {}
+    if "uuid" in d["box"] and "Unique ID" not in smi:  # round 5's contract line: box = {uuid, arch, sclk}
+        smi = {"Unique ID": d["box"].get("uuid"), "sclk clock speed:": d["box"].get("sclk")}
+    host = d.get("host_load") or {}
     t512 = (d.get("roofline") or {}).get("target_512") or {}
     rows.append({"file": f, "box": smi.get("Unique ID"), "sclk": smi.get("sclk clock speed:"), "workload": d["config"].get("workload"),
+                 "host_512_update_ms": (host.get("512") or {}).get("update_ms") if "update_ms" in (host.get("512") or {}) else ((host.get("512") or {}).get("dense") or {}).get("update_ms"),
                  "n_gpus": d["n_gpus"], "pipeline": d.get("pipeline"), "fill_ms": d.get("ms_per_step_fill"),
                  "march_ms": d.get("ms_per_step_raymarch"), "value_Mvoxels_s": d["value"], "frac": (d.get("roofline") or {}).get("frac"),
                  "frac_bus": (d.get("roofline") or {}).get("frac_bus"),
