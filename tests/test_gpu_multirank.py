@@ -106,6 +106,7 @@ def test_bench_line_carries_the_whole_contract(tmp_path):
         assert key in c["cpu_baseline"], key
     assert c["roofline"]["bound"] == "hbm" and c["cpu_baseline"]["kind"] == "port" and c["incomplete"] is None
     assert c["roofline"]["target_512"]["plain"]["frac_8d"] > 0 and c["roofline"]["target_512"]["fused"]["frac_8d"] > 0
+    assert c["roofline"]["target_512"]["fused_ilv"]["frac_8d"] > 0  # the fill SDFViewer runs at that size
     assert c["host_load"]["64"]["update_ms"] > 0 and c["progressive"]["64"]["virgin_load_2_passes"][0] > 0
     for key in CONTRACT_KEYS + ("cpu_baseline", "ms_per_step_median", "ms_per_step_p95", "per_step"):
         assert key in d, key
