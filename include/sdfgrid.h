@@ -191,6 +191,10 @@ typedef enum sdfv_option {
     SDFV_OPT_PASS_FORM = 13,           /* 0 auto (default) | 1: a pass the caller says nothing about (no flags, no box) with step >= 2 takes
                                         * the per-voxel kernel (one texel in every `step`) instead of the whole-rows kernel whose
                                         * waves decide on the volume they read (sdfv_fill_grid_pass_ex).  A/B runs; same texels */
+    SDFV_OPT_RCCL_LIBRARY = 14,        /* PROCESS-wide, before the first communicator: value = address of a NUL-terminated path of the RCCL-ABI
+                                        * library sdfv_slab_comm_* loads (copied; 0 = "librccl.so.1" by name, the default).  For
+                                        * installations whose RCCL is not on the loader's path -- and how tests/c/mock_rccl.cpp stands
+                                        * in for RCCL so that several ranks can run on one device.  Refused once RCCL is loaded */
     SDFV_OPT_TUNING_WAVE_TIMING = 100, /* tuning build only (-DSDFV_TUNING): DEVICE address of 32 B per raymarch wave */
     SDFV_OPT_TUNING_TILE_ORDER = 102,  /* tuning build only: DEVICE address of tiles_x * tiles_y uint32 tile numbers (row-major
                                         * tile index by * tiles_x + bx): workgroup L of a single-camera launch renders tile

@@ -190,6 +190,7 @@ OPT_RAYMARCH_BATCH_STREAMS = 9
 OPT_PASS_INDEX_LIMIT = 11
 OPT_RAYMARCH_CAMERA_STAGING = 12
 OPT_PASS_FORM = 13  # 0 auto | 1 per-voxel kernels for unflagged passes (A/B)
+OPT_RCCL_LIBRARY = 14  # process-wide: address of the path of the RCCL-ABI library to load (before the first communicator)
 OPT_EXT_SRGB_QUANT = 10  # Srgba::from(Vec3): 0 truncate (default) | 1 round
 OPT_TUNING_WAVE_TIMING = 100
 OPT_TUNING_PRIORITY_MAP = 101

@@ -26,6 +26,10 @@ struct Options {
     unsigned long long tile_order = 0;    // tuning build only
 };
 const Options& options();
+// SDFV_OPT_RCCL_LIBRARY: process-wide path of the RCCL-ABI library the communicator loads (empty = librccl.so.1 by name)
+const char* rccl_library_path();
+bool rccl_loaded();
+void mark_rccl_loaded();
 // Formats the thread-local message sdfv_last_error() returns and hands `code` back.
 int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 // The first and the last slice of `slab` (the ones the z-neighbours need) in one launch; o0/o1 address the first

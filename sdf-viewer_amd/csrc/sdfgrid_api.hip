@@ -3,6 +3,10 @@
 // no CPU fallback: without a HIP device every compute entry point fails with SDFV_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <mutex>
+#include <string>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
@@ -359,6 +363,22 @@ int check_lights(const sdfv_render_params* rp) {
 
 namespace sdfv {
 const Options& options() { return g_options; }
+
+namespace {
+std::mutex g_rccl_path_mutex;
+std::string g_rccl_path;         // SDFV_OPT_RCCL_LIBRARY (process-wide: RCCL is loaded once per process)
+std::atomic<bool> g_rccl_loaded{false};
+}  // namespace
+const char* rccl_library_path() {
+    std::lock_guard<std::mutex> lock(g_rccl_path_mutex);
+    return g_rccl_path.c_str();  // (stable: the string is not modified once RCCL has been loaded)
+}
+bool rccl_loaded() { return g_rccl_loaded.load(); }
+void mark_rccl_loaded() { g_rccl_loaded.store(true); }
+static void set_rccl_library_path(const char* path) {
+    std::lock_guard<std::mutex> lock(g_rccl_path_mutex);
+    g_rccl_path = path ? path : "";
+}
 int set_error(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -527,6 +547,15 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             if (value > 1) break;
             g_options.ext_srgb_quant = (uint32_t)value;
             return SDFV_OK;
+        case SDFV_OPT_RCCL_LIBRARY: {
+            // value = address of a NUL-terminated path (copied), or 0 = librccl.so.1 by name; process-wide, before the first
+            // communicator -- RCCL is loaded once
+            if (sdfv::rccl_loaded()) return fail(SDFV_ERR_INVALID_ARGUMENT, "SDFV_OPT_RCCL_LIBRARY: RCCL has already been loaded in this process");
+            const char* path = reinterpret_cast<const char*>((uintptr_t)value);
+            if (path && strnlen(path, 4096) >= 4096) break;
+            sdfv::set_rccl_library_path(path);
+            return SDFV_OK;
+        }
         case SDFV_OPT_PASS_FORM:
             if (value > 1) break;
             g_options.pass_form = (uint32_t)value;
@@ -581,6 +610,7 @@ int sdfv_get_option(uint32_t option, uint64_t* value) {
         case SDFV_OPT_EXT_SRGB_QUANT: *value = g_options.ext_srgb_quant; return SDFV_OK;
         case SDFV_OPT_PASS_INDEX_LIMIT: *value = g_options.pass_index_limit; return SDFV_OK;
         case SDFV_OPT_PASS_FORM: *value = g_options.pass_form; return SDFV_OK;
+        case SDFV_OPT_RCCL_LIBRARY: *value = (uint64_t)(uintptr_t)sdfv::rccl_library_path(); return SDFV_OK;  // (address of the library's copy; "" = by name)
         default: return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown option %u", option);
     }
 }

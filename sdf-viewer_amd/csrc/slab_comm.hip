@@ -52,8 +52,18 @@ bool bind(void* h, const char* name, F& fn) {
 const Rccl* rccl() {
     static const Rccl lib = [] {
         Rccl r;
-        r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!r.handle) r.handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        sdfv::mark_rccl_loaded();  // (from here on SDFV_OPT_RCCL_LIBRARY is refused: one RCCL per process)
+        const char* path = sdfv::rccl_library_path();
+        if (path && path[0]) {  // SDFV_OPT_RCCL_LIBRARY: this file and nothing else
+            r.handle = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+            if (!r.handle) {
+                r.load_error = "the library named by SDFV_OPT_RCCL_LIBRARY could not be loaded";
+                return r;
+            }
+        } else {
+            r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (!r.handle) r.handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        }
         if (!r.handle) {
             r.load_error = "librccl.so.1 not found";
             return r;

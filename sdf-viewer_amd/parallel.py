@@ -160,14 +160,26 @@ class SlabComm:
     torch.distributed only carries its 128 bytes to the other ranks; after that no torch call is on the step path.
     `periodic` wraps the end ranks around -- with world 1 a rank exchanges with itself (single-GPU tests)."""
 
-    def __init__(self, pkg, rank, world, group=None, periodic=False, halo_hi=1):
+    def __init__(self, pkg, rank, world, group=None, periodic=False, halo_hi=1, ident=None):
         """Collective over the ranks.  Every stage that can fail on one rank only (drawing the id, creating the RCCL
         communicator) is followed by an agreement (all-reduce of a flag) so that a failure raises on EVERY rank instead of
-        leaving the others inside a collective nobody else joins."""
+        leaving the others inside a collective nobody else joins.
+        ident: the 128 bytes of SlabComm.unique_id(), carried to every rank by the HOST's own channel -- then nothing here touches
+        torch.distributed (include/sdfgrid.h: "the HOST hands the 128 bytes to every rank by whatever channel it has"): ranks
+        that are threads of one process, an MPI host, a test."""
         capi = pkg._capi
         self.pkg, self.rank, self.world, self.periodic, self.halo_hi = pkg, rank, world, periodic, halo_hi
         self.handle = None
         assert halo_hi in (1, 2)
+        if ident is not None:
+            ident = bytes(ident)
+            assert len(ident) == capi.COMM_ID_BYTES
+            handle = C.c_void_p()
+            flags = (capi.COMM_PERIODIC if periodic else 0) | (capi.COMM_HALO2 if halo_hi == 2 else 0)
+            enter_stage(f"SlabComm.__init__: sdfv_slab_comm_create(rank {rank} of {world}) with the host's own id")
+            pkg.check(pkg.lib.sdfv_slab_comm_create((C.c_ubyte * capi.COMM_ID_BYTES)(*ident), rank, world, flags, C.byref(handle)))
+            self.handle = handle
+            return
         on_gpu = world > 1 and c10d.get_backend(group) == "nccl"
         dev = "cuda" if on_gpu else "cpu"
 
@@ -203,6 +215,13 @@ class SlabComm:
             self.close()
             raise
         enter_stage("SlabComm.__init__: done")
+
+    @staticmethod
+    def unique_id(pkg):
+        """sdfv_slab_comm_unique_id: the 128 bytes one rank draws and the host hands to the others (SlabComm(ident=...))."""
+        ident = (C.c_ubyte * pkg._capi.COMM_ID_BYTES)()
+        pkg.check(pkg.lib.sdfv_slab_comm_unique_id(ident))
+        return bytes(ident)
 
     @property
     def ghost_lo(self):

@@ -243,3 +243,48 @@ def test_watchdog_prints_the_measured_line_when_an_extra_hangs(tmp_path):
     c, d, out = run_bench(cmd, env, tmp_path, timeout=600)
     assert c["value"] > 0 and c["value_rays"] > 0 and c["incomplete"] is True and "watchdog" in c and "WATCHDOG" in out.stderr
     assert d["value"] > 0 and d["value_rays"] > 0 and "watchdog" in d
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_library_multi_rank_paths_over_a_mock_rccl_on_one_gpu(world, tmp_path):
+    """The C++ library's multi-rank code between DIFFERENT ranks on one GPU: tests/c/mock_rccl.cpp stands in for librccl.so.1
+    (in-process rendezvous, device-to-device copies, stream-ordered like NCCL), tests/c/multirank_mock.cpp runs `world` ranks as
+    threads of one process -- a rank with an upper neighbour only, with both (world 3), with a lower one only: the fill step in
+    both message forms, the halo exchange, one and two upper ghost slices, the all-gather of slabs, both gathers of config 5 to
+    rank 0 and to the last rank, and sdfv_slab_march's rounds with the merge -- each compared bit for bit with the library's
+    single-device result.  RCCL refuses two ranks on one device (test above) and no run here has had two devices: this is the
+    only execution those branches get before real hardware."""
+    mock_dir = tmp_path / "mock"
+    mock_dir.mkdir()
+    hip = ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", *hip,
+                        os.path.join(ROOT, "tests", "c", "mock_rccl.cpp"), "-o", str(mock_dir / "librccl.so.1"),
+                        "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-soname,librccl.so.1", "-lpthread"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exe = tmp_path / "multirank_mock"
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", *hip, "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "c", "multirank_mock.cpp"), "-o", str(exe),
+                        "-L", os.path.join(ROOT, "sdf-viewer_amd"), "-lsdfgrid", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread",
+                        "-Wl,-rpath," + os.path.join(ROOT, "sdf-viewer_amd"), "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, LD_LIBRARY_PATH=str(mock_dir) + ":" + os.environ.get("LD_LIBRARY_PATH", ""), GPU_MAX_HW_QUEUES="8")
+    out = subprocess.run(["timeout", "-s", "KILL", "240", str(exe), str(world)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith(f"ok {world} ranks"), (out.returncode, out.stdout[-800:], out.stderr[-2500:])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_python_multi_rank_paths_over_a_mock_rccl_on_one_gpu(world, tmp_path):
+    """... and the Python layer above it (tests/mock_ranks.py): parallel.SlabComm with a host-carried id, SlabFiller(transport=
+    "rccl"), raymarch_sharded / SlabComm.march, gather_replica, gather_images, gather_bands over the library communicator, the
+    ranks as THREADS of one process (the mock is loaded through SDFV_OPT_RCCL_LIBRARY; a process of its own because RCCL is
+    loaded once per process).  Every rank's result against the single-device one, bit for bit."""
+    mock = tmp_path / "libsdfv_mock_rccl.so"
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-D__HIP_PLATFORM_AMD__",
+                        "-I/opt/rocm/include", os.path.join(ROOT, "tests", "c", "mock_rccl.cpp"), "-o", str(mock),
+                        "-L/opt/rocm/lib", "-lamdhip64", "-lpthread"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    out = subprocess.run(["timeout", "-s", "KILL", "280", sys.executable, os.path.join(ROOT, "tests", "mock_ranks.py"), str(mock), str(world)],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=320)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith(f"ok {world} ranks as threads"), \
+        (out.returncode, out.stdout[-2500:], out.stderr[-1500:])
