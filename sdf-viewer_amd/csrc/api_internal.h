@@ -27,9 +27,10 @@ struct Options {
 };
 const Options& options();
 // SDFV_OPT_RCCL_LIBRARY: process-wide path of the RCCL-ABI library the communicator loads (empty = librccl.so.1 by name)
+// (claim_rccl_library_path: the path, and from that moment on SDFV_OPT_RCCL_LIBRARY is refused -- one RCCL per process)
 const char* rccl_library_path();
 bool rccl_loaded();
-void mark_rccl_loaded();
+const char* claim_rccl_library_path();
 // Formats the thread-local message sdfv_last_error() returns and hands `code` back.
 int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 // The first and the last slice of `slab` (the ones the z-neighbours need) in one launch; o0/o1 address the first

@@ -374,10 +374,16 @@ const char* rccl_library_path() {
     return g_rccl_path.c_str();  // (stable: the string is not modified once RCCL has been loaded)
 }
 bool rccl_loaded() { return g_rccl_loaded.load(); }
-void mark_rccl_loaded() { g_rccl_loaded.store(true); }
-static void set_rccl_library_path(const char* path) {
+const char* claim_rccl_library_path() {
     std::lock_guard<std::mutex> lock(g_rccl_path_mutex);
+    g_rccl_loaded.store(true);
+    return g_rccl_path.c_str();
+}
+static bool set_rccl_library_path(const char* path) {
+    std::lock_guard<std::mutex> lock(g_rccl_path_mutex);
+    if (g_rccl_loaded.load()) return false;  // (decided under the same lock the loader claims the path under)
     g_rccl_path = path ? path : "";
+    return true;
 }
 int set_error(int code, const char* fmt, ...) {
     va_list ap;
@@ -550,10 +556,10 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
         case SDFV_OPT_RCCL_LIBRARY: {
             // value = address of a NUL-terminated path (copied), or 0 = librccl.so.1 by name; process-wide, before the first
             // communicator -- RCCL is loaded once
-            if (sdfv::rccl_loaded()) return fail(SDFV_ERR_INVALID_ARGUMENT, "SDFV_OPT_RCCL_LIBRARY: RCCL has already been loaded in this process");
             const char* path = reinterpret_cast<const char*>((uintptr_t)value);
             if (path && strnlen(path, 4096) >= 4096) break;
-            sdfv::set_rccl_library_path(path);
+            if (!sdfv::set_rccl_library_path(path))
+                return fail(SDFV_ERR_INVALID_ARGUMENT, "SDFV_OPT_RCCL_LIBRARY: RCCL has already been loaded in this process");
             return SDFV_OK;
         }
         case SDFV_OPT_PASS_FORM:

@@ -52,8 +52,7 @@ bool bind(void* h, const char* name, F& fn) {
 const Rccl* rccl() {
     static const Rccl lib = [] {
         Rccl r;
-        sdfv::mark_rccl_loaded();  // (from here on SDFV_OPT_RCCL_LIBRARY is refused: one RCCL per process)
-        const char* path = sdfv::rccl_library_path();
+        const char* path = sdfv::claim_rccl_library_path();  // (from here on SDFV_OPT_RCCL_LIBRARY is refused: one RCCL per process)
         if (path && path[0]) {  // SDFV_OPT_RCCL_LIBRARY: this file and nothing else
             r.handle = dlopen(path, RTLD_NOW | RTLD_LOCAL);
             if (!r.handle) {

@@ -307,3 +307,27 @@ def test_integration_guide_binds_every_entry_point():
     declared, _inline = header_functions()  # what the library EXPORTS; the header-only wrappers are the binder's to restate
     missing = sorted(f for f in declared if f not in guide)
     assert not missing, missing
+
+
+def test_rccl_library_option_is_process_wide_and_final_once_loaded():
+    """SDFV_OPT_RCCL_LIBRARY: the one process-wide option -- the path of the RCCL-ABI library the communicator loads (how
+    tests/c/mock_rccl.cpp stands in for RCCL); a path that cannot be loaded is a clean SDFV_ERR_COMM, and once RCCL has been
+    loaded (or has failed to load) the option is refused.  In a process of its own: loading is once per process."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, importlib, sys
+sys.path.insert(0, %r)
+pkg = importlib.import_module("sdf-viewer_amd"); K = pkg._capi
+assert C.string_at(pkg.get_option(K.OPT_RCCL_LIBRARY)) == b""
+buf = C.create_string_buffer(b"/nonexistent/librccl.so")
+pkg.set_option(K.OPT_RCCL_LIBRARY, C.addressof(buf))
+buf.value = b"overwritten"                                   # (the library keeps its own copy)
+assert C.string_at(pkg.get_option(K.OPT_RCCL_LIBRARY)) == b"/nonexistent/librccl.so"
+ident = (C.c_ubyte * 128)()
+assert pkg.lib.sdfv_slab_comm_unique_id(ident) == -5 and b"SDFV_OPT_RCCL_LIBRARY" in pkg.lib.sdfv_last_error()
+assert pkg.lib.sdfv_set_option(K.OPT_RCCL_LIBRARY, 0) == -1 and b"already been loaded" in pkg.lib.sdfv_last_error()
+print("ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
