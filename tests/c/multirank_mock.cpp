@@ -41,7 +41,8 @@
         }                                                                                                    \
     } while (0)
 
-static const uint32_t W = 64, H = 48, D = 41;  // (rows of whole workgroups: the boundary-first step applies; D not a multiple of any world)
+static uint32_t W = 64, H = 48, D = 41;  // set per geometry in main(): rows of whole workgroups (the boundary-first step applies) /
+                                         // rows that are not and slabs of two slices (the step falls back to fill, then exchange)
 static const uint32_t IW = 160, IH = 88;       // image: 5.5 bands of 16 rows
 static std::atomic<int> g_failures{0};
 
@@ -108,15 +109,23 @@ static void rank_main(int rank, int world, const unsigned char* id, uint32_t com
         HIP(hipMemsetAsync(dv, 0xA5, held * slice * 4, st));
     };
     // ---- the fill step, both message forms, with and without the fused volume ----
-    const uint64_t forms[2] = {SDFV_STEP_SIDE_BOUNDARY, SDFV_STEP_SIDE_BOUNDARY | SDFV_STEP_UNPACKED};
-    for (int f = 0; f < 2; ++f) {
+    const uint64_t forms[4] = {SDFV_STEP_SIDE_BOUNDARY, SDFV_STEP_SIDE_BOUNDARY | SDFV_STEP_UNPACKED, SDFV_STEP_SIDE_BOUNDARY | SDFV_STEP_START_EVENT,
+                               SDFV_STEP_SIDE_BOUNDARY | SDFV_STEP_DEFER_JOIN};
+    const char* form_names[4] = {"packed messages", "per-texture messages", "packed, start event", "packed, deferred join"};
+    for (int f = 0; f < 4; ++f) {
         SDFV(sdfv_set_option(SDFV_OPT_SLAB_STEP_FORM, forms[f]));
         poison();
         SDFV(sdfv_slab_fill_step_commit(comm, &ref->prm, SDFV_SDF_DEMO, &slab, t0, t1, dv, st));
-        check_slab(f ? "fused step, per-texture messages" : "fused step, packed messages", true);
+        if (f == 3) {  // two more steps without a join, then ONE join before anything reads the ghosts
+            SDFV(sdfv_slab_fill_step_commit(comm, &ref->prm, SDFV_SDF_DEMO, &slab, t0, t1, dv, st));
+            SDFV(sdfv_slab_fill_step_commit(comm, &ref->prm, SDFV_SDF_DEMO, &slab, t0, t1, dv, st));
+            SDFV(sdfv_slab_comm_join(comm, st));
+        }
+        check_slab((std::string("fused step, ") + form_names[f]).c_str(), true);
         poison();
         SDFV(sdfv_slab_fill_step(comm, &ref->prm, SDFV_SDF_DEMO, &slab, t0, t1, st));
-        check_slab(f ? "step, per-texture messages" : "step, packed messages", false);
+        if (f == 3) SDFV(sdfv_slab_comm_join(comm, st));
+        check_slab((std::string("step, ") + form_names[f]).c_str(), false);
     }
     SDFV(sdfv_set_option(SDFV_OPT_SLAB_STEP_FORM, 0));
     for (int k = 0; k < 3; ++k) SDFV(sdfv_slab_fill_step_commit(comm, &ref->prm, SDFV_SDF_DEMO, &slab, t0, t1, dv, st));  // back to back
@@ -239,6 +248,12 @@ int main(int argc, char** argv) {
         return 1;
     }
     HIP(hipSetDevice(0));
+    int sets = 0;
+    size_t hits = 0;
+    const uint32_t geometries[2][3] = {{64, 48, 41}, {40, 20, 17}};
+    for (int gi = 0; gi < 2; ++gi) {
+    W = geometries[gi][0], H = geometries[gi][1], D = geometries[gi][2];
+    if (D < (uint32_t)world * 2) continue;  // (every rank needs two slices: the halo's second slice comes from ONE neighbour)
     Reference ref;
     sdfv_demo_params_default(&ref.prm);
     memset(&ref.grid, 0, sizeof ref.grid);
@@ -274,7 +289,7 @@ int main(int argc, char** argv) {
     HIP(hipDeviceSynchronize());
     ref.batch.resize(5 * image);
     HIP(hipMemcpy(ref.batch.data(), img, 5 * image * 4, hipMemcpyDeviceToHost));
-    size_t hits = 0;
+    hits = 0;
     for (size_t i = 3; i < image; i += 4) hits += ref.frame[i] > 0.0f;
     if (hits < 500) {
         fprintf(stderr, "the reference frame shows almost nothing (%zu hits)\n", hits);
@@ -284,7 +299,6 @@ int main(int argc, char** argv) {
     HIP(hipFree(t1));
     HIP(hipFree(dv));
     HIP(hipFree(img));
-    int sets = 0;
     for (uint32_t flags : {0u, (uint32_t)SDFV_COMM_HALO2}) {
         unsigned char id[SDFV_COMM_ID_BYTES];
         SDFV(sdfv_slab_comm_unique_id(id));
@@ -293,11 +307,12 @@ int main(int argc, char** argv) {
         for (auto& t : ranks) t.join();
         sets += 1;
     }
+    }
     if (g_failures.load() != 0) {
         printf("FAILED: %d mismatches over %d communicator sets of %d ranks\n", g_failures.load(), sets, world);
         return 1;
     }
-    printf("ok %d ranks x %d communicator sets (one / two upper ghost slices) on one device over the mock RCCL: fill steps, halo, "
-           "all-gather, both gathers, sharded march (%zu hit pixels)\n", world, sets, hits);
+    printf("ok %d ranks x %d communicator sets (two geometries; one / two upper ghost slices) on one device over the mock RCCL: fill steps "
+           "in four forms, halo, all-gather, both gathers, sharded march (%zu hit pixels in the last reference frame)\n", world, sets, hits);
     return 0;
 }
