@@ -331,3 +331,23 @@ print("ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
+
+
+def test_mock_rccl_and_its_driver_compile(tmp_path):
+    """tests/c/mock_rccl.cpp and tests/c/multirank_mock.cpp (the multi-rank paths between different ranks on one GPU) build with
+    g++ against the HIP runtime headers and include/sdfgrid.h, and the mock exports the eleven entry points csrc/slab_comm.hip
+    binds.  (They RUN in tests/test_gpu_multirank.py.)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hip = ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
+    mock = tmp_path / "librccl.so.1"
+    r = subprocess.run(["g++", "-O0", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Werror", *hip,
+                        os.path.join(root, "tests", "c", "mock_rccl.cpp"), "-o", str(mock), "-L/opt/rocm/lib", "-lamdhip64", "-lpthread"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    nm = subprocess.run(["nm", "-D", "--defined-only", str(mock)], capture_output=True, text=True).stdout
+    bound = set(re.findall(r'bind\(r\.handle, "(nccl\w+)"', open(os.path.join(root, "sdf-viewer_amd", "csrc", "slab_comm.hip")).read()))
+    assert len(bound) == 11 and all(f" T {name}\n" in nm for name in bound), (sorted(bound), nm)
+    r = subprocess.run(["g++", "-O0", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", *hip, "-I", os.path.join(root, "include"),
+                        os.path.join(root, "tests", "c", "multirank_mock.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
