@@ -75,9 +75,9 @@ def parse_args():
                          "nccl), torch = torch.distributed P2P ops")
     ap.add_argument("--prewarm-ms", type=float, default=250.0,
                     help="untimed busy period before the warm-up steps of each timed region (device clock ramp)")
-    ap.add_argument("--no-tuned-placement", action="store_true",
-                    help="allocate tex0 and tex1 separately instead of letting sdfv_tune_texture_placement choose the "
-                         "distance between them inside one block")
+    ap.add_argument("--separate-textures", "--no-tuned-placement", dest="separate_textures", action="store_true",
+                    help="allocate tex0 and tex1 separately instead of in one block at SDFViewer::new_voxels' fixed distance "
+                         "(pkg.alloc_textures_placed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the extra 64-camera batch (profiling runs)")
     ap.add_argument("--batch-split", choices=["both", "all", "tiles", "cameras", "rows"], default="all",
@@ -288,6 +288,11 @@ def contract_line(line, full_path):
         c["host_load"] = {k: {"update_ms": v["dense"].get("update_ms"), "load_ms": v["dense"].get("load_ms"),
                               "progressive_load_ms": (v.get("progressive") or {}).get("load_ms")}
                           for k, v in h.items() if isinstance(v, dict) and isinstance(v.get("dense"), dict)}
+    ing = line.get("ingest")
+    if isinstance(ing, dict) and isinstance(ing.get("whole_load"), dict):
+        c["ingest"] = {"Mvoxels_per_s": ing["whole_load"].get("Mvoxels_per_s"), "threads": ing.get("threads"),
+                       "one_thread": (ing.get("whole_load_1_thread") or {}).get("Mvoxels_per_s"),
+                       "worst_30ms_call": (ing.get("frame_loop_30ms") or {}).get("worst_call_ms")}
     p = line.get("progressive")
     if isinstance(p, dict):
         c["progressive"] = {side: {name: [case.get("ms"), case.get("frac")] for name, case in cases.items()
@@ -315,7 +320,7 @@ def contract_line(line, full_path):
     c["full"] = full_path
     c = _finite(c)
     # the limit is part of the contract: drop the optional blocks, least important first, should the line ever outgrow it
-    for drop in ("progressive", "halo_loopback", "host_load", "batch_raymarch", "roofline_raymarch", "box"):
+    for drop in ("progressive", "halo_loopback", "ingest", "host_load", "batch_raymarch", "roofline_raymarch", "box"):
         if len(json.dumps(c, separators=(",", ":"), allow_nan=False)) < CONTRACT_LIMIT:
             break
         c.pop(drop, None)
@@ -499,7 +504,7 @@ def run(redirect):
 
     # ---------------- the grid: side^3 voxels per rank, z-slab of the weak-scaled global grid ----------------
     gdims = par.weak_scaling_dims(side, world, args.weak_geometry)
-    slab = par.alloc_slab(gdims, rank, world, device, pkg=None if args.no_tuned_placement else pkg, periodic=loopback)
+    slab = par.alloc_slab(gdims, rank, world, device, pkg=None if args.separate_textures else pkg, periodic=loopback)
     grid = pkg.make_grid(gdims, z_begin=slab.z_begin, z_end=slab.z_end)
     owned0, owned1 = slab.owned0, slab.owned1
     voxels_per_rank = pkg.slab_voxels(grid)
@@ -760,7 +765,7 @@ def run(redirect):
     line["raymarch_kernel_ms"] = round(march_ev, 4)
     line["incomplete"] = None  # True only when the watchdog had to print the line for an extra that hung
     line["box"] = box_stamp(torch, device)
-    for key in ("batch_raymarch", "target_512", "progressive", "host_load", "halo_loopback", "config4"):
+    for key in ("batch_raymarch", "target_512", "progressive", "host_load", "ingest", "halo_loopback", "config4"):
         line[key] = None
     PARTIAL["line"], PARTIAL["since"] = line, time.monotonic()
 

@@ -78,12 +78,10 @@ def timed_region(fn, steps, torch, dist, world, device):
 
 def placement_note(args, slab):
     """How tex0 and tex1 were placed (the dense fill's two store streams run up to ~10 % faster or slower with it)."""
-    if args.no_tuned_placement:
-        return "two separate allocations, not probed"
+    if args.separate_textures:
+        return "two separate allocations"
     gap = slab.tex1.data_ptr() - slab.tex0.data_ptr() - slab.tex0.numel() * 4
-    if 0 <= gap <= (64 << 10):
-        return f"placement probe kept: one block, tex1 {gap} B after tex0's end (sdfv_tune_texture_placement)"
-    return "placement probe kept: two separate allocations (faster here than the block candidates)"
+    return f"one block, tex1 {gap} B after tex0's end: SDFViewer::new_voxels' fixed placement for this texture size (no probe)"
 
 
 def load_traffic(workload_key, name="fill_pmc_traffic.json"):

@@ -63,19 +63,42 @@ def host_load_block(sides):
     exe = os.path.join(ROOT, "sdf-viewer_amd", "sdf-viewer-host-bench")
     out = {}
     for side in sides:
-        for tuned in (False, True):
-            key = f"{side}" + ("_tuned" if tuned else "")
-            try:
-                r = subprocess.run([exe, "--side", str(side), "--reps", "20"] + (["--tune"] if tuned else []), capture_output=True,
-                                   text=True, timeout=300)
-                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                out[key] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": (r.stderr or r.stdout)[-300:]}
-            except Exception as e:  # noqa: BLE001 -- an extra, never fatal
-                out[key] = {"error": f"{type(e).__name__}: {e}"}
+        key = f"{side}"
+        try:
+            r = subprocess.run([exe, "--side", str(side), "--reps", "20"], capture_output=True, text=True, timeout=300)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out[key] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:  # noqa: BLE001 -- an extra, never fatal
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
     out["note"] = ("C++ SDFViewer (libsdfviewer_host.so): load_ms = update() to completion + commit() on the GPU (HIP events); dense = "
                    "one update() with the reference's 30 ms budget (the fused fill; new_voxels writes nothing), progressive = one "
                    "LoadingManager pass per update() (2 passes: whole visited rows, then the dense kernel); commit_ms = the march "
-                   "volume the following frames read; *_tuned = after SDFViewer::tune() (explicit, tune_ms, once per size)")
+                   "volume the following frames read")
+    return out
+
+
+def ingest_block(side=128):
+    """VERDICT r05 next 1: SDFViewer::update for an SDF only the HOST can sample (any `impl SDFSurface`, scene/sdf/mod.rs:128):
+    tests/c/gyroid_provider.c (a library behind include/sdf_provider.h's per-point ABI) built here with gcc, loaded through
+    ProviderSDF, loaded into a side^3-bounded grid by sdf-viewer-host-bench --ingest.  CPU-bound by construction (one malloc'ing
+    FFI call per voxel, like the reference's wasm provider): the figure is host sampling throughput, the device's share (H2D of 32 B
+    per voxel + sdfv_pack_samples) hides behind it."""
+    import tempfile
+    exe = os.path.join(ROOT, "sdf-viewer_amd", "sdf-viewer-host-bench")
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            lib = os.path.join(tmp, "libgyroid_provider.so")
+            subprocess.run(["gcc", "-std=c11", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-I",
+                            os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "gyroid_provider.c"), "-o", lib, "-lm"],
+                           check=True, capture_output=True, timeout=120)
+            r = subprocess.run([exe, "--ingest", lib, "--side", str(side), "--passes", "2"], capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        out = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": (r.stderr or r.stdout)[-300:]}
+    except Exception as e:  # noqa: BLE001 -- an extra, never fatal
+        out = {"error": f"{type(e).__name__}: {e}"}
+    out["note"] = ("host-sampled SDF (gyroid behind the per-point ABI) -> pinned H2D -> sdfv_pack_samples; whole_load = one update() with "
+                   "an unlimited budget on `threads` host threads, frame_loop_30ms = the reference's frame loop (30 ms per call; "
+                   "worst_call_ms = the longest call), whole_load_1_thread = the reference's single-threaded loop; CPU-bound")
     return out
 
 
@@ -260,7 +283,7 @@ def run_extras(c):
                 if side == 512:
                     t_slab, t_grid = slab, grid
                 else:
-                    t_slab = par.alloc_slab((512, 512, 512), 0, 1, device, pkg=None if args.no_tuned_placement else pkg)
+                    t_slab = par.alloc_slab((512, 512, 512), 0, 1, device, pkg=None if args.separate_textures else pkg)
                     t_grid = pkg.make_grid((512, 512, 512))
                 t_dist = torch.empty((512, 512, 512), dtype=torch.float32, device=device)
                 ts = max(5, min(K, 20))
@@ -328,6 +351,7 @@ def run_extras(c):
     if not multi and not args.no_batch and not args.no_host_load:
         host_load = host_load_block(sorted({side, 512}))
     line["host_load"] = host_load
+    line["ingest"] = ingest_block() if (not multi and not args.no_batch and not args.no_host_load) else None
     progressive = None
     if not multi and not args.no_batch and not args.no_progressive:
         try:
@@ -475,7 +499,7 @@ def run_extras(c):
             try:
                 cside = args.config4_side
                 cdims = par.weak_scaling_dims(cside, world, "cube")
-                cslab = par.alloc_slab(cdims, rank, world, device, pkg=None if args.no_tuned_placement else pkg, periodic=loopback)
+                cslab = par.alloc_slab(cdims, rank, world, device, pkg=None if args.separate_textures else pkg, periodic=loopback)
                 cgrid = pkg.make_grid(cdims, z_begin=cslab.z_begin, z_end=cslab.z_end)
                 cdist = torch.empty(tuple(cslab.tex0.shape[:3]), dtype=torch.float32, device=device)
                 c_own = cdist[cslab.ghost_lo:cslab.ghost_lo + (cslab.z_end - cslab.z_begin)]

@@ -80,6 +80,11 @@ void init(void);                                                     /* demo/ffi
 /* extension: (re)build the registry from the demo's CLI flags, e.g. {"-t","normal","-s","0.9"}; 0 on success */
 int  init_with_args(int argc, const char *const *argv);
 
+/* extension, OPTIONAL for any provider: how many host threads may call sample() at once (a provider whose registry is
+ * thread-local, like ffi.rs:15-17's, does not export it or -- libsdfdemo_provider.so -- answers 1).  The host mirror's SDFViewer::update
+ * samples a host-only SDF on that many threads (sdf-viewer_amd/host/provider_sdf.hpp, sdf_viewer_ingest.cpp). */
+uint32_t sample_concurrency(void);
+
 SDFBoundingBox *bounding_box(uint32_t sdf_id);                       /* ffi.rs:42-50 */
 void bounding_box_free(SDFBoundingBox *ret);                         /* ffi.rs:52-55 */
 SDFSample *sample(uint32_t sdf_id, SDFVec3 p, bool distance_only);   /* ffi.rs:57-65 */

@@ -38,7 +38,9 @@ extern "C" {
  * the positional forms of version 3 are header-only wrappers (source compatible, no longer exported).  Added SDFV_PASS_VIRGIN_GRID,
  * sdfv_grid_init_unvisited, SDFV_OPT_EXT_SRGB_QUANT, SDFV_OPT_PASS_INDEX_LIMIT, sdfv_bands_scatter and the sdfv_comm_* collectives.
  * The descriptor is size-prefixed: further layouts / outputs are new fields, not new versions. */
-#define SDFV_ABI_VERSION 4
+/* 5 (round 6): added sdfv_pack_samples (the device half of SDFViewer::update for host-sampled SDFs); removed
+ * sdfv_tune_texture_placement / SDFV_PLACEMENT_SLACK (a probe that never beat the fixed placement in the driver's runs). */
+#define SDFV_ABI_VERSION 5
 
 typedef enum sdfv_status {
     SDFV_OK = 0,
@@ -255,21 +257,6 @@ int sdfv_grid_init_unvisited_ex(const sdfv_grid *grid, uint32_t step, float *tex
 int sdfv_fill_grid(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid,
                    float *tex0, float *tex1, void *stream);
 
-/* Placement of the two textures inside ONE caller-owned device block.  The dense fill advances two store streams in
- * lockstep (tex0 and tex1, the same offset into each); how fast the memory system takes them depends on the distance
- * between the two bases -- reproducibly, by up to 12 % (256^3: tex1 starting 0 / 4 / 12 KiB after tex0's end:
- * 0.0886 / 0.0826 / 0.0783 ms; 512^3 prefers 0) -- in a way that follows the device's address hashing, not a rule a
- * caller could know.  This helper measures: it times the dense fill of `grid` (default demo parameters, a handful of
- * launches per candidate) for a few small skews and returns the byte offsets of the fastest placement.  On entry
- * *tex1_offset names the INCUMBENT -- the placement the caller would use without the probe (a value that is no placement
- * inside the block's slack means "tex1 right after tex0") -- which only gives way to a candidate that beats it by 2 % in both
- * of the probe's rounds: the result is never a coin toss between equals.  `block`:
- * DEVICE, 16-byte aligned, at least 2 * texture_bytes + SDFV_PLACEMENT_SLACK bytes; its contents are overwritten.
- * Synchronises `stream`.  Optional: any 16-byte aligned pair of pointers is a valid placement. */
-#define SDFV_PLACEMENT_SLACK (64u << 10)
-int sdfv_tune_texture_placement(const sdfv_grid *grid, void *block, size_t block_bytes, size_t *tex0_offset,
-                                size_t *tex1_offset, void *stream);
-
 /* sdfv_fill_grid and sdfv_commit_distance in ONE pass: the dense fill also writes the compact distance volume
  * (dist: DEVICE, one float per voxel of the slab, or NULL = plain sdfv_fill_grid).  +4 B/voxel of stores instead of a
  * second pass that re-reads tex0 (SDFViewer::update to completion followed by SDFViewer::commit, scene/sdf/mod.rs:128-239). */
@@ -323,6 +310,26 @@ int sdfv_fill_grid_commit(const sdfv_demo_params *params, uint32_t sdf_id, const
 #define SDFV_PASS_VOLUME_INTERLEAVED 8u
 int sdfv_fill_grid_pass_ex(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid, uint32_t step,
                            const float *changed_box, float *tex0, float *tex1, float *dist, uint32_t flags, void *stream);
+
+/* ---- ingest: SDFViewer::update for an SDF that only the HOST can sample (any `impl SDFSurface`: a wasm / FFI provider,
+ * src/sdf/wasm/native.rs:188-217, src/sdf/ffi.rs:57-65) ----
+ * The host evaluates SDFSurface::sample(pos, false) for the voxels its LoadingManager visits and update_required lets through
+ * (scene/sdf/mod.rs:173-193) and hands the RAW 28-byte records over; everything update() does with a sample afterwards
+ * (scene/sdf/mod.rs:196-208: 0.1 + distance clamped to [0, 1], an all-zero colour replaced by 0.5 grey, Srgba::from +
+ * to_linear_srgb, occlusion <= 0 -> 1) runs on the device, with the packing code of the fill kernels, bit for bit.
+ *   samples     DEVICE, n records (4-byte aligned)
+ *   indices     DEVICE, n uint32, or NULL: record i belongs to the voxel with flat index index_base + indices[i] (NULL: index_base
+ *               + i, a contiguous run) of the SLAB the texture pointers address -- flat = ((z - z_begin) * H + y) * W + x
+ *               (scene/sdf/mod.rs:177).  The indices of one call must be distinct (two records for one voxel race).  A record
+ *               addressed beyond the slab's voxels is skipped: a host may mark records it does not want stored that way
+ *   tex0, tex1  DEVICE, the slab's textures; tex0 is written whole, tex1 .rgb only -- .a keeps what the grid holds (the
+ *               reference never writes it, scene/sdf/mod.rs:205-208), so the textures must be initialised (sdfv_grid_init, a
+ *               fill, or sdfv_grid_init_unvisited for a virgin grid)
+ *   dist        DEVICE or NULL: the compact distance volume, kept equal to tex0.r
+ *   flags       SDFV_PASS_VOLUME_INTERLEAVED (the layout of dist) or 0
+ * SDFV_OPT_EXT_SRGB_QUANT applies.  Enqueues one launch; `samples` / `indices` may be reused once it has run. */
+int sdfv_pack_samples(const sdfv_grid *grid, uint64_t index_base, const uint32_t *indices, const sdfv_sample *samples, size_t n,
+                      float *tex0, float *tex1, float *dist, uint32_t flags, void *stream);
 
 /* ---- batched point sampling (the "Batched sampling" TODO, src/sdf/mod.rs:39) ---- */
 /* points: DEVICE, n x 3 floats.  out: DEVICE, n x sdfv_sample.  SDFSurface::sample(p, distance_only). */

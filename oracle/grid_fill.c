@@ -195,11 +195,11 @@ uint64_t or_lm_passes_left(const OrLoadingManager *m) {
     return (uint64_t)log2f((float)m->step_size) + 1;
 }
 
-/* scene/sdf/mod.rs:173-215 */
-uint64_t or_viewer_update(const OrDemoParams *prm, uint32_t sdf_id, const uint32_t dims[3],
-                          const float bb_min[3], const float bb_max[3],
-                          OrLoadingManager *lm, const float *cb, uint64_t max_iterations,
-                          float *tex0, float *tex1) {
+/* scene/sdf/mod.rs:173-215 with `sdf` ANY SDFSurface: sample() is the caller's function */
+uint64_t or_viewer_update_fn(or_sample_fn sample, void *user, const uint32_t dims[3],
+                             const float bb_min[3], const float bb_max[3],
+                             OrLoadingManager *lm, const float *cb, uint64_t max_iterations,
+                             float *tex0, float *tex1) {
     const float air = or_air_dist();
     uint64_t start = lm->total_iterations;
     while (lm->total_iterations - start < max_iterations) {
@@ -217,9 +217,26 @@ uint64_t or_viewer_update(const OrDemoParams *prm, uint32_t sdf_id, const uint32
         }
         if (update_required) {
             OrSample s;
-            or_sample(prm, sdf_id, pos, 0, &s);
+            sample(user, pos, 0, &s);
             or_pack_sample(&s, tex0 + flat * 4, tex1 + flat * 4);
         }
     }
     return lm->total_iterations - start;
+}
+
+/* ... with `sdf` the demo */
+typedef struct {
+    const OrDemoParams *prm;
+    uint32_t sdf_id;
+} DemoSdf;
+static void demo_sample_fn(void *user, const float p[3], int distance_only, OrSample *out) {
+    const DemoSdf *d = (const DemoSdf *)user;
+    or_sample(d->prm, d->sdf_id, p, distance_only, out);
+}
+uint64_t or_viewer_update(const OrDemoParams *prm, uint32_t sdf_id, const uint32_t dims[3],
+                          const float bb_min[3], const float bb_max[3],
+                          OrLoadingManager *lm, const float *cb, uint64_t max_iterations,
+                          float *tex0, float *tex1) {
+    DemoSdf d = {prm, sdf_id};
+    return or_viewer_update_fn(demo_sample_fn, &d, dims, bb_min, bb_max, lm, cb, max_iterations, tex0, tex1);
 }

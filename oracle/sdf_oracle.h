@@ -135,6 +135,14 @@ uint64_t or_viewer_update(const OrDemoParams *prm, uint32_t sdf_id, const uint32
                           OrLoadingManager *lm, const float *changed_box /* 6 floats or NULL */,
                           uint64_t max_iterations, float *tex0, float *tex1);
 
+/* The same loop over ANY SDFSurface (`sdf: impl SDFSurface`, scene/sdf/mod.rs:128): sample() is a callback with the trait
+ * method's meaning (src/sdf/mod.rs:43).  The checker of the product's ingest path (host-sampled SDFs). */
+typedef void (*or_sample_fn)(void *user, const float p[3], int distance_only, OrSample *out);
+uint64_t or_viewer_update_fn(or_sample_fn sample, void *user, const uint32_t dims[3],
+                             const float bb_min[3], const float bb_max[3],
+                             OrLoadingManager *lm, const float *changed_box /* 6 floats or NULL */,
+                             uint64_t max_iterations, float *tex0, float *tex1);
+
 /* ---- raymarch ---- */
 /* three-d Camera::new_perspective restated as a POD: the library and the oracle are handed the same
  * block, so the basis/tan/matrix arithmetic is not part of the parity surface. */

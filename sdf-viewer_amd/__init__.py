@@ -69,42 +69,6 @@ def slab_voxels(grid):
     return int(grid.dims[0]) * int(grid.dims[1]) * (int(grid.z_end) - int(grid.z_begin))
 
 
-def _fill_rate_probe(grid, pairs, rounds=2):
-    """ms per dense fill (default demo parameters, first slices only) of every (tex0, tex1) pair, candidates
-    interleaved over `rounds` so that clock drift hits them alike."""
-    probe = Grid.from_buffer_copy(grid)
-    slice_voxels = int(grid.dims[0]) * int(grid.dims[1])
-    max_slices = max(1, -(-(16 << 20) // max(slice_voxels, 1)))
-    if int(probe.z_end) - int(probe.z_begin) > max_slices:
-        probe.z_end = int(probe.z_begin) + max_slices
-    prm = default_params()
-    n_slices = int(probe.z_end) - int(probe.z_begin)
-
-    def run(t0, t1, n):
-        for _ in range(n):
-            check(lib.sdfv_fill_grid(C.byref(prm), SDF_DEMO, C.byref(probe), _dev_ptr(t0[:n_slices], "tex0"),
-                                     _dev_ptr(t1[:n_slices], "tex1"), _stream_ptr()))
-
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    run(*pairs[0], 8)
-    e0.record()
-    run(*pairs[0], 8)
-    e1.record()
-    torch.cuda.synchronize()
-    per = max(e0.elapsed_time(e1) / 8, 1e-3)
-    n = int(min(64, max(8, 3.0 / per)))
-    total = [0.0] * len(pairs)
-    for _ in range(rounds):
-        for k, (t0, t1) in enumerate(pairs):
-            run(t0, t1, 3)
-            e0.record()
-            run(t0, t1, n)
-            e1.record()
-            torch.cuda.synchronize()
-            total[k] += e0.elapsed_time(e1) / n
-    return [t / rounds for t in total]
-
-
 def default_texture_skew(texture_bytes):
     """host/sdf_viewer.cpp's untuned placement: bytes between the end of tex0 and the start of tex1 in ONE block that MI355X has
     shown to be best, reproducibly, for the texture sizes that matter (EXPERIMENTS R4.1: the fill's rate is periodic in that
@@ -122,42 +86,11 @@ def alloc_textures_placed(grid, device="cuda"):
     return block[pad:pad + n].view(shape), block[pad + n + skew:pad + 2 * n + skew].view(shape)
 
 
-def alloc_textures(grid, device="cuda", tuned=False, attempts=4):
-    """Two RGBA32F textures for the slab described by `grid` (uninitialised device memory).
-
-    tuned=True: WHERE the two textures sit changes the dense fill's store rate by up to ~10 % (two store streams in
-    lockstep; it depends on the distance between the bases and on where the allocations landed physically, DESIGN.md
-    3.1), so a few placements are tried and the fastest is kept: one block with the distance chosen by
-    sdfv_tune_texture_placement, plus up to `attempts` - 1 pairs of separate allocations (as many as fit in a quarter
-    of the free memory).  The probe overwrites the textures' contents."""
+def alloc_textures(grid, device="cuda"):
+    """Two RGBA32F textures for the slab described by `grid` (uninitialised device memory), two separate allocations
+    (alloc_textures_placed: one block, the distance between them the one MI355X fills fastest)."""
     shape = (int(grid.z_end) - int(grid.z_begin), int(grid.dims[1]), int(grid.dims[0]), 4)
-    n = shape[0] * shape[1] * shape[2] * 4
-
-    def separate():
-        return (torch.empty(shape, dtype=torch.float32, device=device),
-                torch.empty(shape, dtype=torch.float32, device=device))
-
-    if not tuned or n == 0:
-        return separate()
-    with torch.cuda.device(torch.device(device)):
-        block = torch.empty(2 * n + _capi.PLACEMENT_SLACK // 4, dtype=torch.float32, device=device)
-        o0, o1 = C.c_size_t(0), C.c_size_t(n * 4)
-        # a failed probe is not fatal: the untuned placement (tex1 right after tex0) is as valid as any
-        lib.sdfv_tune_texture_placement(C.byref(grid), C.c_void_p(block.data_ptr()), block.numel() * 4,
-                                        C.byref(o0), C.byref(o1), _stream_ptr())
-        a, b = o0.value // 4, o1.value // 4
-        pairs = [(block[a:a + n].view(shape), block[b:b + n].view(shape))]
-        free = torch.cuda.mem_get_info()[0]
-        extra = int(min(max(attempts - 1, 0), (free // 4) // max(8 * n, 1)))
-        try:
-            for _ in range(extra):
-                pairs.append(separate())
-            if len(pairs) > 1:
-                ms = _fill_rate_probe(grid, pairs)
-                return pairs[min(range(len(pairs)), key=lambda k: ms[k])]
-        except (RuntimeError, SdfvError):
-            pass
-        return pairs[0]
+    return (torch.empty(shape, dtype=torch.float32, device=device), torch.empty(shape, dtype=torch.float32, device=device))
 
 
 def _stream_ptr(stream=None):
@@ -201,6 +134,18 @@ def fill_grid_pass(params, grid, step, tex0, tex1, changed_box=None, sdf_id=SDF_
     check(lib.sdfv_fill_grid_pass_ex(C.byref(params), sdf_id, C.byref(grid), int(step), box, _dev_ptr(tex0, "tex0"),
                                      _dev_ptr(tex1, "tex1"), None if dist is None else _dev_ptr(dist, "dist"), int(flags),
                                      _stream_ptr(stream)))
+
+
+def pack_samples(grid, samples, tex0, tex1, indices=None, index_base=0, dist=None, flags=0, stream=None):
+    """sdfv_pack_samples: SDFViewer::update's packing (scene/sdf/mod.rs:196-208) of host-taken samples, on the device.
+    samples: CUDA float32 [n, 7] (SDFSample records); indices: CUDA int32/uint32-as-int32 [n] offsets from index_base, or None
+    (a contiguous run from index_base)."""
+    assert samples.is_cuda and samples.dtype == torch.float32 and samples.is_contiguous() and samples.shape[-1] == 7
+    n = samples.numel() // 7
+    assert indices is None or (indices.is_cuda and indices.is_contiguous() and indices.element_size() == 4 and indices.numel() == n)
+    check(lib.sdfv_pack_samples(C.byref(grid), int(index_base), None if indices is None else C.c_void_p(indices.data_ptr()),
+                                C.c_void_p(samples.data_ptr()), n, _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1"),
+                                None if dist is None else _dev_ptr(dist, "dist"), int(flags), _stream_ptr(stream)))
 
 
 def sample_points(params, points, distance_only=False, sdf_id=SDF_DEMO, stream=None):

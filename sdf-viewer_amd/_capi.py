@@ -98,8 +98,8 @@ PROTOTYPES = {
     "sdfv_grid_init_unvisited_ex": (C.c_int, [C.POINTER(Grid), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "sdfv_fill_grid": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
-    "sdfv_tune_texture_placement": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
-                                              C.POINTER(C.c_size_t), C.c_void_p]),
+    "sdfv_pack_samples": (C.c_int, [C.POINTER(Grid), C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_uint32, C.c_void_p]),
     "sdfv_fill_grid_commit": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
     "sdfv_fill_grid_pass_ex": (C.c_int, [C.POINTER(DemoParams), C.c_uint32, C.POINTER(Grid), C.c_uint32,
@@ -199,7 +199,6 @@ RM_NO_FAST_INDEX, RM_NO_POW2_EXTENT, RM_NO_POW2_SIZE, RM_NO_SYMMETRIC, RM_NO_ASM
 STEP_SIDE_BOUNDARY, STEP_UNPACKED, STEP_START_EVENT, STEP_DEFER_JOIN = 3, 4, 8, 16
 PASS_FRESH_GRID, PASS_SAME_LOAD, PASS_VIRGIN_GRID, PASS_VOLUME_INTERLEAVED = 1, 2, 4, 8
 FILL_FORM = {"auto": 0, "rows": 1, "flat": 2}
-PLACEMENT_SLACK = 64 << 10
 COMM_ID_BYTES = 128
 RAY_BUFFER_HEADER_BYTES = 16
 MARCH_MERGE = 1

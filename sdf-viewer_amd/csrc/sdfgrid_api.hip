@@ -16,6 +16,7 @@
 #include "../../include/sdfgrid.h"
 #include "api_internal.h"
 #include "fill_kernels.h"
+#include "ingest_kernels.h"
 #include "mesh_kernels.h"
 #include "points_kernels.h"
 #include "raymarch_kernels.h"
@@ -764,92 +765,6 @@ int sdfv_fill_grid_commit(const sdfv_demo_params* params, uint32_t sdf_id, const
     return SDFV_OK;
 }
 
-int sdfv_tune_texture_placement(const sdfv_grid* grid, void* block, size_t block_bytes, size_t* tex0_offset,
-                                size_t* tex1_offset, void* stream) {
-    if (!tex0_offset || !tex1_offset) return fail(SDFV_ERR_INVALID_ARGUMENT, "offset pointer is NULL");
-    if (int rc = check_grid(grid)) return rc;
-    if (!block || ((uintptr_t)block & 15)) return fail(SDFV_ERR_INVALID_ARGUMENT, "block must be a 16-byte aligned device pointer");
-    const size_t tex_bytes = (size_t)grid->dims[0] * grid->dims[1] * (grid->z_end - grid->z_begin) * 16;
-    // The INCUMBENT: the placement the caller would use without this probe, handed in through *tex1_offset (anything that is not
-    // a placement inside the block's slack counts as "tex1 right after tex0").  It is measured beside the candidates and only
-    // gives way to one that beats it by 2 % in BOTH rounds: between placements that differ by less the probe's own noise
-    // decided (a tuned 512^3 viewer ran 4 % slower than the untuned one in the driver's run).
-    size_t incumbent = *tex1_offset;
-    if (incumbent < tex_bytes || incumbent - tex_bytes >= SDFV_PLACEMENT_SLACK || (incumbent & 15)) incumbent = tex_bytes;
-    *tex0_offset = 0;
-    *tex1_offset = incumbent;
-    if (block_bytes < 2 * tex_bytes + SDFV_PLACEMENT_SLACK)
-        return fail(SDFV_ERR_INVALID_ARGUMENT, "block of %zu bytes is smaller than 2 x %zu + %u", block_bytes, tex_bytes,
-                    SDFV_PLACEMENT_SLACK);
-    if (tex_bytes == 0) return SDFV_OK;
-    if (int rc = need_device()) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    sdfv_demo_params prm;
-    sdfv_demo_params_default(&prm);
-    // What is being measured is how the two streams interact at a given distance between the bases, which is the same
-    // all along the textures: probing the first slices only (at most ~16 M voxels) keeps the probe at tens of
-    // milliseconds for any grid size.
-    sdfv_grid probe = *grid;
-    {
-        const uint64_t slice = (uint64_t)grid->dims[0] * grid->dims[1];
-        const uint64_t max_slices = slice ? ((16ull << 20) + slice - 1) / slice : 1;
-        if ((uint64_t)(probe.z_end - probe.z_begin) > max_slices) probe.z_end = probe.z_begin + (uint32_t)max_slices;
-    }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    SDFV_HIP(hipEventCreate(&e0));
-    hipError_t err = hipEventCreate(&e1);
-    if (err != hipSuccess) {
-        (void)hipEventDestroy(e0);
-        return hip_fail(err, "hipEventCreate");
-    }
-    constexpr int kCandidates = 9;
-    // the rate is periodic in the distance with a period of 16 or 32 KiB (EXPERIMENTS R4.1): the eight residues cover it;
-    // candidate 0 is the incumbent
-    const size_t skews[kCandidates] = {incumbent - tex_bytes, 0, 4096, 8192, 12288, 16384, 20480, 24576, 28672};
-    float round_ms[2][kCandidates] = {{0}};
-    int rc = SDFV_OK;
-    int timed = 8;  // launches per measurement; raised below so that one measurement lasts about 3 ms
-    // Two interleaved rounds over the candidates (drift of the device's clocks then hits all of them alike); the first
-    // measurement of all also warms the device up and sizes the others, and is not counted.
-    for (int round = -1; round < 2 && rc == SDFV_OK && err == hipSuccess; ++round) {
-        for (int c = 0; c < (round < 0 ? 1 : kCandidates) && rc == SDFV_OK && err == hipSuccess; ++c) {
-            float* t0 = reinterpret_cast<float*>(block);
-            float* t1 = reinterpret_cast<float*>(static_cast<char*>(block) + tex_bytes + skews[c]);
-            const int warm = 3;
-            for (int i = 0; i < warm + timed && rc == SDFV_OK; ++i) {
-                if (i == warm) err = hipEventRecord(e0, st);
-                rc = sdfv_fill_grid(&prm, SDFV_SDF_DEMO, &probe, t0, t1, st);
-            }
-            if (rc != SDFV_OK) break;
-            if (err == hipSuccess) err = hipEventRecord(e1, st);
-            if (err == hipSuccess) err = hipEventSynchronize(e1);
-            float ms = 0.0f;
-            if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
-            if (err != hipSuccess) break;
-            if (round < 0) {
-                const float per_launch = ms / (float)timed;
-                if (per_launch > 0.0f) timed = (int)fminf(64.0f, fmaxf(8.0f, 3.0f / per_launch));
-            } else {
-                round_ms[round][c] = ms;
-            }
-        }
-    }
-    if (rc == SDFV_OK && err == hipSuccess) {
-        int best = 0;
-        for (int c = 1; c < kCandidates; ++c) {
-            const bool beats_incumbent = round_ms[0][c] < 0.98f * round_ms[0][0] && round_ms[1][c] < 0.98f * round_ms[1][0];
-            const float total = round_ms[0][c] + round_ms[1][c], best_total = round_ms[0][best] + round_ms[1][best];
-            if (beats_incumbent && (best == 0 || total < best_total)) best = c;
-        }
-        *tex1_offset = tex_bytes + skews[best];
-    }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (rc != SDFV_OK) return rc;
-    if (err != hipSuccess) return hip_fail(err, "placement probe");
-    return SDFV_OK;
-}
-
 int sdfv_fill_grid(const sdfv_demo_params* params, uint32_t sdf_id, const sdfv_grid* grid, float* tex0, float* tex1,
                    void* stream) {
     return sdfv_fill_grid_commit(params, sdf_id, grid, tex0, tex1, nullptr, stream);
@@ -910,6 +825,38 @@ int sdfv_fill_grid_pass_ex(const sdfv_demo_params* params, uint32_t sdf_id, cons
     p.no_adaptive = g_options.pass_form == 1 ? 1u : 0u;
     p.all_required = (knowledge != 0 || covers) ? 1u : 0u;
     SDFV_HIP(sdfv::launch_fill_pass(a, p, fill_launch_config(dist != nullptr), (hipStream_t)stream));
+    return SDFV_OK;
+}
+
+int sdfv_pack_samples(const sdfv_grid* grid, uint64_t index_base, const uint32_t* indices, const sdfv_sample* samples, size_t n,
+                      float* tex0, float* tex1, float* dist, uint32_t flags, void* stream) {
+    if (int rc = check_grid(grid)) return rc;
+    if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
+    if (n && !samples) return fail(SDFV_ERR_INVALID_ARGUMENT, "samples is NULL");
+    if (flags & ~SDFV_PASS_VOLUME_INTERLEAVED) return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", flags);
+    if (flags & SDFV_PASS_VOLUME_INTERLEAVED) {
+        if (!dist) return fail(SDFV_ERR_INVALID_ARGUMENT, "SDFV_PASS_VOLUME_INTERLEAVED without a volume");
+        if ((grid->dims[1] & 1u) || ((uintptr_t)dist & 7))
+            return fail(SDFV_ERR_INVALID_ARGUMENT, "the interleaved volume pairs rows: H = %u must be even and the volume 8-byte aligned", grid->dims[1]);
+    }
+    if (int rc = check_texel_alignment(tex0, tex1)) return rc;
+    if (((uintptr_t)dist | (uintptr_t)samples | (uintptr_t)indices) & 3)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "samples, indices and dist must be 4-byte aligned");
+    if (int rc = need_device()) return rc;
+    sdfv::PackArgs a;
+    memset(&a, 0, sizeof(a));
+    a.samples = samples;
+    a.indices = indices;
+    a.index_base = index_base;
+    a.n = n;
+    a.n_voxels = (uint64_t)grid->dims[0] * grid->dims[1] * (grid->z_end - grid->z_begin);
+    a.W = grid->dims[0];
+    a.tex0 = reinterpret_cast<float4*>(tex0);
+    a.tex1 = tex1;
+    a.dist = dist;
+    a.dist_ilv = (flags & SDFV_PASS_VOLUME_INTERLEAVED) ? 1u : 0u;
+    a.srgb_round = g_options.ext_srgb_quant;
+    SDFV_HIP(sdfv::launch_pack_samples(a, (hipStream_t)stream));
     return SDFV_OK;
 }
 

@@ -13,6 +13,7 @@
 
 #include "loading_manager.hpp"
 #include "mesh.hpp"
+#include "provider_sdf.hpp"
 #include "sdf_demo.hpp"
 #include "scene.hpp"
 #include "sdf_viewer.hpp"
@@ -36,6 +37,13 @@ size_t sdfvh_lm_total_iterations(void* m) { return static_cast<LoadingManager*>(
 size_t sdfvh_lm_passes_left(void* m) { return static_cast<LoadingManager*>(m)->passes_left(); }
 size_t sdfvh_lm_step_size(void* m) { return static_cast<LoadingManager*>(m)->step_size(); }
 size_t sdfvh_lm_finish_pass(void* m) { return static_cast<LoadingManager*>(m)->finish_pass(); }
+void sdfvh_lm_advance(void* m, size_t n) { static_cast<LoadingManager*>(m)->advance(n); }
+size_t sdfvh_lm_cursor(void* m) { return static_cast<LoadingManager*>(m)->cursor(); }
+size_t sdfvh_lm_pass_remaining(void* m) { return static_cast<LoadingManager*>(m)->pass_remaining(); }
+void sdfvh_lm_pass_point(void* m, size_t k, size_t out[3]) {
+    auto p = static_cast<LoadingManager*>(m)->pass_point(k);
+    out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
+}
 uint32_t sdfvh_prev_power_of_2(uint32_t x) { return prev_power_of_2(x); }
 
 // ---- SDFDemo (handle = shared_ptr<SDFSurface>*) ----
@@ -51,6 +59,19 @@ void* sdfvh_demo_new(int argc, const char* const* argv, char* err, size_t err_le
         return nullptr;
     }
     return new std::shared_ptr<SDFSurface>(d);
+}
+// ---- ProviderSDF (same handle type) ----
+void* sdfvh_provider_load(const char* path, char* err, size_t err_len) {
+    std::string e;
+    auto p = ProviderSDF::load(path ? path : "", &e);
+    if (!p) {
+        if (err && err_len) {
+            strncpy(err, e.c_str(), err_len - 1);
+            err[err_len - 1] = 0;
+        }
+        return nullptr;
+    }
+    return new std::shared_ptr<SDFSurface>(p);
 }
 void sdfvh_sdf_free(void* h) { delete static_cast<std::shared_ptr<SDFSurface>*>(h); }
 static SDFSurface& S(void* h) { return **static_cast<std::shared_ptr<SDFSurface>*>(h); }
@@ -135,7 +156,11 @@ void* sdfvh_viewer_new_voxels(size_t w, size_t h, size_t d, const float bb[6], s
     BoundingBox b{Vec3{bb[0], bb[1], bb[2]}, Vec3{bb[3], bb[4], bb[5]}};
     return SDFViewer::new_voxels({w, h, d}, b, loading_passes).release();
 }
-int sdfvh_viewer_tune(size_t w, size_t h, size_t d) { return SDFViewer::tune({w, h, d}); }
+// layout: 0 auto, 1 texture order, 2 y-interleaved
+void* sdfvh_viewer_new_voxels_layout(size_t w, size_t h, size_t d, const float bb[6], size_t loading_passes, int layout) {
+    BoundingBox b{Vec3{bb[0], bb[1], bb[2]}, Vec3{bb[3], bb[4], bb[5]}};
+    return SDFViewer::new_voxels({w, h, d}, b, loading_passes, (SDFViewer::VolumeLayout)layout).release();
+}
 void sdfvh_viewer_free(void* v) { delete static_cast<SDFViewer*>(v); }
 static SDFViewer& V(void* v) { return *static_cast<SDFViewer*>(v); }
 void sdfvh_viewer_dims(void* v, uint32_t out[3]) {
@@ -144,6 +169,20 @@ void sdfvh_viewer_dims(void* v, uint32_t out[3]) {
 size_t sdfvh_viewer_update(void* v, void* sdf, double max_delta_seconds) {
     return V(v).update(S(sdf), std::chrono::nanoseconds((long long)(max_delta_seconds * 1e9)));
 }
+// ingest path knobs (0 = keep): host threads, records per transfer buffer
+void sdfvh_viewer_set_ingest(void* v, unsigned host_threads, size_t capacity) {
+    V(v).host_threads = host_threads;
+    if (capacity) V(v).ingest_capacity = capacity;
+}
+size_t sdfvh_viewer_last_error(void* v, char* out, size_t n) {
+    const std::string s = V(v).last_error();
+    if (out && n) {
+        strncpy(out, s.c_str(), n - 1);
+        out[n - 1] = 0;
+    }
+    return s.size();
+}
+unsigned sdfvh_sdf_sample_concurrency(void* h) { return S(h).sample_concurrency(); }
 void sdfvh_viewer_commit(void* v) { V(v).commit(); }
 float sdfvh_viewer_lod(void* v) { return V(v).material.lod_dist_between_samples; }
 size_t sdfvh_viewer_remaining(void* v) { return V(v).loading_mgr.len(); }

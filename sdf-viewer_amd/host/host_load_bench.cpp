@@ -11,6 +11,9 @@
 // Forms: "dense" = one update() with the reference's 30 ms budget (every pass fits: the dense shortcut); "progressive" = one
 // pass per update() call (zero budget), the reference's order of passes.  A fresh viewer per repetition (a load starts from
 // new_voxels), created outside the timed region.
+// --ingest <provider.so>: the same load for an SDF that only the HOST can sample (a library exporting include/sdf_provider.h,
+// loaded through ProviderSDF): update() samples on `threads` host threads and the device packs (sdf_viewer_ingest.cpp).  CPU-bound
+// by construction; reported: whole-load Mvoxels/s with an unlimited budget, and the reference's frame loop (30 ms per call).
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -19,8 +22,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
+#include "provider_sdf.hpp"
 #include "sdf_demo.hpp"
 #include "sdf_viewer.hpp"
 
@@ -76,17 +81,51 @@ static bool one_load(size_t side, size_t passes, bool progressive, hipEvent_t e0
     return v->material.lod_dist_between_samples == 1.0f && !v->material.undefined_rows;
 }
 
+// One load of a host-sampled SDF.  budget_ms < 0: one update() with an unlimited budget; otherwise the frame loop.
+static int ingest_load(SDFSurface& sdf, size_t side, size_t passes, unsigned threads, double budget_ms, const char* key) {
+    auto v = SDFViewer::from_bb(sdf.bounding_box(), side, passes);
+    if (!v) return 1;
+    v->host_threads = threads;
+    hipStream_t st = (hipStream_t)v->stream;
+    size_t iterations = 0, calls = 0;
+    double worst_call_ms = 0.0;
+    const auto budget = budget_ms < 0 ? std::chrono::nanoseconds(std::chrono::hours(24))
+                                      : std::chrono::nanoseconds((long long)(budget_ms * 1e6));
+    const auto t0 = Clock::now();
+    for (;;) {
+        const auto c0 = Clock::now();
+        const size_t n = v->update(sdf, budget);
+        worst_call_ms = std::max(worst_call_ms, std::chrono::duration<double, std::milli>(Clock::now() - c0).count());
+        if (n == 0) break;
+        iterations += n;
+        ++calls;
+    }
+    if (*v->last_error()) {
+        fprintf(stderr, "ingest failed: %s\n", v->last_error());
+        return 1;
+    }
+    v->commit();
+    if (hipStreamSynchronize(st) != hipSuccess) return 1;
+    const double ms = std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
+    const double voxels = (double)v->material.tex_size[0] * v->material.tex_size[1] * v->material.tex_size[2];
+    printf(", \"%s\": {\"load_ms\": %.2f, \"update_calls\": %zu, \"iterations\": %zu, \"worst_call_ms\": %.2f, "
+           "\"Mvoxels_per_s\": %.2f}", key, ms, calls, iterations, worst_call_ms, ms > 0 ? voxels / (ms * 1e-3) / 1e6 : 0.0);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     size_t side = 256, passes = 2;
     int reps = 20;
-    bool tune = false;
+    const char* ingest = nullptr;
+    unsigned threads = 0;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--side") && i + 1 < argc) side = strtoul(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "--passes") && i + 1 < argc) passes = strtoul(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
-        else if (!strcmp(argv[i], "--tune")) tune = true;
+        else if (!strcmp(argv[i], "--ingest") && i + 1 < argc) ingest = argv[++i];
+        else if (!strcmp(argv[i], "--threads") && i + 1 < argc) threads = (unsigned)atoi(argv[++i]);
         else {
-            fprintf(stderr, "usage: %s [--side N] [--passes P] [--reps R] [--tune]\n", argv[0]);
+            fprintf(stderr, "usage: %s [--side N] [--passes P] [--reps R] [--ingest provider.so [--threads T]]\n", argv[0]);
             return 2;
         }
     }
@@ -94,17 +133,27 @@ int main(int argc, char** argv) {
         fprintf(stderr, "no HIP device\n");
         return 3;
     }
-    double tune_ms = 0.0;
-    if (tune) {
-        const auto t0 = Clock::now();
-        if (SDFViewer::tune({side, side, side}) != 0) fprintf(stderr, "tune failed: %s\n", sdfv_last_error());
-        tune_ms = std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
+    if (ingest) {
+        std::string err;
+        auto sdf = ProviderSDF::load(ingest, &err);
+        if (!sdf) {
+            fprintf(stderr, "%s\n", err.c_str());
+            return 2;
+        }
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned used = std::max(1u, std::min(sdf->sample_concurrency(), threads ? threads : hw));
+        printf("{\"side\": %zu, \"loading_passes\": %zu, \"provider\": \"%s\", \"host_cores\": %u, \"threads\": %u", side, passes,
+               sdf->name().c_str(), hw, used);
+        if (ingest_load(*sdf, side, passes, threads, -1.0, "whole_load") != 0) return 1;
+        if (ingest_load(*sdf, side, passes, threads, 30.0, "frame_loop_30ms") != 0) return 1;
+        if (ingest_load(*sdf, side, passes, 1, -1.0, "whole_load_1_thread") != 0) return 1;
+        printf("}\n");
+        return 0;
     }
     hipEvent_t e0, e1, e2;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) return 3;
     const double voxels = (double)side * side * side;
-    printf("{\"side\": %zu, \"loading_passes\": %zu, \"reps\": %d, \"tuned_placement\": %s, \"tune_ms\": %.1f", side, passes, reps,
-           tune ? "true" : "false", tune_ms);
+    printf("{\"side\": %zu, \"loading_passes\": %zu, \"reps\": %d", side, passes, reps);
     for (int form = 0; form < 2; ++form) {
         const bool progressive = form == 1;
         std::vector<double> load, update, commit, create, enqueue;

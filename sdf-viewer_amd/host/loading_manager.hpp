@@ -68,6 +68,22 @@ class LoadingManager {
         return n;
     }
 
+    // ---- runs of a pass (what a host that samples on the CPU hands to its worker threads) ----
+    size_t cursor() const { return cursor_; }
+    // Points of the current pass not handed out yet (0 once loaded).
+    size_t pass_remaining() const { return step_ ? pass_points(step_) - cursor_ : 0; }
+    // The k-th point of the current pass, in next()'s order.
+    Index pass_point(size_t k) const { return lattice_point(step_, k); }
+    // Points per axis of the walk of the current pass (x fastest, then y, then z).
+    Index pass_walk() const { return {walk_points(0, step_), walk_points(1, step_), walk_points(2, step_)}; }
+    // Hand out the next n points of the current pass at once (n <= pass_remaining()): n calls of next().
+    void advance(size_t n) {
+        if (step_ == 0 || n == 0) return;
+        handed_out_ += n;
+        cursor_ += n;
+        if (cursor_ >= pass_points(step_)) next_pass();
+    }
+
     Index limits;   // voxels per axis
     size_t passes;  // as configured (--loading-passes)
 

@@ -129,6 +129,9 @@ int init_with_args(int argc, const char* const* argv) {
     return 0;
 }
 
+// the registry is thread-local (ffi.rs:15-17) and sample() drives the GPU through one-point batches: one thread
+uint32_t sample_concurrency(void) { return 1; }
+
 SDFBoundingBox* bounding_box(uint32_t sdf_id) {
     auto* ret = static_cast<SDFBoundingBox*>(calloc(1, sizeof(SDFBoundingBox)));  // [Vector3::zero(); 2] on failure
     if (auto* sdf = find(sdf_id)) {

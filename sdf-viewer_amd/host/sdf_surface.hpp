@@ -108,6 +108,13 @@ class SDFSurface {
     // ============ OPTIONAL: UTILITIES ============ (defaults.rs:49-56)
     virtual Vec3 normal(Vec3 p, std::optional<float> eps) const;
 
+    // ============ host sampling (not in the reference) ============
+    // How many host threads may call sample() on this object at once.  1 (the default) = only the thread that calls
+    // SDFViewer::update, which is all the reference's trait promises (its SDFs are !Send: Rc<RefCell>, demo/mod.rs:160-198,
+    // and its loop is single-threaded with "TODO: Cross-platform parallel iteration?", scene/sdf/mod.rs:174).  A stateless
+    // SDF answers with the parallelism it tolerates; SDFViewer::update then samples a pass on that many threads.
+    virtual unsigned sample_concurrency() const { return 1; }
+
     // ============ batched / device evaluation (not in the reference) ============
     // nullopt = this SDF can only be sampled point by point on the host (e.g. a wasm provider).
     virtual std::optional<DeviceSDF> device_sdf() const { return std::nullopt; }

@@ -6,8 +6,6 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
-#include <map>
-#include <mutex>
 
 namespace sdfviewer {
 
@@ -99,61 +97,24 @@ int SDFViewerMaterial::render(const Camera& camera, float* rgba_device, sdfv_mar
 
 // ---- SDFViewer ----
 namespace {
-// tune()'s verdicts: (device, bytes per texture) -> distance of tex1 from tex0's end
-std::mutex g_placement_mutex;
-std::map<std::pair<int, size_t>, size_t> g_placement_skew;
-
-int current_device() {
-    int d = -1;
-    if (hipGetDevice(&d) != hipSuccess) {
-        (void)hipGetLastError();
-        return -1;
-    }
-    return d;
-}
-
-// The untuned distance of tex1 from tex0's end (see the constructor).
+// The distance of tex1 from tex0's end (see the constructor).
+constexpr size_t kPlacementSlack = 64u << 10;
 size_t default_skew(size_t texture_bytes) {
     return texture_bytes == ((size_t)1 << 28) ? 12288 : (texture_bytes == ((size_t)1 << 30) ? 20480 : 0);
 }
 }  // namespace
 
-int SDFViewer::tune(std::array<size_t, 3> voxels, void* stream) {
-    const size_t bytes = voxels[0] * voxels[1] * voxels[2] * 16;
-    if (bytes == 0) return 0;
-    DeviceBuffer block(2 * bytes + SDFV_PLACEMENT_SLACK);
-    if (!block.ok()) return SDFV_ERR_HIP;
-    sdfv_grid g{};
-    for (int i = 0; i < 3; ++i) {
-        g.dims[i] = (uint32_t)voxels[i];
-        g.bb_min[i] = -1.0f;  // the probe times the demo's default fill; the box it samples plays no part in the store rate
-        g.bb_max[i] = 1.0f;
-    }
-    g.z_end = g.dims[2];
-    size_t o0 = 0, o1 = bytes + default_skew(bytes);  // the incumbent: what the constructor would use untuned
-    const int rc = sdfv_tune_texture_placement(&g, block.get(), block.bytes(), &o0, &o1, stream);
-    if (rc != 0) return rc;
-    std::lock_guard<std::mutex> lock(g_placement_mutex);
-    g_placement_skew[{current_device(), bytes}] = o1 - o0 - bytes;
-    return 0;
-}
-
 SDFViewer::SDFViewer(std::array<size_t, 3> voxels, const BoundingBox& bb, size_t passes)
     : loading_mgr(voxels, passes), bounding_box(bb) {
     const size_t bytes = voxels[0] * voxels[1] * voxels[2] * 16;
-    // Both textures in one block, tex1 at the distance tune() measured for this size on this device (0 when nobody asked:
-    // allocation only, nothing is launched or waited for here).  If the block cannot be had, two plain allocations do.
-    // Untuned default: what MI355X boxes have shown reproducibly since round 1 for the texture sizes that matter (the fill's
-    // rate is periodic in the distance between the textures, EXPERIMENTS R4.1, profiles/r04_place_width.json): textures of
-    // 256 MiB (256^3 and every other shape of that size) run 6-8 % faster with tex1 12 KiB after tex0's end, textures of 1 GiB
-    // with 20 KiB, 4 GiB (512^3) with none.  Anything else: none.  tune() replaces the guess by a measurement.
-    size_t skew = default_skew(bytes);
-    {
-        std::lock_guard<std::mutex> lock(g_placement_mutex);
-        const auto it = g_placement_skew.find({current_device(), bytes});
-        if (it != g_placement_skew.end()) skew = it->second;
-    }
-    block_ = std::make_shared<DeviceBuffer>(2 * bytes + SDFV_PLACEMENT_SLACK);
+    // Both textures in one block (allocation only, nothing is launched or waited for here).  If the block cannot be had, two
+    // plain allocations do.  The distance between them: what MI355X boxes have shown reproducibly since round 1 for the
+    // texture sizes that matter (the fill's rate is periodic in the distance between the textures, EXPERIMENTS R4.1,
+    // profiles/r04_place_width.json): textures of 256 MiB (256^3 and every other shape of that size) run 6-8 % faster with
+    // tex1 12 KiB after tex0's end, textures of 1 GiB with 20 KiB, 4 GiB (512^3) with none.  Anything else: none.  (Rounds 3-5
+    // also shipped a run-time probe, SDFViewer::tune(): in two driver runs it cost 100 ms and never beat these constants.)
+    const size_t skew = default_skew(bytes);
+    block_ = std::make_shared<DeviceBuffer>(2 * bytes + kPlacementSlack);
     if (bytes > 0 && block_->ok()) {
         material.tex0 = std::make_shared<DeviceBuffer>(static_cast<char*>(block_->get()), bytes);
         material.tex1 = std::make_shared<DeviceBuffer>(static_cast<char*>(block_->get()) + bytes + skew, bytes);
@@ -175,7 +136,7 @@ std::unique_ptr<SDFViewer> SDFViewer::from_bb(const BoundingBox& bb, size_t max_
 }
 
 std::unique_ptr<SDFViewer> SDFViewer::new_voxels(std::array<size_t, 3> voxels, const BoundingBox& bb,
-                                                 size_t loading_passes) {
+                                                 size_t loading_passes, VolumeLayout layout) {
     std::unique_ptr<SDFViewer> v(new SDFViewer(voxels, bb, loading_passes));
     if (!v->material.tex0->ok() || !v->material.tex1->ok()) return nullptr;
     // The reference fills both textures with [AIR_DIST; 4] here (:76-77).  This grid is VIRGIN instead: that state is
@@ -191,10 +152,13 @@ std::unique_ptr<SDFViewer> SDFViewer::new_voxels(std::array<size_t, 3> voxels, c
     // fills and passes of THIS viewer write the volume in that layout from the start, so a load ends with the march's volume
     // in place and commit() builds nothing (512^3: 0.70 + 0.20 ms -> 0.70).  Smaller cubic grids keep the plain volume and
     // let commit() derive the pair volume from it.
-    if (v->dist_synced_) {
+    if (v->dist_synced_ && layout == VolumeLayout::Auto) {
         const sdfv_grid g = v->grid();
         uint32_t kind = SDFV_MARCH_VOLUME_NONE;
         if (sdfv_march_volume_advice(&g, &kind) == 0 && kind == SDFV_MARCH_VOLUME_INTERLEAVED) v->material.dist_interleaved = true;
+    } else if (v->dist_synced_ && layout == VolumeLayout::Interleaved) {
+        if (voxels[1] & 1) return nullptr;  // rows are paired
+        v->material.dist_interleaved = true;
     }
     return v;
 }
@@ -239,10 +203,8 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
 
     const size_t start_iter = loading_mgr.total_iterations();
     const auto dev = sdf.device_sdf();
-    if (!dev) {
-        error_ = "this SDFSurface cannot be evaluated on the device (no device_sdf())";
-        return 0;
-    }
+    if (!dev) return update_host(sdf, max_delta_time);  // any `impl SDFSurface`: sampled on the host, packed on the device
+    host_mirror_valid_ = false;  // (whatever runs below rewrites tex0.r on the device)
     const sdfv_grid g = grid();
     const auto start_time = std::chrono::steady_clock::now();
     // Fresh grid, nothing pending, and a budget that lets every pass be enqueued in this call anyway (a pass is

@@ -97,20 +97,23 @@ class SDFViewer {
     // scene/sdf/mod.rs:46-72
     static std::unique_ptr<SDFViewer> from_bb(const BoundingBox& bb, size_t max_voxels_side, size_t loading_passes);
     // scene/sdf/mod.rs:75-101 (allocates both textures on the device and fills them with AIR_DIST)
+    // `layout`: how the 4 B/voxel distance volume next to the textures is laid out.  Auto = what the march gathers fastest
+    // from for this grid (sdfv_march_volume_advice: y-interleaved beyond the last-level cache, texture order below); the
+    // other two pin it (Interleaved needs an even height) -- same textures, same frames; A/B runs and tests.
+    enum class VolumeLayout { Auto, Plain, Interleaved };
     static std::unique_ptr<SDFViewer> new_voxels(std::array<size_t, 3> voxels, const BoundingBox& bb,
-                                                 size_t loading_passes);
-
-    // Texture placement.  The dense fill's two store streams run up to 12 % apart with the distance between the texture
-    // bases (include/sdfgrid.h, sdfv_tune_texture_placement).  tune() MEASURES it for grids of this size on the current
-    // device -- tens of milliseconds, blocking -- and remembers the verdict process-wide; viewers created afterwards for a
-    // grid of the same byte size on that device are placed accordingly.  Never called implicitly: from_bb / new_voxels
-    // allocate and return (untuned placement: tex1 right after tex0, or at the small distance MI355X has shown to be best
-    // for textures of exactly 256 MiB / 1 GiB -- sdf_viewer.cpp).  Returns 0, or the library's error code.
-    static int tune(std::array<size_t, 3> voxels, void* stream = nullptr);
+                                                 size_t loading_passes, VolumeLayout layout = VolumeLayout::Auto);
 
     // scene/sdf/mod.rs:128-217.  Returns the number of LoadingManager iterations consumed, like the reference.
-    // The time budget is checked between passes (the GPU does a whole pass per launch).
+    // An SDF with a device form (device_sdf()): the time budget is checked between passes (the GPU does a whole pass per
+    // launch).  ANY other SDFSurface (a ProviderSDF, an application's own class): the ingest path -- sample() runs on the
+    // host, on sample_concurrency() threads, run after run of the LoadingManager's order until the budget is spent (at least
+    // one voxel, like the reference); the raw 28-byte samples go to the device through pinned double buffers and
+    // sdfv_pack_samples does update()'s packing there.  update_required is decided on a host mirror of tex0.r.
     size_t update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_time);
+    // Ingest path knobs: host threads (0 = what the SDF allows, at most the machine's), records per transfer buffer.
+    unsigned host_threads = 0;
+    size_t ingest_capacity = (size_t)1 << 18;
     // scene/sdf/mod.rs:220-239
     void commit();
     // lod_dist_between_samples = 2^passes_left (scene/sdf/mod.rs:226), published with the data it describes
@@ -131,12 +134,19 @@ class SDFViewer {
 
    private:
     SDFViewer(std::array<size_t, 3> voxels, const BoundingBox& bb, size_t passes);
+    size_t update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delta_time);  // sdf_viewer_ingest.cpp
+    struct Ingest;  // pinned / device transfer buffers, the host mirror of tex0.r, the worker threads
+    struct IngestDeleter {
+        void operator()(Ingest* p) const;
+    };
+    std::unique_ptr<Ingest, IngestDeleter> ingest_;  // created by the first update() with a host-only SDF
+    bool host_mirror_valid_ = false;  // ingest_'s mirror equals tex0.r (cleared by every fill the device path runs)
     std::string error_;
     bool fresh_ = true;  // both textures still hold new_voxels' AIR_DIST everywhere
     bool same_load_ = true;  // every pass so far belongs to ONE load: the SDF and parameters of load_sdf_, no change reported
     std::optional<DeviceSDF> load_sdf_;  // what that load samples
     bool dist_synced_ = false;  // material.dist exists and mirrors tex0.r (kept so by every fill)
-    std::shared_ptr<DeviceBuffer> block_;  // owns tex0 and tex1 when they share one tuned allocation
+    std::shared_ptr<DeviceBuffer> block_;  // owns tex0 and tex1 when they share one allocation
 };
 
 }  // namespace sdfviewer

@@ -82,8 +82,8 @@ class SlabTextures:
 
 
 def alloc_slab(dims, rank, world, device, fill_value=None, periodic=False, pkg=None, halo_hi=1):
-    """pkg given (and a GPU device): the two textures share one block and sdfv_tune_texture_placement chooses the
-    distance between them (see pkg.alloc_textures(tuned=True)).
+    """pkg given (and a GPU device): the two textures share one block, tex1 at the distance from tex0's end that MI355X fills
+    fastest for textures of this size (pkg.alloc_textures_placed = what SDFViewer::new_voxels allocates; no probe).
     halo_hi = 2: two ghost slices on the upper side (what sdfNormal's taps need in the sharded march): the library's
     communicator fills them when created with SDFV_COMM_HALO2 (SlabComm(halo_hi=2)), halo_exchange() below handles either
     depth over torch.distributed."""
@@ -93,7 +93,7 @@ def alloc_slab(dims, rank, world, device, fill_value=None, periodic=False, pkg=N
     shape = (glo + (z1 - z0) + ghi, dims[1], dims[0], 4)
     if pkg is not None and torch.device(device).type == "cuda":
         with torch.cuda.device(torch.device(device)):
-            t0, t1 = pkg.alloc_textures(pkg.make_grid((dims[0], dims[1], shape[0])), device=device, tuned=True)
+            t0, t1 = pkg.alloc_textures_placed(pkg.make_grid((dims[0], dims[1], shape[0])), device=device)
     else:
         t0 = torch.empty(shape, dtype=torch.float32, device=device)
         t1 = torch.empty(shape, dtype=torch.float32, device=device)

@@ -45,3 +45,13 @@ def host():
 def oracle():
     import oracle_binding
     return oracle_binding
+
+
+@pytest.fixture(scope="session")
+def gyroid_provider(tmp_path_factory):
+    """tests/c/gyroid_provider.c built as a shared object: a HOST-ONLY SDF behind include/sdf_provider.h's per-point ABI."""
+    out = tmp_path_factory.mktemp("gyroid") / "libgyroid_provider.so"
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall",
+                           "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "gyroid_provider.c"), "-o", str(out), "-lm"])
+    return str(out)

@@ -23,6 +23,11 @@ for name, res, args in [
     ("sdfvh_lm_step_size", SZ, [C.c_void_p]), ("sdfvh_lm_finish_pass", SZ, [C.c_void_p]),
     ("sdfvh_prev_power_of_2", C.c_uint32, [C.c_uint32]),
     ("sdfvh_demo_new", C.c_void_p, [C.c_int, C.POINTER(C.c_char_p), C.c_char_p, SZ]),
+    ("sdfvh_provider_load", C.c_void_p, [C.c_char_p, C.c_char_p, SZ]),
+    ("sdfvh_sdf_sample_concurrency", C.c_uint, [C.c_void_p]),
+    ("sdfvh_viewer_set_ingest", None, [C.c_void_p, C.c_uint, SZ]), ("sdfvh_viewer_last_error", SZ, [C.c_void_p, C.c_char_p, SZ]),
+    ("sdfvh_lm_advance", None, [C.c_void_p, SZ]), ("sdfvh_lm_cursor", SZ, [C.c_void_p]),
+    ("sdfvh_lm_pass_remaining", SZ, [C.c_void_p]), ("sdfvh_lm_pass_point", None, [C.c_void_p, SZ, C.POINTER(SZ)]),
     ("sdfvh_sdf_free", None, [C.c_void_p]), ("sdfvh_sdf_id", C.c_uint32, [C.c_void_p]),
     ("sdfvh_sdf_name", SZ, [C.c_void_p, C.c_char_p, SZ]), ("sdfvh_sdf_n_children", SZ, [C.c_void_p]),
     ("sdfvh_sdf_child", C.c_void_p, [C.c_void_p, SZ]), ("sdfvh_sdf_bounding_box", None, [C.c_void_p, C.c_void_p]),
@@ -33,8 +38,9 @@ for name, res, args in [
     ("sdfvh_sdf_set_parameter", C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_char_p, C.c_char_p, SZ]),
     ("sdfvh_sdf_changed", C.c_int, [C.c_void_p, C.c_void_p]), ("sdfvh_sdf_parameters", SZ, [C.c_void_p, C.c_char_p, SZ]),
     ("sdfvh_viewer_from_bb", C.c_void_p, [C.c_void_p, SZ, SZ]),
-    ("sdfvh_viewer_new_voxels", C.c_void_p, [SZ, SZ, SZ, C.c_void_p, SZ]), ("sdfvh_viewer_free", None, [C.c_void_p]),
-    ("sdfvh_viewer_dims", None, [C.c_void_p, C.c_void_p]), ("sdfvh_viewer_tune", C.c_int, [SZ, SZ, SZ]),
+    ("sdfvh_viewer_new_voxels", C.c_void_p, [SZ, SZ, SZ, C.c_void_p, SZ]),
+    ("sdfvh_viewer_new_voxels_layout", C.c_void_p, [SZ, SZ, SZ, C.c_void_p, SZ, C.c_int]), ("sdfvh_viewer_free", None, [C.c_void_p]),
+    ("sdfvh_viewer_dims", None, [C.c_void_p, C.c_void_p]),
     ("sdfvh_viewer_update", SZ, [C.c_void_p, C.c_void_p, C.c_double]), ("sdfvh_viewer_commit", None, [C.c_void_p]),
     ("sdfvh_viewer_lod", C.c_float, [C.c_void_p]), ("sdfvh_viewer_remaining", SZ, [C.c_void_p]),
     ("sdfvh_viewer_passes_left", SZ, [C.c_void_p]), ("sdfvh_viewer_has_changed_box", C.c_int, [C.c_void_p]),
@@ -88,6 +94,20 @@ class LoadingManager:
     def finish_pass(self):
         return H.sdfvh_lm_finish_pass(self.h)
 
+    def advance(self, n):
+        H.sdfvh_lm_advance(self.h, n)
+
+    def cursor(self):
+        return H.sdfvh_lm_cursor(self.h)
+
+    def pass_remaining(self):
+        return H.sdfvh_lm_pass_remaining(self.h)
+
+    def pass_point(self, k):
+        out = (SZ * 3)()
+        H.sdfvh_lm_pass_point(self.h, k, out)
+        return tuple(out)
+
 
 class SDF:
     def __init__(self, handle):
@@ -106,6 +126,18 @@ class SDF:
         if not h:
             raise ValueError(err.value.decode())
         return SDF(h)
+
+    @staticmethod
+    def provider(path):
+        """ProviderSDF::load: an SDF behind the per-point ABI of include/sdf_provider.h (host-sampled only)."""
+        err = C.create_string_buffer(512)
+        h = H.sdfvh_provider_load(str(path).encode(), err, 512)
+        if not h:
+            raise OSError(err.value.decode())
+        return SDF(h)
+
+    def sample_concurrency(self):
+        return H.sdfvh_sdf_sample_concurrency(self.h)
 
     def id(self):
         return H.sdfvh_sdf_id(self.h)
@@ -178,14 +210,11 @@ class Viewer:
         return Viewer(H.sdfvh_viewer_from_bb(bb.ctypes.data, max_voxels_side, passes))
 
     @staticmethod
-    def new_voxels(dims, bb, passes):
+    def new_voxels(dims, bb, passes, layout="auto"):
+        """layout: how the distance volume is laid out -- "auto" (the march's preference), "plain", "interleaved"."""
         bb = np.asarray(bb, np.float32).reshape(6)
-        return Viewer(H.sdfvh_viewer_new_voxels(dims[0], dims[1], dims[2], bb.ctypes.data, passes))
-
-    @staticmethod
-    def tune(dims):
-        """SDFViewer::tune: measure the texture placement for grids of this size (blocking), remember it process-wide."""
-        return H.sdfvh_viewer_tune(dims[0], dims[1], dims[2])
+        return Viewer(H.sdfvh_viewer_new_voxels_layout(dims[0], dims[1], dims[2], bb.ctypes.data, passes,
+                                                       {"auto": 0, "plain": 1, "interleaved": 2}[layout]))
 
     def texture_gap(self):
         """Bytes between the end of tex0 and the start of tex1 (the placement the constructor used)."""
@@ -199,6 +228,15 @@ class Viewer:
 
     def update(self, sdf, max_delta_seconds):
         return H.sdfvh_viewer_update(self.h, sdf.h, max_delta_seconds)
+
+    def set_ingest(self, host_threads=0, capacity=0):
+        """Knobs of the ingest path (host-sampled SDFs): worker threads (0 = what the SDF allows), records per buffer."""
+        H.sdfvh_viewer_set_ingest(self.h, host_threads, capacity)
+
+    def last_error(self):
+        b = C.create_string_buffer(512)
+        H.sdfvh_viewer_last_error(self.h, b, 512)
+        return b.value.decode()
 
     def commit(self):
         H.sdfvh_viewer_commit(self.h)

@@ -172,6 +172,22 @@ def viewer_update(params, dims, lm, t0, t1, changed_box=None, max_iterations=2 *
                               max_iterations, t0.ctypes.data, t1.ctypes.data)
 
 
+SAMPLE_FN = C.CFUNCTYPE(None, C.c_void_p, FP, C.c_int, FP)
+L.or_viewer_update_fn.restype = C.c_uint64
+L.or_viewer_update_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_uint64, C.c_void_p, C.c_void_p]
+
+
+def viewer_update_fn(sample_fn, dims, lm, t0, t1, changed_box=None, max_iterations=2 ** 62, bb_min=(-1, -1, -1),
+                     bb_max=(1, 1, 1), user=None):
+    """SDFViewer::update's loop over ANY sample function: `sample_fn` is the address of a C function with or_sample_fn's
+    signature (or a SAMPLE_FN-wrapped Python callable)."""
+    cb = None if changed_box is None else (C.c_float * 6)(*[float(x) for x in changed_box])
+    fn = C.cast(sample_fn, C.c_void_p)
+    return L.or_viewer_update_fn(fn, user, u3(dims), f3(bb_min), f3(bb_max), C.byref(lm), cb, max_iterations,
+                                 t0.ctypes.data, t1.ctypes.data)
+
+
 def default_render_params(dims, bb_min=(-1, -1, -1), bb_max=(1, 1, 1)):
     rp = RenderParams()
     L.or_default_render_params(C.byref(rp), u3(dims), f3(bb_min), f3(bb_max))

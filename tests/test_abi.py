@@ -49,7 +49,7 @@ def test_struct_layouts(pkg):
     assert C.sizeof(pkg.Light) == 32
     assert C.sizeof(pkg.RenderParams) == 80 + 4 + 4 * 32
     assert C.sizeof(pkg.MarchAux) == 72
-    assert pkg.lib.sdfv_abi_version() == 4
+    assert pkg.lib.sdfv_abi_version() == 5
     assert C.sizeof(pkg._capi.MarchDesc) == 120  # 2 + 7 pointers ... : the layout a binder mirrors
 
 

@@ -412,31 +412,23 @@ def check_boxed_edit(pkg, oracle, dims, bb, prm, edited, box, expect_change):
             assert torch.equal(dist, t0[..., 0])
 
 
-def test_tuned_texture_placement(pkg, oracle):
-    """sdfv_tune_texture_placement only chooses WHERE tex1 starts inside a shared block: 16-byte aligned, no overlap,
-    inside the block; a fill into the tuned pair gives the usual texels."""
-    import ctypes as C
+def test_placed_textures(pkg, oracle):
+    """alloc_textures_placed = what SDFViewer::new_voxels allocates: one block, tex1 at the fixed distance for that byte size
+    (16-byte aligned, no overlap); a fill into the pair gives the usual texels.  No probe entry point is exported any more."""
     dims = (64, 48, 40)
     g = pkg.make_grid(dims)
     n_bytes = dims[0] * dims[1] * dims[2] * 16
-    # attempts=1: only the block candidates of sdfv_tune_texture_placement
-    t0, t1 = pkg.alloc_textures(g, tuned=True, attempts=1)
-    gap = t1.data_ptr() - t0.data_ptr() - n_bytes
-    assert 0 <= gap <= pkg._capi.PLACEMENT_SLACK and gap % 16 == 0 and t1.data_ptr() % 16 == 0
-    # default: the probe may also keep a pair of separate allocations; either way two disjoint, aligned textures
-    t0, t1 = pkg.alloc_textures(g, tuned=True)
+    t0, t1 = pkg.alloc_textures_placed(g)
+    assert t1.data_ptr() - t0.data_ptr() - n_bytes == pkg.default_texture_skew(n_bytes) == 0
     assert t0.shape == t1.shape == (dims[2], dims[1], dims[0], 4) and t0.data_ptr() % 16 == 0 and t1.data_ptr() % 16 == 0
-    assert abs(t1.data_ptr() - t0.data_ptr()) >= n_bytes
+    assert pkg.default_texture_skew(1 << 28) == 12288 and pkg.default_texture_skew(1 << 30) == 20480
     prm = pkg.default_params(cube_material=1)
     pkg.fill_grid(prm, g, t0, t1)
     torch.cuda.synchronize()
     r0, r1 = oracle.fill_dense(oracle.params_from(prm), dims)
     assert_bits_equal(t0, r0)
     assert_bits_equal(t1, r1)
-    small = torch.empty(1024, device="cuda")
-    o0, o1 = C.c_size_t(), C.c_size_t()
-    assert pkg.lib.sdfv_tune_texture_placement(C.byref(g), C.c_void_p(small.data_ptr()), 4096, C.byref(o0), C.byref(o1), None) == -1
-    assert b"smaller than" in pkg.lib.sdfv_last_error()
+    assert not hasattr(pkg.lib, "sdfv_tune_texture_placement")
 
 
 @pytest.mark.parametrize("dims,z_range", [((64, 32, 16), (0, 16)), ((37, 20, 29), (0, 29)), ((40, 12, 29), (7, 22)),

@@ -124,23 +124,14 @@ def test_viewer_virgin_load_never_writes_the_initial_state_it_does_not_need(host
     np.testing.assert_array_equal(t1.view(np.uint32), e1.view(np.uint32))
 
 
-def test_texture_placement_is_measured_only_on_request(host, oracle):
-    """from_bb / new_voxels allocate and return (the constructor used to run a blocking 16-candidate probe on
-    every set_sdf).  SDFViewer::tune() is the explicit form: it measures once, and viewers made afterwards for that size on
-    that device are placed where it said; a viewer of another size keeps the plain placement; the load is the same bits."""
-    dims = (64, 64, 48)
-    plain = host.Viewer.new_voxels(dims, [-1, -1, -1, 1, 1, 1], 2)
-    assert plain.texture_gap() == 0
-    assert host.Viewer.tune(dims) == 0
-    tuned = host.Viewer.new_voxels(dims, [-1, -1, -1, 1, 1, 1], 2)
-    assert tuned.texture_gap() in range(0, 32768, 4096)
-    assert host.Viewer.new_voxels((32, 32, 32), [-1, -1, -1, 1, 1, 1], 2).texture_gap() == 0
-    sdf = host.SDF.demo()
-    for v in (plain, tuned):
-        while v.update(sdf, 1.0):
-            pass
-    for a, b in zip(plain.download(), tuned.download()):
-        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+def test_texture_placement_is_a_constant_of_the_texture_size(host, oracle):
+    """from_bb / new_voxels allocate and return: no probe, nothing launched.  Both textures share one block, tex1 at the distance
+    from tex0's end that MI355X fills fastest for textures of that byte size (12 KiB for 256 MiB, 20 KiB for 1 GiB, else 0:
+    host/sdf_viewer.cpp; rounds 3-5's run-time probe is gone -- it never beat these constants in the driver's runs)."""
+    assert host.Viewer.new_voxels((64, 64, 48), [-1, -1, -1, 1, 1, 1], 2).texture_gap() == 0
+    assert host.Viewer.new_voxels((256, 256, 256), [-1, -1, -1, 1, 1, 1], 2).texture_gap() == 12288
+    assert host.Viewer.new_voxels((512, 256, 128), [-1, -1, -1, 1, 1, 1], 2).texture_gap() == 12288  # same bytes, other shape
+    assert not hasattr(host.Viewer, "tune")
 
 
 def test_viewer_parameter_edit_refills_changed_box(host, oracle):

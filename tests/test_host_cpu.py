@@ -282,3 +282,77 @@ def test_serialize_ply_structure(host):
     empty = host.Mesh.from_arrays(np.zeros((0, 12), np.float32), []).serialize_ply()
     assert "element vertex 0" in empty and "element face 0" in empty
     assert "element face 1" in host.Mesh.from_arrays(v, [0, 1, 2, 1]).serialize_ply()
+
+
+# ---- host sampling: runs of a pass, and an SDF behind the per-point ABI (the ingest path's host half; no GPU) ----
+def test_advance_equals_stepping(host):
+    """LoadingManager::advance(n) = n calls of next(): same cursor, same pass changes, same totals; pass_point(k) is the
+    k-th point next() yields in the current pass (what SDFViewer::update hands its worker threads)."""
+    for limits, passes in (((8, 11, 17), 3), ((5, 1, 3), 2), ((4, 4, 4), 1), ((9, 7, 5), 4)):
+        a, b = host.LoadingManager(limits, passes), host.LoadingManager(limits, passes)
+        chunk = 1
+        while b.step_size():
+            n = min(chunk, b.pass_remaining())
+            want = [a.next() for _ in range(n)]
+            got = [b.pass_point(b.cursor() + k) for k in range(n)]
+            assert got == want, (limits, passes, chunk)
+            b.advance(n)
+            assert (a.len(), a.total_iterations(), a.step_size(), a.passes_left()) == \
+                   (b.len(), b.total_iterations(), b.step_size(), b.passes_left())
+            chunk = chunk * 3 % 101 + 1
+        assert a.next() is None and b.pass_remaining() == 0
+
+
+def test_provider_sdf_consumes_the_per_point_abi(host, gyroid_provider):
+    """ProviderSDF (host/provider_sdf.cpp) = WasmerSDF's role (wasm/native.rs:163-521) for a native library: required exports
+    called and freed, optional exports used when present, the trait's defaults when absent."""
+    import ctypes as C
+    sdf = host.SDF.provider(gyroid_provider)
+    raw = C.CDLL(gyroid_provider)
+    assert sdf.id() == 0                               # the root SDF (native.rs:78)
+    assert np.array_equal(sdf.bounding_box(), np.float32([-1, -0.5, -0.75, 1, 0.5, 0.75]))
+    assert sdf.name() == "Object"                      # no `name` export: name_default_impl (defaults.rs:19-21)
+    assert sdf.children() == []                        # no `children` export
+    assert np.array_equal(sdf.normal([0.1, 0.2, 0.3], 0.001), np.zeros(3, np.float32))  # no `normal` export: zero (native.rs:498)
+    assert sdf.sample_concurrency() == 64              # the optional extension export
+    assert sdf.device_params.__self__ is sdf           # (binding sanity)
+    want = np.zeros(7, np.float32)
+    for p in ([0.3, -0.2, 0.5], [-1, -0.5, -0.75], [0.9, 0.4, -0.7]):
+        q = np.float32(p)
+        raw.gyroid_sample_raw(None, q.ctypes.data_as(C.c_void_p), 0, want.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(sdf.sample(p).view(np.uint32), want.view(np.uint32))
+        raw.gyroid_sample_raw(None, q.ctypes.data_as(C.c_void_p), 1, want.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(sdf.sample(p, True).view(np.uint32), want.view(np.uint32))
+    assert np.isnan(sdf.sample([-1, -0.5, -0.75])[0])
+    prm = sdf.parameters()
+    assert len(prm) == 1 and prm[0][:3] == ["0", "thickness", "2"] and prm[0][4] == "shell thickness"
+    assert sdf.changed() is None
+    assert sdf.set_parameter(7, 0.5) == "unknown parameter"
+    assert sdf.set_parameter(0, 0.25) is None
+    assert sdf.parameters()[0][3] == "Float(0.25)"
+    box = sdf.changed()
+    assert box is not None and np.array_equal(box, np.float32([-1, -0.3, -0.75, 0.1, 0.5, 0.75]))
+    assert sdf.changed() is None                       # reported once
+    assert sdf.set_parameter(0, 0.15) is None and sdf.changed() is not None  # (back to the default for later tests)
+
+
+def test_provider_sdf_load_errors(host, tmp_path):
+    import subprocess
+    with pytest.raises(OSError, match="cannot load SDF provider"):
+        host.SDF.provider(tmp_path / "missing.so")
+    src = tmp_path / "half.c"
+    src.write_text("void *bounding_box(unsigned id) { (void)id; return 0; }\n")
+    lib = tmp_path / "libhalf.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", str(src), "-o", str(lib)])
+    with pytest.raises(OSError, match="does not export sample"):  # native.rs:62: `sample` is required
+        host.SDF.provider(lib)
+
+
+def test_demo_provider_is_an_ordinary_provider(host):
+    """libsdfdemo_provider.so loads through ProviderSDF like any other library: hierarchy, names, parameters (metadata only
+    here: its sample() runs on the GPU)."""
+    sdf = host.SDF.provider(host.PROVIDER_PATH)
+    assert sdf.name() == "Demo" and sdf.sample_concurrency() == 1   # thread-local registry
+    assert sorted((c.id(), c.name()) for c in sdf.children()) == [(1, "DemoCube"), (2, "DemoSphere")]
+    assert np.array_equal(sdf.bounding_box(), np.float32([-1, -1, -1, 1, 1, 1]))
+    assert [p[1] for p in sdf.parameters()] == [p[1] for p in host.SDF.demo().parameters()]

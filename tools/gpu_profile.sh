@@ -12,13 +12,8 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 # --pipeline: ONE kernel variant per kernel name (plain 32 B/voxel fill + tex0 march, or fused 36 B/voxel fill + distance-
 # volume march), so that per-kernel averages belong to one variant; --no-batch: no 64-camera batch, 512^3 block or
-# loopback probe; --no-tuned-placement: the placement probe launches the same kernel over the first slices only, which
-# would mix shorter launches into the averages
-# PROFILE_TUNED=1 keeps the probe (its launches are fill_dense_kernel<256, false>: another kernel NAME than the fused_ilv
-# pipeline's fill at 512^3, fill_dense_ilv_paired_kernel, so nothing mixes there)
-PLACE=${PROFILE_TUNED:+}
-[ -z "$PROFILE_TUNED" ] && PLACE="--no-tuned-placement"
-CMD="python bench.py --steps 10 --warmup 2 --workload $WL --pipeline $PIPE --no-cpu-baseline --no-batch $PLACE --no-overlapped"
+# loopback probe
+CMD="python bench.py --steps 10 --warmup 2 --workload $WL --pipeline $PIPE --no-cpu-baseline --no-batch --no-overlapped"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $CMD > $OUT/trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS -d $OUT/pmc_sq -o pmc --output-format csv -- $CMD > $OUT/pmc_sq.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE GRBM_GUI_ACTIVE -d $OUT/pmc_wr -o pmc --output-format csv -- $CMD > $OUT/pmc_wr.log 2>&1
