@@ -77,7 +77,7 @@ def host_load_block(sides):
     return out
 
 
-def ingest_block(side=128):
+def ingest_block(side=384):
     """VERDICT r05 next 1: SDFViewer::update for an SDF only the HOST can sample (any `impl SDFSurface`, scene/sdf/mod.rs:128):
     tests/c/gyroid_provider.c (a library behind include/sdf_provider.h's per-point ABI) built here with gcc, loaded through
     ProviderSDF, loaded into a side^3-bounded grid by sdf-viewer-host-bench --ingest.  CPU-bound by construction (one malloc'ing
@@ -98,7 +98,7 @@ def ingest_block(side=128):
         out = {"error": f"{type(e).__name__}: {e}"}
     out["note"] = ("host-sampled SDF (gyroid behind the per-point ABI) -> pinned H2D -> sdfv_pack_samples; whole_load = one update() with "
                    "an unlimited budget on `threads` host threads, frame_loop_30ms = the reference's frame loop (30 ms per call; "
-                   "worst_call_ms = the longest call), whole_load_1_thread = the reference's single-threaded loop; CPU-bound")
+                   "worst_call_ms = the longest call), setup_ms = the first call (transfer buffers, host mirror, workers; not in load_ms), whole_load_1_thread = the reference's single-threaded loop; CPU-bound")
     return out
 
 

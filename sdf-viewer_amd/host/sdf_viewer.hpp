@@ -111,9 +111,10 @@ class SDFViewer {
     // one voxel, like the reference); the raw 28-byte samples go to the device through pinned double buffers and
     // sdfv_pack_samples does update()'s packing there.  update_required is decided on a host mirror of tex0.r.
     size_t update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_time);
-    // Ingest path knobs: host threads (0 = what the SDF allows, at most the machine's), records per transfer buffer.
+    // Ingest path knobs: host threads (0 = what the SDF allows, at most the machine's), records per transfer buffer (0 = 16 Ki
+    // per thread, between 64 Ki and 4 Mi: a run must outlast the fork/join of its workers by far; 32 B of pinned memory each).
     unsigned host_threads = 0;
-    size_t ingest_capacity = (size_t)1 << 18;
+    size_t ingest_capacity = 0;
     // scene/sdf/mod.rs:220-239
     void commit();
     // lod_dist_between_samples = 2^passes_left (scene/sdf/mod.rs:226), published with the data it describes

@@ -162,7 +162,11 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
     hipStream_t st = (hipStream_t)stream;
     if (!ingest_) ingest_.reset(new Ingest());
     Ingest& in = *ingest_;
-    if (!in.reserve(ingest_capacity ? ingest_capacity : 1)) {
+    unsigned threads = sdf.sample_concurrency();
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    threads = std::max(1u, std::min(threads, host_threads ? host_threads : hw));
+    const size_t auto_capacity = std::min<size_t>(std::max<size_t>((size_t)threads << 14, (size_t)1 << 16), (size_t)1 << 22);
+    if (!in.reserve(ingest_capacity ? ingest_capacity : std::min(auto_capacity, n_voxels))) {
         error_ = "cannot allocate the ingest buffers (pinned host + device)";
         return 0;
     }
@@ -230,9 +234,6 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
     fresh_ = false;
     material.pairs_valid = false;
 
-    unsigned threads = sdf.sample_concurrency();
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    threads = std::max(1u, std::min(threads, host_threads ? host_threads : hw));
     const uint32_t pack_flags = (dist_synced_ && material.dist_interleaved) ? SDFV_PASS_VOLUME_INTERLEAVED : 0u;
     float* dist_dev = dist_synced_ ? material.dist->f32() : nullptr;
     const bool has_box = changed_box.has_value();

@@ -172,7 +172,7 @@ def test_host_sdf_loads_progressively_like_the_reference(host, oracle, gyroid_pr
     v.set_ingest(threads, capacity)
     ref = RefViewer(oracle, dims, bb, 3, raw.gyroid_sample_raw)
     rng = np.random.default_rng(threads)
-    budgets = [0.0, 2e-5, 2e-4, 2e-3]
+    budgets = [0.0, 1e-6, 5e-6, 2e-5]
     calls = 0
     while v.remaining():
         n = v.update(sdf, budgets[rng.integers(len(budgets))])
