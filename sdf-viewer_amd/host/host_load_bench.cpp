@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "provider_sdf.hpp"
+#include "worker_pool.hpp"
 #include "sdf_demo.hpp"
 #include "sdf_viewer.hpp"
 
@@ -113,6 +114,9 @@ static int ingest_load(SDFSurface& sdf, size_t side, size_t passes, unsigned thr
     if (hipStreamSynchronize(st) != hipSuccess) return 1;
     const double ms = std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
     const double voxels = (double)v->material.tex_size[0] * v->material.tex_size[1] * v->material.tex_size[2];
+    const auto& is = v->ingest_stats;
+    fprintf(stderr, "%s: runs %zu, records %zu of %zu visited; host ms: wait for a buffer %.2f, sample %.2f, ship %.2f\n", key, is.runs,
+            is.records, is.visited, is.wait_buffer * 1e3, is.sample * 1e3, is.ship * 1e3);
     printf(", \"%s\": {\"setup_ms\": %.2f, \"load_ms\": %.2f, \"update_calls\": %zu, \"iterations\": %zu, \"worst_call_ms\": %.2f, "
            "\"Mvoxels_per_s\": %.2f}", key, setup_ms, ms, calls, iterations, worst_call_ms, ms > 0 ? voxels / (ms * 1e-3) / 1e6 : 0.0);
     return 0;
@@ -145,7 +149,7 @@ int main(int argc, char** argv) {
             fprintf(stderr, "%s\n", err.c_str());
             return 2;
         }
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned hw = WorkerPool::usable_cpus();
         const unsigned used = std::max(1u, std::min(sdf->sample_concurrency(), threads ? threads : hw));
         printf("{\"side\": %zu, \"loading_passes\": %zu, \"provider\": \"%s\", \"host_cores\": %u, \"threads\": %u", side, passes,
                sdf->name().c_str(), hw, used);

@@ -115,6 +115,12 @@ class SDFViewer {
     // per thread, between 64 Ki and 4 Mi: a run must outlast the fork/join of its workers by far; 32 B of pinned memory each).
     unsigned host_threads = 0;
     size_t ingest_capacity = 0;
+    // Where the ingest path's host time went since the viewer was created (seconds; runs = fork/joins of the workers).
+    struct IngestStats {
+        double wait_buffer = 0, sample = 0, ship = 0;
+        size_t runs = 0, records = 0, visited = 0;
+    };
+    IngestStats ingest_stats;
     // scene/sdf/mod.rs:220-239
     void commit();
     // lod_dist_between_samples = 2^passes_left (scene/sdf/mod.rs:226), published with the data it describes

@@ -18,14 +18,12 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
-#include <condition_variable>
 #include <cstring>
-#include <functional>
-#include <mutex>
 #include <thread>
 #include <vector>
 
 #include "sdf_viewer.hpp"
+#include "worker_pool.hpp"
 
 namespace sdfviewer {
 
@@ -33,67 +31,6 @@ namespace {
 
 // f32::clamp(0.0, 1.0) of scene/sdf/mod.rs:196 (a NaN stays a NaN), the same three lines the device packs with
 inline float clamp01_rust(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
-
-// Persistent workers: run(n, fn) calls fn(0) on the calling thread and fn(1) .. fn(n - 1) on background threads.
-class WorkerPool {
-   public:
-    ~WorkerPool() {
-        {
-            std::lock_guard<std::mutex> lock(m_);
-            stop_ = true;
-        }
-        wake_.notify_all();
-        for (auto& t : threads_) t.join();
-    }
-    void run(unsigned n, const std::function<void(unsigned)>& fn) {
-        if (n <= 1) {
-            if (n == 1) fn(0);
-            return;
-        }
-        while (threads_.size() + 1 < n) {
-            const unsigned id = (unsigned)threads_.size() + 1;
-            threads_.emplace_back([this, id] { loop(id); });
-        }
-        {
-            std::lock_guard<std::mutex> lock(m_);
-            fn_ = &fn;
-            active_ = n;
-            pending_ = n - 1;
-            ++generation_;
-        }
-        wake_.notify_all();
-        fn(0);
-        std::unique_lock<std::mutex> lock(m_);
-        done_.wait(lock, [this] { return pending_ == 0; });
-        fn_ = nullptr;
-    }
-
-   private:
-    void loop(unsigned id) {
-        unsigned long long seen = 0;
-        for (;;) {
-            const std::function<void(unsigned)>* fn = nullptr;
-            {
-                std::unique_lock<std::mutex> lock(m_);
-                wake_.wait(lock, [&] { return stop_ || generation_ != seen; });
-                if (stop_) return;
-                seen = generation_;
-                if (id < active_) fn = fn_;
-            }
-            if (!fn) continue;
-            (*fn)(id);
-            std::lock_guard<std::mutex> lock(m_);
-            if (--pending_ == 0) done_.notify_one();
-        }
-    }
-    std::mutex m_;
-    std::condition_variable wake_, done_;
-    std::vector<std::thread> threads_;
-    const std::function<void(unsigned)>* fn_ = nullptr;
-    unsigned active_ = 0, pending_ = 0;
-    unsigned long long generation_ = 0;
-    bool stop_ = false;
-};
 
 }  // namespace
 
@@ -163,8 +100,8 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
     if (!ingest_) ingest_.reset(new Ingest());
     Ingest& in = *ingest_;
     unsigned threads = sdf.sample_concurrency();
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    threads = std::max(1u, std::min(threads, host_threads ? host_threads : hw));
+    const unsigned hw = WorkerPool::usable_cpus();
+    threads = std::max(1u, std::min({threads, host_threads ? host_threads : hw, 0xffffu}));
     const size_t auto_capacity = std::min<size_t>(std::max<size_t>((size_t)threads << 14, (size_t)1 << 16), (size_t)1 << 22);
     if (!in.reserve(ingest_capacity ? ingest_capacity : std::min(auto_capacity, n_voxels))) {
         error_ = "cannot allocate the ingest buffers (pinned host + device)";
@@ -242,6 +179,11 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
     std::vector<size_t> counts(threads);
     size_t run_len = threads;  // the first run: one voxel per worker
     bool first = true;
+    in.pool.begin(threads);
+    struct EndSession {
+        WorkerPool& pool;
+        ~EndSession() { pool.end(); }
+    } end_session{in.pool};
     // "while first || start_time.elapsed() < max_delta_time" with a run as the unit of work  (:173)
     while (first || std::chrono::steady_clock::now() - start_time < max_delta_time) {
         first = false;
@@ -250,11 +192,13 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
         const size_t n = std::min({run_len, loading_mgr.pass_remaining(), in.capacity});
         Ingest::Buffer& b = in.buf[in.next];
         in.next ^= 1;
+        const auto wait_start = std::chrono::steady_clock::now();
         if (b.in_flight) {  // the launch that read this buffer two runs ago
             (void)hipEventSynchronize(b.done);
             b.in_flight = false;
         }
         const auto run_start = std::chrono::steady_clock::now();
+        ingest_stats.wait_buffer += std::chrono::duration<double>(run_start - wait_start).count();
         const size_t c0 = loading_mgr.cursor();
         const LoadingManager::Index walk = loading_mgr.pass_walk();
         const unsigned workers = (unsigned)std::min<size_t>(threads, n);
@@ -292,6 +236,8 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
             counts[t] = count;
         };
         in.pool.run(workers, work);
+        const auto sampled = std::chrono::steady_clock::now();
+        ingest_stats.sample += std::chrono::duration<double>(sampled - run_start).count();
         // ---- ship the run: the workers' stretches, packed back to back on the device ----
         size_t total = 0;
         bool failed = false;
@@ -322,6 +268,10 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
         if (total && hipEventRecord(b.done, st) == hipSuccess) b.in_flight = true;
         loading_mgr.advance(n);
         publish_lod();
+        ingest_stats.ship += std::chrono::duration<double>(std::chrono::steady_clock::now() - sampled).count();
+        ingest_stats.runs += 1;
+        ingest_stats.records += total;
+        ingest_stats.visited += n;
         // ---- the next run: sized to end within half of the budget that is left, growing by at most 8x ----
         const auto now = std::chrono::steady_clock::now();
         const double per_voxel = std::chrono::duration<double>(now - run_start).count() / (double)n;

@@ -356,3 +356,17 @@ def test_demo_provider_is_an_ordinary_provider(host):
     assert sorted((c.id(), c.name()) for c in sdf.children()) == [(1, "DemoCube"), (2, "DemoSphere")]
     assert np.array_equal(sdf.bounding_box(), np.float32([-1, -1, -1, 1, 1, 1]))
     assert [p[1] for p in sdf.parameters()] == [p[1] for p in host.SDF.demo().parameters()]
+
+
+def test_worker_pool_sessions_never_lose_a_run(tmp_path):
+    """The ingest path's WorkerPool (host/worker_pool.hpp): sessions of varying size, threads created mid-life, runs back to
+    back -- every worker of every run executes exactly once, also with more workers than CPUs (bounded spin, then yield)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "worker_pool_stress"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-Werror", "-I", os.path.join(root, "sdf-viewer_amd", "host"),
+                           os.path.join(root, "tests", "c", "worker_pool_stress.cpp"), "-o", str(exe)])
+    for workers in (5, 3 * (os.cpu_count() or 4)):
+        r = subprocess.run([str(exe), str(workers)], capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0 and r.stdout.startswith("ok"), (workers, r.stdout, r.stderr)
