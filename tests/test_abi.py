@@ -259,30 +259,117 @@ def test_power_of_two_modulus_identity():
     np.testing.assert_array_equal(np.maximum(-mx - d, d - mx).view(np.uint32), (np.abs(d) - mx).view(np.uint32))
 
 
-def test_no_kernel_needs_more_than_4_kb_of_arguments(tmp_path):
-    """ADVICE r03: HIP documents 4 KB of kernel arguments; round 3's march carried 64 cameras in an 8 KB block.  Every gfx950
-    code object inside libsdfgrid.so is unbundled and its kernels' kernarg sizes read from the metadata notes."""
+LLVM_TOOLS = "/opt/rocm/lib/llvm/bin"
+
+
+@pytest.fixture(scope="module")
+def code_objects(tmp_path_factory):
+    """Every gfx950 code object inside libsdfgrid.so, unbundled: [(path of the .co, text of its metadata notes)]."""
     import subprocess
-    tools = "/opt/rocm/lib/llvm/bin"
+    tmp_path = tmp_path_factory.mktemp("code_objects")
     lib = os.path.join(ROOT, "sdf-viewer_amd", "libsdfgrid.so")
-    if not all(os.path.exists(os.path.join(tools, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
+    if not all(os.path.exists(os.path.join(LLVM_TOOLS, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf", "llvm-objdump")):
         pytest.skip("LLVM binary tools not installed")
     fat = tmp_path / "fat.bin"
-    subprocess.run([f"{tools}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", lib, str(tmp_path / "unused.so")], check=True)
+    subprocess.run([f"{LLVM_TOOLS}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", lib, str(tmp_path / "unused.so")], check=True)
     blob = fat.read_bytes()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
     starts = [m.start() for m in re.finditer(magic, blob)]
     assert starts, "no offload bundle in the library"
-    sizes = []
+    out = []
     for k, at in enumerate(starts):
         piece = tmp_path / f"bundle{k}.bin"
         piece.write_bytes(blob[at:starts[k + 1] if k + 1 < len(starts) else len(blob)])
         co = tmp_path / f"bundle{k}.co"
-        subprocess.run([f"{tools}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+        subprocess.run([f"{LLVM_TOOLS}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                         f"--input={piece}", f"--output={co}"], check=True)
-        notes = subprocess.run([f"{tools}/llvm-readelf", "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+        notes = subprocess.run([f"{LLVM_TOOLS}/llvm-readelf", "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+        out.append((co, notes))
+    return out
+
+
+def test_no_kernel_needs_more_than_4_kb_of_arguments(code_objects):
+    """ADVICE r03: HIP documents 4 KB of kernel arguments; round 3's march carried 64 cameras in an 8 KB block.  Every gfx950
+    code object inside libsdfgrid.so is unbundled and its kernels' kernarg sizes read from the metadata notes."""
+    sizes = []
+    for _, notes in code_objects:
         sizes += [int(v) for v in re.findall(r"\.kernarg_segment_size:\s+(\d+)", notes)]
     assert len(sizes) > 100 and max(sizes) <= 4096, (len(sizes), max(sizes))
+
+
+def _kernel_table(code_objects):
+    """mangled name -> {vgpr, vgpr_spill, sgpr_spill, lds, scratch, co} from the code objects' metadata."""
+    table = {}
+    for co, notes in code_objects:
+        for blk in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
+            def field(key, blk=blk):
+                return int(re.search(r"\." + key + r":\s+(\d+)", blk).group(1))
+            name = re.search(r"\n\s+\.name:\s+(\S+)\n\s+\.private_segment_fixed_size", blk).group(1)
+            table[name] = dict(vgpr=field("vgpr_count"), vgpr_spill=field("vgpr_spill_count"), sgpr_spill=field("sgpr_spill_count"),
+                               lds=field("group_segment_fixed_size"), scratch=field("private_segment_fixed_size"), co=co)
+    return table
+
+
+def _opcodes(co, symbol, cache={}):
+    """The instruction stream of one kernel: ["opcode", "opcode nt", ...] (llvm-objdump -d of its code object)."""
+    import subprocess
+    if co not in cache:
+        text = subprocess.run([f"{LLVM_TOOLS}/llvm-objdump", "-d", str(co)], check=True, capture_output=True, text=True).stdout
+        parts = re.split(r"\n[0-9a-f]{16} <([^>]+)>:\n", text)
+        cache[co] = dict(zip(parts[1::2], parts[2::2]))
+    ops = []
+    for line in cache[co][symbol].split("\n"):
+        code = line.split("//")[0].split()
+        if code:
+            ops.append(code[0] + (" nt" if "nt" in code[1:] else ""))
+    return ops
+
+
+def test_hot_kernels_keep_their_performance_contract(code_objects):
+    """what DESIGN.md claims about the kernels the bench times is read back from the BUILT library, so that a
+    live register added to the march loop, a spill, or a toolchain that stops emitting the streaming stores fails here (CPU, no
+    GPU) instead of showing up as a slower bench line.  The march loop stands in for material.frag:92-128, the fill for
+    scene/sdf/mod.rs:173-215."""
+    from collections import Counter
+    table = _kernel_table(code_objects)
+    assert len(table) > 250
+    # nothing in the library spills vector registers or uses scratch; a few cold kernels spill SGPRs (to VGPR lanes)
+    assert max(k["vgpr_spill"] for k in table.values()) == 0 and max(k["scratch"] for k in table.values()) == 0
+    # ---- the march kernels the bench and SDFViewerMaterial::render launch (hand-written gfx950 loop, NORMAL off) ----
+    for cams in (1, 2, 4):
+        name = f"_ZN4sdfv12_GLOBAL__N_115raymarch_kernelILi{cams}ELb1ELi2ELb1ELb0ELb1ELb0EEEvNS_12RaymarchArgsE"
+        k = table[name]
+        assert k["vgpr"] <= 72, (cams, k)              # 7 waves per SIMD (512 / 72); 73 would drop to 6 (DESIGN.md 3.3)
+        assert k["sgpr_spill"] == 0 and k["lds"] == 0  # (unused dynamic LDS is the launcher's occupancy cap)
+        ops = Counter(_opcodes(k["co"], name))
+        # the loop's shape: EXEC = marching lanes narrowed by v_cmpx, skipped blocks by s_cbranch_execz, packed fp32 lerps
+        assert ops["v_cmpx_nlt_f32_e32"] >= 1 and ops["v_cmpx_ngt_f32_e32"] >= 1 and ops["s_cbranch_execz"] >= 8, cams
+        assert ops["v_pk_mul_f32"] >= 60 and ops["v_pk_add_f32"] >= 40 and ops["v_mad_u32_u24"] >= 16, cams
+        assert ops["v_pk_fma_f32"] == 0, "the reference's shader arithmetic is not contracted"
+        assert not any(o.startswith(("scratch_", "buffer_")) for o in ops), cams
+    # ---- the dense fills: store-only, 16-byte stores, the textures streamed (nt) in the fused form ----
+    def fill(tx, fused, cfg="NS_11DefaultCfgTILb0EEE", last="Lb0"):
+        return f"_ZN4sdfv12_GLOBAL__N_117fill_dense_kernelILi{tx}ELb{int(fused)}E{cfg}{last}EEEvNS_8FillArgsE"
+    fused = table[fill(256, True)]
+    assert fused["vgpr"] <= 24 and fused["sgpr_spill"] == 0 and fused["lds"] <= 1100, fused   # the 1 KiB sRGB table + a row's (y, z)
+    ops = Counter(_opcodes(fused["co"], fill(256, True)))
+    assert ops["global_store_dwordx4 nt"] == 2 and ops["global_store_dwordx4"] == 0, ops     # tex0 + tex1, past L2
+    assert ops["global_load_dword"] == 1 and sum(v for o, v in ops.items() if o.startswith("global_load")) == 1, ops  # the LUT staging
+    assert ops["global_store_dword"] >= 1                                                      # the distance volume stays cacheable
+    plain = table[fill(256, False)]
+    assert plain["vgpr"] <= 24 and plain["sgpr_spill"] == 0
+    ops = Counter(_opcodes(plain["co"], fill(256, False)))
+    assert ops["global_store_dwordx4"] + ops["global_store_dwordx4 nt"] == 2 and sum(v for o, v in ops.items() if o.startswith("global_load")) == 1
+    for n, k in table.items():
+        if "fill_dense" in n:
+            assert k["vgpr"] <= 40 and k["sgpr_spill"] == 0, (n, k)   # >= 12 waves per SIMD for every dense form
+    # ---- the ingest kernel: LUT + a workgroup's 256 records in LDS, one 16-byte and one 12-byte store per record ----
+    for rnd in (0, 1):
+        name = f"_ZN4sdfv12_GLOBAL__N_119pack_samples_kernelILb{rnd}EEEvNS_8PackArgsE"
+        k = table[name]
+        assert k["vgpr"] <= 24 and k["sgpr_spill"] == 0 and k["lds"] == 1024 + 256 * 28, k
+        ops = Counter(_opcodes(k["co"], name))
+        assert ops["global_store_dwordx4"] == 1 and ops["global_store_dwordx3"] == 1, ops
 
 
 def test_headers_compile_as_plain_c_and_the_library_links(tmp_path):
