@@ -280,6 +280,8 @@ def contract_line(line, full_path):
     b = line.get("batch_raymarch")
     if isinstance(b, dict):
         c["batch_raymarch"] = _pick(b, "cameras", "value", "unit", "ms_per_batch", "split", "gather_ms", "value_incl_gather")
+        if isinstance(b.get("rgba8_only"), dict):
+            c["batch_raymarch"]["rgba8_ms"] = b["rgba8_only"].get("ms_per_batch")
         for k in ("camera_split", "contiguous_rows_split"):
             if isinstance(b.get(k), dict):
                 c["batch_raymarch"][k] = _pick(b[k], "value", "ms_per_batch", "gather_ms")

@@ -418,6 +418,17 @@ def run_extras(c):
                 batch_step()
                 ms_resident = timed_region(batch_step, batch_steps, torch, dist, world, device)[0] / batch_steps * 1e3
                 mine = host_cams
+            # the same batch into the 8-bit UNORM plane only (sdfv_march_desc.rgba8: the reference's framebuffer format): 4 B per
+            # pixel stored instead of 16 -- what a host that displays, encodes or gathers the images wants
+            batch_out8 = torch.empty((len(mine), n_rows, W, 4), dtype=torch.uint8, device=device)
+
+            def batch_step8():
+                pkg.raymarch(rp, r0, r1, mine, W, H, dist=dist_vol, rgba8=batch_out8, f32=False, **where, **(accel_kw if use_pairs else {}))
+
+            ms_rgba8 = None
+            if use_pairs:
+                batch_step8()
+                ms_rgba8 = timed_region(batch_step8, batch_steps, torch, dist, world, device)[0] / batch_steps * 1e3
             rep = {"split": split if world > 1 else None, "band_height": where["bands"][2] if "bands" in where else None,
                    "cameras_per_gpu": len(mine), "rows_per_gpu": n_rows,
                    "value": round(n_batch * W * H / ms / 1e3, 1), "unit": "Mrays/s", "ms_per_batch": round(ms, 4),
@@ -425,6 +436,9 @@ def run_extras(c):
                                  else "distance volume"}
             if ms_resident is not None:
                 rep["ms_per_batch_cameras_in_device_memory"] = round(ms_resident, 4)
+            if ms_rgba8 is not None:
+                rep["rgba8_only"] = {"ms_per_batch": round(ms_rgba8, 4), "value": round(n_batch * W * H / ms_rgba8 / 1e3, 1),
+                                     "note": "same batch, outColor stored as 8-bit UNORM only (sdfv_march_desc.rgba8, rgba = NULL)"}
             if multi and use_pairs:
                 # SURVEY 8(e)'s collective of config 5: the images assembled on rank 0.  Over the library communicator when the
                 # step runs on it (sdfv_comm_gather_bands / _gather_cameras: one message per peer, all links into one rank),

@@ -424,7 +424,14 @@ int sdfv_mesh_trim(void);
  *   depth             DEVICE or NULL, n_cameras x rows x W floats: gl_FragDepth (material.frag:180-181: (BVP * vec4(hit, 1)).z /
  *                     .w at a hit; 1.0 for a fragment that hits nothing, :147; 1.0 where the ray misses the box) -- equal bit for
  *                     bit to sdfv_march_aux.depth without the 72-byte record
- *   aux               DEVICE or NULL, same pixel layout: everything main() knows before shading */
+ *   aux               DEVICE or NULL, same pixel layout: everything main() knows before shading
+ *   rgba8             DEVICE or NULL, n_cameras x rows x W pixels of 4 bytes (R, G, B, A in memory order): outColor as the 8-bit
+ *                     UNORM framebuffer the reference renders into holds it (src/app/frameinput.rs:19-24; no FRAMEBUFFER_SRGB
+ *                     re-encoding: the shader's own colour mapping already produced display values) -- each channel
+ *                     rint(clamp(c, 0, 1) * 255), a NaN as 0.  With rgba8 given, `rgba` may be NULL: the launch then stores 4
+ *                     bytes per pixel instead of 16 -- what a 64-camera batch wants when the images go on to a display, an
+ *                     encoder or another rank (a quarter of the store traffic and of the gather: 0.53 GB instead of 2.1).
+ *                     fp32 `rgba` stays the parity output; at least one of the two must be given */
 typedef struct sdfv_march_desc {
     uint32_t size;
     uint32_t reserved; /* 0 */
@@ -440,6 +447,7 @@ typedef struct sdfv_march_desc {
     float *rgba;
     float *depth;
     sdfv_march_aux *aux;
+    uint32_t *rgba8; /* (added in ABI 5) */
 } sdfv_march_desc;
 int sdfv_raymarch_ex(const sdfv_march_desc *desc, void *stream);
 /* rows a band set holds: bands of band_height (16 or 8; 0 = 16) rows, the last one of the image possibly short */

@@ -360,13 +360,15 @@ def upload_cameras(cameras, device="cuda"):
 
 
 def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=False, stream=None, out=None, dist=None,
-             want_depth=False, depth_out=None, pairs=None, ilv=None, bands=None):
+             want_depth=False, depth_out=None, pairs=None, ilv=None, bands=None, rgba8=None, f32=True):
     """material.frag main() over rows [y0,y1) -- or, bands=(first, step), over the 16-row tile bands first, first + step, ...
     stored one after the other (sdfv_march_desc.band_first / band_step).  Returns rgba [n_cam, rows, W, 4] (+ aux [n_cam, rows, W, 18] words).
     cameras: a Camera, a list of them, or upload_cameras()'s device tensor (any number of cameras).
     `dist` = optional compact distance volume from commit_distance(); `pairs` = optional y-pair volume from commit_pairs()
     (sdfv_march_desc.pairs), `ilv` = the y-interleaved volume (desc.ilv).  want_depth / depth_out: also return the
-    gl_FragDepth plane [n_cam, rows, W] (desc.depth); return order: rgba[, depth][, aux].  One export: sdfv_raymarch_ex."""
+    gl_FragDepth plane [n_cam, rows, W] (desc.depth); return order: rgba[, depth][, aux].  One export: sdfv_raymarch_ex.
+    rgba8: "both" or a uint8 tensor [n_cam, rows, W, 4] -> the 8-bit UNORM plane is written too (desc.rgba8) and returned last;
+    f32=False (or rgba8="only") -> the fp32 plane is NOT written (desc.rgba = NULL: 4 B per pixel stored instead of 16)."""
     if isinstance(cameras, Camera):
         cameras = [cameras]
     y1 = height if y1 is None else y1
@@ -391,23 +393,31 @@ def raymarch(rp, tex0, tex1, cameras, width, height, y0=0, y1=None, want_aux=Fal
     else:
         rows = y1 - y0
         d.y0, d.y1 = y0, y1
-    rgba = out if out is not None else torch.empty((n, rows, width, 4), dtype=torch.float32, device=tex0.device)
+    img8 = None
+    if rgba8 is not None:
+        img8 = rgba8 if isinstance(rgba8, torch.Tensor) else torch.empty((n, rows, width, 4), dtype=torch.uint8, device=tex0.device)
+        assert img8.dtype == torch.uint8 and img8.is_contiguous() and img8.numel() == n * rows * width * 4
+    only8 = (isinstance(rgba8, str) and rgba8 == "only") or (img8 is not None and not f32)
+    rgba = None if only8 else (out if out is not None else torch.empty((n, rows, width, 4), dtype=torch.float32, device=tex0.device))
     aux = torch.empty((n, rows, width, AUX_FLOATS), dtype=torch.int32, device=tex0.device) if want_aux else None
     depth = depth_out
     if depth is None and want_depth:
         depth = torch.empty((n, rows, width), dtype=torch.float32, device=tex0.device)
+    def result():
+        ret = (() if only8 else (rgba,)) + ((depth,) if (want_depth or depth_out is not None) else ()) + ((aux,) if want_aux else ()) + \
+              (() if img8 is None else (img8,))
+        return ret if len(ret) > 1 else ret[0]
     if rows == 0 and bands is not None and int(bands[1]) > 0:  # a band set below the image: nothing to render (empty tensors have no address)
-        ret = (rgba,) + ((depth,) if (want_depth or depth_out is not None) else ()) + ((aux,) if want_aux else ())
-        return ret if len(ret) > 1 else rgba
+        return result()
     d.rp = C.pointer(rp)
     d.tex0, d.tex1 = _dev_ptr(tex0, "tex0"), _dev_ptr(tex1, "tex1")
     d.dist = None if dist is None else _dev_ptr(dist, "dist")
     d.pairs = None if pairs is None else _dev_ptr(pairs, "pairs")
     d.ilv = None if ilv is None else _dev_ptr(ilv, "ilv")
     d.cameras, d.n_cameras, d.width, d.height = cam_arr, n, width, height
-    d.rgba = rgba.data_ptr()
+    d.rgba = None if rgba is None else rgba.data_ptr()
     d.depth = None if depth is None else _dev_ptr(depth, "depth")
     d.aux = aux.data_ptr() if want_aux else None
+    d.rgba8 = None if img8 is None else img8.data_ptr()
     check(lib.sdfv_raymarch_ex(C.byref(d), _stream_ptr(stream)))
-    ret = (rgba,) + ((depth,) if (want_depth or depth_out is not None) else ()) + ((aux,) if want_aux else ())
-    return ret if len(ret) > 1 else rgba
+    return result()

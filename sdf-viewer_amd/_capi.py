@@ -77,7 +77,8 @@ class MarchDesc(C.Structure):
                 ("tex1", C.c_void_p), ("dist", C.c_void_p), ("pairs", C.c_void_p), ("ilv", C.c_void_p),
                 ("cameras", C.POINTER(Camera)), ("n_cameras", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
                 ("y0", C.c_uint32), ("y1", C.c_uint32), ("band_first", C.c_uint32), ("band_step", C.c_uint32),
-                ("band_height", C.c_uint32), ("rgba", C.c_void_p), ("depth", C.c_void_p), ("aux", C.c_void_p)]
+                ("band_height", C.c_uint32), ("rgba", C.c_void_p), ("depth", C.c_void_p), ("aux", C.c_void_p),
+                ("rgba8", C.c_void_p)]
 
 
 PROTOTYPES = {

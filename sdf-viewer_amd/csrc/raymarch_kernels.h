@@ -49,7 +49,8 @@ struct RaymarchArgs {
     uint32_t band_skip;          // 0: rows [y0, y1).  B * (step - 1): the B-row bands y0/B, y0/B + step, ... below y1, stored one
                                  // after the other (the balanced image-tile split); B = 1 << band_shift = 16 or 8 (a wave's tile)
     uint32_t band_shift;
-    float4* rgba;                // n_cameras x rows_out x width
+    float4* rgba;                // n_cameras x rows_out x width, or nullptr (rgba8 only)
+    uint32_t* rgba8;             // same pixels as 8-bit UNORM RGBA (rint(clamp(c, 0, 1) * 255), R in the low byte), or nullptr
     sdfv_march_aux* aux;         // same layout or nullptr
     float* depth;                // gl_FragDepth plane, same pixel layout, or nullptr
 #ifdef SDFV_TUNING

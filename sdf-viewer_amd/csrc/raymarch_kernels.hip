@@ -699,6 +699,16 @@ __device__ __forceinline__ void store_rgba(float4* dst, float4 v) {
     v4f t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(dst));
 }
+// float -> 8-bit UNORM as a GL framebuffer converts it: clamp to [0, 1], scale by 255, round to nearest (even); NaN -> 0
+__device__ __forceinline__ uint32_t unorm8(float c) {
+    return (uint32_t)__float2uint_rn(fminf(fmaxf(c, 0.0f), 1.0f) * 255.0f);
+}
+// outColor into whichever output planes the caller asked for (wave-uniform pointers)
+__device__ __forceinline__ void store_color(const RaymarchArgs& a, uint64_t out_index, float4 v) {
+    if (a.rgba) store_rgba(a.rgba + out_index, v);
+    if (a.rgba8)
+        __builtin_nontemporal_store(unorm8(v.x) | unorm8(v.y) << 8 | unorm8(v.z) << 16 | unorm8(v.w) << 24, a.rgba8 + out_index);
+}
 
 __device__ __forceinline__ void aux_clear(sdfv_march_aux& aux) {
     aux.status = 0; aux.steps = 0;
@@ -864,7 +874,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
         const bool miss = mm > r2 && (md >= 0.0f || mm * dd - md * md > r2 * dd);
         if (__ballot(in_image && !miss) == 0ull) {
             if (in_image) {
-                store_rgba(a.rgba + out_index, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                store_color(a, out_index, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                 if (AUX) {
                     sdfv_march_aux aux;
                     aux_clear(aux);
@@ -1016,7 +1026,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
         stamp_wave(a, bx, by, wave, t_start, t_start_rt, iterations, ((t_loop0 - t_start) & 0xffffffffull) | ((t_loop1 - t_loop0) << 32));
 #endif
     if (in_image) {
-        store_rgba(a.rgba + out_index, rgba);
+        store_color(a, out_index, rgba);
         if (a.depth) a.depth[out_index] = frag_depth;
         if (AUX) a.aux[out_index] = aux;
     }

@@ -486,7 +486,7 @@ int fill_boundary_slices(const sdfv_demo_params* params, uint32_t sdf_id, const 
 static int raymarch_rows(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
                          const float* pairs, const float* ilv, const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width,
                          uint32_t height, uint32_t y0, uint32_t y1, uint32_t band_step, uint32_t band_height, float* rgba, float* depth,
-                         sdfv_march_aux* aux, void* stream);
+                         sdfv_march_aux* aux, uint32_t* rgba8, void* stream);
 
 extern "C" {
 
@@ -1079,12 +1079,12 @@ int sdfv_raymarch_ex(const sdfv_march_desc* desc, void* stream) {
         return fail(SDFV_ERR_INVALID_ARGUMENT, "band_height %u with band_step 0: a band set needs band_step >= 1 (0 = rows [y0, y1))", d.band_height);
     if (d.band_step == 0)
         return raymarch_rows(d.rp, d.tex0, d.tex1, d.dist, d.pairs, d.ilv, d.cameras, d.n_cameras, d.width, d.height, d.y0, d.y1, 1, 16,
-                             d.rgba, d.depth, d.aux, stream);
+                             d.rgba, d.depth, d.aux, d.rgba8, stream);
     const uint32_t B = d.band_height ? d.band_height : 16u;
     if (B != 8u && B != 16u) return fail(SDFV_ERR_INVALID_ARGUMENT, "band_height %u: 8 or 16 (0 = 16)", d.band_height);
     if (sdfv_band_rows_ex(d.height, d.band_first, d.band_step, B) == 0) return SDFV_OK;  // a band set below the image: nothing to render
     return raymarch_rows(d.rp, d.tex0, d.tex1, d.dist, d.pairs, d.ilv, d.cameras, d.n_cameras, d.width, d.height, d.band_first * B,
-                         d.height, d.band_step, B, d.rgba, d.depth, d.aux, stream);
+                         d.height, d.band_step, B, d.rgba, d.depth, d.aux, d.rgba8, stream);
 }
 
 uint32_t sdfv_band_rows_ex(uint32_t height, uint32_t band_first, uint32_t band_step, uint32_t band_height) {
@@ -1104,12 +1104,13 @@ uint32_t sdfv_band_rows(uint32_t height, uint32_t band_first, uint32_t band_step
 static int raymarch_rows(const sdfv_render_params* rp, const float* tex0, const float* tex1, const float* dist,
                          const float* pairs, const float* ilv, const sdfv_camera* cameras, uint32_t n_cameras, uint32_t width,
                          uint32_t height, uint32_t y0, uint32_t y1, uint32_t band_step, uint32_t band_height, float* rgba, float* depth,
-                         sdfv_march_aux* aux, void* stream) {
-    if (!rp || !tex0 || !tex1 || !rgba) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
+                         sdfv_march_aux* aux, uint32_t* rgba8, void* stream) {
+    if (!rp || !tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!rgba && !rgba8) return fail(SDFV_ERR_INVALID_ARGUMENT, "no colour output: rgba and rgba8 are both NULL");
     if (int rc = check_lights(rp)) return rc;
     if (int rc = check_texel_alignment(tex0, tex1, rgba)) return rc;
-    if ((uintptr_t)dist & 3 || (uintptr_t)depth & 3 || (uintptr_t)aux & 3)
-        return fail(SDFV_ERR_INVALID_ARGUMENT, "dist, depth and aux must be 4-byte aligned");
+    if ((uintptr_t)dist & 3 || (uintptr_t)depth & 3 || (uintptr_t)aux & 3 || (uintptr_t)rgba8 & 3)
+        return fail(SDFV_ERR_INVALID_ARGUMENT, "dist, depth, aux and rgba8 must be 4-byte aligned");
     if (((uintptr_t)pairs | (uintptr_t)ilv) & 7) return fail(SDFV_ERR_INVALID_ARGUMENT, "pairs and ilv must be 8-byte aligned");
     if (n_cameras && !cameras) return fail(SDFV_ERR_INVALID_ARGUMENT, "cameras is NULL");
     if (y0 > y1 || y1 > height) return fail(SDFV_ERR_INVALID_ARGUMENT, "rows [%u,%u) outside height %u", y0, y1, height);
@@ -1205,7 +1206,8 @@ static int raymarch_rows(const sdfv_render_params* rp, const float* tex0, const 
         a.n_cameras = nc;
         if (device_cameras) a.camera_list = device_cameras + c0;
         else if (!ring) memcpy(a.cameras, cameras + c0, nc * sizeof(sdfv_camera));
-        a.rgba = reinterpret_cast<float4*>(rgba) + c0 * pixels_per_cam;
+        a.rgba = rgba ? reinterpret_cast<float4*>(rgba) + c0 * pixels_per_cam : nullptr;
+        a.rgba8 = rgba8 ? rgba8 + c0 * pixels_per_cam : nullptr;
         a.aux = aux ? aux + c0 * pixels_per_cam : nullptr;
         a.depth = depth ? depth + c0 * pixels_per_cam : nullptr;
         hipStream_t on = main;

@@ -50,7 +50,7 @@ def test_struct_layouts(pkg):
     assert C.sizeof(pkg.RenderParams) == 80 + 4 + 4 * 32
     assert C.sizeof(pkg.MarchAux) == 72
     assert pkg.lib.sdfv_abi_version() == 5
-    assert C.sizeof(pkg._capi.MarchDesc) == 120  # 2 + 7 pointers ... : the layout a binder mirrors
+    assert C.sizeof(pkg._capi.MarchDesc) == 128  # the layout a binder mirrors (120 bytes before rgba8: size-prefixed, both work)
 
 
 def test_options_are_explicit_and_the_library_reads_no_environment(pkg):

@@ -4,6 +4,7 @@ Everything fully determined by in-tree reference source (hit flag, step count, h
 samples, normal, depth) must be BIT-EXACT.  The shaded RGBA goes through pow() (ACES -> sRGB), where the
 device's libm differs from the host's in the last ulps: tolerance 1e-4 (BASELINE.json north_star), stated
 against the oracle's full-fp32 restatement."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -730,3 +731,75 @@ def test_small_launches_of_a_batch_overlap_on_side_streams_and_change_nothing(pk
     again = pkg.raymarch(rp, t0, t1, cams, W, H)
     torch.cuda.synchronize()
     assert torch.equal(again.view(torch.int32), ref.view(torch.int32))
+
+
+def unorm8_of(rgba):
+    """The 8-bit UNORM image of an fp32 one: rint(clamp(c, 0, 1) * 255), NaN -> 0 (sdfv_march_desc.rgba8)."""
+    return torch.nan_to_num(rgba, nan=0.0).clamp(0.0, 1.0).mul(255.0).round().to(torch.uint8)
+
+
+def test_rgba8_output_is_the_quantised_fp32_output(pkg):
+    """sdfv_march_desc.rgba8 = outColor as the reference's 8-bit framebuffer holds it (frameinput.rs:19-24):
+    equal to rint(clip(fp32) * 255) on EVERY pixel of the 64-camera 1080p batch (config 5), whether written beside the fp32 plane
+    or instead of it; fp32 stays bit-identical with or without it; single frames, row ranges and tile bands alike."""
+    W, H, n = 1920, 1080, 64
+    prm = pkg.default_params()
+    g = pkg.make_grid((256, 256, 256))
+    t0, t1 = pkg.alloc_textures(g)
+    dist = torch.empty((256, 256, 256), dtype=torch.float32, device="cuda")
+    pkg.fill_grid(prm, g, t0, t1, dist=dist)
+    rp = pkg.default_render_params(g)
+    cams = pkg.orbit_cameras(n, aspect=W / H)
+    ref = pkg.raymarch(rp, t0, t1, cams, W, H, dist=dist)
+    both, img8 = pkg.raymarch(rp, t0, t1, cams, W, H, dist=dist, rgba8="both")
+    only8 = pkg.raymarch(rp, t0, t1, cams, W, H, dist=dist, rgba8="only")
+    torch.cuda.synchronize()
+    assert only8.dtype == torch.uint8 and only8.shape == (n, H, W, 4)
+    assert torch.equal(both.view(torch.int32), ref.view(torch.int32))
+    want = unorm8_of(ref)
+    assert torch.equal(img8, want) and torch.equal(only8, want)
+    assert int((want[..., 3] == 255).sum()) > 0 and int((want[..., 3] == 0).sum()) > 0 and len(torch.unique(want)) > 200
+    # one camera (the box-first tile order), a row range, a band set; the aux kernel's colour path as well
+    one = pkg.raymarch(rp, t0, t1, cams[5], W, H, dist=dist, rgba8="only")
+    assert torch.equal(one[0], want[5])
+    rows = pkg.raymarch(rp, t0, t1, cams[5], W, H, y0=301, y1=777, rgba8="only")
+    assert torch.equal(rows[0], want[5, 301:777])
+    bands = pkg.raymarch(rp, t0, t1, cams[:2], W, H, dist=dist, bands=(1, 4, 8), rgba8="only")
+    rows_of = np.concatenate([np.arange(b * 8, min(b * 8 + 8, H)) for b in range(1, (H + 7) // 8, 4)])
+    assert torch.equal(bands, want[:2][:, torch.from_numpy(rows_of).cuda()])
+    _, aux, aux8 = pkg.raymarch(rp, t0, t1, cams[5], 640, 360, want_aux=True, rgba8="both")
+    plain = pkg.raymarch(rp, t0, t1, cams[5], 640, 360)
+    assert torch.equal(aux8, unorm8_of(plain))
+    # quantisation edges through the shading options: no tone / colour mapping leaves values beyond [0, 1] to clamp
+    rp2 = pkg.default_render_params(g)
+    rp2.tone_mapping, rp2.color_mapping = 0, 0
+    rp2.ambient[0], rp2.ambient[1], rp2.ambient[2] = 3.0, 0.5, 0.01
+    f32, u8 = pkg.raymarch(rp2, t0, t1, cams[0], 800, 450, rgba8="both")
+    assert float(f32.max()) > 1.0 and torch.equal(u8, unorm8_of(f32))
+    with pytest.raises(pkg.SdfvError, match="no colour output"):
+        d = pkg._capi.MarchDesc()
+        d.size = C.sizeof(d)
+        d.rp = C.pointer(rp)
+        d.tex0, d.tex1 = t0.data_ptr(), t1.data_ptr()
+        cam = (pkg.Camera * 1)(cams[0])
+        d.cameras, d.n_cameras, d.width, d.height, d.y0, d.y1 = cam, 1, 64, 64, 0, 64
+        pkg.check(pkg.lib.sdfv_raymarch_ex(C.byref(d), None))
+
+
+def test_a_binder_built_against_the_120_byte_descriptor_still_renders(pkg):
+    """The descriptor is size-prefixed: rgba8 (ABI 5) lies beyond what an ABI 4 binder hands over and reads as NULL."""
+    g = pkg.make_grid((32, 32, 32))
+    t0, t1 = pkg.alloc_textures(g)
+    pkg.fill_grid(pkg.default_params(), g, t0, t1)
+    rp = pkg.default_render_params(g)
+    cam = (pkg.Camera * 1)(pkg.camera_look_at(aspect=1.0))
+    out = torch.zeros((48, 48, 4), device="cuda")
+    d = pkg._capi.MarchDesc()
+    d.size = 120
+    d.rp = C.pointer(rp)
+    d.tex0, d.tex1, d.rgba = t0.data_ptr(), t1.data_ptr(), out.data_ptr()
+    d.cameras, d.n_cameras, d.width, d.height, d.y0, d.y1 = cam, 1, 48, 48, 0, 48
+    d.rgba8 = 0xdead0000  # beyond `size`: must not be read
+    pkg.check(pkg.lib.sdfv_raymarch_ex(C.byref(d), None))
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int32), pkg.raymarch(rp, t0, t1, cam[0], 48, 48)[0].view(torch.int32))
