@@ -464,6 +464,23 @@ def run_extras(c):
                                 "value_incl_gather": round(n_batch * W * H / (ms + g_ms) / 1e3, 1)})
                 except Exception as e:  # noqa: BLE001 -- an extra, never fatal
                     rep["gather_ms"] = f"error: {type(e).__name__}: {e}"
+                # the same gather of the 8-bit UNORM plane (what the reference's framebuffer holds): a quarter of the bytes
+                try:
+                    def gather_step8():
+                        if split == "tiles" and world > 1:
+                            return par.gather_bands(batch_out8, H, rank, world, comm=lib_comm, band_height=where["bands"][2])
+                        if split == "cameras":
+                            return par.gather_images(batch_out8, n_batch, rank, world, comm=lib_comm)
+                        return par.gather_rows(batch_out8, H, rank, world) if world > 1 else batch_out8
+                    STAGE(f"batch gather of the rgba8 plane ({split}) to rank 0")
+                    gather_step8()
+                    g8 = timed_region(gather_step8, 2, torch, dist, world, device)[0] / 2 * 1e3
+                    rep["rgba8_only"].update({"gather_ms": round(g8, 4), "gather_bytes_to_rank0": n_batch * W * H * 4 * (world - 1) // max(world, 1),
+                                              "value_incl_gather": round(n_batch * W * H / (ms_rgba8 + g8) / 1e3, 1)})
+                except Exception as e:  # noqa: BLE001 -- an extra, never fatal
+                    rep["rgba8_only"]["gather_ms"] = f"error: {type(e).__name__}: {e}"
+                rep["headline"] = ("`value`: every rank keeps the bands it rendered (SURVEY 8(e): the gather is optional); value_incl_gather / "
+                                   "rgba8_only.value_incl_gather = with the images assembled on rank 0 as fp32 / as the 8-bit framebuffer format")
             return rep
 
         splits = ["tiles"] if world == 1 else (["tiles", "rows", "cameras"] if args.batch_split in ("all", "both") else [args.batch_split])

@@ -300,6 +300,9 @@ class SlabComm:
         `dst` the images [n_cam, height, W, C] (None elsewhere)."""
         pkg = self.pkg
         stream = torch.cuda.current_stream() if stream is None else stream
+        if part.dtype == torch.uint8:  # the 8-bit UNORM plane (sdfv_march_desc.rgba8): 4 bytes per pixel = one word per pixel
+            out = self.gather_bands(part.view(torch.float32), height, dst=dst, stream=stream, band_height=band_height)
+            return None if out is None else out.view(torch.uint8)
         n_cam, _, width, ch = (int(v) for v in part.shape)
         with torch.cuda.stream(stream):
             out = scratch = None
@@ -319,6 +322,9 @@ class SlabComm:
         """sdfv_comm_gather_cameras: part = [cameras of this rank, H, W, C] (split_cameras) -> on `dst` [n_cameras, H, W, C]."""
         pkg = self.pkg
         stream = torch.cuda.current_stream() if stream is None else stream
+        if part.dtype == torch.uint8:  # the 8-bit UNORM plane: one 4-byte word per pixel
+            out = self.gather_cameras(part.view(torch.float32), n_cameras, dst=dst, stream=stream)
+            return None if out is None else out.view(torch.uint8)
         _, height, width, ch = (int(v) for v in part.shape)
         with torch.cuda.stream(stream):
             out = torch.empty((n_cameras, height, width, ch), dtype=torch.float32, device=part.device) if self.rank == dst else None

@@ -96,6 +96,19 @@ def rank_main(rank):
                     st.synchronize()
                     if rank == dst:
                         assert same(out, want_batch), f"gather_bands ({bh}-row bands)"
+                # the 8-bit UNORM plane (sdfv_march_desc.rgba8): a quarter of the bytes through the same collectives
+                want8 = want_batch.clamp(0.0, 1.0).mul(255.0).round().to(torch.uint8)
+                bands = par.split_bands(H, rank, world, band_height=8)
+                b8 = pkg.raymarch(rp, r0, r1, cams, W, H, bands=bands, dist=gd, rgba8="only")
+                out = par.gather_bands(b8, H, rank, world, dst=dst, comm=comm, band_height=8)
+                st.synchronize()
+                if rank == dst:
+                    assert out.dtype == torch.uint8 and torch.equal(out, want8), "gather_bands of the rgba8 plane"
+                p8 = pkg.raymarch(rp, r0, r1, mine, W, H, rgba8="only") if mine else torch.empty((0, H, W, 4), dtype=torch.uint8, device="cuda")
+                out = par.gather_images(p8, n_cam, rank, world, dst=dst, comm=comm)
+                st.synchronize()
+                if rank == dst:
+                    assert torch.equal(out, want8), "gather_images of the rgba8 plane"
             st.synchronize()
             comm.close()
         with lock:

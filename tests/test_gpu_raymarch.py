@@ -773,9 +773,13 @@ def test_rgba8_output_is_the_quantised_fp32_output(pkg):
     # quantisation edges through the shading options: no tone / colour mapping leaves values beyond [0, 1] to clamp
     rp2 = pkg.default_render_params(g)
     rp2.tone_mapping, rp2.color_mapping = 0, 0
-    rp2.ambient[0], rp2.ambient[1], rp2.ambient[2] = 3.0, 0.5, 0.01
+    rp2.ambient[0], rp2.ambient[1], rp2.ambient[2] = 40.0, 0.5, 0.01
+    rp2.tint[3] = 1.75                                   # surfaceColorTint.a passes through unclamped: beyond 1 in fp32, 255 in UNORM
     f32, u8 = pkg.raymarch(rp2, t0, t1, cams[0], 800, 450, rgba8="both")
-    assert float(f32.max()) > 1.0 and torch.equal(u8, unorm8_of(f32))
+    assert float(f32.max()) == 1.75 and int(u8.max()) == 255 and torch.equal(u8, unorm8_of(f32))
+    rp2.tint[3] = float("nan")
+    f32, u8 = pkg.raymarch(rp2, t0, t1, cams[0], 800, 450, rgba8="both")
+    assert bool(torch.isnan(f32).any()) and torch.equal(u8, unorm8_of(f32))
     with pytest.raises(pkg.SdfvError, match="no colour output"):
         d = pkg._capi.MarchDesc()
         d.size = C.sizeof(d)
