@@ -686,6 +686,7 @@ SDFV_INLINE int sdfv_raymarch_volumes(const sdfv_render_params *rp, const float 
     d.rgba = rgba;
     d.depth = depth;
     d.aux = aux;
+    d.rgba8 = (uint32_t *)0;
     return sdfv_raymarch_ex(&d, stream);
 }
 /* material.frag main() over tex0.r in place: the batched raymarch SURVEY 8(b) names */
@@ -745,6 +746,7 @@ SDFV_INLINE int sdfv_raymarch_bands(const sdfv_render_params *rp, const float *t
     d.rgba = rgba;
     d.depth = depth;
     d.aux = aux;
+    d.rgba8 = (uint32_t *)0;
     return sdfv_raymarch_ex(&d, stream);
 }
 
