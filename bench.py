@@ -52,6 +52,7 @@ from types import SimpleNamespace
 
 import bench_common
 from bench_common import (FILL_8D_PEAK_MVOX, FILL_BYTES_PER_VOXEL, HBM_PEAK_GBS, STAGE, fill_roofline, load_traffic,  # noqa: F401
+                          running_build_id, traffic_stale,
                           per_step_stats, placement_note, region)
 
 WORKLOADS = {
@@ -261,13 +262,14 @@ def contract_line(line, full_path):
                    "parallelism": cfg["parallelism"]}
     c["pipeline"] = line.get("pipeline")
     r = line.get("roofline") or {}
-    c["roofline"] = _pick(r, "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+    c["roofline"] = _pick(r, "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "algorithmic_bytes_per_launch",
                           "avg_launch_ms", "frac_bus", "rccl_ranks")
+    c["build_id"] = line.get("build_id")
     t = r.get("target_512")
     if isinstance(t, dict):
         c["roofline"]["target_512"] = {k: _pick(v, "ms", "frac_8d") for k, v in t.items() if isinstance(v, dict)}
     rr = line.get("roofline_raymarch") or {}
-    c["roofline_raymarch"] = _pick(rr, "bound", "achieved", "frac", "traffic", "compulsory_bytes", "avg_launch_ms")
+    c["roofline_raymarch"] = _pick(rr, "bound", "achieved", "frac", "traffic", "traffic_stale", "compulsory_bytes", "avg_launch_ms")
     if "bound" in c["roofline_raymarch"]:
         c["roofline_raymarch"]["bound"] = "latency"
     cb = line.get("cpu_baseline")
@@ -667,10 +669,12 @@ def run(redirect):
         out["commit_ms"] = round(commit_ms, 4) if commit_ms != INF else None
         out["commit_note"] = ("sdfv_commit_distance as a pass of its own (device-side SDFViewer::commit for a grid filled "
                               "without the volume); not part of either pipeline")
-        traffic = None
+        traffic, stale = None, None
         for key in {"plain": ("",), "fused": ("_fused",), "fused_ilv": ("_fused_ilv", "_fused")}[chosen]:  # (ilv: the same bytes)
-            traffic = traffic if traffic is not None else load_traffic(args.workload + key)
+            if traffic is None:
+                traffic, stale = load_traffic(args.workload + key), traffic_stale(args.workload + key)
         out["roofline"] = fill_roofline(kern_ms, voxels_per_rank, bpv, traffic)
+        out["roofline"]["traffic_stale"] = stale  # True: the PMC pass traced another build than the one timed here
         if chosen == "fused_ilv" and side % 256 == 0 and side >= 512:  # (csrc/fill_kernels.hip launch_fill_dense: rows two workgroups wide)
             out["roofline"]["kernel"] = "fill_dense_ilv_paired_kernel"
         out["roofline_raymarch"] = raymarch_traffic_report(args.workload, march_ev,
@@ -691,6 +695,7 @@ def run(redirect):
         _, kern_ms = region(lambda: pkg.fill_grid(prm, grid, owned0, owned1, dist=own_dist), K, 1, torch, dist, world, device)
         fill_mvox = total_voxels / fill_ms / 1e3
         out["roofline"] = fill_roofline(kern_ms, voxels_per_rank, 36, load_traffic(args.workload + "_fused"))
+        out["roofline"]["traffic_stale"] = traffic_stale(args.workload + "_fused")
         out["fill_step_fraction_of_plain_fill"] = round(kern_ms / fill_ms, 3)
         # raymarch: one camera per rank over a replica of the N = 1 grid, filled by the same fused fill
         rgrid = pkg.make_grid((side, side, side))
@@ -767,6 +772,7 @@ def run(redirect):
     line["raymarch_kernel_ms"] = round(march_ev, 4)
     line["incomplete"] = None  # True only when the watchdog had to print the line for an extra that hung
     line["box"] = box_stamp(torch, device)
+    line["build_id"] = running_build_id()  # sdfv_build_id(): which kernel sources the timed library was built from
     for key in ("batch_raymarch", "target_512", "progressive", "host_load", "ingest", "halo_loopback", "config4"):
         line[key] = None
     PARTIAL["line"], PARTIAL["since"] = line, time.monotonic()

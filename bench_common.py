@@ -84,12 +84,35 @@ def placement_note(args, slab):
     return f"one block, tex1 {gap} B after tex0's end: SDFViewer::new_voxels' fixed placement for this texture size (no probe)"
 
 
+def _traffic_entry(workload_key, name):
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", name))).get(workload_key)
+        return e if isinstance(e, dict) else None
+    except Exception:
+        return None
+
+
 def load_traffic(workload_key, name="fill_pmc_traffic.json"):
     """HBM bytes per launch from the committed PMC pass (profiles/*_pmc_traffic.json), or None."""
-    path = os.path.join(ROOT, "profiles", name)
+    e = _traffic_entry(workload_key, name)
+    return None if e is None else e.get("hbm_bytes_per_launch")
+
+
+def traffic_stale(workload_key, name="fill_pmc_traffic.json"):
+    """Does the committed PMC pass describe ANOTHER build than the library that is running?  The pass is stamped with the build
+    id of the library it traced (tools/pmc_to_traffic.py, from the summary's header); True when that differs from
+    sdfv_build_id() of the running library (or the entry predates the stamp), None when there is no entry."""
+    e = _traffic_entry(workload_key, name)
+    if e is None:
+        return None
+    return e.get("build_id") != running_build_id()
+
+
+def running_build_id():
+    """sdfv_build_id() of the library the bench runs: sha256[:12] over the kernel sources it was built from."""
     try:
-        d = json.load(open(path))
-        return d.get(workload_key, {}).get("hbm_bytes_per_launch")
+        import importlib
+        return importlib.import_module("sdf-viewer_amd").lib.sdfv_build_id().decode()
     except Exception:
         return None
 

@@ -10,7 +10,7 @@ import subprocess
 import sys
 import time
 
-from bench_common import (HBM_PEAK_GBS, ROOT, STAGE, load_traffic, per_step_stats, placement_note, region, timed_region)
+from bench_common import (HBM_PEAK_GBS, ROOT, STAGE, load_traffic, per_step_stats, placement_note, region, timed_region, traffic_stale)
 
 
 def raymarch_traffic_report(workload_key, launch_ms, path_key="product_path", traffic_key=None):
@@ -21,8 +21,10 @@ def raymarch_traffic_report(workload_key, launch_ms, path_key="product_path", tr
     rep = {"kernel": "raymarch_kernel", "bound": "latency (<=255 dependent gathers per ray), not hbm",
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": round(launch_ms, 5)}
     traffic = load_traffic(traffic_key or workload_key, "raymarch_pmc_traffic.json") if workload_key else None
+    stale = traffic_stale(traffic_key or workload_key, "raymarch_pmc_traffic.json") if workload_key else None
     if traffic is None and traffic_key and traffic_key.endswith("_ilv"):  # no PMC pass of the interleaved march yet: the distance-volume one
-        traffic = load_traffic(workload_key, "raymarch_pmc_traffic.json")
+        traffic, stale = load_traffic(workload_key, "raymarch_pmc_traffic.json"), traffic_stale(workload_key, "raymarch_pmc_traffic.json")
+    rep["traffic_stale"] = stale
     model = None
     try:
         model = json.load(open(os.path.join(ROOT, "profiles", "raymarch_model_bytes.json"))).get(workload_key)
@@ -199,7 +201,10 @@ def progressive_block(pkg, torch, prm, sides, reps=7):
         # HBM bytes per case from the committed PMC passes, and the same kernels' durations under rocprofv3 (warm, 100
         # repetitions: tools/gpu_profile_pass.sh -> profiles/pass_traffic.json, regenerated per round) next to the times measured here
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "pass_traffic.json")))[str(side)]["cases"]
+            whole = json.load(open(os.path.join(ROOT, "profiles", "pass_traffic.json")))[str(side)]
+            prof = whole["cases"]
+            from bench_common import running_build_id
+            res["traffic_stale"] = whole.get("build_id") != running_build_id()  # the PMC passes traced another build
         except Exception:  # noqa: BLE001
             prof = {}
         for name, c in res.items():

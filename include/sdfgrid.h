@@ -140,6 +140,8 @@ typedef struct sdfv_march_aux {
 /* ---- library ---- */
 uint32_t    sdfv_abi_version(void);
 const char *sdfv_last_error(void);  /* thread-local, never NULL */
+const char *sdfv_build_id(void);    /* 12 hex digits: sha256 over the kernel sources this library was built from (csrc/Makefile;
+                                      * tools/source_hash.py computes it from a tree) -- profiles/ stamps its evidence with it */
 int         sdfv_device_count(void); /* number of HIP devices visible, 0 if none */
 float       sdfv_air_dist(void);     /* AIR_DIST, scene/sdf/mod.rs:42 */
 

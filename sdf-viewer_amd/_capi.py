@@ -85,6 +85,7 @@ PROTOTYPES = {
     "sdfv_raymarch_ex": (C.c_int, [C.POINTER(MarchDesc), C.c_void_p]),
     "sdfv_abi_version": (C.c_uint32, []),
     "sdfv_last_error": (C.c_char_p, []),
+    "sdfv_build_id": (C.c_char_p, []),
     "sdfv_device_count": (C.c_int, []),
     "sdfv_air_dist": (C.c_float, []),
     "sdfv_set_option": (C.c_int, [C.c_uint32, C.c_uint64]),

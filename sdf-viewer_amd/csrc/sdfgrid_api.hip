@@ -494,6 +494,11 @@ uint32_t sdfv_abi_version(void) { return SDFV_ABI_VERSION; }
 
 const char* sdfv_last_error(void) { return g_err; }
 
+#ifndef SDFV_BUILD_ID
+#define SDFV_BUILD_ID "unknown"
+#endif
+const char* sdfv_build_id(void) { return SDFV_BUILD_ID; }
+
 int sdfv_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {

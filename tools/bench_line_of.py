@@ -12,6 +12,8 @@ for line in open(sys.argv[1], errors="replace"):
 if full is None:
     print("# (no bench record in the log)")
     sys.exit(0)
+smi = ((full.get("box") or {}).get("rocm_smi") or {}) if isinstance((full.get("box") or {}).get("rocm_smi"), dict) else {}
+print(f"# build_id: {full.get('build_id')}  box: {smi.get('Unique ID') or (full.get('box') or {}).get('uuid')}")
 keep = ("value", "value_rays", "ms_per_step", "ms_per_step_fill", "ms_per_step_raymarch", "pipeline", "texture_placement", "raymarch_kernel_ms")
 print("# bench line of THIS process:", json.dumps({k: full.get(k) for k in keep}))
 r = full.get("roofline") or {}

@@ -52,7 +52,13 @@ CASES = {
     "edit_eighth_box_3_passes": ("edit_eighth", [(PASS, n // 64), (PASS, n // 8), (QUAD, n // 4)]),
     "noop_pass_step_1": ("noop", [(QUAD, n // 4)]),
 }
-out = {"side": side, "source": "tools/gpu_profile_pass.sh (rocprofv3 --kernel-trace / --pmc WRITE_SIZE / --pmc FETCH_SIZE, one group of cases "
+try:  # which build / box the traces describe (this runs on the box, right after them)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import stamp
+    STAMP = {"build_id": stamp.running_build_id(), "box": stamp.box_uuid()}
+except Exception:
+    STAMP = {"build_id": None, "box": None}
+out = {"side": side, **STAMP, "source": "tools/gpu_profile_pass.sh (rocprofv3 --kernel-trace / --pmc WRITE_SIZE / --pmc FETCH_SIZE, one group of cases "
                                "per process, warm, 100 repetitions); hbm_bytes = (WRITE_SIZE + 2 x FETCH_SIZE) KiB x 1024", "cases": {}}
 cache = {}
 for case, (group, kernels) in CASES.items():
