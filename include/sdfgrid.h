@@ -192,13 +192,22 @@ typedef enum sdfv_option {
                                         * stream (kernels that carry 32 cameras each as arguments: no copy engine, no allocation
                                         * per call), so that 64 cameras are one launch; 0 = launches of 16 cameras instead (what a
                                         * stream under capture gets anyway).  A DEVICE array is always read in place.  Same pixels */
-    SDFV_OPT_PASS_FORM = 13,           /* 0 auto (default) | 1: a pass the caller says nothing about (no flags, no box) with step >= 2 takes
+    SDFV_OPT_PASS_FORM = 13,           /* 0 auto (default) | 1: a pass the caller says nothing about (no flags, no box) with step 2..8 takes
                                         * the per-voxel kernel (one texel in every `step`) instead of the whole-rows kernel whose
-                                        * waves decide on the volume they read (sdfv_fill_grid_pass_ex).  A/B runs; same texels */
+                                        * waves decide on the volume they read (sdfv_fill_grid_pass_ex).  A/B runs; same texels --
+                                        * with one caveat the whole-rows form shares with the reference's own reading of the value:
+                                        * where 64 consecutive voxels of a visited row ALL store exactly AIR_DIST it takes them for
+                                        * new_voxels' state and writes the ones between lattice points as [AIR_DIST; 4]; a voxel
+                                        * SAMPLED to exactly 0.1 + d == AIR_DIST there (update_required re-samples such a voxel on
+                                        * every visit anyway, scene/sdf/mod.rs:184) would lose its colour until then.  Option 1 and
+                                        * the reference leave off-lattice texels alone */
     SDFV_OPT_RCCL_LIBRARY = 14,        /* PROCESS-wide, before the first communicator: value = address of a NUL-terminated path of the RCCL-ABI
                                         * library sdfv_slab_comm_* loads (copied; 0 = "librccl.so.1" by name, the default).  For
                                         * installations whose RCCL is not on the loader's path -- and how tests/c/mock_rccl.cpp stands
-                                        * in for RCCL so that several ranks can run on one device.  Refused once RCCL is loaded */
+                                        * in for RCCL so that several ranks can run on one device.  Refused once RCCL is loaded (a
+                                        * path that fails to load is final too: one attempt per process, its dlerror() text is in
+                                        * sdfv_last_error()).  sdfv_get_option hands back the address of a copy of the path that
+                                        * belongs to the calling thread, valid until that thread asks again */
     SDFV_OPT_TUNING_WAVE_TIMING = 100, /* tuning build only (-DSDFV_TUNING): DEVICE address of 32 B per raymarch wave */
     SDFV_OPT_TUNING_TILE_ORDER = 102,  /* tuning build only: DEVICE address of tiles_x * tiles_y uint32 tile numbers (row-major
                                         * tile index by * tiles_x + bx): workgroup L of a single-camera launch renders tile
@@ -413,7 +422,10 @@ int sdfv_mesh_trim(void);
  *   cameras           HOST array of n_cameras, free again when the call returns (up to 16 ride in a launch's kernel arguments; a
  *                     larger batch goes through the library's ring of device memory, SDFV_OPT_RAYMARCH_CAMERA_STAGING, so that
  *                     64 cameras are one launch).  The array may instead lie in DEVICE (or managed) memory, whatever its
- *                     length: read in place by the launches, nothing copied (the library asks hipPointerGetAttributes)
+ *                     length: read in place by the launches, nothing copied (the library asks hipPointerGetAttributes).  One
+ *                     consequence: a SINGLE camera handed over in device memory renders in plain tile order -- the launcher's
+ *                     box-first order and occupancy rule read the camera on the host (same pixels; hand single frames over
+ *                     as a host struct)
  *   y0, y1            rows [y0, y1) when band_step == 0
  *   band_first, band_step, band_height   band_step >= 1: the balanced image-tile split of BASELINE config 5 -- rank r of N renders
  *                     (r, N): the bands band_first, band_first + band_step, ... of band_height = 16 (also 0) or 8 rows -- a

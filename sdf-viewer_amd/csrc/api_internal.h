@@ -2,6 +2,7 @@
 #pragma once
 
 #include <cstdint>
+#include <string>
 
 #include "../../include/sdfgrid.h"
 
@@ -29,6 +30,7 @@ const Options& options();
 // SDFV_OPT_RCCL_LIBRARY: process-wide path of the RCCL-ABI library the communicator loads (empty = librccl.so.1 by name)
 // (claim_rccl_library_path: the path, and from that moment on SDFV_OPT_RCCL_LIBRARY is refused -- one RCCL per process)
 const char* rccl_library_path();
+std::string rccl_library_path_copy();
 bool rccl_loaded();
 const char* claim_rccl_library_path();
 // Formats the thread-local message sdfv_last_error() returns and hands `code` back.

@@ -880,8 +880,10 @@ hipError_t launch_fill_pass(const FillArgs& a, const PassArgs& pass, const FillL
         return hipGetLastError();
     }
     const bool vol16 = p.dist && a.W % 4 == 0 && ((uintptr_t)p.dist & 15) == 0;  // (either layout: 16-byte loads of the volume)
-    if (!p.all_required && !p.has_box && p.step >= 2 && vol16 && !p.no_adaptive && (uint64_t)a.W * p.ny * p.nz < (1ull << 32)) {
-        // nothing known, nothing boxed: whole visited rows, every wave deciding on what it reads (rows_adaptive above)
+    if (!p.all_required && !p.has_box && p.step >= 2 && p.step <= 8 && vol16 && !p.no_adaptive && (uint64_t)a.W * p.ny * p.nz < (1ull << 32)) {
+        // nothing known, nothing boxed: whole visited rows, every wave deciding on what it reads (rows_adaptive above).  Up to
+        // step 8, like the all_required rows form: the rows hold W * ny * nz voxels against the lattice's nx * ny * nz, so at
+        // larger steps a no-op pass would scan step / 4 times the lanes of the per-voxel kernel below
         const uint64_t lanes = ((uint64_t)a.W * p.ny * p.nz + (a.dist_ilv ? 1 : 3)) / (a.dist_ilv ? 2 : 4);
         const uint32_t blocks = (uint32_t)((lanes + kBlock - 1) / kBlock);
         if (a.dist_ilv) {

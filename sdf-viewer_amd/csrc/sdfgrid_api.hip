@@ -374,6 +374,10 @@ const char* rccl_library_path() {
     std::lock_guard<std::mutex> lock(g_rccl_path_mutex);
     return g_rccl_path.c_str();  // (stable: the string is not modified once RCCL has been loaded)
 }
+std::string rccl_library_path_copy() {
+    std::lock_guard<std::mutex> lock(g_rccl_path_mutex);
+    return g_rccl_path;
+}
 bool rccl_loaded() { return g_rccl_loaded.load(); }
 const char* claim_rccl_library_path() {
     std::lock_guard<std::mutex> lock(g_rccl_path_mutex);
@@ -622,7 +626,12 @@ int sdfv_get_option(uint32_t option, uint64_t* value) {
         case SDFV_OPT_EXT_SRGB_QUANT: *value = g_options.ext_srgb_quant; return SDFV_OK;
         case SDFV_OPT_PASS_INDEX_LIMIT: *value = g_options.pass_index_limit; return SDFV_OK;
         case SDFV_OPT_PASS_FORM: *value = g_options.pass_form; return SDFV_OK;
-        case SDFV_OPT_RCCL_LIBRARY: *value = (uint64_t)(uintptr_t)sdfv::rccl_library_path(); return SDFV_OK;  // (address of the library's copy; "" = by name)
+        case SDFV_OPT_RCCL_LIBRARY: {  // address of a copy that belongs to the CALLING THREAD ("" = by name): valid until this
+            thread_local std::string copy;  // thread asks again, whatever another thread sets meanwhile
+            copy = sdfv::rccl_library_path_copy();
+            *value = (uint64_t)(uintptr_t)copy.c_str();
+            return SDFV_OK;
+        }
         default: return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown option %u", option);
     }
 }

@@ -56,7 +56,10 @@ const Rccl* rccl() {
         if (path && path[0]) {  // SDFV_OPT_RCCL_LIBRARY: this file and nothing else
             r.handle = dlopen(path, RTLD_NOW | RTLD_LOCAL);
             if (!r.handle) {
-                r.load_error = "the library named by SDFV_OPT_RCCL_LIBRARY could not be loaded";
+                const char* why = dlerror();
+                static std::string message;  // (this initialiser runs once per process)
+                message = std::string("the library named by SDFV_OPT_RCCL_LIBRARY could not be loaded: ") + (why ? why : "dlopen failed");
+                r.load_error = message.c_str();
                 return r;
             }
         } else {

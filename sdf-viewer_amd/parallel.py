@@ -514,9 +514,6 @@ def _exchange_rays(down, up, rank, world, group):
     return torch.cat([b.to(dev) for b in bufs], dim=0)
 
 
-_SHARDED_CAPACITY = {}  # (width, height, world) -> ray-list capacity the last frame of that size needed (None = the default)
-
-
 def merge_sharded_aux(aux_sum):
     """Merge of the ranks' aux images (summed bit patterns) -> the single-GPU record: pixels no rank reports (status 0) get the
     cleared record's depth of 1.0 back (aux words: status, steps, hit_pos[3], t, raw0[4], raw1[4], normal[3], depth)."""
@@ -538,12 +535,23 @@ def raymarch_sharded(pkg, rp, grid, slab, camera, width, height, rank, world, gr
         # size, so that the frames that follow start where this one ended.  The retry needs every rank to agree
         # (an overflow on ONE rank sends all of them round again): that takes a torch.distributed group; with the library
         # communicator alone the lists simply hold every pixel and nothing can overflow.
+        # A message of the march is 16 + 24 * capacity bytes WHATEVER it carries: every rank of the communicator must pass the same
+        # capacity, or the sends and receives differ in size.  The remembered capacity therefore lives ON the communicator (not in
+        # a process-wide table shared by other communicators, restarted peers or ranks that run as threads), and the ranks agree
+        # on it -- all-reduce(MAX) -- before the first march of every frame.
         agree = world > 1 and c10d.is_available() and c10d.is_initialized()
-        key = (int(width), int(height), int(world))
+        remembered = comm.__dict__.setdefault("_sharded_capacity", {})  # (width, height) -> capacity the last frame needed
+        key = (int(width), int(height))
         if world > 1 and not agree:
             attempts = [width * height]
         else:
-            attempts = [_SHARDED_CAPACITY.get(key), width * height] if _SHARDED_CAPACITY.get(key) != width * height else [width * height]
+            first = remembered.get(key) or 0  # 0 = the library's bounded default
+            if agree:
+                want = torch.tensor([first], dtype=torch.int64, device=slab.tex0.device if c10d.get_backend(group) == "nccl" else "cpu")
+                enter_stage("raymarch_sharded: all_reduce(MAX) of the ray-list capacity")
+                c10d.all_reduce(want, op=c10d.ReduceOp.MAX, group=group)
+                first = int(want.item())
+            attempts = [first or None, width * height] if first != width * height else [width * height]
         overflow = left = 0
         for capacity in attempts:
             rgba, aux, status = comm.march(rp, grid, slab, camera, width, height, want_aux=want_aux, capacity=capacity)
@@ -556,7 +564,7 @@ def raymarch_sharded(pkg, rp, grid, slab, camera, width, height, rank, world, gr
                 return (rgba, aux) if want_aux else rgba
             if not overflow:
                 break  # rays left over after `world` rounds without any list overflowing: larger lists cannot help
-            _SHARDED_CAPACITY[key] = width * height
+            remembered[key] = width * height
         raise pkg.SdfvError(-1, f"sdfv_slab_march: ray lists overflowed ({overflow}) / {left} rays left over")
     m = ShardedMarch(pkg, rp, grid, slab, camera, width, height, want_aux)
     incoming = None
