@@ -146,11 +146,13 @@ def progressive_block(pkg, torch, prm, sides, reps=7):
             # what host/sdf_viewer.cpp enqueues since round 4: new_voxels writes nothing, every pass of the load says so
             return lambda: [pkg.fill_grid_pass(prm, g, st, t0, t1, dist=dist, flags=VIRGIN | SAME) for st in steps]
 
-        def passes(steps, box=None, flagged=False):
+        NOOP = pkg._capi.PASS_EXPECT_NOOP
+
+        def passes(steps, box=None, flagged=False, hint=0):
             # flagged: what host/sdf_viewer.cpp's LoadingManager tells the library (sdfv_fill_grid_pass_ex): the first pass
             # of a load sees a fresh grid, the later ones revisit what the same load wrote -- nothing is read
             return lambda: [pkg.fill_grid_pass(prm, g, st, t0, t1, changed_box=box, dist=dist,
-                                               flags=((FRESH | SAME) if k == 0 else SAME) if flagged else 0)
+                                               flags=((FRESH | SAME) if k == 0 else SAME) if flagged else hint)
                             for k, st in enumerate(steps)]
 
         def visited(steps):
@@ -196,7 +198,11 @@ def progressive_block(pkg, torch, prm, sides, reps=7):
         res["edit_eighth_box_3_passes"] = case(timed(passes((4, 2, 1), eighth), loaded), visited((4, 2, 1)),
                                                sum((-(-in_box_axis // st)) ** 3 for st in (4, 2, 1)),
                                                "changed_box = [-0.5, 0.5]^3 (1/8 of the volume); updated count approximate for step > 1")
-        res["noop_pass_step_1"] = case(timed(passes((1,)), loaded), n, 0, "step-1 pass over a loaded grid, no box: reads the volume, writes nothing")
+        res["noop_pass_step_1"] = case(timed(passes((1,), hint=NOOP), loaded), n, 0,
+                                       "step-1 pass over a loaded grid, no box, as SDFViewer::update enqueues it once an edit has been worked off "
+                                       "(SDFV_PASS_EXPECT_NOOP: beyond the last-level cache the scan streams the volume with nontemporal loads): "
+                                       "reads the volume, writes nothing")
+        res["noop_pass_step_1_unhinted"] = case(timed(passes((1,)), loaded), n, 0, "the same pass from a caller that says nothing (cached loads)")
         res["dense_fused_fill_ms"] = round(timed(lambda: pkg.fill_grid(prm, g, t0, t1, dist=dist), lambda: None), 4)
         # HBM bytes per case from the committed PMC passes, and the same kernels' durations under rocprofv3 (warm, 100
         # repetitions: tools/gpu_profile_pass.sh -> profiles/pass_traffic.json, regenerated per round) next to the times measured here

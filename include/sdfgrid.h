@@ -201,6 +201,9 @@ typedef enum sdfv_option {
                                         * SAMPLED to exactly 0.1 + d == AIR_DIST there (update_required re-samples such a voxel on
                                         * every visit anyway, scene/sdf/mod.rs:184) would lose its colour until then.  Option 1 and
                                         * the reference leave off-lattice texels alone */
+    SDFV_OPT_PASS_LOADS = 15,          /* how a pass reads the volume (or tex0.r) for update_required: 0 auto (default: nontemporal loads
+                                        * when the caller passes SDFV_PASS_EXPECT_NOOP, cached loads otherwise) | 1 cached | 2
+                                        * nontemporal.  A/B runs; same texels */
     SDFV_OPT_RCCL_LIBRARY = 14,        /* PROCESS-wide, before the first communicator: value = address of a NUL-terminated path of the RCCL-ABI
                                         * library sdfv_slab_comm_* loads (copied; 0 = "librccl.so.1" by name, the default).  For
                                         * installations whose RCCL is not on the loader's path -- and how tests/c/mock_rccl.cpp stands
@@ -319,6 +322,16 @@ int sdfv_fill_grid_commit(const sdfv_demo_params *params, uint32_t sdf_id, const
  *                         afterwards: 512^3 0.70 + 0.20 ms -> 0.70), and every later pass reads and maintains it in place.
  *                         Pass the same buffer as sdfv_march_desc.ilv. */
 #define SDFV_PASS_VOLUME_INTERLEAVED 8u
+/*   SDFV_PASS_EXPECT_NOOP a HINT, not knowledge (a wrong hint costs time, never texels): the caller expects the pass to leave most of
+ *                         what it visits alone -- the passes a LoadingManager runs over a loaded grid once a changed box has been
+ *                         worked off (scene/sdf/mod.rs:146-156: one more full manager, without the box).  The pass then scans the
+ *                         volume with NONTEMPORAL loads where the volume is larger than the last-level cache: nothing is
+ *                         allocated in L2 / the Infinity Cache, so the scan does not push the previous fill's dirty lines out
+ *                         first -- a step-1 no-op pass over 512^3 reads at 6.3 TB/s instead of 4.2 (0.085 against 0.128 ms, same
+ *                         box).  A pass that does update most voxels runs 7-13 % slower with such loads (its partial-line stores
+ *                         find the lines gone), and a volume that fits the cache is read faster through it: leave the hint off
+ *                         for loads; the library ignores it for small volumes. */
+#define SDFV_PASS_EXPECT_NOOP 16u
 int sdfv_fill_grid_pass_ex(const sdfv_demo_params *params, uint32_t sdf_id, const sdfv_grid *grid, uint32_t step,
                            const float *changed_box, float *tex0, float *tex1, float *dist, uint32_t flags, void *stream);
 

@@ -193,13 +193,14 @@ OPT_PASS_INDEX_LIMIT = 11
 OPT_RAYMARCH_CAMERA_STAGING = 12
 OPT_PASS_FORM = 13  # 0 auto | 1 per-voxel kernels for unflagged passes (A/B)
 OPT_RCCL_LIBRARY = 14  # process-wide: address of the path of the RCCL-ABI library to load (before the first communicator)
+OPT_PASS_LOADS = 15  # 0 auto (SDFV_PASS_EXPECT_NOOP decides) | 1 cached | 2 nontemporal loads for update_required
 OPT_EXT_SRGB_QUANT = 10  # Srgba::from(Vec3): 0 truncate (default) | 1 round
 OPT_TUNING_WAVE_TIMING = 100
 OPT_TUNING_PRIORITY_MAP = 101
 OPT_TUNING_TILE_ORDER = 102
 RM_NO_FAST_INDEX, RM_NO_POW2_EXTENT, RM_NO_POW2_SIZE, RM_NO_SYMMETRIC, RM_NO_ASM_LOOP, RM_NO_INTERIOR_FETCH = 1, 2, 4, 8, 16, 32
 STEP_SIDE_BOUNDARY, STEP_UNPACKED, STEP_START_EVENT, STEP_DEFER_JOIN = 3, 4, 8, 16
-PASS_FRESH_GRID, PASS_SAME_LOAD, PASS_VIRGIN_GRID, PASS_VOLUME_INTERLEAVED = 1, 2, 4, 8
+PASS_FRESH_GRID, PASS_SAME_LOAD, PASS_VIRGIN_GRID, PASS_VOLUME_INTERLEAVED, PASS_EXPECT_NOOP = 1, 2, 4, 8, 16
 FILL_FORM = {"auto": 0, "rows": 1, "flat": 2}
 COMM_ID_BYTES = 128
 RAY_BUFFER_HEADER_BYTES = 16

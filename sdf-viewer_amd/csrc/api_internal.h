@@ -21,6 +21,7 @@ struct Options {
     uint32_t slab_step_form = 0;     // 0 auto, SDFV_STEP_* otherwise
     uint32_t ext_srgb_quant = 0;     // Srgba::from(Vec3): 0 truncate (default), 1 round
     uint32_t pass_form = 0;          // 0 auto, 1 = unflagged passes take the per-voxel kernels only
+    uint32_t pass_loads = 0;         // 0 auto (SDFV_PASS_EXPECT_NOOP decides), 1 cached loads, 2 nontemporal loads for update_required
     unsigned long long pass_index_limit = 0;  // 0 = 2^32: voxels per piece of a pass over a slab too large for 32-bit indices
     unsigned long long wave_timing = 0;  // tuning build only
     unsigned long long priority_map = 0;  // tuning build only

@@ -64,6 +64,8 @@ struct PassArgs {
     uint32_t fresh;          // every voxel of the slab holds [AIR_DIST; 4] on entry (first pass of a fresh load)
     uint32_t virgin;         // SDFV_PASS_VIRGIN_GRID: the slab's contents are undefined wherever no pass of this load has written
     uint32_t no_adaptive;    // SDFV_OPT_PASS_FORM 1: unflagged passes take the per-voxel kernels only (A/B runs)
+    uint32_t stream_loads;   // the update_required test reads the volume / tex0.r with nontemporal loads (a scan that expects to
+                             // leave most of what it reads alone: fill_kernels.hip load_once)
     uint64_t index_limit;    // 0 = 2^32: slabs of this many voxels or more are passed over in pieces of whole slices
     // set by the launcher:
     uint32_t n_visited;      // nx * ny * nz

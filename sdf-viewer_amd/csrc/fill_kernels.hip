@@ -42,6 +42,22 @@ __device__ __forceinline__ void store_texel(float4* dst, const float4& v) {
     }
 }
 
+// A load of data this kernel looks at ONCE (the distance volume under a pass's update_required test, tex0 under a commit):
+// nontemporal -- global_load ... nt does not allocate in L2 / the Infinity Cache, so a scan that follows a fill does not have to
+// push the fill's dirty lines out of the way first.  tools/ubench/read_stream.hip, 512 MiB read once behind 1 GiB of stores:
+// plain loads 0.128 ms (4.2 TB/s), nt loads 0.080 ms (6.7 TB/s); eight reads in a row: 6.7 vs 7.0 TB/s.  The step-1 no-op pass
+// of a loaded 512^3 grid went 0.144 -> see EXPERIMENTS R6.2.
+__device__ __forceinline__ float4 load_once(const float4* p) {
+    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ float load_once(const float* p) { return __builtin_nontemporal_load(p); }
+// ... chosen per launch (PassArgs::stream_loads, wave-uniform)
+template <typename T>
+__device__ __forceinline__ T load_scan(const T* p, uint32_t stream) {
+    return stream ? load_once(p) : *p;
+}
+
 // Entry of the distance volume for voxel x of slab row `row` (= z_local * H + y) in either layout (FillArgs::dist_ilv).
 __device__ __forceinline__ uint64_t vol_index(uint32_t ilv, uint64_t row, uint32_t x, uint32_t W) {
     return ilv ? ((row >> 1) * W + x) * 2 + (row & 1) : row * W + x;
@@ -344,7 +360,7 @@ __global__ __launch_bounds__(kBlock) void fill_pass_kernel(FillArgs a, PassArgs 
     const uint64_t row = (uint64_t)(z - a.z_begin) * a.H + y;
     const uint64_t flat = row * a.W + x;
     if (!p.all_required) {
-        const bool is_air = (p.dist ? p.dist[vol_index(a.dist_ilv, row, x, a.W)] : a.tex0[flat].x) == a.air_dist;
+        const bool is_air = (p.dist ? load_scan(p.dist + vol_index(a.dist_ilv, row, x, a.W), p.stream_loads) : load_scan(&a.tex0[flat].x, p.stream_loads)) == a.air_dist;
         // most visited voxels of a loaded grid need nothing: leave before paying three correctly rounded divides
         if (!is_air && (!p.has_box || !maybe_in_box(a, p, x, y, z))) return;
         const float px = voxel_coord(x, a.dm1[0], a.bb_size[0], a.bb_min[0]);
@@ -379,10 +395,10 @@ __global__ __launch_bounds__(kBlock) void fill_pass_quad_kernel(FillArgs a, Pass
         if (a.dist_ilv) {  // the quad's four x-neighbours are every other float of 32 contiguous bytes of its pair-row
             const uint32_t qr = div_u32(4u * q, p.div_nx), qx = 4u * q - qr * a.W;
             const float* b = p.dist + ((uint64_t)(qr >> 1) * a.W + qx) * 2;
-            const float4 lo = *reinterpret_cast<const float4*>(b), hi = *reinterpret_cast<const float4*>(b + 4);
+            const float4 lo = load_scan(reinterpret_cast<const float4*>(b), p.stream_loads), hi = load_scan(reinterpret_cast<const float4*>(b + 4), p.stream_loads);
             d = (qr & 1u) ? make_float4(lo.y, lo.w, hi.y, hi.w) : make_float4(lo.x, lo.z, hi.x, hi.z);
         } else {
-            d = *reinterpret_cast<const float4*>(p.dist + (size_t)q * 4);
+            d = load_scan(reinterpret_cast<const float4*>(p.dist + (size_t)q * 4), p.stream_loads);
         }
         air_bits = (d.x == a.air_dist ? 1u : 0u) | (d.y == a.air_dist ? 2u : 0u) | (d.z == a.air_dist ? 4u : 0u) |
                    (d.w == a.air_dist ? 8u : 0u);
@@ -501,11 +517,11 @@ __global__ __launch_bounds__(kBlock) void fill_pass_rows_adaptive_kernel(FillArg
         const uint64_t row = (uint64_t)(p.z_first - a.z_begin + iz * p.step) * a.H + iy * p.step;
         const uint32_t m = p.step - 1u;
         if (Q == 2) {  // a visited row is an even row (step >= 2, H even): the .x halves of its pair-row
-            const float4 d = *reinterpret_cast<const float4*>(p.dist + ((row >> 1) * a.W + x) * 2);
+            const float4 d = load_scan(reinterpret_cast<const float4*>(p.dist + ((row >> 1) * a.W + x) * 2), p.stream_loads);
             odd0 = d.y, odd1 = d.w;
             bits = (d.x == a.air_dist ? 1u : 0u) | (d.z == a.air_dist ? 2u : 0u) | ((x & m) == 0 ? 16u : 0u) | (((x + 1u) & m) == 0 ? 32u : 0u);
         } else {
-            const float4 d = *reinterpret_cast<const float4*>(p.dist + row * a.W + x);
+            const float4 d = load_scan(reinterpret_cast<const float4*>(p.dist + row * a.W + x), p.stream_loads);
             bits = (d.x == a.air_dist ? 1u : 0u) | (d.y == a.air_dist ? 2u : 0u) | (d.z == a.air_dist ? 4u : 0u) |
                    (d.w == a.air_dist ? 8u : 0u) | ((x & m) == 0 ? 16u : 0u) | (((x + 1u) & m) == 0 ? 32u : 0u) |
                    (((x + 2u) & m) == 0 ? 64u : 0u) | (((x + 3u) & m) == 0 ? 128u : 0u);
@@ -615,7 +631,7 @@ void with_cfg(const FillArgs& a, Launch&& launch) {
 __global__ __launch_bounds__(kBlock) void commit_distance_kernel(const float4* __restrict__ tex0,
                                                                  float* __restrict__ dist, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
-        dist[i] = tex0[i].x;
+        dist[i] = load_once(tex0 + i).x;
 }
 
 // The y-pair volume the hand-written march loop gathers from (raymarch_kernels.hip SDFV_MARCH_ASM_INTERIOR_PAIRS): texel

@@ -576,6 +576,10 @@ int sdfv_set_option(uint32_t option, uint64_t value) {
             if (value > 1) break;
             g_options.pass_form = (uint32_t)value;
             return SDFV_OK;
+        case SDFV_OPT_PASS_LOADS:
+            if (value > 2) break;
+            g_options.pass_loads = (uint32_t)value;
+            return SDFV_OK;
         case SDFV_OPT_RAYMARCH_WAVES_PER_SIMD:
             if (value == 1 || value > 7) break;  // 0 auto (the launcher's rule) | 2..6 cap | 7 never cap
             g_options.raymarch_waves_per_simd = (uint32_t)value;
@@ -626,6 +630,7 @@ int sdfv_get_option(uint32_t option, uint64_t* value) {
         case SDFV_OPT_EXT_SRGB_QUANT: *value = g_options.ext_srgb_quant; return SDFV_OK;
         case SDFV_OPT_PASS_INDEX_LIMIT: *value = g_options.pass_index_limit; return SDFV_OK;
         case SDFV_OPT_PASS_FORM: *value = g_options.pass_form; return SDFV_OK;
+        case SDFV_OPT_PASS_LOADS: *value = g_options.pass_loads; return SDFV_OK;
         case SDFV_OPT_RCCL_LIBRARY: {  // address of a copy that belongs to the CALLING THREAD ("" = by name): valid until this
             thread_local std::string copy;  // thread asks again, whatever another thread sets meanwhile
             copy = sdfv::rccl_library_path_copy();
@@ -790,7 +795,7 @@ int sdfv_fill_grid_pass_ex(const sdfv_demo_params* params, uint32_t sdf_id, cons
     if (int rc = check_grid(grid)) return rc;
     if (!tex0 || !tex1) return fail(SDFV_ERR_INVALID_ARGUMENT, "texture pointer is NULL");
     if (step == 0 || (step & (step - 1))) return fail(SDFV_ERR_INVALID_ARGUMENT, "step %u is not a power of two", step);
-    if (flags & ~(SDFV_PASS_FRESH_GRID | SDFV_PASS_SAME_LOAD | SDFV_PASS_VIRGIN_GRID | SDFV_PASS_VOLUME_INTERLEAVED))
+    if (flags & ~(SDFV_PASS_FRESH_GRID | SDFV_PASS_SAME_LOAD | SDFV_PASS_VIRGIN_GRID | SDFV_PASS_VOLUME_INTERLEAVED | SDFV_PASS_EXPECT_NOOP))
         return fail(SDFV_ERR_INVALID_ARGUMENT, "unknown pass flags 0x%x", flags);
     if (flags & SDFV_PASS_VOLUME_INTERLEAVED) {
         if (!dist) return fail(SDFV_ERR_INVALID_ARGUMENT, "SDFV_PASS_VOLUME_INTERLEAVED without a volume");
@@ -804,7 +809,8 @@ int sdfv_fill_grid_pass_ex(const sdfv_demo_params* params, uint32_t sdf_id, cons
     if (int rc = need_device()) return rc;
     sdfv::FillArgs a = make_fill_args(*params, sdf_id, *grid, tex0, tex1);
     a.dist_ilv = (flags & SDFV_PASS_VOLUME_INTERLEAVED) ? 1u : 0u;
-    const uint32_t knowledge = flags & ~SDFV_PASS_VOLUME_INTERLEAVED;  // what the caller KNOWS about the grid (the layout bit says nothing)
+    // what the caller KNOWS about the grid (the layout bit and the hint say nothing about update_required)
+    const uint32_t knowledge = flags & ~(SDFV_PASS_VOLUME_INTERLEAVED | SDFV_PASS_EXPECT_NOOP);
     sdfv::PassArgs p;
     memset(&p, 0, sizeof(p));
     p.step = step;
@@ -837,6 +843,14 @@ int sdfv_fill_grid_pass_ex(const sdfv_demo_params* params, uint32_t sdf_id, cons
     p.virgin = (flags & SDFV_PASS_VIRGIN_GRID) ? 1u : 0u;
     p.index_limit = g_options.pass_index_limit;
     p.no_adaptive = g_options.pass_form == 1 ? 1u : 0u;
+    // The scan's loads.  Auto: nontemporal when the caller expects a no-op pass AND the volume is larger than the last-level
+    // cache -- a smaller one is still resident from the fill that wrote it, and cached loads hit (same box, tools/pass_loads_ab.py:
+    // no-op pass at 512^3 0.128 -> 0.085 ms with nt loads, at 256^3 0.0128 -> 0.0150; passes that update most voxels +7..13 %).
+    {
+        const uint64_t volume_bytes = (uint64_t)a.W * a.H * a.slab_d * 4u, llc = device_facts().last_level_cache_bytes;
+        const bool hinted = (flags & SDFV_PASS_EXPECT_NOOP) != 0 && (llc == 0 || volume_bytes > llc);
+        p.stream_loads = g_options.pass_loads == 0 ? (hinted ? 1u : 0u) : (g_options.pass_loads == 2 ? 1u : 0u);
+    }
     p.all_required = (knowledge != 0 || covers) ? 1u : 0u;
     SDFV_HIP(sdfv::launch_fill_pass(a, p, fill_launch_config(dist != nullptr), (hipStream_t)stream));
     return SDFV_OK;

@@ -266,6 +266,7 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
         material.undefined_rows = false;  // the dense fill wrote every voxel
         material.pairs_valid = false;
         while (loading_mgr.step_size() != 0) loading_mgr.finish_pass();
+        loaded_once_ = true;
         publish_lod();
         return loading_mgr.total_iterations() - start_iter;
     }
@@ -297,6 +298,9 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
             break;
         }
         if (dist_synced_ && material.dist_interleaved) flags |= SDFV_PASS_VOLUME_INTERLEAVED;
+        // the manager the reference runs once a changed box has been worked off (:146-156, no box any more) scans a loaded grid
+        // and finds nothing: say so (a hint: the scan streams the volume past the caches)
+        if (loaded_once_ && !changed_box && flags == (flags & SDFV_PASS_VOLUME_INTERLEAVED)) flags |= SDFV_PASS_EXPECT_NOOP;
         if (sdfv_fill_grid_pass_ex(&dev->params, dev->sdf_id, &g, (uint32_t)step, box_ptr, tex0_device(), tex1_device(),
                                    dist_synced_ ? material.dist->f32() : nullptr, flags, stream) != 0) {
             error_ = sdfv_last_error();
@@ -309,6 +313,7 @@ size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_tim
         }
         material.pairs_valid = false;
         loading_mgr.finish_pass();
+        if (loading_mgr.step_size() == 0) loaded_once_ = true;
         publish_lod();
     }
     return loading_mgr.total_iterations() - start_iter;

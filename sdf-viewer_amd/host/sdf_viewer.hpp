@@ -150,6 +150,7 @@ class SDFViewer {
     bool host_mirror_valid_ = false;  // ingest_'s mirror equals tex0.r (cleared by every fill the device path runs)
     std::string error_;
     bool fresh_ = true;  // both textures still hold new_voxels' AIR_DIST everywhere
+    bool loaded_once_ = false;  // some LoadingManager has run to its end over this grid: a later pass without a box finds nothing to do
     bool same_load_ = true;  // every pass so far belongs to ONE load: the SDF and parameters of load_sdf_, no change reported
     std::optional<DeviceSDF> load_sdf_;  // what that load samples
     bool dist_synced_ = false;  // material.dist exists and mirrors tex0.r (kept so by every fill)

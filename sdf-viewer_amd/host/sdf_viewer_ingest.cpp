@@ -267,6 +267,7 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
         }
         if (total && hipEventRecord(b.done, st) == hipSuccess) b.in_flight = true;
         loading_mgr.advance(n);
+        if (loading_mgr.step_size() == 0) loaded_once_ = true;
         publish_lod();
         ingest_stats.ship += std::chrono::duration<double>(std::chrono::steady_clock::now() - sampled).count();
         ingest_stats.runs += 1;

@@ -824,3 +824,50 @@ def test_interleaved_volume_argument_checks_and_the_march_over_it(pkg, oracle):
     b = pkg.raymarch(rp, t0, t1, cam, 192, 128, dist=dist)
     torch.cuda.synchronize()
     assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and bool((a[..., 3] > 0).any())
+
+
+@pytest.mark.parametrize("dims,ilv", [((64, 12, 9), False), ((40, 12, 29), True), ((37, 20, 29), False), ((256, 8, 6), True)])
+def test_scan_loads_and_the_noop_hint_change_nothing_but_speed(pkg, oracle, dims, ilv):
+    """SDFV_PASS_EXPECT_NOOP is a HINT and SDFV_OPT_PASS_LOADS an A/B switch: however update_required reads the volume (cached or
+    nontemporal loads; per-voxel, quad and whole-rows kernels; with and without a volume, either layout), a fresh load, a boxed
+    edit and the no-op passes that follow leave the same texels."""
+    K = pkg._capi
+    g = pkg.make_grid(dims, (-1.0, -0.75, -1.0), (1.0, 1.0, 0.5))
+    prm, edited = pkg.default_params(), pkg.default_params(sphere_radius=0.8, cube_material=1)
+    box = (-0.6, -0.5, -0.7, 0.3, 0.9, 0.2)
+    layout = K.PASS_VOLUME_INTERLEAVED if ilv else 0
+
+    def run(loads, hint, use_dist):
+        t0, t1 = pkg.alloc_textures(g)
+        pkg.grid_init(g, t0, t1)
+        dist = None
+        if use_dist:
+            dist = torch.full((dims[2], dims[1], dims[0]), pkg.AIR_DIST, dtype=torch.float32, device="cuda")
+        fl = (layout if use_dist else 0) | hint
+        with pkg.options({K.OPT_PASS_LOADS: loads}):
+            for step in (4, 2, 1):
+                pkg.fill_grid_pass(prm, g, step, t0, t1, dist=dist, flags=fl)
+            for step in (4, 2, 1):
+                pkg.fill_grid_pass(edited, g, step, t0, t1, changed_box=box, dist=dist, flags=fl)
+            for step in (4, 2, 1):  # nothing left to do: the passes the hint is meant for
+                pkg.fill_grid_pass(edited, g, step, t0, t1, dist=dist, flags=fl)
+        torch.cuda.synchronize()
+        return t0, t1, dist
+
+    want = run(1, 0, False)
+    r0, r1 = oracle.grid_init(dims)
+    bb = ((-1.0, -0.75, -1.0), (1.0, 1.0, 0.5))
+    oracle.viewer_update(oracle.params_from(prm), dims, oracle.lm_new(dims, 3), r0, r1, bb_min=bb[0], bb_max=bb[1])
+    oracle.viewer_update(oracle.params_from(edited), dims, oracle.lm_new(dims, 3), r0, r1, changed_box=box, bb_min=bb[0], bb_max=bb[1])
+    assert_bits_equal(want[0], r0)
+    assert_bits_equal(want[1], r1)
+    for loads in (0, 1, 2):
+        for hint in (0, K.PASS_EXPECT_NOOP):
+            for use_dist in (False, True):
+                t0, t1, dist = run(loads, hint, use_dist)
+                assert torch.equal(t0, want[0]) and torch.equal(t1, want[1]), (loads, hint, use_dist)
+                if dist is not None:
+                    d = dist.reshape(-1, dims[0], 2).transpose(1, 2).reshape(dims[2], dims[1], dims[0]) if ilv else dist
+                    assert torch.equal(d, t0[..., 0])
+    with pytest.raises(pkg.SdfvError):
+        pkg.set_option(K.OPT_PASS_LOADS, 3)

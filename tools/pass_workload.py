@@ -53,8 +53,8 @@ def edit_eighth():     # fill_pass_kernel x 2, fill_pass_quad_kernel: 1/8 of the
         pkg.fill_grid_pass(prm, g, st, t0, t1, changed_box=eighth, dist=dist)
 
 
-def noop():            # step-1 pass over a loaded grid, no box: reads the volume, writes nothing
-    pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=dist)
+def noop():            # step-1 pass over a loaded grid, no box, hinted as SDFViewer::update does: reads the volume, writes nothing
+    pkg.fill_grid_pass(prm, g, 1, t0, t1, dist=dist, flags=pkg._capi.PASS_EXPECT_NOOP)
 
 
 GROUPS = {"load_virgin": (None, load_virgin), "load_unflagged": (None, load_unflagged), "fresh_step1": (None, fresh_step1),
