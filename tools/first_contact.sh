@@ -5,7 +5,8 @@
 # gpurun_out/first_contact/<step>.json (stderr beside it) -- and stops at the first step that fails.
 #   usage: tools/first_contact.sh [N=8]        (from the repository root, on a node with N GPUs)
 #          SDFV_BENCH_BACKEND=gloo tools/first_contact.sh 2    rehearsal on ONE GPU (ranks share it, gloo carries the exchanges)
-# Steps:  1  --gpus 2, tiny workload: ncclCommInitRank sees two devices; fill step + ghosts + sharded march verified
+# Steps:  1  --gpus 2, tiny workload: ncclCommInitRank sees two devices; fill step + ghosts + sharded march verified; RCCL's
+#            warnings / topology (NCCL_DEBUG=INFO, INIT + GRAPH) and rocm-smi's link types summarised in 1_summary.json
 #         2  --gpus 2, the default workload (256^3 + 1080p): the first real number
 #         3  --gpus N, 256^3 per rank, slab geometry: what the driver's SCALE run does at N
 #         4  --gpus N, config 4: cube geometry at 512^3 per rank (N = 8: 1024^3), halo 33.5 MB per direction
@@ -32,7 +33,28 @@ run() {  # name, ranks, bench arguments...
         exit 1
     fi
 }
+# Step 1 explains itself should it be slow or fail: RCCL's own warnings and what it says about the topology go into the step's
+# stderr file, and a summary line -- the ranks RCCL connected, its warnings, the links it found, rocm-smi's link-type matrix --
+# is printed and kept in $OUT/1_summary.json.
+NCCL_DEBUG=${NCCL_DEBUG:-INFO} NCCL_DEBUG_SUBSYS=${NCCL_DEBUG_SUBSYS:-INIT,GRAPH,ENV} \
 run 1_two_ranks_tiny 2 --steps 3 --warmup 1 --workload 64 --config4-side 32 --prewarm-ms 5 --per-step-samples 4
+python - "$OUT" <<'PY' | tee $OUT/1_summary.json
+import json, re, subprocess, sys
+out = sys.argv[1]
+line = json.loads(open(f"{out}/1_two_ranks_tiny.json").read().strip().splitlines()[-1])
+err = open(f"{out}/1_two_ranks_tiny.err", errors="replace").read().splitlines()
+warn = [l.strip()[:200] for l in err if " NCCL WARN " in l or "RCCL WARN" in l]
+topo = [l.strip()[:200] for l in err if re.search(r"XGMI|xGMI|P2P|Channel \d+/\d+ :|nChannels|via ", l)]
+try:
+    smi = subprocess.run(["rocm-smi", "--showtopotype"], capture_output=True, text=True, timeout=60).stdout
+    xgmi_per_gpu = [row.count("XGMI") for row in smi.splitlines() if row.startswith("GPU")]
+except Exception as e:  # noqa: BLE001
+    smi, xgmi_per_gpu = f"{type(e).__name__}: {e}", None
+print(json.dumps({"step": "1_two_ranks_tiny", "rccl_ranks": line.get("rccl_ranks"), "torch_world_size": line.get("torch_world_size"),
+                  "backend": line.get("backend"), "halo_transport": line.get("halo_transport"), "ms_per_step_fill": line.get("ms_per_step_fill"),
+                  "nccl_warnings": warn[:20], "rccl_topology_lines": len(topo), "rccl_topology_sample": topo[:12],
+                  "rocm_smi_xgmi_peers_per_gpu": xgmi_per_gpu}))
+PY
 run 2_two_ranks_256 2 --steps 20 --warmup 5
 run 3_n_ranks_256 $N --steps 20 --warmup 5 --no-config4 --no-batch
 run 4_n_ranks_config4 $N --steps 10 --warmup 3 --workload 512 --weak-geometry cube --no-batch --no-config4
