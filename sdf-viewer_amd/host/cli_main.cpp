@@ -2,6 +2,12 @@
 //
 //   sdf-viewer-gpu app [--max-voxels-side N] [--loading-passes P] demo [-t M] [-c F] [-l M] [-s F] [-m F] [-d B]
 //                  [--width W] [--height H] [--out image.ppm] [--dump-textures prefix] [--frames K]
+//   sdf-viewer-gpu app [...] url <library.so | file://library.so>
+//
+// `url` is the reference's second provider (CliSDFProvider::Url, src/app/cli/mod.rs:41-46: a WebAssembly file exporting the
+// per-point ABI).  There is no wasm runtime here; what takes its place is a NATIVE library exporting the same ABI
+// (include/sdf_provider.h), loaded through ProviderSDF: the host samples it, the device packs (SDFViewer's ingest path).
+// http(s):// and ?wait=true (the file watcher) are out of scope.
 //
 // Flag names and defaults are the reference's: CliApp (src/app/cli/mod.rs:10-22: max_voxels_side 64,
 // loading_passes 2) and the demo SDF's flags (src/sdf/demo/cube.rs:15-18, sphere.rs:11-14, demo/mod.rs:26-29).
@@ -27,6 +33,7 @@
 #include <iostream>
 
 #include "mesh.hpp"
+#include "provider_sdf.hpp"
 #include "sdf_demo.hpp"
 #include "sdf_viewer.hpp"
 
@@ -37,6 +44,7 @@ static int usage(const char* msg) {
     fprintf(stderr,
             "USAGE:\n    sdf-viewer-gpu app [--max-voxels-side <N>] [--loading-passes <P>] demo [demo flags]\n"
             "                   [--width <W>] [--height <H>] [--out <file.ppm>] [--dump-textures <prefix>] [--frames <K>]\n"
+            "    sdf-viewer-gpu app [...] url <library.so>      a native SDF provider (include/sdf_provider.h), sampled on the host\n"
             "    sdf-viewer-gpu mesh [-o <mesh.ply|->] [-v <max-voxels-per-axis>] [marching-cubes] [demo [demo flags]]\n"
             "demo flags: -t/--cube-material <brick|normal>  -c/--cube-half-side <f>  -l/--sphere-material <brick|normal>\n"
             "            -s/--sphere-radius <f>  -m/--max-distance-custom-material <f>  -d/--disable-sphere <true|false>\n");
@@ -118,7 +126,7 @@ int main(int argc, char** argv) {
     size_t max_voxels_side = 64, loading_passes = 2;  // src/app/cli/mod.rs:13-18
     uint32_t width = 1280, height = 720;
     int frames = 1;
-    std::string out = "sdf-viewer-gpu.ppm", dump;
+    std::string out = "sdf-viewer-gpu.ppm", dump, url;
     std::vector<std::string> demo_args;
     bool in_demo = false;
     for (size_t i = 1; i < args.size(); ++i) {
@@ -138,13 +146,25 @@ int main(int argc, char** argv) {
         else if (a == "--out") out = next("--out");
         else if (a == "--dump-textures") dump = next("--dump-textures");
         else if (a == "demo") in_demo = true;
-        else if (a == "url") return usage("the `url` provider (arbitrary wasm) cannot run on the GPU; use the reference");
+        else if (a == "url") url = next("url <URL>");
         else if (in_demo) demo_args.push_back(a);
         else return usage(("Found argument '" + a + "' which wasn't expected").c_str());
     }
     std::string err;
-    auto sdf = SDFDemo::from_args(demo_args, &err);
-    if (!sdf) return usage(err.c_str());
+    std::shared_ptr<SDFSurface> sdf;
+    if (!url.empty()) {
+        if (url.rfind("http://", 0) == 0 || url.rfind("https://", 0) == 0)
+            return usage("url: only local provider libraries are supported (no network, no wasm runtime)");
+        if (url.rfind("file://", 0) == 0) url = url.substr(7);
+        sdf = ProviderSDF::load(url, &err);
+        if (!sdf) {
+            fprintf(stderr, "error: %s\n", err.c_str());
+            return 1;
+        }
+    } else {
+        sdf = SDFDemo::from_args(demo_args, &err);
+        if (!sdf) return usage(err.c_str());
+    }
 
     if (sdfv_device_count() == 0) {
         fprintf(stderr, "error: no HIP device visible: sdf-viewer-gpu has no CPU path\n");
@@ -160,11 +180,15 @@ int main(int argc, char** argv) {
     for (;;) {
         const auto t0 = std::chrono::steady_clock::now();
         const size_t updates = viewer->update(*sdf, std::chrono::milliseconds(30));
+        if (*viewer->last_error()) {
+            fprintf(stderr, "error: %s\n", viewer->last_error());
+            return 1;
+        }
         if (updates == 0) break;
         viewer->commit();
         (void)hipStreamSynchronize((hipStream_t)viewer->stream);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        fprintf(stderr, "Loaded SDF chunk (%zu updates) in %.3fms (GPU)\n", updates, ms);
+        fprintf(stderr, "Loaded SDF chunk (%zu updates) in %.3fms\n", updates, ms);
     }
     viewer->commit();
     fprintf(stderr, "Loaded last SDF chunk (lod %g)\n", (double)viewer->material.lod_dist_between_samples);

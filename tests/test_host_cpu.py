@@ -231,6 +231,11 @@ def test_cli_flag_surface_and_no_cpu_path():
     assert r.returncode == 2 and "wasn't expected" in r.stderr
     r = subprocess.run([exe, "server"], capture_output=True, text=True)
     assert r.returncode == 2
+    # `url` (CliSDFProvider::Url, app/cli/mod.rs:41-46): a native provider library stands where the wasm file stands
+    r = subprocess.run([exe, "app", "url", "/nonexistent/libsdf.so"], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot load SDF provider" in r.stderr
+    r = subprocess.run([exe, "app", "url", "https://example.org/sdf.wasm"], capture_output=True, text=True)
+    assert r.returncode == 2 and "only local provider libraries" in r.stderr
     if not torch.cuda.is_available():
         r = subprocess.run([exe, "app", "--max-voxels-side", "8", "demo"], capture_output=True, text=True)
         assert r.returncode == 1 and "no HIP device" in r.stderr
