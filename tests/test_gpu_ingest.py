@@ -301,3 +301,27 @@ def test_cli_url_provider_loads_through_the_ingest_path(oracle, gyroid_provider,
     img = np.frombuffer(data[len(header):], np.uint8).reshape(90, 160, 3).astype(np.int32)
     want8 = np.rint(np.clip(np.nan_to_num(want[..., :3] * want[..., 3:4]), 0, 1) * 255).astype(np.int32)
     assert np.abs(img - want8).max() <= 1
+
+
+@pytest.mark.parametrize("dims,passes", [((2, 2, 2), 1), ((4, 4, 4), 5), ((1, 5, 7), 2), ((9, 1, 1), 3), ((33, 2, 3), 2)])
+def test_ingest_over_degenerate_grids(host, oracle, gyroid_provider, dims, passes):
+    """Grids the reference's loop handles without noticing: a single voxel along an axis (its coordinate is 0 / 0 = NaN,
+    scene/sdf/mod.rs:179-182 -- the sample function is handed the NaN, the box test fails on it), more passes than the grid has
+    levels (the coarse passes visit voxel (0, 0, 0) only), rows shorter than a wave.  Whole loads under a zero budget and a generous
+    one, one thread and several."""
+    sdf = host.SDF.provider(gyroid_provider)
+    raw = C.CDLL(gyroid_provider)
+    bb = sdf.bounding_box()
+    for threads, budget in ((1, 0.0), (4, 1.0)):
+        v = host.Viewer.new_voxels(dims, bb, passes)
+        v.set_ingest(threads, 0)
+        ref = RefViewer(oracle, dims, bb, passes, raw.gyroid_sample_raw)
+        total = 0
+        while v.remaining():
+            n = v.update(sdf, budget)
+            assert n > 0 and v.last_error() == ""
+            assert ref.update(None, n) == n
+            total += n
+        assert total == sum(-(-dims[0] // s) * -(-dims[1] // s) * -(-dims[2] // s) for s in (2 ** k for k in range(passes)))
+        assert_viewer_equals(v, ref, (dims, passes, threads))
+        assert v.update(sdf, budget) == 0 and v.lod() == 1.0
