@@ -296,7 +296,8 @@ def contract_line(line, full_path):
     if isinstance(ing, dict) and isinstance(ing.get("whole_load"), dict):
         c["ingest"] = {"Mvoxels_per_s": ing["whole_load"].get("Mvoxels_per_s"), "threads": ing.get("threads"),
                        "one_thread": (ing.get("whole_load_1_thread") or {}).get("Mvoxels_per_s"),
-                       "worst_30ms_call": (ing.get("frame_loop_30ms") or {}).get("worst_call_ms")}
+                       "worst_30ms_call": (ing.get("frame_loop_30ms") or {}).get("worst_call_ms"),
+                       "batched": ((ing.get("batched") or {}).get("whole_load") or {}).get("Mvoxels_per_s")}
     p = line.get("progressive")
     if isinstance(p, dict):
         c["progressive"] = {side: {name: [case.get("ms"), case.get("frac")] for name, case in cases.items()

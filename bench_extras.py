@@ -84,23 +84,30 @@ def ingest_block(side=384):
     tests/c/gyroid_provider.c (a library behind include/sdf_provider.h's per-point ABI) built here with gcc, loaded through
     ProviderSDF, loaded into a side^3-bounded grid by sdf-viewer-host-bench --ingest.  CPU-bound by construction (one malloc'ing
     FFI call per voxel, like the reference's wasm provider): the figure is host sampling throughput, the device's share (H2D of 32 B
-    per voxel + sdfv_pack_samples) hides behind it."""
+    per voxel + sdfv_pack_samples) hides behind it.  `batched`: the same SDF from a library that also exports the optional
+    `sample_batch` (the trait's "Batched sampling" TODO): one call per gathered block, no allocation per point."""
     import tempfile
     exe = os.path.join(ROOT, "sdf-viewer_amd", "sdf-viewer-host-bench")
-    try:
-        with tempfile.TemporaryDirectory() as tmp:
-            lib = os.path.join(tmp, "libgyroid_provider.so")
-            subprocess.run(["gcc", "-std=c11", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-I",
-                            os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "gyroid_provider.c"), "-o", lib, "-lm"],
-                           check=True, capture_output=True, timeout=120)
-            r = subprocess.run([exe, "--ingest", lib, "--side", str(side), "--passes", "2"], capture_output=True, text=True, timeout=300)
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        out = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": (r.stderr or r.stdout)[-300:]}
-    except Exception as e:  # noqa: BLE001 -- an extra, never fatal
-        out = {"error": f"{type(e).__name__}: {e}"}
+
+    def run(batched):
+        try:
+            with tempfile.TemporaryDirectory() as tmp:
+                lib = os.path.join(tmp, "libgyroid_provider.so")
+                subprocess.run(["gcc", "-std=c11", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-I",
+                                os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "gyroid_provider.c"), "-o", lib, "-lm"] +
+                               (["-DGYROID_BATCH"] if batched else []), check=True, capture_output=True, timeout=120)
+                r = subprocess.run([exe, "--ingest", lib, "--side", str(side), "--passes", "2"], capture_output=True, text=True, timeout=300)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            return json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:  # noqa: BLE001 -- an extra, never fatal
+            return {"error": f"{type(e).__name__}: {e}"}
+
+    out = run(False)
+    out["batched"] = run(True)
     out["note"] = ("host-sampled SDF (gyroid behind the per-point ABI) -> pinned H2D -> sdfv_pack_samples; whole_load = one update() with "
                    "an unlimited budget on `threads` host threads, frame_loop_30ms = the reference's frame loop (30 ms per call; "
-                   "worst_call_ms = the longest call), setup_ms = the first call (transfer buffers, host mirror, workers; not in load_ms), whole_load_1_thread = the reference's single-threaded loop; CPU-bound")
+                   "worst_call_ms = the longest call), setup_ms = the first call (transfer buffers, host mirror, workers; not in load_ms), "
+                   "whole_load_1_thread = the reference's single-threaded loop; batched = the provider also exports sample_batch; CPU-bound")
     return out
 
 

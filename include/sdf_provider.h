@@ -85,6 +85,11 @@ int  init_with_args(int argc, const char *const *argv);
  * samples a host-only SDF on that many threads (sdf-viewer_amd/host/provider_sdf.hpp, sdf_viewer_ingest.cpp). */
 uint32_t sample_concurrency(void);
 
+/* extension, OPTIONAL for any provider: the "Batched sampling" the trait leaves as a TODO (src/sdf/mod.rs:39).  out[i] =
+ * *sample(sdf_id, points[i], distance_only) for i in [0, n); BOTH arrays are the caller's (nothing to free): one call and no
+ * allocation per point.  A host that finds the export samples through it (ProviderSDF::sample_batch); an unknown id zeroes out. */
+void sample_batch(uint32_t sdf_id, const SDFVec3 *points, size_t n, bool distance_only, SDFSample *out);
+
 SDFBoundingBox *bounding_box(uint32_t sdf_id);                       /* ffi.rs:42-50 */
 void bounding_box_free(SDFBoundingBox *ret);                         /* ffi.rs:52-55 */
 SDFSample *sample(uint32_t sdf_id, SDFVec3 p, bool distance_only);   /* ffi.rs:57-65 */

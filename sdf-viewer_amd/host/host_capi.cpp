@@ -104,6 +104,9 @@ void sdfvh_sdf_sample(void* h, const float p[3], int distance_only, float out[7]
     SDFSample s = S(h).sample(Vec3{p[0], p[1], p[2]}, distance_only != 0);
     memcpy(out, &s, 28);
 }
+void sdfvh_sdf_sample_batch(void* h, const float* p, size_t n, int distance_only, float* out) {
+    S(h).sample_batch(reinterpret_cast<const Vec3*>(p), n, distance_only != 0, reinterpret_cast<SDFSample*>(out));
+}
 void sdfvh_sdf_normal(void* h, const float p[3], float eps, float out[3]) {
     Vec3 n = S(h).normal(Vec3{p[0], p[1], p[2]}, eps > 0 ? std::optional<float>(eps) : std::nullopt);
     memcpy(out, &n, 12);

@@ -153,6 +153,13 @@ SDFSample* sample(uint32_t sdf_id, SDFVec3 p, bool distance_only) {
 }
 void sample_free(SDFSample* ret) { free(ret); }
 
+// extension (sdf_provider.h): n points for the price of one call -- for this provider, of one device batch
+void sample_batch(uint32_t sdf_id, const SDFVec3* points, size_t n, bool distance_only, SDFSample* out) {
+    static_assert(sizeof(SDFVec3) == sizeof(Vec3) && sizeof(SDFSample) == sizeof(sv::SDFSample), "repr(C) on both sides");
+    if (auto* sdf = find(sdf_id)) sdf->sample_batch(reinterpret_cast<const Vec3*>(points), n, distance_only, reinterpret_cast<sv::SDFSample*>(out));
+    else if (n) memset(out, 0, n * sizeof(SDFSample));
+}
+
 PointerLength* children(uint32_t sdf_id) {
     auto* ret = static_cast<PointerLength*>(malloc(sizeof(PointerLength)));
     *ret = pl_null();

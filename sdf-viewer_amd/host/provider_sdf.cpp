@@ -32,6 +32,7 @@ struct ProviderSDF::Library {
     SDFVec3* (*f_normal)(uint32_t, SDFVec3, float) = nullptr;
     void (*f_normal_free)(SDFVec3*) = nullptr;
     uint32_t (*f_sample_concurrency)(void) = nullptr;
+    void (*f_sample_batch)(uint32_t, const SDFVec3*, size_t, bool, ::SDFSample*) = nullptr;
     ~Library() {
         if (handle) dlclose(handle);
     }
@@ -77,6 +78,7 @@ std::shared_ptr<ProviderSDF> ProviderSDF::load(const std::string& path, std::str
     resolve(h, "normal", lib->f_normal);
     resolve(h, "normal_free", lib->f_normal_free);
     resolve(h, "sample_concurrency", lib->f_sample_concurrency);
+    resolve(h, "sample_batch", lib->f_sample_batch);
     void (*f_init)(void) = nullptr;
     resolve(h, "init", f_init);  // "Call init() to initialize the module (optional)", native.rs:51-56
     if (f_init) f_init();
@@ -104,6 +106,12 @@ SDFSample ProviderSDF::sample(Vec3 p, bool distance_only) const {  // native.rs:
     memcpy(static_cast<void*>(&s), ret, sizeof(s));
     if (lib_->f_sample_free) lib_->f_sample_free(ret);
     return s;
+}
+
+void ProviderSDF::sample_batch(const Vec3* p, size_t n, bool distance_only, SDFSample* out) const {
+    static_assert(sizeof(Vec3) == sizeof(SDFVec3) && sizeof(SDFSample) == sizeof(::SDFSample), "repr(C) on both sides");
+    if (!lib_->f_sample_batch) return SDFSurface::sample_batch(p, n, distance_only, out);
+    lib_->f_sample_batch(sdf_id_, reinterpret_cast<const SDFVec3*>(p), n, distance_only, reinterpret_cast<::SDFSample*>(out));
 }
 
 std::vector<std::shared_ptr<SDFSurface>> ProviderSDF::children() const {  // native.rs:219-253

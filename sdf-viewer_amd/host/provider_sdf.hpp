@@ -23,6 +23,8 @@ class ProviderSDF : public SDFSurface {
 
     BoundingBox bounding_box() const override;
     SDFSample sample(Vec3 p, bool distance_only) const override;
+    // through the optional export `sample_batch` (sdf_provider.h) when the library has it, else the per-point loop
+    void sample_batch(const Vec3* p, size_t n, bool distance_only, SDFSample* out) const override;
     std::vector<std::shared_ptr<SDFSurface>> children() const override;
     uint32_t id() const override { return sdf_id_; }
     std::string name() const override;

@@ -64,6 +64,15 @@ SDFSample SDFDemoBase::sample(Vec3 p, bool distance_only) const {
     return out;
 }
 
+void SDFDemoBase::sample_batch(const Vec3* p, size_t n, bool distance_only, SDFSample* out) const {
+    if (n == 0) return;
+    sdfv_demo_params prm = st_->to_device();
+    if (sdfv_sample_points_host(&prm, id(), &p[0].x, n, distance_only ? 1 : 0, reinterpret_cast<sdfv_sample*>(out)) != 0) {
+        fprintf(stderr, "SDFDemo::sample_batch: %s\n", sdfv_last_error());
+        for (size_t i = 0; i < n; ++i) out[i] = SDFSample::make(1.0f, Vec3{});
+    }
+}
+
 Vec3 SDFDemoBase::normal(Vec3 p, std::optional<float> eps) const {
     // the demo's overrides (demo/mod.rs:147-156, cube.rs:164-177, sphere.rs:122-124) ignore eps
     (void)eps;

@@ -36,6 +36,7 @@ class SDFDemoBase : public SDFSurface {
     explicit SDFDemoBase(std::shared_ptr<DemoState> st) : st_(std::move(st)) {}
     BoundingBox bounding_box() const override { return {Vec3{-1, -1, -1}, Vec3{1, 1, 1}}; }
     SDFSample sample(Vec3 p, bool distance_only) const override;
+    void sample_batch(const Vec3* p, size_t n, bool distance_only, SDFSample* out) const override;  // ONE device batch
     Vec3 normal(Vec3 p, std::optional<float> eps) const override;
     std::optional<DeviceSDF> device_sdf() const override { return DeviceSDF{st_->to_device(), id()}; }
     const std::shared_ptr<DemoState>& state() const { return st_; }

@@ -108,6 +108,14 @@ class SDFSurface {
     // ============ OPTIONAL: UTILITIES ============ (defaults.rs:49-56)
     virtual Vec3 normal(Vec3 p, std::optional<float> eps) const;
 
+    // ============ batched sampling (the trait's own TODO, src/sdf/mod.rs:39: "Batched sampling to speed up operations") ============
+    // out[i] = sample(p[i], distance_only) for i in [0, n).  The default IS that loop; an SDF that can answer many points for
+    // the price of one call overrides it (ProviderSDF: one FFI call and no allocation per point when the library exports
+    // `sample_batch`; the demo SDF: one batch of the device kernel).  SDFViewer::update's host path samples through it.
+    virtual void sample_batch(const Vec3* p, size_t n, bool distance_only, SDFSample* out) const {
+        for (size_t i = 0; i < n; ++i) out[i] = sample(p[i], distance_only);
+    }
+
     // ============ host sampling (not in the reference) ============
     // How many host threads may call sample() on this object at once.  1 (the default) = only the thread that calls
     // SDFViewer::update, which is all the reference's trait promises (its SDFs are !Send: Rc<RefCell>, demo/mod.rs:160-198,

@@ -209,6 +209,22 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
             size_t count = 0;
             size_t k = c0 + lo;
             size_t kx = k % walk[0], ky = k / walk[0] % walk[1], kz = k / (walk[0] * walk[1]);
+            // The voxels update_required lets through are gathered kGather at a time and sampled with ONE sample_batch call
+            // (src/sdf/mod.rs:39's "Batched sampling"; for an SDF that does not override it, the loop of sample() calls it
+            // stands for), straight into the pinned records.  A run lies within one pass, so no voxel is visited twice in it:
+            // the mirror may be brought up to date after the batch.
+            constexpr size_t kGather = 2048;
+            Vec3 pos_buf[kGather];
+            size_t m = 0;
+            auto flush = [&] {
+                if (m == 0) return;
+                SDFSample* rec = reinterpret_cast<SDFSample*>(out_s + count);
+                sdf.sample_batch(pos_buf, m, false, rec);  // :193
+                for (size_t j = 0; j < m; ++j)
+                    in.mirror[out_i[count + j]] = clamp01_rust(1e-1f + rec[j].distance);  // :196, what the device stores in tex0.r
+                count += m;
+                m = 0;
+            };
             for (size_t i = lo; i < hi; ++i) {
                 const size_t x = kx * step, y = ky * step, z = kz * step;
                 const size_t flat = (z * H + y) * W + x;  // :177
@@ -219,11 +235,9 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
                     update_required = update_required || (pos.x >= box[0].x && pos.x <= box[1].x && pos.y >= box[0].y &&
                                                           pos.y <= box[1].y && pos.z >= box[0].z && pos.z <= box[1].z);
                 if (update_required) {
-                    const SDFSample s = sdf.sample(pos, false);  // :193
-                    memcpy(&out_s[count], &s, sizeof(sdfv_sample));
-                    out_i[count] = (uint32_t)flat;
-                    ++count;
-                    in.mirror[flat] = clamp01_rust(1e-1f + s.distance);  // :196, what the device stores in tex0.r
+                    pos_buf[m] = pos;
+                    out_i[count + m] = (uint32_t)flat;
+                    if (++m == kGather) flush();
                 }
                 if (++kx == walk[0]) {
                     kx = 0;
@@ -233,6 +247,7 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
                     }
                 }
             }
+            flush();
             counts[t] = count;
         };
         in.pool.run(workers, work);

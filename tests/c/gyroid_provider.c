@@ -62,6 +62,21 @@ EXPORT SDFSample *sample(uint32_t sdf_id, SDFVec3 p, bool distance_only) {
 }
 EXPORT void sample_free(SDFSample *ret) { free(ret); }
 
+/* extension (sdf_provider.h): batched sampling into the caller's array.  Built only with -DGYROID_BATCH: the suite loads the
+ * fixture both ways, so that a consumer is checked with and without the export. */
+#ifdef GYROID_BATCH
+EXPORT void sample_batch(uint32_t sdf_id, const SDFVec3 *points, size_t n, bool distance_only, SDFSample *out) {
+    for (size_t i = 0; i < n; ++i) {
+        if (sdf_id == 0) {
+            const float q[3] = {points[i].x, points[i].y, points[i].z};
+            gyroid(q, distance_only, (float *)&out[i]);
+        } else {
+            memset(&out[i], 0, sizeof out[i]);
+        }
+    }
+}
+#endif
+
 static PointerLength pl_copy(const void *data, size_t n) {
     PointerLength p = {NULL, n};
     if (n) {

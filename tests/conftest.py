@@ -47,11 +47,21 @@ def oracle():
     return oracle_binding
 
 
+def _build_gyroid(tmp_path_factory, name, *defines):
+    out = tmp_path_factory.mktemp(name) / f"lib{name}.so"
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall",
+                           "-Wextra", "-Werror", *defines, "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "gyroid_provider.c"), "-o", str(out), "-lm"])
+    return str(out)
+
+
 @pytest.fixture(scope="session")
 def gyroid_provider(tmp_path_factory):
     """tests/c/gyroid_provider.c built as a shared object: a HOST-ONLY SDF behind include/sdf_provider.h's per-point ABI."""
-    out = tmp_path_factory.mktemp("gyroid") / "libgyroid_provider.so"
-    subprocess.check_call(["gcc", "-std=c11", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall",
-                           "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "c", "gyroid_provider.c"), "-o", str(out), "-lm"])
-    return str(out)
+    return _build_gyroid(tmp_path_factory, "gyroid_provider")
+
+
+@pytest.fixture(scope="session")
+def gyroid_provider_batch(tmp_path_factory):
+    """... the same SDF from a library that ALSO exports the optional `sample_batch` (batched sampling, sdf_provider.h)."""
+    return _build_gyroid(tmp_path_factory, "gyroid_provider_batch", "-DGYROID_BATCH")

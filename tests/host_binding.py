@@ -33,6 +33,7 @@ for name, res, args in [
     ("sdfvh_sdf_child", C.c_void_p, [C.c_void_p, SZ]), ("sdfvh_sdf_bounding_box", None, [C.c_void_p, C.c_void_p]),
     ("sdfvh_sdf_device_params", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     ("sdfvh_sdf_sample", None, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    ("sdfvh_sdf_sample_batch", None, [C.c_void_p, C.c_void_p, SZ, C.c_int, C.c_void_p]),
     ("sdfvh_sdf_normal", None, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     ("sdfvh_sdf_normal_default", None, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     ("sdfvh_sdf_set_parameter", C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_char_p, C.c_char_p, SZ]),
@@ -165,6 +166,13 @@ class SDF:
         p = np.asarray(p, np.float32)
         out = np.zeros(7, np.float32)
         H.sdfvh_sdf_sample(self.h, p.ctypes.data, int(distance_only), out.ctypes.data)
+        return out
+
+    def sample_batch(self, points, distance_only=False):
+        """SDFSurface::sample_batch: [n, 3] points -> [n, 7] samples."""
+        p = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        out = np.zeros((len(p), 7), np.float32)
+        H.sdfvh_sdf_sample_batch(self.h, p.ctypes.data, len(p), int(distance_only), out.ctypes.data)
         return out
 
     def normal(self, p, eps=0.0, default=False):

@@ -213,7 +213,7 @@ def test_demo_through_the_per_point_abi_equals_the_device_fill(host, pkg, oracle
     """the demo SDF consumed as an ORDINARY provider (libsdfdemo_provider.so loaded through ProviderSDF:
     no device form, every sample a call through include/sdf_provider.h) fills the same textures as sdfv_fill_grid."""
     sdf = host.SDF.provider(host.PROVIDER_PATH)
-    dims = (20, 20, 20)
+    dims = (52, 52, 52)   # (the provider exports `sample_batch`: a gathered block of voxels is ONE device batch)
     v = host.Viewer.new_voxels(dims, sdf.bounding_box(), 2)
     while v.update(sdf, 0.05):
         pass
@@ -265,6 +265,27 @@ def test_ingest_after_the_device_path_rebuilds_the_host_mirror(host, oracle, gyr
     t0, t1 = v.download()
     assert np.array_equal(bits(t0), bits(e0)) and np.array_equal(bits(t1), bits(e1))
     assert gy.set_parameter(0, 0.15) is None and gy.changed() is not None
+
+
+def test_provider_with_batched_sampling_loads_the_same_grid(host, oracle, gyroid_provider_batch):
+    """A provider that exports `sample_batch` is sampled through it (one call per gathered block, no allocation per point): the
+    same textures, call by call, as the oracle's per-voxel loop."""
+    sdf = host.SDF.provider(gyroid_provider_batch)
+    raw = C.CDLL(gyroid_provider_batch)
+    bb = sdf.bounding_box()
+    dims = (48, 24, 36)
+    for threads, budget in ((1, 2e-4), (0, 1e-3)):
+        v = host.Viewer.new_voxels(dims, bb, 2)
+        v.set_ingest(threads, 0)
+        ref = RefViewer(oracle, dims, bb, 2, raw.gyroid_sample_raw)
+        calls = 0
+        while v.remaining():
+            n = v.update(sdf, budget)
+            assert n > 0 and v.last_error() == "" and ref.update(None, n) == n
+            calls += 1
+            if calls % 5 == 0:
+                assert_viewer_equals(v, ref, f"call {calls}")
+        assert_viewer_equals(v, ref, "loaded")
 
 
 def test_meshing_a_host_only_sdf_stays_refused(host, gyroid_provider):

@@ -375,3 +375,21 @@ def test_worker_pool_sessions_never_lose_a_run(tmp_path):
     for workers in (5, 3 * (os.cpu_count() or 4)):
         r = subprocess.run([str(exe), str(workers)], capture_output=True, text=True, timeout=240)
         assert r.returncode == 0 and r.stdout.startswith("ok"), (workers, r.stdout, r.stderr)
+
+
+def test_batched_sampling_equals_the_per_point_loop(host, gyroid_provider, gyroid_provider_batch):
+    """SDFSurface::sample_batch (the trait's "Batched sampling" TODO, src/sdf/mod.rs:39): the default is the loop of sample()
+    calls; a provider that exports `sample_batch` answers through it -- same samples, bit for bit, either way."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-1, 1, size=(777, 3)).astype(np.float32)
+    pts[0] = [-1, -0.5, -0.75]                                    # the fixture's NaN voxel
+    plain, batch = host.SDF.provider(gyroid_provider), host.SDF.provider(gyroid_provider_batch)
+    assert not hasattr(C.CDLL(gyroid_provider), "sample_batch") and hasattr(C.CDLL(gyroid_provider_batch), "sample_batch")
+    want = np.stack([plain.sample(p) for p in pts])
+    for sdf in (plain, batch):
+        for distance_only in (False, True):
+            ref = want if not distance_only else np.stack([plain.sample(p, True) for p in pts])
+            got = sdf.sample_batch(pts, distance_only)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert batch.sample_batch(np.zeros((0, 3), np.float32)).shape == (0, 7)
