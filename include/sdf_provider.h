@@ -16,8 +16,10 @@
  * reference reclaims it as a Rust Vec (ffi.rs:228-229), which is only sound when caller and callee share an
  * allocator (its wasm host writes the bytes at a fixed scratch address instead, wasm/native.rs:408-411).
  *
- * All arithmetic runs on the GPU (one-point batches of the libsdfgrid kernels): this ABI is the
- * compatibility path; the hot path is the batched API in sdfgrid.h.
+ * All arithmetic of libsdfdemo_provider.so runs on the GPU (sample(): one-point batches of the libsdfgrid kernels;
+ * sample_batch(): one batch per call): this ABI is the compatibility path; the hot path is the batched API in sdfgrid.h.
+ * The CONSUMER side of this ABI -- any library that exports it becomes an SDFSurface of the host mirror, loaded into the
+ * viewer's device textures -- is sdf-viewer_amd/host/provider_sdf.hpp (ProviderSDF) + SDFViewer::update's ingest path.
  */
 #ifndef SDF_PROVIDER_H
 #define SDF_PROVIDER_H
