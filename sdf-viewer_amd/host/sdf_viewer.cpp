@@ -174,6 +174,7 @@ sdfv_grid SDFViewer::grid() const {
 }
 
 size_t SDFViewer::update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_time) {
+    error_.clear();  // last_error() describes THIS call
     // Check whether the SDF self-reports updates.  (:130-141)
     bool just_changed_box = false;
     // the passes of ONE load share one SDF and one set of parameters: a different device SDF (or parameter block) than the

@@ -109,7 +109,8 @@ class SDFViewer {
     // launch).  ANY other SDFSurface (a ProviderSDF, an application's own class): the ingest path -- sample() runs on the
     // host, on sample_concurrency() threads, run after run of the LoadingManager's order until the budget is spent (at least
     // one voxel, like the reference); the raw 28-byte samples go to the device through pinned double buffers and
-    // sdfv_pack_samples does update()'s packing there.  update_required is decided on a host mirror of tex0.r.
+    // sdfv_pack_samples does update()'s packing there.  update_required is decided on a host mirror of tex0.r.  (sample() is
+    // the caller's code: an exception it throws on a worker thread ends the process, as a panic ends the reference's loop.)
     size_t update(SDFSurface& sdf, std::chrono::nanoseconds max_delta_time);
     // Ingest path knobs: host threads (0 = what the SDF allows, at most the machine's), records per transfer buffer (0 = 16 Ki
     // per thread, between 64 Ki and 4 Mi: a run must outlast the fork/join of its workers by far; 32 B of pinned memory each).
@@ -130,7 +131,7 @@ class SDFViewer {
     float* tex0_device() const { return material.tex0->f32(); }
     float* tex1_device() const { return material.tex1->f32(); }
     int download(float* tex0_host, float* tex1_host) const;  // D2H copy of both textures (debug / GL interop)
-    const char* last_error() const { return error_.c_str(); }
+    const char* last_error() const { return error_.c_str(); }  // of the most recent update(): "" when it went through
 
     SDFViewerMaterial material;      // volume.material
     LoadingManager loading_mgr;
