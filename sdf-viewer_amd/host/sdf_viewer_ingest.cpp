@@ -176,20 +176,69 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
     const bool has_box = changed_box.has_value();
     const BoundingBox box = has_box ? *changed_box : BoundingBox{};
 
-    std::vector<size_t> counts(threads);
+    // A run that has been sampled into its buffer and waits to be shipped.
+    struct Run {
+        Ingest::Buffer* b = nullptr;
+        size_t n = 0;
+        unsigned workers = 0;
+        std::vector<size_t> counts;
+    };
+    Run runs[2];
+    for (auto& r : runs) r.counts.resize(threads);
+    bool failed = false;
+    // Ship a run: the workers' stretches packed back to back on the device (full adjacent stretches in one copy), one launch.
+    auto ship = [&](Run& r) {
+        if (!r.b || failed) return;
+        const auto t0 = std::chrono::steady_clock::now();
+        Ingest::Buffer& b = *r.b;
+        size_t total = 0;
+        for (unsigned t = 0; t < r.workers && !failed; ++t) {
+            const size_t lo = r.n * t / r.workers;
+            size_t records = r.counts[t];
+            unsigned last = t;
+            while (last + 1 < r.workers && r.counts[last] == r.n * (last + 1) / r.workers - r.n * last / r.workers) {
+                ++last;
+                records += r.counts[last];
+            }
+            if (records) {
+                failed = hipMemcpyAsync(b.d_samples + total, b.samples + lo, records * sizeof(sdfv_sample), hipMemcpyHostToDevice, st) != hipSuccess ||
+                         hipMemcpyAsync(b.d_indices + total, b.indices + lo, records * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess;
+                total += records;
+            }
+            t = last;
+        }
+        if (!failed && total)
+            failed = sdfv_pack_samples(&g, 0, b.d_indices, b.d_samples, total, tex0_device(), tex1_device(), dist_dev, pack_flags, stream) != 0;
+        if (failed) {
+            (void)hipGetLastError();
+            error_ = std::string("ingest: ") + sdfv_last_error();
+            host_mirror_valid_ = false;  // the mirror holds samples the device never received
+        } else if (total && hipEventRecord(b.done, st) == hipSuccess) {
+            b.in_flight = true;
+        }
+        ingest_stats.ship += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        ingest_stats.records += total;
+        r.b = nullptr;
+    };
+    // With an SDF that tolerates several threads the CALLING thread does not sample: it ships run k - 1 (copies + launch:
+    // tens of host calls) while the workers sample run k.  An SDF that is the calling thread's alone is sampled, then shipped,
+    // by that thread.
+    const bool overlapped = threads > 1;
+    Run* pending = nullptr;
     size_t run_len = threads;  // the first run: one voxel per worker
     bool first = true;
-    in.pool.begin(threads);
+    in.pool.begin(threads + (overlapped ? 1u : 0u));
     struct EndSession {
         WorkerPool& pool;
         ~EndSession() { pool.end(); }
     } end_session{in.pool};
     // "while first || start_time.elapsed() < max_delta_time" with a run as the unit of work  (:173)
-    while (first || std::chrono::steady_clock::now() - start_time < max_delta_time) {
+    while (!failed && (first || std::chrono::steady_clock::now() - start_time < max_delta_time)) {
         first = false;
         const size_t step = loading_mgr.step_size();
         if (step == 0) break;  // No more work to do!
         const size_t n = std::min({run_len, loading_mgr.pass_remaining(), in.capacity});
+        Run& run = runs[in.next];
         Ingest::Buffer& b = in.buf[in.next];
         in.next ^= 1;
         const auto wait_start = std::chrono::steady_clock::now();
@@ -202,7 +251,10 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
         const size_t c0 = loading_mgr.cursor();
         const LoadingManager::Index walk = loading_mgr.pass_walk();
         const unsigned workers = (unsigned)std::min<size_t>(threads, n);
-        auto work = [&](unsigned t) {
+        run.b = &b;
+        run.n = n;
+        run.workers = workers;
+        auto sample_stretch = [&](unsigned t) {
             const size_t lo = n * t / workers, hi = n * (t + 1) / workers;  // this worker's stretch of the run (and of the buffer)
             sdfv_sample* out_s = b.samples + lo;
             uint32_t* out_i = b.indices + lo;
@@ -248,45 +300,27 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
                 }
             }
             flush();
-            counts[t] = count;
+            run.counts[t] = count;
         };
-        in.pool.run(workers, work);
-        const auto sampled = std::chrono::steady_clock::now();
-        ingest_stats.sample += std::chrono::duration<double>(sampled - run_start).count();
-        // ---- ship the run: the workers' stretches, packed back to back on the device ----
-        size_t total = 0;
-        bool failed = false;
-        for (unsigned t = 0; t < workers && !failed; ++t) {
-            const size_t lo = n * t / workers;
-            // stretches that are full and adjacent go in one copy
-            size_t records = counts[t];
-            unsigned last = t;
-            while (last + 1 < workers && counts[last] == n * (last + 1) / workers - n * last / workers) {
-                ++last;
-                records += counts[last];
-            }
-            if (records) {
-                failed = hipMemcpyAsync(b.d_samples + total, b.samples + lo, records * sizeof(sdfv_sample), hipMemcpyHostToDevice, st) != hipSuccess ||
-                         hipMemcpyAsync(b.d_indices + total, b.indices + lo, records * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess;
-                total += records;
-            }
-            t = last;
+        if (overlapped) {
+            in.pool.run(workers + 1, [&](unsigned t) {
+                if (t == 0) {
+                    if (pending) ship(*pending);
+                } else {
+                    sample_stretch(t - 1);
+                }
+            });
+            pending = &run;
+        } else {
+            sample_stretch(0);
         }
-        if (!failed && total)
-            failed = sdfv_pack_samples(&g, 0, b.d_indices, b.d_samples, total, tex0_device(), tex1_device(), dist_dev, pack_flags, stream) != 0;
-        if (failed) {
-            (void)hipGetLastError();
-            error_ = std::string("ingest: ") + sdfv_last_error();
-            host_mirror_valid_ = false;  // the mirror already holds this run
-            break;
-        }
-        if (total && hipEventRecord(b.done, st) == hipSuccess) b.in_flight = true;
+        ingest_stats.sample += std::chrono::duration<double>(std::chrono::steady_clock::now() - run_start).count();
+        if (!overlapped) ship(run);
+        if (failed) break;
         loading_mgr.advance(n);
         if (loading_mgr.step_size() == 0) loaded_once_ = true;
         publish_lod();
-        ingest_stats.ship += std::chrono::duration<double>(std::chrono::steady_clock::now() - sampled).count();
         ingest_stats.runs += 1;
-        ingest_stats.records += total;
         ingest_stats.visited += n;
         // ---- the next run: sized to end within half of the budget that is left, growing by at most 8x ----
         const auto now = std::chrono::steady_clock::now();
@@ -296,6 +330,7 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
         want = std::min(want, 8.0 * (double)n);
         run_len = want < 1.0 ? 1 : (size_t)std::min(want, (double)in.capacity);
     }
+    if (pending) ship(*pending);  // the last run of the call: everything this call sampled is enqueued when it returns
     return loading_mgr.total_iterations() - start_iter;
 }
 
