@@ -58,7 +58,13 @@ class WorkerPool {
         sequence_ += 1;
         generation_.store(sequence_ << 16 | n, std::memory_order_release);
         fn(0);
-        for (unsigned spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins) relax(spins);
+        // the caller's own share may be much shorter than the workers' (it ships while they sample): spin briefly, then SLEEP --
+        // a yielding spin still burns a CPU's worth of a cgroup quota the workers need
+        for (unsigned spins = 0; spins < 256 && pending_.load(std::memory_order_acquire) != 0; ++spins) __builtin_ia32_pause();
+        if (pending_.load(std::memory_order_acquire) != 0) {
+            std::unique_lock<std::mutex> lock(done_m_);
+            done_.wait(lock, [this] { return pending_.load(std::memory_order_acquire) == 0; });
+        }
     }
     // CPUs this process may actually use at once: the machine's hardware threads, cut down to the scheduler affinity mask and
     // to a cgroup CPU quota (cpu.max: a container limited to 16 CPUs' worth of time on a 256-thread host reports 256 hardware
@@ -84,7 +90,10 @@ class WorkerPool {
                 seen = g;
                 if (id < (g & 0xffff)) {  // (fn_ was written before the generation was published)
                     (*fn_)(id);
-                    pending_.fetch_sub(1, std::memory_order_release);
+                    if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {  // the last one out wakes the caller
+                        std::lock_guard<std::mutex> lock(done_m_);
+                        done_.notify_one();
+                    }
                 }
             }
         }
@@ -97,8 +106,8 @@ class WorkerPool {
         else
             std::this_thread::yield();
     }
-    std::mutex m_;
-    std::condition_variable wake_;
+    std::mutex m_, done_m_;
+    std::condition_variable wake_, done_;
     std::vector<std::thread> threads_;
     const std::function<void(unsigned)>* fn_ = nullptr;
     unsigned long long sequence_ = 0;
