@@ -176,7 +176,7 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
     const bool has_box = changed_box.has_value();
     const BoundingBox box = has_box ? *changed_box : BoundingBox{};
 
-    // A run that has been sampled into its buffer and waits to be shipped.
+    // A run that has been sampled into its buffer.
     struct Run {
         Ingest::Buffer* b = nullptr;
         size_t n = 0;
@@ -220,14 +220,12 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
         ingest_stats.records += total;
         r.b = nullptr;
     };
-    // With an SDF that tolerates several threads the CALLING thread does not sample: it ships run k - 1 (copies + launch:
-    // tens of host calls) while the workers sample run k.  An SDF that is the calling thread's alone is sampled, then shipped,
-    // by that thread.
-    const bool overlapped = threads > 1;
-    Run* pending = nullptr;
+    // (Shipping run k - 1 from the calling thread while the workers sample run k was built and measured: on the GPU boxes'
+    // 16-CPU quota the 17th thread costs the samplers what the overlap saves -- 69-71 ms against 60-66 for the load of R6.1's
+    // grid.  The calling thread is worker 0, then ships.)
     size_t run_len = threads;  // the first run: one voxel per worker
     bool first = true;
-    in.pool.begin(threads + (overlapped ? 1u : 0u));
+    in.pool.begin(threads);
     struct EndSession {
         WorkerPool& pool;
         ~EndSession() { pool.end(); }
@@ -302,20 +300,10 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
             flush();
             run.counts[t] = count;
         };
-        if (overlapped) {
-            in.pool.run(workers + 1, [&](unsigned t) {
-                if (t == 0) {
-                    if (pending) ship(*pending);
-                } else {
-                    sample_stretch(t - 1);
-                }
-            });
-            pending = &run;
-        } else {
-            sample_stretch(0);
-        }
+        if (workers > 1) in.pool.run(workers, sample_stretch);
+        else sample_stretch(0);
         ingest_stats.sample += std::chrono::duration<double>(std::chrono::steady_clock::now() - run_start).count();
-        if (!overlapped) ship(run);
+        ship(run);
         if (failed) break;
         loading_mgr.advance(n);
         if (loading_mgr.step_size() == 0) loaded_once_ = true;
@@ -330,7 +318,6 @@ size_t SDFViewer::update_host(SDFSurface& sdf, std::chrono::nanoseconds max_delt
         want = std::min(want, 8.0 * (double)n);
         run_len = want < 1.0 ? 1 : (size_t)std::min(want, (double)in.capacity);
     }
-    if (pending) ship(*pending);  // the last run of the call: everything this call sampled is enqueued when it returns
     return loading_mgr.total_iterations() - start_iter;
 }
 
