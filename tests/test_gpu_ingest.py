@@ -346,3 +346,48 @@ def test_ingest_over_degenerate_grids(host, oracle, gyroid_provider, dims, passe
         assert total == sum(-(-dims[0] // s) * -(-dims[1] // s) * -(-dims[2] // s) for s in (2 ** k for k in range(passes)))
         assert_viewer_equals(v, ref, (dims, passes, threads))
         assert v.update(sdf, budget) == 0 and v.lod() == 1.0
+
+
+def test_randomised_ingest_loads_and_edits(host, oracle, gyroid_provider, gyroid_provider_batch):
+    """Seeded sweep (tools/soak.sh varies the seed): random grid shapes, pass counts, worker counts, buffer sizes, budgets and
+    volume layouts; a load, then zero to two parameter edits, each worked off to the end -- every state compared with the oracle's
+    loop, after random calls and at the end of every phase."""
+    import os
+    seed = int(os.environ.get("SDFV_SOAK_SEED", 11))
+    trials = int(os.environ.get("SDFV_SOAK_TRIALS", 6))
+    rng = np.random.default_rng(seed)
+    for trial in range(max(2, trials // 4)):
+        lib = gyroid_provider_batch if rng.integers(2) else gyroid_provider
+        sdf, raw = host.SDF.provider(lib), C.CDLL(lib)
+        bb = sdf.bounding_box()
+        dims = tuple(int(v) for v in rng.integers(1, 41, size=3))
+        layout = "plain"
+        if dims[1] % 2 == 0 and rng.integers(2):
+            layout = "interleaved"
+        passes = int(rng.integers(1, 5))
+        threads, capacity = int(rng.choice([1, 2, 5, 0])), int(rng.choice([0, 7, 64, 1000]))
+        budgets = [0.0, 1e-6, 2e-5, 3e-4]
+        what = (seed, trial, dims, layout, passes, threads, capacity)
+        v = host.Viewer.new_voxels(dims, bb, passes, layout=layout)
+        v.set_ingest(threads, capacity)
+        ref = RefViewer(oracle, dims, bb, passes, raw.gyroid_sample_raw)
+        while v.remaining():
+            n = v.update(sdf, budgets[rng.integers(4)])
+            assert n > 0 and v.last_error() == "", what
+            assert ref.update(None, n) == n, what
+            if rng.integers(8) == 0:
+                assert_viewer_equals(v, ref, what)
+        assert_viewer_equals(v, ref, what)
+        box = np.float32([bb[0], -0.3, bb[2], 0.1, bb[4], bb[5]])
+        for edit in range(int(rng.integers(0, 3))):
+            assert sdf.set_parameter(0, float(rng.uniform(0.05, 0.4))) is None
+            first = True
+            for _ in range(100000):
+                n = v.update(sdf, budgets[rng.integers(4)])
+                assert ref.update(box if first else None, n) == n, what
+                first = False
+                if n == 0 and not v.has_changed_box():
+                    break
+            assert not v.has_changed_box() and ref.box is None, what
+            assert_viewer_equals(v, ref, what + (edit,))
+        assert sdf.set_parameter(0, 0.15) is None and sdf.changed() is not None   # the fixture's default for the next trial

@@ -15,10 +15,11 @@ while [ $(date +%s) -lt $END ]; do
         tests/test_gpu_raymarch.py::test_randomised_tile_orders \
         tests/test_gpu_points.py::test_random_points_match_oracle \
         tests/test_gpu_mesh_extract.py::test_randomised_extractions_match_numpy_restatement \
-        tests/test_gpu_sharded_march.py::test_randomised_slabs_and_cameras > gpurun_out/soak_last.log 2>&1; then
+        tests/test_gpu_sharded_march.py::test_randomised_slabs_and_cameras \
+        tests/test_gpu_ingest.py::test_randomised_ingest_loads_and_edits > gpurun_out/soak_last.log 2>&1; then
     echo "SOAK FAILURE at seed $SEED"; grep -v "^RCCL\|^HIP \|^ROCm\|^Host\|^Libr" gpurun_out/soak_last.log | tail -40
     exit 1
   fi
   N=$((N + 1))
 done
-echo "soak: $N rounds of 7 sweeps x 40 trials passed, seeds $(( SEED - N + 1 ))..$SEED"
+echo "soak: $N rounds of 8 sweeps x 40 trials passed, seeds $(( SEED - N + 1 ))..$SEED"
