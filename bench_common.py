@@ -23,9 +23,9 @@ def STAGE(name):
 
 def prewarm(fn, torch, dist=None, world=1, device=None, seconds=None):
     """Untimed: keep the device busy with `fn` for ~0.25 s so that the timed steps run at the clocks a busy GPU runs at.
-    The MI355X idles at a few hundred MHz and needs ~10 ms of load to ramp (tools/clock_ramp.py: the first 8 ms of
+    The MI355X idles at a few hundred MHz and needs ~10 ms of load to ramp (EXPERIMENTS, round 1 clock-ramp probe: the first 8 ms of
     256^3 fills after an idle period are 9 % slower than the steady state, and on some boxes the rate keeps drifting
-    for about a second: tools/tex_skew_sweep.py); a few warm-up steps of 0.1 ms each do not get it there.  At N > 1 the steps contain exchanges, so every rank must make the SAME number of calls: the
+    for about a second: round 2 texture-skew sweep); a few warm-up steps of 0.1 ms each do not get it there.  At N > 1 the steps contain exchanges, so every rank must make the SAME number of calls: the
     count is agreed on (MAX over ranks) before the loop."""
     seconds = PREWARM_S if seconds is None else seconds
     if seconds <= 0:

@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256, SDFV_RM_MIN_WAVES) void raymarch_kernel(Raymar
         // their linear number and every XCD works through ITS share at its own pace: the launch is as long as the busiest
         // XCD's share.  With a tile row a multiple of 8 wide (1080p: 120, 4K: 240, 1440p: 160) XCD k would render tile columns
         // k, k + 8, ... of EVERY row of EVERY camera -- and an object 44 columns wide gives six columns to some XCDs and five
-        // to others: 24 % more marching on the busiest XCD than on the idlest (tools/batch_timeline.py: they finish 290 us
+        // to others: 24 % more marching on the busiest XCD than on the idlest (profiles/r04_batch_timeline_*.json, EXPERIMENTS R4.12: they finish 290 us
         // apart in a 1.75 ms batch).  Rotating the columns by row and camera deals every XCD every column in turn.
         const uint32_t tiles_x = gridDim.x;
         const uint32_t r = (blockIdx.y + blockIdx.z) % tiles_x;  // scalar
@@ -1400,7 +1400,7 @@ static void box_first_rectangle(RaymarchArgs& ag, uint32_t groups_y) {
 // started first (box-first order: those under the box) finish sooner and the rest fill in behind them.  That only pays when
 // (i) the frame is bound by its long waves, not by throughput -- a box covering a small multiple of the machine, not the
 // whole image; (ii) a gather that misses L2 is expensive -- a marched volume larger than the Infinity Cache; smaller ones
-// (256^3: 64 MB) move by +-3 % either way (tools/occupancy_rule_bench.py, profiles/r03_occupancy_rule.json: 13 views x
+// (256^3: 64 MB) move by +-3 % either way (profiles/r03_occupancy_rule.json: 13 views x
 // 1080p/256^3, 1440p/512^3, 4K/512^3 x every cap).  What the launcher knows: the screen rectangle of the projected bounding
 // box (box-first order) in waves, the machine's wave slots, the volume's bytes.  Rule: cap at 4 when the rectangle holds
 // between 1x and 3.5x the slots at 7 per SIMD and the volume exceeds the last-level cache; no cap otherwise (camera
@@ -1408,7 +1408,7 @@ static void box_first_rectangle(RaymarchArgs& ag, uint32_t groups_y) {
 // Which volume the hand-written loop marches over, of those the caller handed in: 4 the y-interleaved volume, 3 the pair
 // volume, 0 neither (the loop's specialisation does not apply, or neither was given).  With both: the pair volume while its
 // 8 B/voxel fit the last-level cache (fewest gathers), the interleaved one beyond (half the footprint) --
-// tools/pairs_bench.py, profiles/r03_pairs_bench.json.
+// profiles/r03_pairs_bench.json.
 // Does the hand-written loop's specialisation apply to these render parameters, and may it address a volume of `kind` (3 the
 // pair volume, 4 the y-interleaved one)?  Pointers apart, everything march_volume_mode decides on -- sdfv_march_volume_advice
 // asks the same question BEFORE a volume exists (the advice once checked less than the launcher, so a host could

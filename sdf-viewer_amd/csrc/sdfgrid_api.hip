@@ -119,7 +119,7 @@ sdfv::FillArgs make_fill_args(const sdfv_demo_params& p, uint32_t sdf_id, const 
 // Store policy and index form of the dense fill (SDFV_OPT_FILL_*).  Store policy "auto": a launch that also writes the
 // compact distance volume streams the two textures past L2 (nt) -- nothing re-reads them before the march's few texels
 // under the hits, while the distance volume, which the march gathers from, keeps its place in the caches: the fused
-// fill itself runs 6 % faster (0.097 -> 0.091 ms at 256^3) and fill + march 0.188 -> 0.177 ms (tools/pipeline_nt.py).
+// fill itself runs 6 % faster (0.097 -> 0.091 ms at 256^3) and fill + march 0.188 -> 0.177 ms (EXPERIMENTS, round 2 store-policy probe).
 // The plain fill keeps plain stores (nt: within noise alone, +3 % on the 256^3 pipeline, -3 % on the 512^3 one).
 struct DeviceFacts;
 const DeviceFacts& device_facts();
@@ -1168,7 +1168,7 @@ static int raymarch_rows(const sdfv_render_params* rp, const float* tex0, const 
     // directional light uses it).
     a.compute_normal = g_options.raymarch_keep_normal ? 1u : 0u;
     // tile order: auto = for a single frame the launcher's XCD-aware choice (groups of 2 x 2 tiles, those under the projected
-    // bounding box first; tools/box_first_bench.py, tools/tile_group_bench.py), launch order for batches of cameras, which
+    // bounding box first; profiles/r02/box_first_*.json, EXPERIMENTS R2-R3), launch order for batches of cameras, which
     // lose 3-8 % with any grouping
     // w waves per SIMD = w workgroups per CU: each asks for a w-th of the CU's 160 KB of LDS (less a little for rounding)
     const uint32_t w = g_options.raymarch_waves_per_simd;

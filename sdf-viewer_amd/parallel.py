@@ -11,7 +11,7 @@ xGMI link per direction.  On CPU (tests) the same code runs over gloo.
 
 Two transports carry the halo: `SlabComm` (the library's own RCCL communicator, include/sdfgrid.h sdfv_slab_*: one
 C call enqueues a whole fill step, ~10 us of host time) and torch.distributed P2P ops (c10d spends ~120 us of
-host time per exchange, more than the 256^3 fill takes on the GPU -- tools/halo_loopback.py).  `SlabFiller` uses
+host time per exchange, more than the 256^3 fill takes on the GPU -- EXPERIMENTS, round 2).  `SlabFiller` uses
 the first on GPUs with the nccl backend and the second everywhere else (gloo tests).
 """
 import ctypes as C
