@@ -83,7 +83,23 @@ static bool one_load(size_t side, size_t passes, bool progressive, hipEvent_t e0
 }
 
 // One load of a host-sampled SDF.  budget_ms < 0: one update() with an unlimited budget; otherwise the frame loop.
-static int ingest_load(SDFSurface& sdf, size_t side, size_t passes, unsigned threads, double budget_ms, const char* key) {
+// (the median of `repeats` loads by load time: the host cores are shared and rationed -- one load in three runs 30 % off)
+static int ingest_load_once(SDFSurface& sdf, size_t side, size_t passes, unsigned threads, double budget_ms, const char* key,
+                            std::string* line, double* load_ms);
+static int ingest_load(SDFSurface& sdf, size_t side, size_t passes, unsigned threads, double budget_ms, const char* key, int repeats = 3) {
+    std::vector<std::pair<double, std::string>> loads;
+    for (int i = 0; i < repeats; ++i) {
+        std::string line;
+        double ms = 0.0;
+        if (ingest_load_once(sdf, side, passes, threads, budget_ms, key, &line, &ms) != 0) return 1;
+        loads.emplace_back(ms, line);
+    }
+    std::sort(loads.begin(), loads.end());
+    printf("%s", loads[loads.size() / 2].second.c_str());
+    return 0;
+}
+static int ingest_load_once(SDFSurface& sdf, size_t side, size_t passes, unsigned threads, double budget_ms, const char* key,
+                            std::string* line, double* load_ms) {
     auto v = SDFViewer::from_bb(sdf.bounding_box(), side, passes);
     if (!v) return 1;
     v->host_threads = threads;
@@ -117,8 +133,11 @@ static int ingest_load(SDFSurface& sdf, size_t side, size_t passes, unsigned thr
     const auto& is = v->ingest_stats;
     fprintf(stderr, "%s: runs %zu, records %zu of %zu visited; host ms: wait for a buffer %.2f, sample %.2f, ship %.2f\n", key, is.runs,
             is.records, is.visited, is.wait_buffer * 1e3, is.sample * 1e3, is.ship * 1e3);
-    printf(", \"%s\": {\"setup_ms\": %.2f, \"load_ms\": %.2f, \"update_calls\": %zu, \"iterations\": %zu, \"worst_call_ms\": %.2f, "
-           "\"Mvoxels_per_s\": %.2f}", key, setup_ms, ms, calls, iterations, worst_call_ms, ms > 0 ? voxels / (ms * 1e-3) / 1e6 : 0.0);
+    char buf[512];
+    snprintf(buf, sizeof buf, ", \"%s\": {\"setup_ms\": %.2f, \"load_ms\": %.2f, \"update_calls\": %zu, \"iterations\": %zu, \"worst_call_ms\": %.2f, "
+             "\"Mvoxels_per_s\": %.2f}", key, setup_ms, ms, calls, iterations, worst_call_ms, ms > 0 ? voxels / (ms * 1e-3) / 1e6 : 0.0);
+    *line = buf;
+    *load_ms = ms;
     return 0;
 }
 
@@ -155,7 +174,7 @@ int main(int argc, char** argv) {
                sdf->name().c_str(), hw, used);
         if (ingest_load(*sdf, side, passes, threads, -1.0, "whole_load") != 0) return 1;
         if (ingest_load(*sdf, side, passes, threads, 30.0, "frame_loop_30ms") != 0) return 1;
-        if (ingest_load(*sdf, side, passes, 1, -1.0, "whole_load_1_thread") != 0) return 1;
+        if (ingest_load(*sdf, side, passes, 1, -1.0, "whole_load_1_thread", 1) != 0) return 1;
         printf("}\n");
         return 0;
     }
