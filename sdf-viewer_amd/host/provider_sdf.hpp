@@ -18,7 +18,9 @@ class ProviderSDF : public SDFSurface {
    public:
     // dlopen()s `path`, calls its init() if it exports one (native.rs:51-56) and returns the root SDF (id 0, native.rs:78).
     // bounding_box and sample are required (native.rs:60,62); nullptr + *error when the library or one of them is missing.
-    // The provider's registry is thread-local (ffi.rs:15-17): use the object on the thread that loaded it.
+    // The provider's registry is thread-local (ffi.rs:15-17): use the object on the thread that loaded it.  A native library's
+    // globals are the PROCESS's (dlopen counts references): two loads of one path share them -- and init() of the second resets
+    // what the first set up -- where two instances of a wasm module would not.
     static std::shared_ptr<ProviderSDF> load(const std::string& path, std::string* error);
 
     BoundingBox bounding_box() const override;

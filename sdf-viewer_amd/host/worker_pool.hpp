@@ -20,6 +20,7 @@ namespace sdfviewer {
 // returns when all are done, end() parks them again.  Inside a session the workers SPIN on a generation counter between runs:
 // a run lasts a fraction of a millisecond, and waking 63 threads through one mutex costs about as much (measured on a
 // 2 x 64-core host: 64 workers reached 25 % of their single-thread rate with a condition variable per run).
+// One caller at a time (begin / run / end are the owning viewer's, which is single-owner like everything behind the C ABI).
 class WorkerPool {
    public:
     ~WorkerPool() {
@@ -70,6 +71,7 @@ class WorkerPool {
     // to a cgroup CPU quota (cpu.max: a container limited to 16 CPUs' worth of time on a 256-thread host reports 256 hardware
     // threads; 64 workers there only take turns).
     static unsigned usable_cpus();
+    static unsigned probe_usable_cpus();
 
    private:
     void loop(unsigned id, unsigned long long seen) {
@@ -119,6 +121,11 @@ class WorkerPool {
 
 
 inline unsigned WorkerPool::usable_cpus() {
+    static const unsigned cached = [] { return probe_usable_cpus(); }();  // (asked once per process: update() runs every frame)
+    return cached;
+}
+
+inline unsigned WorkerPool::probe_usable_cpus() {
     unsigned n = std::thread::hardware_concurrency();
     if (n == 0) n = 1;
     cpu_set_t set;
