@@ -47,12 +47,22 @@ def oracle():
     return oracle_binding
 
 
-def _build_gyroid(tmp_path_factory, name, *defines):
+def _build_provider(tmp_path_factory, name, *defines, source="gyroid_provider.c"):
     out = tmp_path_factory.mktemp(name) / f"lib{name}.so"
     subprocess.check_call(["gcc", "-std=c11", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall",
                            "-Wextra", "-Werror", *defines, "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "c", "gyroid_provider.c"), "-o", str(out), "-lm"])
+                           os.path.join(ROOT, "tests", "c", source), "-o", str(out), "-lm"])
     return str(out)
+
+
+_build_gyroid = _build_provider
+
+
+@pytest.fixture(scope="session")
+def failing_provider(tmp_path_factory):
+    """tests/c/failing_provider.c: a provider whose calls fail the ways wasm/native.rs guards against (NULL results, unknown tags,
+    ragged lengths)."""
+    return _build_provider(tmp_path_factory, "failing_provider", source="failing_provider.c")
 
 
 @pytest.fixture(scope="session")

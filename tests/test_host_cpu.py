@@ -341,6 +341,42 @@ def test_provider_sdf_consumes_the_per_point_abi(host, gyroid_provider):
     assert sdf.set_parameter(0, 0.15) is None and sdf.changed() is not None  # (back to the default for later tests)
 
 
+def test_provider_sdf_maps_failed_calls_to_the_defaults(host, failing_provider, capfd):
+    """A provider call that fails is logged and answered with the trait's default, never a crash (wasm/native.rs:164-521:
+    bounding box [0, 1]^3 :172, sample = SDFSample::new(1.0, 0) :203, no children :226, name_default_impl :266, no parameters
+    :290, set_parameter's default error :413, not changed :468, zero normal :506); malformed blocks are read as far as they
+    are whole records: unknown enum tags drop the parameter (:333,:368), a child list naming the SDF itself skips that entry
+    (:241-244)."""
+    import ctypes as C
+    raw = C.CDLL(failing_provider)
+    sdf = host.SDF.provider(failing_provider)
+    default_error = "no parameters implemented by default, overwrite this method"
+    raw.set_fail_mode(0)                                          # every call returns NULL
+    assert np.array_equal(sdf.bounding_box(), np.float32([0, 0, 0, 1, 1, 1]))
+    assert np.array_equal(sdf.sample([0.1, 0.2, 0.3]), np.float32([1, 0, 0, 0, 0, 0, 0]))
+    got = sdf.sample_batch(np.zeros((5, 3), np.float32))           # the default loop over sample()
+    assert got.shape == (5, 7) and np.array_equal(got, np.tile(np.float32([1, 0, 0, 0, 0, 0, 0]), (5, 1)))
+    assert sdf.children() == [] and sdf.name() == "Object" and sdf.parameters() == []
+    assert sdf.set_parameter(0, 1.5) == default_error and sdf.changed() is None
+    assert np.array_equal(sdf.normal([0.1, 0.2, 0.3], 0.001), np.zeros(3, np.float32))
+    assert sdf.sample_concurrency() == 1                           # an export that answers 0
+    assert "Failed to get bounding box" in capfd.readouterr().err
+    raw.set_fail_mode(1)                                          # well-formed blocks, values a consumer must refuse
+    kids = sdf.children()
+    assert [k.id() for k in kids] == [5]                           # itself skipped, the cut-off third id never read
+    assert sdf.name() == ""
+    prm = sdf.parameters()
+    assert len(prm) == 1 and prm[0][:4] == ["12", "ok", "1", "Int(2)"]
+    assert sdf.set_parameter(12, 1) == "Unknown SDF set parameter result kind enum type"
+    assert sdf.changed() is None
+    err = capfd.readouterr().err
+    assert "include itself" in err and "Unknown SDF param kind enum type 9" in err and "Unknown SDF param value enum type 77" in err
+    assert "Unknown SDF changed result kind enum type 3" in err
+    raw.set_fail_mode(2)                                          # lengths without data
+    assert sdf.children() == [] and sdf.name() == "" and sdf.parameters() == []
+    assert sdf.set_parameter(12, 1) == ""                          # an Err without a message is still an Err
+
+
 def test_provider_sdf_load_errors(host, tmp_path):
     import subprocess
     with pytest.raises(OSError, match="cannot load SDF provider"):
