@@ -96,6 +96,13 @@ EXPORT SDFChangedResult *changed(uint32_t sdf_id) {
     return ret;
 }
 
+/* what a consumer samples instead (native.rs:203: SDFSample::new(1.0, 0)), with the oracle's callback signature (oracle/sdf_oracle.h) */
+EXPORT void failing_sample_raw(void *user, const float p[3], int distance_only, float out[7]) {
+    (void)user, (void)p, (void)distance_only;
+    memset(out, 0, 7 * sizeof(float));
+    out[0] = 1.0f;
+}
+
 EXPORT SDFVec3 *normal(uint32_t sdf_id, SDFVec3 p, float eps) {
     (void)sdf_id, (void)p, (void)eps;
     return NULL;

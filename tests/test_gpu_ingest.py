@@ -324,6 +324,26 @@ def test_cli_url_provider_loads_through_the_ingest_path(oracle, gyroid_provider,
     assert np.abs(img - want8).max() <= 1
 
 
+def test_a_provider_whose_sample_fails_loads_as_the_default_sample(host, oracle, failing_provider):
+    """wasm/native.rs:172,203: a failed bounding_box() is [0, 1]^3, a failed sample() is SDFSample::new(1.0, 0) -- and the viewer
+    loads THAT, like the reference would: distance 1.0 everywhere (tex0.r clamps to 1), the all-zero colour replaced by grey."""
+    sdf = host.SDF.provider(failing_provider)
+    raw = C.CDLL(failing_provider)
+    raw.set_fail_mode(0)
+    bb = sdf.bounding_box()
+    assert np.array_equal(bb, np.float32([0, 0, 0, 1, 1, 1]))
+    dims = (10, 6, 8)
+    v = host.Viewer.new_voxels(dims, bb, 2)
+    ref = RefViewer(oracle, dims, bb, 2, raw.failing_sample_raw)
+    while v.remaining():
+        n = v.update(sdf, 1.0)
+        assert n > 0 and v.last_error() == "" and ref.update(None, n) == n
+    assert_viewer_equals(v, ref, "default samples")
+    t0, t1 = v.download()
+    assert (t0[..., 0] == 1.0).all() and (t1[..., 2] == 1.0).all()   # clamp(0.1 + 1.0); occlusion 0 -> 1
+    assert np.unique(t0[..., 1:]).size == 1                           # one grey
+
+
 @pytest.mark.parametrize("dims,passes", [((2, 2, 2), 1), ((4, 4, 4), 5), ((1, 5, 7), 2), ((9, 1, 1), 3), ((33, 2, 3), 2)])
 def test_ingest_over_degenerate_grids(host, oracle, gyroid_provider, dims, passes):
     """Grids the reference's loop handles without noticing: a single voxel along an axis (its coordinate is 0 / 0 = NaN,
