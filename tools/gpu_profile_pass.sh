@@ -17,7 +17,7 @@ for G in load_virgin load_unflagged fresh_step1 edit_full edit_eighth noop; do
 done
 python tools/pass_traffic.py $OUT $SIDE > $OUT/pass_traffic_$SIDE.json 2> $OUT/pass_traffic.err
 {
-  python tools/stamp.py
+  python tools/source_hash.py --stamp
   echo "# rocprofv3 --kernel-trace --stats / --pmc WRITE_SIZE / --pmc FETCH_SIZE -- python tools/pass_workload.py $SIDE <group>"
   echo "# one group of cases per process, 0.3 s of pre-warm, 100 repetitions (PASS_REPS); per (kernel, grid size)"
   for G in load_virgin load_unflagged fresh_step1 edit_full edit_eighth noop; do

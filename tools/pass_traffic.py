@@ -54,8 +54,10 @@ CASES = {
 }
 try:  # which build / box the traces describe (this runs on the box, right after them)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    import stamp
-    STAMP = {"build_id": stamp.running_build_id(), "box": stamp.box_uuid()}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import source_hash
+    from bench_common import running_build_id
+    STAMP = {"build_id": running_build_id(), "box": source_hash.box_uuid()}
 except Exception:
     STAMP = {"build_id": None, "box": None}
 out = {"side": side, **STAMP, "source": "tools/gpu_profile_pass.sh (rocprofv3 --kernel-trace / --pmc WRITE_SIZE / --pmc FETCH_SIZE, one group of cases "

@@ -31,10 +31,10 @@ done
 python tools/full_parity.py 256 512 > $D/full_workload_parity.txt 2>&1
 # round 6: the scan-load A/B (one process, one box), the no-op pass in its contexts, the read-stream microbenchmark, the ingest path
 python tools/pass_loads_ab.py 256 512 > $D/${R}_pass_loads_ab.json 2> $D/pass_loads_ab.err
-{ python tools/stamp.py; python tools/noop_gap.py 512; python tools/noop_gap.py 256; } > $D/${R}_noop_gap.txt 2>&1
-{ python tools/stamp.py; ( cd tools/ubench && { [ -x ./read_stream ] || hipcc --offload-arch=gfx950 -O3 read_stream.hip -o read_stream; } && ./read_stream 512 && ./read_stream 64 && ./read_stream 2048 ); } > $D/${R}_read_stream_ubench.txt 2>&1
+{ python tools/source_hash.py --stamp; python tools/noop_gap.py 512; python tools/noop_gap.py 256; } > $D/${R}_noop_gap.txt 2>&1
+{ python tools/source_hash.py --stamp; ( cd tools/ubench && { [ -x ./read_stream ] || hipcc --offload-arch=gfx950 -O3 read_stream.hip -o read_stream; } && ./read_stream 512 && ./read_stream 64 && ./read_stream 2048 ); } > $D/${R}_read_stream_ubench.txt 2>&1
 gcc -std=c11 -O2 -ffp-contract=off -fPIC -shared -fvisibility=hidden -Iinclude tests/c/gyroid_provider.c -o /tmp/libgyroid_provider.so -lm
-{ python tools/stamp.py; for t in 1 4 16 32; do ./sdf-viewer_amd/sdf-viewer-host-bench --ingest /tmp/libgyroid_provider.so --side 384 --threads $t 2>&1 | grep -v Using; done; } > $D/${R}_ingest_bench.txt 2>&1
+{ python tools/source_hash.py --stamp; for t in 1 4 16 32; do ./sdf-viewer_amd/sdf-viewer-host-bench --ingest /tmp/libgyroid_provider.so --side 384 --threads $t 2>&1 | grep -v Using; done; } > $D/${R}_ingest_bench.txt 2>&1
 SDFV_BENCH_FORCE_MULTI=1 WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29655 SDFV_BENCH_FULL_JSON=$D/bench_rccl_loopback_256_full.json \
   python bench.py --gpus 1 --no-cpu-baseline > $D/bench_rccl_loopback_256.json 2> $D/loopback.err
 (rocm-smi --showclocks --showuniqueid 2>&1 | grep -i "sclk\|mclk\|fclk\|unique") > $D/box_after.txt

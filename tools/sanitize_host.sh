@@ -18,7 +18,7 @@ LINK="-Lsdf-viewer_amd -lsdfgrid -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm
 T=/tmp/sdfv_sanitize
 mkdir -p $T
 {
-  python tools/stamp.py
+  python tools/source_hash.py --stamp
   gcc -std=c11 -O2 -ffp-contract=off -fPIC -shared -fvisibility=hidden -Iinclude tests/c/gyroid_provider.c -o $T/libgyroid.so -lm
   gcc -std=c11 -O2 -ffp-contract=off -fPIC -shared -fvisibility=hidden -DGYROID_BATCH -Iinclude tests/c/gyroid_provider.c -o $T/libgyroid_batch.so -lm
   g++ $FLAGS -fsanitize=thread -o $T/bench-tsan $H/host_load_bench.cpp $CORE $LINK
